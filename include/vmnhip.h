@@ -1,0 +1,173 @@
+/*
+ * vmnhip.h — C ABI of the MI355X-native exponentiation / re-encryption / proof-of-shuffle core
+ * for the Verificatum Mix-Net.
+ *
+ * This is the drop-in boundary.  The reference (verificatum-vmn, Java) reaches its
+ * arithmetic through the array classes of VCR 3.1.0 (com.verificatum.arithm.PGroupElementArray,
+ * PRingElementArray, LargeIntegerArray, ...), which are not part of the reference tree; the reference's
+ * own files only show the *call sites*.  Every entry point below is one such array-level call, and
+ * its comment cites the reference call site(s) it serves ("ref:" = path under /root/reference,
+ * P/ = src/java/com/verificatum/protocol/).  A JNI shim maps `long` handles and `byte[]` onto these
+ * functions one-to-one.
+ *
+ * Conventions
+ *   - Plain C, no C++/torch types.  Handles are opaque pointers.
+ *   - Every function returns VMN_OK (0) or a negative vmn_status; nothing throws or aborts
+ *     (the reference replaces malformed inputs by trivial values and carries on:
+ *     ref: P/hvzk/PoSBasicTW.java:794-815, P/mixnet/ShufflerElGamalSession.java:207-214).
+ *   - Verdicts and membership results are returned through int* out-parameters (1 / 0).
+ *   - Host byte buffers use the reference's wire format for fixed-width integers: big-endian,
+ *     `nbytes` bytes per value, values concatenated (the payload of the byte-tree leaves,
+ *     SURVEY.md App. D).  Arrays live on the device; results are fresh arrays (the reference's
+ *     arrays are immutable, ref: P/hvzk/PoSBasicTW.java:1088-1101 for the explicit free()s).
+ *   - All work is enqueued on the context's HIP stream; functions that return host data
+ *     synchronise that stream.  Calls on distinct contexts are independent; calls on one context
+ *     must be serialised by the caller (one protocol thread per party, SURVEY.md §8b "Threading").
+ *   - There is NO CPU fallback: if no gfx950 device is usable, vmn_ctx_create fails with
+ *     VMN_ERR_DEVICE and nothing else can be called.
+ */
+#ifndef VMNHIP_H
+#define VMNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vmn_status {
+    VMN_OK = 0,
+    VMN_ERR_ARG = -1,       /* null/invalid handle, size mismatch, unsupported modulus size */
+    VMN_ERR_DEVICE = -2,    /* HIP error (no device, launch failure); see vmn_last_error() */
+    VMN_ERR_NOMEM = -3,     /* device or host allocation failed */
+    VMN_ERR_FORMAT = -4,    /* value out of range on import (>= modulus) */
+    VMN_ERR_UNSUPPORTED = -5
+} vmn_status;
+
+typedef struct vmn_ctx vmn_ctx;         /* one GPU + one stream + scratch workspace            */
+typedef struct vmn_group vmn_group;     /* ModPGroup: subgroup of order q of Z_p^*, generator g */
+typedef struct vmn_garray vmn_garray;   /* PGroupElementArray over a vmn_group (device)         */
+typedef struct vmn_rarray vmn_rarray;   /* PRingElementArray / PFieldElementArray over Z_q       */
+
+/* ---- library / context ------------------------------------------------------------------- */
+
+const char* vmn_version(void);
+/* Thread-local description of the last failing call in this thread (never NULL). */
+const char* vmn_last_error(void);
+
+/* device: HIP device ordinal.  Fails with VMN_ERR_DEVICE when no gfx950 GPU is present. */
+int vmn_ctx_create(int device, vmn_ctx** out);
+void vmn_ctx_destroy(vmn_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the
+ * context's own stream. */
+int vmn_ctx_set_stream(vmn_ctx* ctx, void* hip_stream);
+void* vmn_ctx_get_stream(vmn_ctx* ctx);
+int vmn_ctx_synchronize(vmn_ctx* ctx);
+/* Number of compute units of the context's device (used by the benchmark to state the roofline). */
+int vmn_ctx_num_cus(vmn_ctx* ctx);
+
+/* ---- groups -------------------------------------------------------------------------------
+ * ModPGroup(p, q, g): ref: P/elgamal/ProtocolElGamal.java:738-800 (group shapes), the marshalled
+ * example at demo/mixnet/benchmarks/bench_config:43.  p, q, g are big-endian, nbytes each.
+ * Supported modulus sizes: 512, 1024, 2048, 3072, 4096 bits (nbytes*8 rounded up to those). */
+int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const uint8_t* q_be, const uint8_t* g_be,
+                          size_t nbytes, vmn_group** out);
+void vmn_group_destroy(vmn_group* grp);
+size_t vmn_group_elem_bytes(const vmn_group* grp);     /* bytes per group element on the wire */
+size_t vmn_group_exp_bytes(const vmn_group* grp);      /* bytes per exponent (ring element) on the wire */
+
+/* ---- group element arrays (PGroupElementArray) --------------------------------------------- */
+
+/* pGroup.toElementArray(size, reader) / unsafeToElementArray: import n fixed-width big-endian
+ * values.  ref: P/hvzk/PoSBasicTW.java:507, 787-792; P/mixnet/ShufflerElGamalSession.java:205.
+ * *all_in_range (may be NULL) is set to 0 if some value is >= p or == 0 (the array is then
+ * still created, offending entries replaced by 1, mirroring the reference's "replace by trivial
+ * value" convention); subgroup membership proper is vmn_garray_is_member. */
+int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_garray** out, int* all_in_range);
+/* array.toByteTree() payload: n * elem_bytes big-endian bytes.  ref: 174 toByteTree call sites, e.g.
+ * P/hvzk/PoSBasicTW.java:694-699. */
+int vmn_garray_to_be(const vmn_garray* a, uint8_t* be_out);
+size_t vmn_garray_size(const vmn_garray* a);
+void vmn_garray_free(vmn_garray* a);                   /* PGroupElementArray.free() */
+
+/* K1a  X.exp(E): out[i] = X[i]^E[i].  ref: P/hvzk/PoSBasicTW.java:1032; P/hvzk/PoSCBasicTW.java:694.
+ * ebits = bit length bound of the exponents actually used (<= 8*exp_bytes; 0 = full width). */
+int vmn_garray_exp_array(const vmn_garray* x, const vmn_rarray* e, int ebits, vmn_garray** out);
+/* Same with integer exponents that are NOT reduced mod q (LargeIntegerArray, e.g. the
+ * n_e+n_v+n_r-bit k_E):  exps_be = n big-endian values of ebytes each. */
+int vmn_garray_exp_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, vmn_garray** out);
+/* K1b  X.exp(e) with one shared exponent.  ref: P/hvzk/PoSBasicTW.java:1028;
+ * P/mixnet/ShufflerElGamalSession.java:506; P/mixnet/PermutationCommitment.java:357;
+ * P/elgamal/DistrElGamalSession.java:384-385. */
+int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, vmn_garray** out);
+/* K2  g.exp(E): out[i] = base^E[i] for one fixed base.  ref: P/mixnet/ShufflerElGamalSession.java:407,
+ * 658; P/hvzk/PoSBasicTW.java:447, 606, 608, 644, 646, 1030; P/mixnet/PermutationCommitment.java:200. */
+int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out);
+/* K3  X.expProd(E) = prod_i X[i]^E[i] -> one element (big-endian, elem_bytes).
+ * ref: P/hvzk/PoSBasicTW.java:408, 409, 481, 690, 1021, 1063; P/hvzk/CCPoSBasicW.java:380, 391, 497-503. */
+int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int ebits, uint8_t* out_be);
+int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, uint8_t* out_be);
+/* K4  X.mul(Y).  ref: P/mixnet/ShufflerElGamalSession.java:273, 789, 850 (the re-encryption);
+ * P/hvzk/PoSBasicTW.java:448, 610, 648, 1029, 1033. */
+int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out);
+/* K5  X.prod() -> one element.  ref: P/hvzk/PoSBasicTW.java:1013; P/hvzk/PoSCBasicTW.java:667. */
+int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be);
+/* K6  X.equals(Y).  ref: P/hvzk/PoSBasicTW.java:1035; P/hvzk/PoSCBasicTW.java:697. */
+int vmn_garray_equals(const vmn_garray* x, const vmn_garray* y, int* equal);
+/* K7  data movement.  permute: out[i] = X[perm[i]] (gather; see SURVEY.md App. B on the convention);
+ * shiftPush: (el, X[0..n-2]); copyOfRange [from, to); extract keeps X[i] where keep[i] != 0.
+ * ref: P/mixnet/ShufflerElGamalSession.java:278, 684-703, 792; P/hvzk/PoSBasicTW.java:451, 637-638, 1031;
+ * P/mixnet/PermutationCommitment.java:398-405, 462-469. */
+int vmn_garray_permute(const vmn_garray* x, const uint32_t* perm_host, vmn_garray** out);
+int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, vmn_garray** out);
+int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to, vmn_garray** out);
+int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host, vmn_garray** out);
+int vmn_garray_get(const vmn_garray* x, size_t i, uint8_t* out_be);
+/* Subgroup membership of every element (x^q == 1); *all_members = 1/0.  Part of K10
+ * (pGroup.toElementArray's check). */
+int vmn_garray_is_member(const vmn_garray* x, int* all_members);
+
+/* ---- ring element arrays over Z_q (PRingElementArray / PFieldElementArray) ------------------ */
+
+int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_rarray** out, int* all_in_range);
+int vmn_rarray_to_be(const vmn_rarray* a, uint8_t* be_out);
+size_t vmn_rarray_size(const vmn_rarray* a);
+void vmn_rarray_free(vmn_rarray* a);
+/* K8.  ref: P/hvzk/PoSBasicTW.java:596 (recLin), 604 (prods), 642-645, 861-863, 873-878, 1014;
+ * P/hvzk/PoSCBasicTW.java:410, 418, 483-486, 612-613, 623-627, 668; P/hvzk/CCPoSBasicW.java:467-478. */
+int vmn_rarray_mul(const vmn_rarray* x, const vmn_rarray* y, vmn_rarray** out);
+int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarray** out);
+int vmn_rarray_neg(const vmn_rarray* x, vmn_rarray** out);
+/* x.mulAdd(v, y): out[i] = x[i]*v + y[i] with scalar v (big-endian, exp_bytes). */
+int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, const vmn_rarray* y, vmn_rarray** out);
+/* b.recLin(e): x[0] = b[0], x[i] = x[i-1]*e[i] + b[i]; last = x[n-1] (may be NULL). */
+int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_rarray** out_x, uint8_t* last_be);
+/* e.prods(): y[i] = prod_{j<=i} e[j]. */
+int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out);
+int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* out_be);
+int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be);
+int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be);
+int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out);
+int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out);
+int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal);
+
+/* ---- partial results for multi-GPU sharding --------------------------------
+ * Each rank holds a contiguous shard; expProd/prod partials are single elements that the host
+ * side exchanges (RCCL all-gather of G x elem_bytes) and multiplies.  This multiplies k partials
+ * given as k*elem_bytes big-endian bytes into one element. */
+int vmn_group_mul_partials(vmn_group* grp, const uint8_t* partials_be, size_t k, uint8_t* out_be);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+/* Name, launch count and accumulated device time (ms, HIP events on the context stream) of the
+ * kernel families since the last reset; used by bench.py for the roofline line.  Timing is off
+ * by default (no events recorded). */
+int vmn_ctx_timing_enable(vmn_ctx* ctx, int on);
+int vmn_ctx_timing_reset(vmn_ctx* ctx);
+/* family: "modpow", "modmul", "fixed", "expprod", ...; returns launches and total ms. */
+int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMNHIP_H */

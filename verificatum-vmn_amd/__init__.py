@@ -1,0 +1,376 @@
+"""verificatum-vmn_amd — host-side mirror of the array interface the Verificatum Mix-Net calls.
+
+The reference (verificatum-vmn, Java) performs all arithmetic through VCR's array classes
+(``PGroupElementArray``, ``PRingElementArray`` …; SURVEY.md §2.3 / App. B list the call sites in
+``/root/reference``).  This package binds the C ABI of ``include/vmnhip.h`` (``libvmnhip.so``,
+hand-written HIP kernels for gfx950) with ``ctypes`` and exposes it under the reference's method
+names (``exp``, ``expProd``, ``mul``, ``prod``, ``permute``, ``shiftPush``, ``recLin``, ``prods``,
+``mulAdd``, ``innerProduct`` …) so that the proof drivers and the parity tests read like the
+reference's own code.
+
+There is no CPU implementation behind these classes: without the HIP library and a gfx950 GPU
+every constructor raises ``VmnError``.
+
+The directory name contains a hyphen (it is fixed by the build contract); import it with
+``load_package()`` from ``__graft_entry__`` or ``importlib`` under the name
+``verificatum_vmn_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmnhip.so")
+
+
+class VmnError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (misuse, device errors)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"vmnhip status {status}: {message}")
+        self.status = status
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load ``libvmnhip.so`` (built in-tree by ``__graft_entry__.build()``).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VmnError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.vmn_last_error.restype = C.c_char_p
+        _lib.vmn_version.restype = C.c_char_p
+        _lib.vmn_ctx_get_stream.restype = C.c_void_p
+        for name in ("vmn_group_elem_bytes", "vmn_group_exp_bytes", "vmn_garray_size", "vmn_rarray_size"):
+            getattr(_lib, name).restype = C.c_size_t
+    return _lib
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        raise VmnError(status, lib().vmn_last_error().decode("utf-8", "replace"))
+
+
+def int_to_be(x: int, nbytes: int) -> bytes:
+    return int(x).to_bytes(nbytes, "big")
+
+
+def ints_to_be(xs: Sequence[int], nbytes: int) -> bytes:
+    return b"".join(int(x).to_bytes(nbytes, "big") for x in xs)
+
+
+def be_to_ints(buf: bytes, nbytes: int) -> list:
+    return [int.from_bytes(buf[i:i + nbytes], "big") for i in range(0, len(buf), nbytes)]
+
+
+class Context:
+    """One GPU, one HIP stream, scratch workspace (``vmn_ctx``)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().vmn_ctx_create(C.c_int(device), C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().vmn_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        """Run on an externally owned ``hipStream_t`` (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        _check(lib().vmn_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    @property
+    def stream(self) -> int:
+        return lib().vmn_ctx_get_stream(self._h) or 0
+
+    def synchronize(self) -> None:
+        _check(lib().vmn_ctx_synchronize(self._h))
+
+    @property
+    def num_cus(self) -> int:
+        return lib().vmn_ctx_num_cus(self._h)
+
+    def timing_enable(self, on: bool = True) -> None:
+        _check(lib().vmn_ctx_timing_enable(self._h, C.c_int(1 if on else 0)))
+
+    def timing_reset(self) -> None:
+        _check(lib().vmn_ctx_timing_reset(self._h))
+
+    def timing_get(self, family: str):
+        n = C.c_long()
+        ms = C.c_double()
+        _check(lib().vmn_ctx_timing_get(self._h, family.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class ModPGroup:
+    """``com.verificatum.arithm.ModPGroup``: the order-q subgroup of Z_p^* with generator g."""
+
+    def __init__(self, ctx: Context, p: int, q: int, g: int, nbytes: Optional[int] = None):
+        self.ctx = ctx
+        self.p, self.q, self.g = int(p), int(q), int(g)
+        self.nbytes = nbytes or (self.p.bit_length() + 7) // 8
+        self._h = C.c_void_p()
+        _check(lib().vmn_modp_group_create(ctx._h, int_to_be(p, self.nbytes), int_to_be(q, self.nbytes),
+                                           int_to_be(g, self.nbytes), C.c_size_t(self.nbytes), C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().vmn_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- constructors mirroring pGroup.toElementArray / pRing.toElementArray --------------------
+    def toElementArray(self, values, checked: bool = True) -> "PGroupElementArray":
+        """values: sequence of ints, or bytes of n*nbytes big-endian."""
+        buf = values if isinstance(values, (bytes, bytearray)) else ints_to_be(values, self.nbytes)
+        n = len(buf) // self.nbytes
+        h = C.c_void_p()
+        ok = C.c_int(1)
+        _check(lib().vmn_garray_from_be(self._h, bytes(buf), C.c_size_t(n), C.byref(h), C.byref(ok)))
+        arr = PGroupElementArray(self, h)
+        arr.all_in_range = bool(ok.value)
+        if checked and not ok.value:
+            arr.free()
+            raise ValueError("ArithmFormatException: group element out of range")
+        return arr
+
+    def ringArray(self, values, checked: bool = True) -> "PRingElementArray":
+        buf = values if isinstance(values, (bytes, bytearray)) else ints_to_be(values, self.nbytes)
+        n = len(buf) // self.nbytes
+        h = C.c_void_p()
+        ok = C.c_int(1)
+        _check(lib().vmn_rarray_from_be(self._h, bytes(buf), C.c_size_t(n), C.byref(h), C.byref(ok)))
+        arr = PRingElementArray(self, h)
+        if checked and not ok.value:
+            arr.free()
+            raise ValueError("ArithmFormatException: ring element out of range")
+        return arr
+
+    def exp(self, base: int, exponents: "PRingElementArray") -> "PGroupElementArray":
+        """``g.exp(PRingElementArray)``: fixed base, one exponent per element (K2)."""
+        h = C.c_void_p()
+        _check(lib().vmn_group_exp_fixed(self._h, int_to_be(base, self.nbytes), exponents._h, C.byref(h)))
+        return PGroupElementArray(self, h)
+
+    def mulPartials(self, partials: Sequence[int]) -> int:
+        out = C.create_string_buffer(self.nbytes)
+        _check(lib().vmn_group_mul_partials(self._h, ints_to_be(partials, self.nbytes), C.c_size_t(len(partials)), out))
+        return int.from_bytes(out.raw, "big")
+
+
+class _ArrayBase:
+    _free_fn = ""
+
+    def __init__(self, group: ModPGroup, handle: C.c_void_p):
+        self.group = group
+        self._h = handle
+
+    def free(self) -> None:
+        if self._h:
+            getattr(lib(), self._free_fn)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PGroupElementArray(_ArrayBase):
+    """Device-resident ``PGroupElementArray`` over a ``ModPGroup``."""
+
+    _free_fn = "vmn_garray_free"
+    all_in_range = True
+
+    def size(self) -> int:
+        return lib().vmn_garray_size(self._h)
+
+    def toBytes(self) -> bytes:
+        out = C.create_string_buffer(max(1, self.size() * self.group.nbytes))
+        _check(lib().vmn_garray_to_be(self._h, out))
+        return out.raw[: self.size() * self.group.nbytes]
+
+    def toInts(self) -> list:
+        return be_to_ints(self.toBytes(), self.group.nbytes)
+
+    def _new(self, h) -> "PGroupElementArray":
+        return PGroupElementArray(self.group, h)
+
+    # K1a / K1b
+    def exp(self, e, ebits: int = 0) -> "PGroupElementArray":
+        """``X.exp(PRingElementArray)`` (per-element exponents) or ``X.exp(int)`` (shared exponent)."""
+        h = C.c_void_p()
+        if isinstance(e, PRingElementArray):
+            _check(lib().vmn_garray_exp_array(self._h, e._h, C.c_int(ebits), C.byref(h)))
+        else:
+            e = int(e)
+            nb = max(1, (e.bit_length() + 7) // 8)
+            _check(lib().vmn_garray_exp_scalar(self._h, int_to_be(e, nb), C.c_size_t(nb), C.byref(h)))
+        return self._new(h)
+
+    def expInts(self, exps: Sequence[int], ebits: int) -> "PGroupElementArray":
+        """Exponents that are plain integers of ``ebits`` bits (not reduced mod q)."""
+        nb = (ebits + 7) // 8
+        h = C.c_void_p()
+        _check(lib().vmn_garray_exp_ints(self._h, ints_to_be(exps, nb), C.c_size_t(nb), C.c_int(ebits), C.byref(h)))
+        return self._new(h)
+
+    # K3
+    def expProd(self, e, ebits: int = 0) -> int:
+        out = C.create_string_buffer(self.group.nbytes)
+        if isinstance(e, PRingElementArray):
+            _check(lib().vmn_garray_expprod(self._h, e._h, C.c_int(ebits), out))
+        else:
+            nb = (ebits + 7) // 8
+            _check(lib().vmn_garray_expprod_ints(self._h, ints_to_be(e, nb), C.c_size_t(nb), C.c_int(ebits), out))
+        return int.from_bytes(out.raw, "big")
+
+    # K4 / K5 / K6
+    def mul(self, other: "PGroupElementArray") -> "PGroupElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_garray_mul(self._h, other._h, C.byref(h)))
+        return self._new(h)
+
+    def prod(self) -> int:
+        out = C.create_string_buffer(self.group.nbytes)
+        _check(lib().vmn_garray_prod(self._h, out))
+        return int.from_bytes(out.raw, "big")
+
+    def equals(self, other: "PGroupElementArray") -> bool:
+        eq = C.c_int()
+        _check(lib().vmn_garray_equals(self._h, other._h, C.byref(eq)))
+        return bool(eq.value)
+
+    # K7
+    def permute(self, perm: Sequence[int]) -> "PGroupElementArray":
+        arr = (C.c_uint32 * len(perm))(*perm)
+        h = C.c_void_p()
+        _check(lib().vmn_garray_permute(self._h, arr, C.byref(h)))
+        return self._new(h)
+
+    def shiftPush(self, el: int) -> "PGroupElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_garray_shift_push(self._h, int_to_be(el, self.group.nbytes), C.byref(h)))
+        return self._new(h)
+
+    def copyOfRange(self, start: int, end: int) -> "PGroupElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_garray_copy_range(self._h, C.c_size_t(start), C.c_size_t(end), C.byref(h)))
+        return self._new(h)
+
+    def extract(self, keep: Sequence[bool]) -> "PGroupElementArray":
+        buf = bytes(1 if k else 0 for k in keep)
+        h = C.c_void_p()
+        _check(lib().vmn_garray_extract(self._h, buf, C.byref(h)))
+        return self._new(h)
+
+    def get(self, i: int) -> int:
+        out = C.create_string_buffer(self.group.nbytes)
+        _check(lib().vmn_garray_get(self._h, C.c_size_t(i), out))
+        return int.from_bytes(out.raw, "big")
+
+    def isMember(self) -> bool:
+        ok = C.c_int()
+        _check(lib().vmn_garray_is_member(self._h, C.byref(ok)))
+        return bool(ok.value)
+
+
+class PRingElementArray(_ArrayBase):
+    """Device-resident ``PRingElementArray`` / ``PFieldElementArray`` over Z_q."""
+
+    _free_fn = "vmn_rarray_free"
+
+    def size(self) -> int:
+        return lib().vmn_rarray_size(self._h)
+
+    def toBytes(self) -> bytes:
+        out = C.create_string_buffer(max(1, self.size() * self.group.nbytes))
+        _check(lib().vmn_rarray_to_be(self._h, out))
+        return out.raw[: self.size() * self.group.nbytes]
+
+    def toInts(self) -> list:
+        return be_to_ints(self.toBytes(), self.group.nbytes)
+
+    def _new(self, h) -> "PRingElementArray":
+        return PRingElementArray(self.group, h)
+
+    def _binary(self, fn: str, other: "PRingElementArray") -> "PRingElementArray":
+        h = C.c_void_p()
+        _check(getattr(lib(), fn)(self._h, other._h, C.byref(h)))
+        return self._new(h)
+
+    def mul(self, other):
+        return self._binary("vmn_rarray_mul", other)
+
+    def add(self, other):
+        return self._binary("vmn_rarray_add", other)
+
+    def neg(self):
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_neg(self._h, C.byref(h)))
+        return self._new(h)
+
+    def mulAdd(self, v: int, other: "PRingElementArray") -> "PRingElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_mul_add(self._h, int_to_be(v, self.group.nbytes), other._h, C.byref(h)))
+        return self._new(h)
+
+    def recLin(self, e: "PRingElementArray"):
+        """``b.recLin(e)`` -> (x, d): x0 = b0, xi = x(i-1)*ei + bi, d = x(N-1)."""
+        h = C.c_void_p()
+        last = C.create_string_buffer(self.group.nbytes)
+        _check(lib().vmn_rarray_rec_lin(self._h, e._h, C.byref(h), last))
+        return self._new(h), int.from_bytes(last.raw, "big")
+
+    def prods(self) -> "PRingElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_prods(self._h, C.byref(h)))
+        return self._new(h)
+
+    def _scalar(self, fn: str, *others) -> int:
+        out = C.create_string_buffer(self.group.nbytes)
+        _check(getattr(lib(), fn)(self._h, *[o._h for o in others], out))
+        return int.from_bytes(out.raw, "big")
+
+    def innerProduct(self, other) -> int:
+        return self._scalar("vmn_rarray_inner_product", other)
+
+    def sum(self) -> int:
+        return self._scalar("vmn_rarray_sum")
+
+    def prod(self) -> int:
+        return self._scalar("vmn_rarray_prod")
+
+    def permute(self, perm: Sequence[int]) -> "PRingElementArray":
+        arr = (C.c_uint32 * len(perm))(*perm)
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_permute(self._h, arr, C.byref(h)))
+        return self._new(h)
+
+    def shiftPush(self, el: int) -> "PRingElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_shift_push(self._h, int_to_be(el, self.group.nbytes), C.byref(h)))
+        return self._new(h)
+
+    def equals(self, other) -> bool:
+        eq = C.c_int()
+        _check(lib().vmn_rarray_equals(self._h, other._h, C.byref(eq)))
+        return bool(eq.value)

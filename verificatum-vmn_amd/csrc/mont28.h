@@ -1,0 +1,101 @@
+// mont28.h — device-side big-number core for gfx950 (MI355X).
+//
+// Representation ("M28 form"): an element x of Z_N is stored as x*R mod N (Montgomery form,
+// R = 2^(28*S)), canonical (< N), in S limbs of 28 bits, one limb per 32-bit word.
+//
+// Why radix 2^28 and not 2^32: on gfx950 v_mad_u64_u32 issues at the same rate as a plain integer
+// add (measured, tools/valu_rate.hip -> profiles/valu_rate_r01.txt: ~4.3 cycles per wave64
+// instruction per SIMD for both), so the cost of a multiplication is its *instruction count*.
+// With 28-bit limbs every 56-bit partial product is accumulated into a 64-bit column with a
+// single v_mad_u64_u32 and no carry fix-up: a column receives at most 2*S products (< 2^56 each,
+// 2*S < 256), so it cannot overflow.  Carries are resolved once per multiplication.
+//
+// One element per lane: `a` lives in VGPRs (static indices), the columns T live in VGPR pairs,
+// the multiplier b is streamed limb by limb from LDS (dynamic index), the modulus limbs are
+// wave-uniform (SGPRs through scalar loads).  No MFMA: this is integer big-number arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vmn {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr u32 LIMB_BITS = 28;
+constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1;
+
+// Number of 28-bit limbs needed for an n-bit modulus plus the slack Montgomery needs so that
+// inputs < 2N give outputs < 2N without a conditional subtraction (R > 4N).
+__host__ __device__ constexpr int limbs_for_bits(int nbits) { return (nbits + 2 + 27) / 28; }
+// Device stride (in 32-bit words) of one element: limbs rounded up to a multiple of 4 (16 B).
+__host__ __device__ constexpr int stride_for_limbs(int s) { return (s + 3) & ~3; }
+
+// Wave-uniform description of a modulus, read through scalar loads.
+struct ModulusDev {
+    const u32* n;      // S limbs of N (radix 2^28)
+    u32 n0inv;         // -N^{-1} mod 2^28
+};
+
+// One "row" of the coarsely integrated operand scanning (CIOS) Montgomery multiplication on the
+// lazy columns P[0..S-1]:
+//     pass 1:  P[j]   = a[j] * bi + P[j]            (top column starts fresh)
+//     m        = P[0] * n0inv mod 2^28
+//     pass 2:  P[j-1] = m * N[j] + P[j]             (destination shifted by one column)
+// After pass 2 column 0 would be = 0 mod 2^28; its upper part is the carry into the new column 0.
+// v_mad_u64_u32 has a destination separate from its addend, so the one-column shift of the
+// running sum costs no instruction at all: a row is exactly 2*S multiply-adds + 5 VALU.
+// The rows are emitted as asm statements by tools/gen_mont_asm.py (gen/mont_rows.inc): hipcc's
+// own allocation of the plain C++ form doubles the live ranges and spills to scratch.
+template <int S> __device__ __forceinline__ void mont_row_asm_first(u64 (&P)[S], const u32 (&a)[S], u32 b, const u32 (&n)[S], u32 n0inv);
+template <int S> __device__ __forceinline__ void mont_row_asm_next(u64 (&P)[S], const u32 (&a)[S], u32 b, const u32 (&n)[S], u32 n0inv);
+#include "gen/mont_rows.inc"
+
+// T (S lazy columns, value < 2N when a, b < 2N and R > 4N) = a * b / R mod N.
+// b is read as b_lds[i * bstride] (one 28-bit limb per row), n[] are the wave-uniform modulus
+// limbs (SGPRs).  Column S-1 is not produced (it is zero: the value lives in columns 0..S-2 plus
+// their carries).
+template <int S>
+__device__ __forceinline__ void mont_mul_columns(u64 (&T)[S], const u32 (&a)[S], const u32* b_lds, int bstride,
+                                                 const u32 (&n)[S], u32 n0inv) {
+    u32 bi = b_lds[0];
+    u32 bn = b_lds[bstride];
+    mont_row_asm_first<S>(T, a, bi, n, n0inv);
+#pragma unroll 1
+    for (int i = 2; i <= S; ++i) {
+        bi = bn;
+        bn = b_lds[(i < S ? i : 0) * bstride];          // prefetch the next limb under this row
+        mont_row_asm_next<S>(T, a, bi, n, n0inv);
+    }
+    T[S - 1] = 0;
+}
+
+// Resolve the lazy columns into 28-bit limbs (value unchanged, < 2N < 2^(28*S)).
+template <int S>
+__device__ __forceinline__ void normalize_columns(u32 (&out)[S], const u64 (&T)[S]) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        c += T[j];
+        out[j] = (u32)c & LIMB_MASK;
+        c >>= LIMB_BITS;
+    }
+}
+
+// x (limbs, value < 2N) -> canonical x mod N (< N), branch-free.
+template <int S>
+__device__ __forceinline__ void canonicalize(u32 (&x)[S], const u32* __restrict__ nmod) {
+    u32 d[S];
+    int32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        int32_t v = (int32_t)x[j] - (int32_t)nmod[j] + borrow;   // limbs < 2^28: no int32 overflow
+        d[j] = (u32)v & LIMB_MASK;
+        borrow = v >> LIMB_BITS;                                  // 0 or -1
+    }
+    bool ge = (borrow == 0);                                      // x >= N
+#pragma unroll
+    for (int j = 0; j < S; ++j) x[j] = ge ? d[j] : x[j];
+}
+
+}  // namespace vmn

@@ -1,0 +1,95 @@
+// vmnhip_internal.h — host-side objects behind the opaque handles of include/vmnhip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/vmnhip.h"
+#include "hostbig.h"
+
+namespace vmn {
+
+void set_error(const char* fmt, ...);
+
+#define VMN_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t err__ = (call);                                                            \
+        if (err__ != hipSuccess) {                                                            \
+            vmn::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+            return err__ == hipErrorOutOfMemory ? VMN_ERR_NOMEM : VMN_ERR_DEVICE;             \
+        }                                                                                     \
+    } while (0)
+
+#define VMN_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != VMN_OK) return rc__; \
+    } while (0)
+
+struct TimingRec {
+    std::string family;
+    hipEvent_t start, stop;
+};
+
+}  // namespace vmn
+
+struct vmn_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    // grow-only scratch (window tables, temporaries)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint32_t* flags = nullptr;            // small device word array for verdicts / range flags
+    std::unordered_set<const void*> lds_attr_set;
+    bool timing = false;
+    std::vector<vmn::TimingRec> recs;
+    std::map<std::string, std::pair<long, double>> timing_acc;
+};
+
+// Device-resident constants of one odd modulus in M28 form.
+struct vmn_modulus {
+    int S = 0;                 // 28-bit limbs
+    int NW = 0;                // 32-bit words of the packed form
+    int nbits = 0;
+    uint32_t n0inv = 0;        // -N^{-1} mod 2^28
+    uint32_t* d_n = nullptr;   // S limbs of N
+    uint32_t* d_rr = nullptr;  // R^2 mod N (limbs), R = 2^(28 S)
+    uint32_t* d_one = nullptr; // R mod N (limbs)  == Montgomery form of 1
+    vmn::hostbig::Big n_words; // NW words
+    vmn::hostbig::Mont* hm = nullptr;     // host Montgomery context (32-bit words, R = 2^(32 NW))
+};
+
+struct vmn_group {
+    vmn_ctx* ctx = nullptr;
+    size_t nbytes = 0;         // wire width of elements and exponents
+    vmn_modulus P;             // arithmetic mod p (group elements)
+    vmn_modulus Q;             // arithmetic mod q (exponents)
+    vmn::hostbig::Big g_words;
+    // fixed-base tables, keyed by the base's big-endian bytes
+    struct FixedTable {
+        uint32_t* d_tab = nullptr;
+        int wbits = 0;
+        int nwin = 0;
+        size_t bytes = 0;
+    };
+    std::map<std::string, FixedTable> fixed;
+};
+
+struct vmn_garray {
+    vmn_group* grp = nullptr;
+    uint32_t* d = nullptr;     // n * W words, M28 form mod p
+    size_t n = 0;
+};
+
+struct vmn_rarray {
+    vmn_group* grp = nullptr;
+    uint32_t* d = nullptr;     // n * W words, M28 form mod q
+    size_t n = 0;
+};
