@@ -1,0 +1,171 @@
+"""GPU suite: the HIP path, called through the C ABI, against the golden vectors, the GMP oracle on
+seeded inputs, and size-independent properties at larger sizes."""
+import pytest
+
+from conftest import ints, load_golden
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def groups(vmn, gpu_ctx):
+    out = {}
+    for bits in (512, 1024, 2048):
+        grp, cases = load_golden(bits)
+        out[bits] = (vmn.ModPGroup(gpu_ctx, grp["p"], grp["q"], grp["g"]), grp, cases)
+    return out
+
+
+@pytest.mark.parametrize("bits", [512, 1024, 2048])
+def test_golden_vectors_through_c_abi(bits, groups):
+    G, grp, cases = groups[bits]
+    for c in cases:
+        op = c["op"]
+        if op == "exp_array":
+            assert G.toElementArray(ints(c["x"])).exp(G.ringArray(ints(c["e"]))).toInts() == ints(c["out"]), (op, c["n"])
+        elif op == "exp_ints":
+            assert G.toElementArray(ints(c["x"])).expInts(ints(c["e"]), c["ebits"]).toInts() == ints(c["out"]), (op, c["n"])
+        elif op == "exp_scalar":
+            assert G.toElementArray(ints(c["x"])).exp(int(c["e"], 16)).toInts() == ints(c["out"]), (op, c["n"])
+        elif op == "exp_fixed":
+            assert G.exp(int(c["base"], 16), G.ringArray(ints(c["e"]))).toInts() == ints(c["out"]), (op, c["n"])
+        elif op == "exp_prod":
+            assert G.toElementArray(ints(c["x"])).expProd(ints(c["e"]), c["ebits"]) == int(c["out"], 16), (op, c["n"])
+        elif op == "exp_prod_ring":
+            assert G.toElementArray(ints(c["x"])).expProd(G.ringArray(ints(c["e"]))) == int(c["out"], 16), (op, c["n"])
+        elif op == "mul":
+            assert G.toElementArray(ints(c["x"])).mul(G.toElementArray(ints(c["y"]))).toInts() == ints(c["out"])
+        elif op == "prod":
+            assert G.toElementArray(ints(c["x"])).prod() == int(c["out"], 16), (op, c["n"])
+        elif op == "permute":
+            assert G.toElementArray(ints(c["x"])).permute(c["perm"]).toInts() == ints(c["out"])
+        elif op == "shift_push":
+            assert G.toElementArray(ints(c["x"])).shiftPush(int(c["el"], 16)).toInts() == ints(c["out"])
+        elif op == "rec_lin":
+            x, d = G.ringArray(ints(c["b"])).recLin(G.ringArray(ints(c["e"])))
+            assert x.toInts() == ints(c["out"]) and d == int(c["last"], 16), (op, c["n"])
+        elif op == "prods":
+            assert G.ringArray(ints(c["e"])).prods().toInts() == ints(c["out"]), (op, c["n"])
+        elif op == "mul_add":
+            got = G.ringArray(ints(c["x"])).mulAdd(int(c["v"], 16), G.ringArray(ints(c["y"]))).toInts()
+            assert got == ints(c["out"])
+        elif op == "ring_mul":
+            assert G.ringArray(ints(c["x"])).mul(G.ringArray(ints(c["y"]))).toInts() == ints(c["out"])
+        elif op == "ring_add":
+            assert G.ringArray(ints(c["x"])).add(G.ringArray(ints(c["y"]))).toInts() == ints(c["out"])
+        elif op == "inner_product":
+            assert G.ringArray(ints(c["x"])).innerProduct(G.ringArray(ints(c["y"]))) == int(c["out"], 16)
+        elif op == "ring_sum":
+            assert G.ringArray(ints(c["x"])).sum() == int(c["out"], 16)
+        elif op == "ring_prod":
+            assert G.ringArray(ints(c["x"])).prod() == int(c["out"], 16)
+
+
+def _inputs(tag, n, p, q):
+    xs = [pow(1 + v % (p - 1), 2, p) for v in pyref.stream_ints(tag + b"/x", n, p)]
+    es = pyref.stream_ints(tag + b"/e", n, q)
+    return xs, es
+
+
+@pytest.mark.parametrize("n", [257, 5000])
+def test_seeded_arrays_against_gmp_oracle_2048(n, groups, oracle_for):
+    """Ragged sizes (not multiples of the 256-lane tile) against the GMP oracle, element for element."""
+    G, grp, _ = groups[2048]
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    orc = oracle_for(p, q)
+    xs, es = _inputs(b"seeded%d" % n, n, p, q)
+    fs = pyref.stream_ints(b"seeded/f", n, q)
+    X, E, F = G.toElementArray(xs), G.ringArray(es), G.ringArray(fs)
+    assert X.exp(E).toInts() == orc.exp_array(xs, es)
+    assert G.exp(g, E).toInts() == orc.exp_fixed(g, es)
+    ys = orc.exp_fixed(g, fs)
+    assert X.mul(G.toElementArray(ys)).toInts() == orc.mul(xs, ys)
+    assert X.prod() == orc.prod(xs)
+    e256 = [v % (1 << 256) for v in es]
+    assert X.expProd(e256, 256) == orc.exp_prod(xs, e256, 256, pippenger_c=8)
+    assert X.expProd(E) == orc.exp_prod(xs, es, pippenger_c=8)
+    x, d = E.recLin(F)
+    want = orc.rec_lin(es, fs)
+    assert x.toInts() == want and d == want[-1]
+    assert F.prods().toInts() == orc.prods(fs)
+    assert E.innerProduct(F) == orc.ring_reduce(es, fs, 0)
+    assert E.sum() == orc.ring_reduce(es, None, 1)
+
+
+def test_empty_and_single(groups):
+    G, grp, _ = groups[512]
+    p, q = grp["p"], grp["q"]
+    X0, E0 = G.toElementArray([]), G.ringArray([])
+    assert X0.size() == 0 and X0.toInts() == []
+    assert X0.exp(E0).toInts() == []
+    assert X0.prod() == 1
+    assert X0.expProd(E0) == 1
+    assert E0.sum() == 0 and E0.prod() == 1
+    X1 = G.toElementArray([4])
+    assert X1.exp(G.ringArray([q - 1])).toInts() == [pow(4, q - 1, p)]
+    assert X1.exp(0).toInts() == [1]
+    assert X1.prod() == 4
+
+
+def test_out_of_range_import_is_reported_not_fatal(groups, vmn):
+    G, grp, _ = groups[512]
+    p = grp["p"]
+    arr = G.toElementArray([5, p, 7], checked=False)
+    assert arr.all_in_range is False
+    assert arr.toInts() == [5, 1, 7]          # offending entry replaced by the trivial value
+    with pytest.raises(ValueError):
+        G.toElementArray([p + 1])
+
+
+def test_equals_extract_range_get_membership(groups):
+    G, grp, _ = groups[512]
+    p, q = grp["p"], grp["q"]
+    xs = [pow(3 + i, 2, p) for i in range(300)]
+    X = G.toElementArray(xs)
+    assert X.equals(G.toElementArray(xs))
+    ys = list(xs)
+    ys[299] = pow(2, 2, p)
+    assert not X.equals(G.toElementArray(ys))
+    keep = [i % 3 == 0 for i in range(300)]
+    assert X.extract(keep).toInts() == [x for x, k in zip(xs, keep) if k]
+    assert X.copyOfRange(10, 20).toInts() == xs[10:20]
+    assert X.get(123) == xs[123]
+    assert X.isMember()
+    assert not G.toElementArray([pow(3, 2, p), p - 1]).isMember()     # p-1 has order 2
+
+
+def test_wire_width_with_sign_byte(vmn, gpu_ctx):
+    """VCR writes fixed-width two's-complement integers: 65 bytes for a 512-bit modulus
+    (1937 bytes for a 15492-bit p).  Import/export must honour any width."""
+    grp, _ = load_golden(512)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=65)
+    xs = [pow(7 + i, 2, p) for i in range(70)]
+    X = G.toElementArray(xs)
+    raw = X.toBytes()
+    assert len(raw) == 70 * 65 and all(raw[i * 65] == 0 for i in range(70))
+    assert X.toInts() == xs
+    assert X.exp(G.ringArray([q - 2] * 70)).toInts() == [pow(x, q - 2, p) for x in xs]
+
+
+def test_properties_at_scale_2048(groups):
+    """Size-independent properties at a size the CPU oracle would need minutes for:
+    (x^e)^f = (x^f)^e ; x^e * x^f = x^(e+f) ; expProd = prod of exps ; g^e via fixed base = var base."""
+    G, grp, _ = groups[2048]
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    n = 40000
+    xs, es = _inputs(b"scale", n, p, q)
+    fs = pyref.stream_ints(b"scale/f", n, q)
+    X, E, F = G.toElementArray(xs), G.ringArray(es), G.ringArray(fs)
+    XE = X.exp(E)
+    XF = X.exp(F)
+    assert XE.exp(F).equals(XF.exp(E))
+    assert XE.mul(XF).equals(X.exp(E.add(F)))
+    assert X.expProd(E) == XE.prod()
+    Gs = G.toElementArray([g] * n)
+    assert G.exp(g, E).equals(Gs.exp(E))
+    # spot-check a few entries against Python
+    got = XE.toInts()
+    for i in (0, 1, n // 2, n - 1):
+        assert got[i] == pow(xs[i], es[i], p)

@@ -341,3 +341,416 @@ k_modpow(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict
 }
 
 }  // namespace vmn
+
+// =============================================================================================
+// second part: fixed-base tables (K2), multi-exponentiation (K3), reductions (K5), comparison
+// (K6), data movement (K7) and the ring kernels over Z_q (K8).
+// =============================================================================================
+namespace vmn {
+
+// ---------------------------------------------------------------------------------------------
+// K6: flags[0] |= 1 if x != y anywhere.  One thread per 16-byte chunk (HBM-bound, coalesced).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_compare(const uint4* __restrict__ x, const uint4* __restrict__ y,
+                                                   size_t nchunks, u32* __restrict__ flags) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool diff = false;
+    for (; i < nchunks; i += (size_t)gridDim.x * BLOCK) {
+        uint4 a = x[i], b = y[i];
+        diff |= (a.x != b.x) | (a.y != b.y) | (a.z != b.z) | (a.w != b.w);
+    }
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: out[i] = in[idx[i]]  (idx[i] == 0xffffffff: out[i] = fill).  One thread per 16-byte chunk of
+// a row: rows are contiguous W-word records, so a gather moves whole aligned rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_gather(uint4* __restrict__ out, const uint4* __restrict__ in,
+                                                  const u32* __restrict__ idx, const uint4* __restrict__ fill,
+                                                  size_t n_out, int chunks_per_row) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t total = n_out * (size_t)chunks_per_row;
+    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
+        size_t row = t / chunks_per_row;
+        int c = (int)(t % chunks_per_row);
+        u32 src = idx[row];
+        out[t] = src == 0xffffffffu ? fill[c] : in[(size_t)src * chunks_per_row + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 and friends: strided reduction.  out[seg][j] = OP_k x[seg][j + k*L], k = 0 .. ceil(len/L)-1,
+// for j < L.  OP = Montgomery product (MUL = true) or modular sum.  nseg segments of `len`
+// elements each; the output has nseg segments of L elements.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void mod_add(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const u32* __restrict__ nmod) {
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        u32 v = a[j] + b[j] + c;
+        r[j] = v & LIMB_MASK;
+        c = v >> LIMB_BITS;
+    }
+    canonicalize<S>(r, nmod);      // a, b < N  =>  a + b < 2N
+}
+
+template <int S, bool MUL>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_reduce_strided(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t L, size_t nseg,
+                 const u32* __restrict__ nmod, u32 n0inv) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    u32 nn[S];
+    load_modulus<S>(nn, nmod);
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = t < nseg * L;
+    size_t tc = live ? t : nseg * L - 1;
+    size_t seg = tc / L, j = tc % L;
+    const u32* base = x + seg * len * W;
+    u32 acc[S];
+    load_elem<S>(acc, base + j * W);
+    size_t cnt = (len - j + L - 1) / L;            // elements j, j+L, ... < len
+    // every lane of the workgroup runs the same number of rounds (the LDS column is private, so no
+    // barrier is involved; lanes with fewer terms multiply by nothing = skip)
+    for (size_t k = 1; k < cnt; ++k) {
+        const u32* src = base + (j + k * L) * W;
+        if constexpr (MUL) {
+            load_elem_to_lds<S>(bl, src);
+            mont_mul<S>(acc, acc, bl, nn, n0inv);
+        } else {
+            u32 b[S];
+            load_elem<S>(b, src);
+            mod_add<S>(acc, acc, b, nmod);
+        }
+    }
+    if constexpr (MUL) canonicalize<S>(acc, nmod);
+    if (live) store_elem<S>(out + t * W, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 element-wise ring kernels:  op 0: x + y   op 1: -x   op 2: x*v + y (v one element, stride 0)
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_ring_elementwise(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ y, const u32* __restrict__ v,
+                   int op, size_t n, const u32* __restrict__ nmod, u32 n0inv) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = el < n;
+    size_t ec = live ? el : n - 1;
+    u32 a[S], r[S];
+    load_elem<S>(a, x + ec * W);
+    if (op == 0) {
+        u32 b[S];
+        load_elem<S>(b, y + ec * W);
+        mod_add<S>(r, a, b, nmod);
+    } else if (op == 1) {
+        // N - a, and 0 stays 0
+        int32_t borrow = 0;
+        u32 nz = 0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            int32_t d = (int32_t)nmod[j] - (int32_t)a[j] + borrow;
+            r[j] = (u32)d & LIMB_MASK;
+            borrow = d >> LIMB_BITS;
+            nz |= a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) r[j] = nz ? r[j] : 0u;
+    } else {
+        u32 nn[S];
+        load_modulus<S>(nn, nmod);
+        load_elem_to_lds<S>(bl, v);
+        u32 t[S], b[S];
+        mont_mul<S>(t, a, bl, nn, n0inv);
+        canonicalize<S>(t, nmod);
+        load_elem<S>(b, y + ec * W);
+        mod_add<S>(r, t, b, nmod);
+    }
+    if (live) store_elem<S>(out + el * W, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 scans.  An affine recurrence x[i] = x[i-1]*e[i] + b[i] (recLin; b == nullptr: prods,
+// y[i] = y[i-1]*e[i]) over segments of `seglen` elements (seglen % C == 0 or one segment),
+// processed in chunks of C consecutive elements per lane:
+//   k_scan_totals : per chunk, the composed map (E = prod e, X = value reached from 0)
+//   (recursion on the totals gives every chunk's incoming value)
+//   k_scan_apply  : per chunk, replay the recurrence from the incoming value and store x[i]
+// `rev`: element i of a segment is read/written at position seglen-1-i (suffix scans of K3).
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_scan_totals(u32* __restrict__ Etot, u32* __restrict__ Xtot, const u32* __restrict__ e, const u32* __restrict__ b,
+              size_t n, size_t C, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
+              const u32* __restrict__ one_m) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    u32 nn[S];
+    load_modulus<S>(nn, nmod);
+    size_t nchunks = (n + C - 1) / C;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = c < nchunks;
+    size_t cc = live ? c : nchunks - 1;
+    size_t lo = cc * C, hi = lo + C < n ? lo + C : n;
+    u32 E[S], X[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        E[j] = one_m[j];
+        X[j] = 0;
+    }
+    for (size_t i = lo; i < lo + C; ++i) {          // uniform trip count; short chunks idle at the end
+        if (i < hi) {
+            size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
+            load_elem_to_lds<S>(bl, e + pos * W);
+            mont_mul<S>(E, E, bl, nn, n0inv);
+            if (b) {
+                u32 t[S], bb[S];
+                mont_mul<S>(t, X, bl, nn, n0inv);
+                canonicalize<S>(t, nmod);
+                load_elem<S>(bb, b + pos * W);
+                mod_add<S>(X, t, bb, nmod);
+            }
+        }
+    }
+    canonicalize<S>(E, nmod);
+    if (live) {
+        store_elem<S>(Etot + c * W, E);
+        if (b) store_elem<S>(Xtot + c * W, X);
+    }
+}
+
+// incoming: per-chunk inclusive results of the level above (chunk c starts from incoming[c-1]),
+// nullptr = every chunk starts fresh.  A chunk that begins a segment starts fresh (0 / one).
+template <int S>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_scan_apply(u32* __restrict__ out, const u32* __restrict__ e, const u32* __restrict__ b, const u32* __restrict__ incoming,
+             size_t n, size_t C, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
+             const u32* __restrict__ one_m) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    u32 nn[S];
+    load_modulus<S>(nn, nmod);
+    size_t nchunks = (n + C - 1) / C;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = c < nchunks;
+    size_t cc = live ? c : nchunks - 1;
+    size_t lo = cc * C, hi = lo + C < n ? lo + C : n;
+    bool fresh = incoming == nullptr || (lo % seglen) == 0;
+    u32 X[S];
+    if (fresh) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) X[j] = b ? 0u : one_m[j];
+    } else {
+        load_elem<S>(X, incoming + (cc - 1) * W);
+    }
+    for (size_t i = lo; i < lo + C; ++i) {
+        if (i < hi) {
+            size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
+            load_elem_to_lds<S>(bl, e + pos * W);
+            u32 t[S];
+            mont_mul<S>(t, X, bl, nn, n0inv);
+            canonicalize<S>(t, nmod);
+            if (b) {
+                u32 bb[S];
+                load_elem<S>(bb, b + pos * W);
+                mod_add<S>(X, t, bb, nmod);
+            } else {
+#pragma unroll
+                for (int j = 0; j < S; ++j) X[j] = t[j];
+            }
+            if (live) store_elem<S>(out + pos * W, X);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 fixed base.  Table T[k][d] = base^(d * 2^(w*k)), k < nwin, d < 2^w, rows of W words at
+// (k*2^w + d)*W.  The host supplies sq[j] = base^(2^j) (the sequential squaring chain); level l
+// fills d in (2^l, 2^(l+1)):  T[k][d] = T[k][d - 2^l] * T[k][2^l].
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_fixed_seed(u32* __restrict__ T, const u32* __restrict__ sq, int w, int nwin,
+                                                      const u32* __restrict__ one_m) {
+    constexpr int W = stride_for_limbs(S);
+    // one thread per (k, l) plus the d = 0 rows
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t total = (size_t)nwin * (w + 1);
+    if (t >= total) return;
+    int k = (int)(t / (w + 1)), l = (int)(t % (w + 1));
+    u32* dst;
+    const u32* src;
+    if (l == w) {                          // d = 0: the Montgomery one
+        dst = T + ((size_t)k << w) * W;
+        src = one_m;
+    } else {
+        dst = T + (((size_t)k << w) + ((size_t)1 << l)) * W;
+        src = sq + ((size_t)k * w + l) * W;
+    }
+    for (int j = 0; j < W; ++j) dst[j] = j < S ? src[j] : 0u;
+}
+
+template <int S>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_fixed_level(u32* __restrict__ T, int w, int nwin, int l, const u32* __restrict__ nmod, u32 n0inv) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    u32 nn[S];
+    load_modulus<S>(nn, nmod);
+    size_t per = ((size_t)1 << l) - 1;                 // d = 2^l + 1 .. 2^(l+1) - 1
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = t < per * nwin;
+    size_t tc = live ? t : per * nwin - 1;
+    size_t k = tc / per, r = tc % per + 1;             // r = d - 2^l in [1, 2^l)
+    u32* row = T + (k << w) * W;
+    u32 a[S];
+    load_elem<S>(a, row + r * W);
+    load_elem_to_lds<S>(bl, row + ((size_t)1 << l) * W);
+    u32 o[S];
+    mont_mul<S>(o, a, bl, nn, n0inv);
+    canonicalize<S>(o, nmod);
+    if (live) store_elem<S>(row + (((size_t)1 << l) + r) * W, o);
+}
+
+// out[i] = prod_k T[k][digit_k(e[i])]
+template <int S>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin, const u32* __restrict__ e, int ewords,
+            size_t n, const u32* __restrict__ nmod, u32 n0inv) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    u32 nn[S];
+    load_modulus<S>(nn, nmod);
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        size_t el = t * BLOCK + threadIdx.x;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        const u32* ep = e + ec * ewords;
+        u32 a[S];
+        u32 d = exp_digit(ep, ewords, 0, w);
+        load_elem<S>(a, T + (size_t)d * W);
+#pragma unroll 1
+        for (int k = 1; k < nwin; ++k) {
+            d = exp_digit(ep, ewords, k * w, w);
+            load_elem_to_lds<S>(bl, T + (((size_t)k << w) + d) * W);
+            mont_mul<S>(a, a, bl, nn, n0inv);
+        }
+        canonicalize<S>(a, nmod);
+        if (live) store_elem<S>(out + el * W, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 multi-exponentiation (Pippenger): counting sort of (window, digit) then one lane per bucket.
+// ---------------------------------------------------------------------------------------------
+// counts[win][d] += 1 for every element; one thread per (element, window).
+__global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts, const u32* __restrict__ e, int ewords,
+                                                       size_t n, int c, int nwin) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t total = n * (size_t)nwin;
+    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
+        size_t i = t % n;
+        int w = (int)(t / n);
+        u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
+        atomicAdd(&counts[((size_t)w << c) + d], 1u);
+    }
+}
+// exclusive prefix sum of each window's 2^c counts; one workgroup per window.  offsets has
+// 2^c + 1 entries per window; cursor is a copy of the first 2^c.
+__global__ void __launch_bounds__(BLOCK) k_bucket_offsets(u32* __restrict__ offsets, u32* __restrict__ cursor,
+                                                          const u32* __restrict__ counts, int c) {
+    __shared__ u32 part[BLOCK];
+    const size_t nb = (size_t)1 << c;
+    const u32* cnt = counts + ((size_t)blockIdx.x << c);
+    u32* off = offsets + (size_t)blockIdx.x * (nb + 1);
+    u32* cur = cursor + ((size_t)blockIdx.x << c);
+    size_t per = (nb + BLOCK - 1) / BLOCK;
+    size_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    u32 s = 0;
+    for (size_t i = lo; i < hi; ++i) s += cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int i = 0; i < BLOCK; ++i) {
+            u32 v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        off[nb] = run;
+    }
+    __syncthreads();
+    u32 run = part[threadIdx.x];
+    for (size_t i = lo; i < hi; ++i) {
+        off[i] = run;
+        cur[i] = run;
+        run += cnt[i];
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ cursor,
+                                                          const u32* __restrict__ e, int ewords, size_t n, int c, int nwin) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t total = n * (size_t)nwin;
+    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
+        size_t i = t % n;
+        int w = (int)(t / n);
+        u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
+        u32 pos = atomicAdd(&cursor[((size_t)w << c) + d], 1u);
+        sorted[(size_t)w * n + pos] = (u32)i;
+    }
+}
+// B[win][d] = prod of x[i] over the bucket (one if empty; d = 0 is forced to one).
+template <int S>
+__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+k_bucket_products(u32* __restrict__ B, const u32* __restrict__ x, const u32* __restrict__ sorted,
+                  const u32* __restrict__ offsets, size_t n, int c, int nwin, const u32* __restrict__ nmod, u32 n0inv,
+                  const u32* __restrict__ one_m) {
+    constexpr int W = stride_for_limbs(S);
+    extern __shared__ u32 lds[];
+    u32* bl = lds + threadIdx.x;
+    u32 nn[S];
+    load_modulus<S>(nn, nmod);
+    const size_t nb = (size_t)1 << c;
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = t < nb * nwin;
+    size_t tc = live ? t : nb * nwin - 1;
+    size_t w = tc >> c, d = tc & (nb - 1);
+    const u32* off = offsets + w * (nb + 1);
+    u32 lo = off[d], hi = d == 0 ? lo : off[d + 1];
+    const u32* idx = sorted + w * n;
+    u32 acc[S];
+    if (hi > lo) {
+        load_elem<S>(acc, x + (size_t)idx[lo] * W);
+    } else {
+#pragma unroll
+        for (int j = 0; j < S; ++j) acc[j] = one_m[j];
+    }
+    for (u32 k = lo + 1; k < hi; ++k) {
+        load_elem_to_lds<S>(bl, x + (size_t)idx[k] * W);
+        mont_mul<S>(acc, acc, bl, nn, n0inv);
+    }
+    canonicalize<S>(acc, nmod);
+    if (live) store_elem<S>(B + t * W, acc);
+}
+// overwrite element 0 of every segment with `one` (the d = 0 slot of the suffix products)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_set_segment_heads(u32* __restrict__ a, size_t seglen, size_t nseg,
+                                                             const u32* __restrict__ one_m) {
+    constexpr int W = stride_for_limbs(S);
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nseg) return;
+    u32* dst = a + t * seglen * W;
+    for (int j = 0; j < W; ++j) dst[j] = j < S ? one_m[j] : 0u;
+}
+
+}  // namespace vmn

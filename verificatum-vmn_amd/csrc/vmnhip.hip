@@ -621,3 +621,691 @@ extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, s
     *out = r;
     return VMN_OK;
 }
+
+// ================================================================================================
+// second part: K2 fixed base, K3 multi-exponentiation, K5 reductions, K6 compare, K7 movement,
+// K8 ring operations
+// ================================================================================================
+static unsigned light_grid(vmn_ctx* ctx, size_t work_items) {
+    size_t blocks = (work_items + BLOCK - 1) / BLOCK;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    return (unsigned)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+// plain (non-LDS) kernel launch with timing
+template <typename... KArgs, typename... Args>
+static int launch_light(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), unsigned grid, Args... args) {
+    TimingRec rec;
+    if (ctx->timing) {
+        rec.family = family;
+        VMN_HIP(hipEventCreate(&rec.start));
+        VMN_HIP(hipEventCreate(&rec.stop));
+        VMN_HIP(hipEventRecord(rec.start, ctx->stream));
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, static_cast<KArgs>(args)...);
+    VMN_HIP(hipGetLastError());
+    if (ctx->timing) {
+        VMN_HIP(hipEventRecord(rec.stop, ctx->stream));
+        ctx->recs.push_back(rec);
+    }
+    return VMN_OK;
+}
+
+static int read_flag(vmn_ctx* ctx, uint32_t* out) {
+    VMN_HIP(hipMemcpyAsync(out, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VMN_HIP(hipStreamSynchronize(ctx->stream));
+    return VMN_OK;
+}
+
+// ---- K6 ------------------------------------------------------------------------------------------
+static int compare_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, size_t n, int* equal) {
+    *equal = 1;
+    if (n == 0) return VMN_OK;
+    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    size_t nchunks = n * elem_words(m) / 4;
+    VMN_TRY(launch_light(ctx, "compare", k_compare, light_grid(ctx, nchunks), reinterpret_cast<const uint4*>(x),
+                         reinterpret_cast<const uint4*>(y), nchunks, ctx->flags));
+    uint32_t fl = 0;
+    VMN_TRY(read_flag(ctx, &fl));
+    *equal = fl ? 0 : 1;
+    return VMN_OK;
+}
+
+extern "C" int vmn_garray_equals(const vmn_garray* x, const vmn_garray* y, int* equal) {
+    ARG_CHECK(x && y && equal, "null argument");
+    ARG_CHECK(x->grp == y->grp, "arrays differ in group");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    if (x->n != y->n) {
+        *equal = 0;
+        return VMN_OK;
+    }
+    return compare_arrays(x->grp->ctx, x->grp->P, x->d, y->d, x->n, equal);
+}
+extern "C" int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal) {
+    ARG_CHECK(x && y && equal, "null argument");
+    ARG_CHECK(x->grp == y->grp, "arrays differ in group");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    if (x->n != y->n) {
+        *equal = 0;
+        return VMN_OK;
+    }
+    return compare_arrays(x->grp->ctx, x->grp->Q, x->d, y->d, x->n, equal);
+}
+
+// ---- K7 ------------------------------------------------------------------------------------------
+// out (n_out rows) = gather of in by host index list; 0xffffffff selects `fill` (device row)
+static int gather_rows(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* in, const std::vector<uint32_t>& idx,
+                       const uint32_t* d_fill, uint32_t* out) {
+    size_t n_out = idx.size();
+    if (n_out == 0) return VMN_OK;
+    DevTmp didx(ctx);
+    VMN_TRY(didx.alloc(n_out * sizeof(uint32_t)));
+    VMN_HIP(hipMemcpy(didx.p, idx.data(), n_out * sizeof(uint32_t), hipMemcpyHostToDevice));
+    int cpr = (int)(elem_words(m) / 4);
+    return launch_light(ctx, "gather", k_gather, light_grid(ctx, n_out * cpr), reinterpret_cast<uint4*>(out),
+                        reinterpret_cast<const uint4*>(in), didx.as<uint32_t>(), reinterpret_cast<const uint4*>(d_fill),
+                        n_out, cpr);
+}
+
+template <typename Arr>
+static int arr_gather(const Arr* x, const vmn_modulus& m, const std::vector<uint32_t>& idx, const uint32_t* d_fill,
+                      int (*mk)(vmn_group*, size_t, Arr**), void (*fr)(Arr*), Arr** out) {
+    Arr* r = nullptr;
+    VMN_TRY(mk(x->grp, idx.size(), &r));
+    int rc = gather_rows(x->grp->ctx, m, x->d, idx, d_fill, r->d);
+    if (rc != VMN_OK) {
+        fr(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
+extern "C" int vmn_garray_permute(const vmn_garray* x, const uint32_t* perm_host, vmn_garray** out) {
+    ARG_CHECK(x && out && (perm_host || x->n == 0), "null argument");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    std::vector<uint32_t> idx(perm_host, perm_host + x->n);
+    for (uint32_t v : idx) ARG_CHECK(v < x->n, "permutation index out of range");
+    return arr_gather<vmn_garray>(x, x->grp->P, idx, nullptr, new_garray, vmn_garray_free, out);
+}
+extern "C" int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out) {
+    ARG_CHECK(x && out && (perm_host || x->n == 0), "null argument");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    std::vector<uint32_t> idx(perm_host, perm_host + x->n);
+    for (uint32_t v : idx) ARG_CHECK(v < x->n, "permutation index out of range");
+    return arr_gather<vmn_rarray>(x, x->grp->Q, idx, nullptr, new_rarray, vmn_rarray_free, out);
+}
+extern "C" int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, vmn_garray** out) {
+    ARG_CHECK(x && el_be && out, "null argument");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    uint32_t* d_el = nullptr;
+    VMN_TRY(import_one(g->ctx, g->P, g->nbytes, el_be, &d_el));
+    std::vector<uint32_t> idx(x->n);
+    for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
+    int rc = arr_gather<vmn_garray>(x, g->P, idx, d_el, new_garray, vmn_garray_free, out);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(d_el);
+    return rc;
+}
+extern "C" int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out) {
+    ARG_CHECK(x && el_be && out, "null argument");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    uint32_t* d_el = nullptr;
+    VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, el_be, &d_el));
+    std::vector<uint32_t> idx(x->n);
+    for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
+    int rc = arr_gather<vmn_rarray>(x, g->Q, idx, d_el, new_rarray, vmn_rarray_free, out);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(d_el);
+    return rc;
+}
+extern "C" int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to, vmn_garray** out) {
+    ARG_CHECK(x && out, "null argument");
+    ARG_CHECK(from <= to && to <= x->n, "range out of bounds");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_garray* r = nullptr;
+    VMN_TRY(new_garray(g, to - from, &r));
+    if (to > from) {
+        hipError_t he = hipMemcpyAsync(r->d, x->d + from * elem_words(g->P), (to - from) * elem_words(g->P) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToDevice, g->ctx->stream);
+        if (he != hipSuccess) {
+            vmn_garray_free(r);
+            set_error("copy failed: %s", hipGetErrorString(he));
+            return VMN_ERR_DEVICE;
+        }
+    }
+    *out = r;
+    return VMN_OK;
+}
+extern "C" int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host, vmn_garray** out) {
+    ARG_CHECK(x && out && (keep_host || x->n == 0), "null argument");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    std::vector<uint32_t> idx;
+    for (size_t i = 0; i < x->n; ++i) {
+        if (keep_host[i]) idx.push_back((uint32_t)i);
+    }
+    return arr_gather<vmn_garray>(x, x->grp->P, idx, nullptr, new_garray, vmn_garray_free, out);
+}
+extern "C" int vmn_garray_get(const vmn_garray* x, size_t i, uint8_t* out_be) {
+    ARG_CHECK(x && out_be, "null argument");
+    ARG_CHECK(i < x->n, "index out of range");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    return export_be(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d + i * elem_words(x->grp->P), 1, out_be);
+}
+
+// ---- K5 / reductions -----------------------------------------------------------------------------
+// Reduce nseg segments of len elements each to nseg single elements (d_out: nseg rows).
+// mul = product, else sum.  Work buffers ping-pong inside one temporary.
+static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, size_t len, size_t nseg, bool mul,
+                           uint32_t* d_out) {
+    const size_t Wd = elem_words(m);
+    if (len == 0) {       // empty product = one, empty sum = zero
+        std::vector<uint32_t> row(Wd, 0);
+        if (mul) {
+            VMN_HIP(hipMemcpy(row.data(), m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        for (size_t s = 0; s < nseg; ++s) VMN_HIP(hipMemcpy(d_out + s * Wd, row.data(), Wd * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return VMN_OK;
+    }
+    const size_t max_lanes = (size_t)ctx->num_cus * blocks_per_cu(m.S) * BLOCK;
+    // first pass: as many lanes as the machine holds, then halve
+    size_t L = std::min(std::max<size_t>(max_lanes / std::max<size_t>(nseg, 1), 1), (len + 1) / 2);
+    if (len == 1) L = 1;
+    DevTmp buf(ctx);
+    size_t cap = nseg * std::max<size_t>(L, 1);
+    VMN_TRY(buf.alloc(2 * cap * Wd * sizeof(uint32_t)));
+    uint32_t* ping = buf.as<uint32_t>();
+    uint32_t* pong = ping + cap * Wd;
+    const uint32_t* src = x;
+    size_t cur = len;
+    while (true) {
+        uint32_t* dst = (L == 1) ? d_out : ping;
+        int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                      \
+    if (m.S == S_) {                                                                                                    \
+        rc = mul ? launch(ctx, "reduce", k_reduce_strided<S_, true>, grid_for(nseg * L), lds_bytes(S_), dst, src, cur, L, \
+                          nseg, m.d_n, m.n0inv)                                                                         \
+                 : launch(ctx, "reduce", k_reduce_strided<S_, false>, grid_for(nseg * L), lds_bytes(S_), dst, src, cur, \
+                          L, nseg, m.d_n, m.n0inv);                                                                     \
+    }
+        VMN_FOR_SIZES(X)
+#undef X
+        VMN_TRY(rc);
+        if (L == 1) break;
+        src = dst;
+        cur = L;
+        L = (cur + 1) / 2;
+        std::swap(ping, pong);
+    }
+    return VMN_OK;
+}
+
+static int reduce_to_host(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* x, size_t n, bool mul,
+                          uint8_t* out_be) {
+    DevTmp one(ctx);
+    VMN_TRY(one.alloc(elem_words(m) * sizeof(uint32_t)));
+    VMN_TRY(reduce_segments(ctx, m, x, n, 1, mul, one.as<uint32_t>()));
+    return export_be(ctx, m, nbytes, one.as<uint32_t>(), 1, out_be);
+}
+
+extern "C" int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be) {
+    ARG_CHECK(x && out_be, "null argument");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    return reduce_to_host(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d, x->n, true, out_be);
+}
+extern "C" int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be) {
+    ARG_CHECK(x && out_be, "null argument");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d, x->n, true, out_be);
+}
+extern "C" int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be) {
+    ARG_CHECK(x && out_be, "null argument");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d, x->n, false, out_be);
+}
+extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* out_be) {
+    ARG_CHECK(x && y && out_be, "null argument");
+    ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    DevTmp prod(g->ctx);
+    VMN_TRY(prod.alloc(std::max<size_t>(x->n, 1) * elem_words(g->Q) * sizeof(uint32_t)));
+    VMN_TRY(mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, prod.as<uint32_t>()));
+    return reduce_to_host(g->ctx, g->Q, g->nbytes, prod.as<uint32_t>(), x->n, false, out_be);
+}
+
+// ---- K8 element-wise -------------------------------------------------------------------------------
+static int ring_elementwise(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, const uint32_t* v,
+                            int op, size_t n, uint32_t* out) {
+    if (n == 0) return VMN_OK;
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_) \
+    if (m.S == S_) rc = launch(ctx, "ring", k_ring_elementwise<S_>, grid_for(n), lds_bytes(S_), out, x, y, v, op, n, m.d_n, m.n0inv);
+    VMN_FOR_SIZES(X)
+#undef X
+    return rc;
+}
+
+extern "C" int vmn_rarray_mul(const vmn_rarray* x, const vmn_rarray* y, vmn_rarray** out) {
+    ARG_CHECK(x && y && out, "null argument");
+    ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_rarray* r = nullptr;
+    VMN_TRY(new_rarray(g, x->n, &r));
+    int rc = mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, r->d);
+    if (rc != VMN_OK) {
+        vmn_rarray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+extern "C" int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarray** out) {
+    ARG_CHECK(x && y && out, "null argument");
+    ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_rarray* r = nullptr;
+    VMN_TRY(new_rarray(g, x->n, &r));
+    int rc = ring_elementwise(g->ctx, g->Q, x->d, y->d, nullptr, 0, x->n, r->d);
+    if (rc != VMN_OK) {
+        vmn_rarray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+extern "C" int vmn_rarray_neg(const vmn_rarray* x, vmn_rarray** out) {
+    ARG_CHECK(x && out, "null argument");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_rarray* r = nullptr;
+    VMN_TRY(new_rarray(g, x->n, &r));
+    int rc = ring_elementwise(g->ctx, g->Q, x->d, nullptr, nullptr, 1, x->n, r->d);
+    if (rc != VMN_OK) {
+        vmn_rarray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, const vmn_rarray* y, vmn_rarray** out) {
+    ARG_CHECK(x && y && v_be && out, "null argument");
+    ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    uint32_t* d_v = nullptr;
+    VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, v_be, &d_v));
+    vmn_rarray* r = nullptr;
+    int rc = new_rarray(g, x->n, &r);
+    if (rc == VMN_OK) rc = ring_elementwise(g->ctx, g->Q, x->d, y->d, d_v, 2, x->n, r->d);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(d_v);
+    if (rc != VMN_OK) {
+        if (r) vmn_rarray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
+// ---- K8 scans --------------------------------------------------------------------------------------
+// out[i] = out[i-1]*e[i] + b[i]  (b == nullptr: out[i] = out[i-1]*e[i], starting from one), per segment.
+// Chunked three-phase scan; the totals of one level are the inputs of the next (same recurrence).
+static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, const uint32_t* b, size_t n, size_t seglen,
+                       int rev, uint32_t* out) {
+    if (n == 0) return VMN_OK;
+    const size_t Wd = elem_words(m);
+    if (seglen == 0 || seglen > n) seglen = n;
+    // chunk length: divides seglen when there are several segments
+    size_t C = 16;
+    if (seglen != n) {
+        while (C > 1 && seglen % C) C >>= 1;
+    }
+    if (seglen <= C) {
+        // every segment fits one chunk: a single apply pass with fresh starts
+        size_t Cs = seglen;
+        int rc = VMN_ERR_ARG;
+        size_t nchunks = (n + Cs - 1) / Cs;
+#define X(S_, NW_)                                                                                                        \
+    if (m.S == S_)                                                                                                        \
+        rc = launch(ctx, "scan", k_scan_apply<S_>, grid_for(nchunks), lds_bytes(S_), out, e, b, (const uint32_t*)nullptr, \
+                    n, Cs, seglen, rev, m.d_n, m.n0inv, m.d_one);
+        VMN_FOR_SIZES(X)
+#undef X
+        return rc;
+    }
+    size_t nchunks = (n + C - 1) / C;
+    DevTmp tot(ctx);
+    VMN_TRY(tot.alloc(3 * nchunks * Wd * sizeof(uint32_t)));
+    uint32_t* Etot = tot.as<uint32_t>();
+    uint32_t* Xtot = Etot + nchunks * Wd;
+    uint32_t* inc = Xtot + nchunks * Wd;
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                     \
+    if (m.S == S_)                                                                                                     \
+        rc = launch(ctx, "scan", k_scan_totals<S_>, grid_for(nchunks), lds_bytes(S_), Etot, Xtot, e, b, n, C, seglen, rev, \
+                    m.d_n, m.n0inv, m.d_one);
+    VMN_FOR_SIZES(X)
+#undef X
+    VMN_TRY(rc);
+    // inclusive scan over the chunk totals with the same recurrence (segments shrink by C)
+    size_t seg_chunks = seglen == n ? nchunks : seglen / C;
+    VMN_TRY(scan_affine(ctx, m, Etot, b ? Xtot : nullptr, nchunks, seg_chunks, 0, inc));
+    rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                  \
+    if (m.S == S_)                                                                                                  \
+        rc = launch(ctx, "scan", k_scan_apply<S_>, grid_for(nchunks), lds_bytes(S_), out, e, b, (const uint32_t*)inc, n, \
+                    C, seglen, rev, m.d_n, m.n0inv, m.d_one);
+    VMN_FOR_SIZES(X)
+#undef X
+    return rc;
+}
+
+extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_rarray** out_x, uint8_t* last_be) {
+    ARG_CHECK(b && e && out_x, "null argument");
+    ARG_CHECK(b->grp == e->grp && b->n == e->n, "arrays differ in group or size");
+    vmn_group* g = b->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_rarray* r = nullptr;
+    VMN_TRY(new_rarray(g, b->n, &r));
+    int rc = scan_affine(g->ctx, g->Q, e->d, b->d, b->n, b->n, 0, r->d);
+    if (rc == VMN_OK && last_be) {
+        if (b->n) rc = export_be(g->ctx, g->Q, g->nbytes, r->d + (b->n - 1) * elem_words(g->Q), 1, last_be);
+        else memset(last_be, 0, g->nbytes);
+    }
+    if (rc != VMN_OK) {
+        vmn_rarray_free(r);
+        return rc;
+    }
+    *out_x = r;
+    return VMN_OK;
+}
+extern "C" int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out) {
+    ARG_CHECK(e && out, "null argument");
+    vmn_group* g = e->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_rarray* r = nullptr;
+    VMN_TRY(new_rarray(g, e->n, &r));
+    int rc = scan_affine(g->ctx, g->Q, e->d, nullptr, e->n, e->n, 0, r->d);
+    if (rc != VMN_OK) {
+        vmn_rarray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
+// ---- K2 fixed base ---------------------------------------------------------------------------------
+static int pick_fixed_window(size_t n, int ebits, size_t row_bytes) {
+    int best = 4;
+    double best_cost = 1e300;
+    for (int w = 2; w <= 18; ++w) {
+        int nwin = (ebits + w - 1) / w;
+        double table_bytes = (double)nwin * (double)((size_t)1 << w) * (double)row_bytes;
+        if (table_bytes > 6e9) break;
+        double cost = (double)nwin * ((double)((size_t)1 << w) + (double)n);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = w;
+        }
+    }
+    return best;
+}
+
+// Table for (base, window) cached in the group; built on the GPU from the host squaring chain.
+static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out) {
+    vmn_ctx* ctx = g->ctx;
+    const vmn_modulus& m = g->P;
+    const size_t Wd = elem_words(m);
+    std::string key(reinterpret_cast<const char*>(base_be), g->nbytes);
+    int w = pick_fixed_window(n, ebits, Wd * sizeof(uint32_t));
+    auto it = g->fixed.find(key);
+    if (it != g->fixed.end()) {
+        vmn_group::FixedTable& ft = it->second;
+        if (ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
+            *out = &ft;
+            return VMN_OK;
+        }
+        VMN_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ft.d_tab);
+        g->fixed.erase(it);
+    }
+    int nwin = (ebits + w - 1) / w;
+    // host: sq[j] = base^(2^j) mod p, j < nwin*w   (sequential chain, 32-bit-word Montgomery)
+    Big base = hostbig::from_be(base_be, g->nbytes, m.NW);
+    if (hostbig::cmp(base, m.n_words) >= 0) {
+        set_error("fixed base out of range");
+        return VMN_ERR_FORMAT;
+    }
+    const hostbig::Mont& hm = *m.hm;
+    Big cur = hm.to_mont(base);
+    const size_t chain = (size_t)nwin * w;
+    std::vector<uint8_t> sq_be(chain * g->nbytes);
+    for (size_t j = 0; j < chain; ++j) {
+        Big std_form = hm.from_mont(cur);
+        hostbig::to_be(std_form, sq_be.data() + j * g->nbytes, g->nbytes);
+        hm.mul(cur, cur, cur);
+    }
+    DevTmp sq(ctx);
+    VMN_TRY(sq.alloc(chain * Wd * sizeof(uint32_t)));
+    int ok = 1;
+    VMN_TRY(import_be(ctx, m, g->nbytes, sq_be.data(), chain, sq.as<uint32_t>(), &ok));
+    vmn_group::FixedTable ft;
+    ft.wbits = w;
+    ft.nwin = nwin;
+    ft.bytes = (size_t)nwin * ((size_t)1 << w) * Wd * sizeof(uint32_t);
+    VMN_HIP(hipMalloc(&ft.d_tab, ft.bytes));
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                              \
+    if (m.S == S_)                                                                                              \
+        rc = launch_light(ctx, "fixed_table", k_fixed_seed<S_>, grid_for((size_t)nwin * (w + 1)), ft.d_tab,     \
+                          sq.as<uint32_t>(), w, nwin, m.d_one);
+    VMN_FOR_SIZES(X)
+#undef X
+    for (int l = 1; l < w && rc == VMN_OK; ++l) {
+        size_t lanes = (((size_t)1 << l) - 1) * nwin;
+#define X(S_, NW_) \
+    if (m.S == S_) rc = launch(ctx, "fixed_table", k_fixed_level<S_>, grid_for(lanes), lds_bytes(S_), ft.d_tab, w, nwin, l, m.d_n, m.n0inv);
+        VMN_FOR_SIZES(X)
+#undef X
+    }
+    if (rc != VMN_OK) {
+        (void)hipFree(ft.d_tab);
+        return rc;
+    }
+    auto ins = g->fixed.emplace(key, ft);
+    *out = &ins.first->second;
+    return VMN_OK;
+}
+
+extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out) {
+    ARG_CHECK(grp && base_be && e && out, "null argument");
+    ARG_CHECK(e->grp == grp, "exponent array belongs to another group");
+    vmn_ctx* ctx = grp->ctx;
+    VMN_HIP(hipSetDevice(ctx->device));
+    const size_t n = e->n;
+    vmn_garray* r = nullptr;
+    VMN_TRY(new_garray(grp, n, &r));
+    if (n == 0) {
+        *out = r;
+        return VMN_OK;
+    }
+    int ebits = grp->Q.nbits;
+    vmn_group::FixedTable* ft = nullptr;
+    DevTmp ew(ctx);
+    int rc = fixed_table(grp, base_be, ebits, n, &ft);
+    if (rc == VMN_OK) rc = ew.alloc(n * (size_t)grp->Q.NW * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = to_words(ctx, grp->Q, e->d, n, ew.as<uint32_t>());
+    if (rc == VMN_OK) {
+        const vmn_modulus& m = grp->P;
+        unsigned grid = std::min<unsigned>(grid_for(n), (unsigned)(ctx->num_cus * blocks_per_cu(m.S)));
+        rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                 \
+    if (m.S == S_)                                                                                                 \
+        rc = launch(ctx, "fixed", k_fixed_exp<S_>, grid, lds_bytes(S_), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+                    ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, m.d_n, m.n0inv);
+        VMN_FOR_SIZES(X)
+#undef X
+    }
+    if (rc != VMN_OK) {
+        vmn_garray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
+// ---- K3 multi-exponentiation -----------------------------------------------------------------------
+static int pick_bucket_bits(size_t n, int ebits) {
+    int best = 1;
+    double best_cost = 1e300;
+    for (int c = 1; c <= 16; ++c) {
+        int nwin = (ebits + c - 1) / c;
+        double cost = (double)nwin * ((double)n + 3.0 * (double)((size_t)1 << c));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+// prod_i x[i]^e[i] with packed-word exponents on the device -> big-endian element on the host
+static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_words, int ewords, int ebits, size_t n,
+                         uint8_t* out_be) {
+    vmn_ctx* ctx = g->ctx;
+    const vmn_modulus& m = g->P;
+    const size_t Wd = elem_words(m);
+    const hostbig::Mont& hm = *m.hm;
+    if (n == 0) {
+        Big one(m.NW, 0);
+        one[0] = 1;
+        hostbig::to_be(one, out_be, g->nbytes);
+        return VMN_OK;
+    }
+    if (ebits < 1) ebits = 1;
+    const int c = pick_bucket_bits(n, ebits);
+    const int nwin = (ebits + c - 1) / c;
+    const size_t nb = (size_t)1 << c;
+    DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx);
+    // counts | cursor : nwin*nb each ; offsets : nwin*(nb+1)
+    VMN_TRY(meta.alloc((2 * (size_t)nwin * nb + (size_t)nwin * (nb + 1)) * sizeof(uint32_t)));
+    uint32_t* counts = meta.as<uint32_t>();
+    uint32_t* cursor = counts + (size_t)nwin * nb;
+    uint32_t* offsets = cursor + (size_t)nwin * nb;
+    VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
+    VMN_TRY(buckets.alloc(2 * (size_t)nwin * nb * Wd * sizeof(uint32_t)));
+    VMN_TRY(wres.alloc((size_t)nwin * Wd * sizeof(uint32_t)));
+    uint32_t* B = buckets.as<uint32_t>();
+    uint32_t* Ssuf = B + (size_t)nwin * nb * Wd;
+    VMN_HIP(hipMemsetAsync(counts, 0, (size_t)nwin * nb * sizeof(uint32_t), ctx->stream));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, light_grid(ctx, n * nwin), counts, e_words, ewords, n, c, nwin));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_offsets, (unsigned)nwin, offsets, cursor, (const uint32_t*)counts, c));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, light_grid(ctx, n * nwin), sorted.as<uint32_t>(), cursor,
+                         e_words, ewords, n, c, nwin));
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                   \
+    if (m.S == S_)                                                                                                   \
+        rc = launch(ctx, "expprod", k_bucket_products<S_>, grid_for(nb * nwin), lds_bytes(S_), B, x,                 \
+                    (const uint32_t*)sorted.as<uint32_t>(), (const uint32_t*)offsets, n, c, nwin, m.d_n, m.n0inv, m.d_one);
+    VMN_FOR_SIZES(X)
+#undef X
+    VMN_TRY(rc);
+    // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce
+    VMN_TRY(scan_affine(ctx, m, B, nullptr, (size_t)nwin * nb, nb, 1, Ssuf));
+    rc = VMN_ERR_ARG;
+#define X(S_, NW_) \
+    if (m.S == S_) rc = launch_light(ctx, "expprod_agg", k_set_segment_heads<S_>, grid_for(nwin), Ssuf, nb, (size_t)nwin, m.d_one);
+    VMN_FOR_SIZES(X)
+#undef X
+    VMN_TRY(rc);
+    VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, nwin, true, wres.as<uint32_t>()));
+    // Horner over the windows on the host: nwin elements, c squarings each (O(ebits) modmuls)
+    std::vector<uint8_t> wbe((size_t)nwin * g->nbytes);
+    VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), nwin, wbe.data()));
+    Big acc = hm.one;
+    for (int w = nwin - 1; w >= 0; --w) {
+        for (int s = 0; s < c; ++s) hm.mul(acc, acc, acc);
+        Big ww = hm.to_mont(hostbig::from_be(wbe.data() + (size_t)w * g->nbytes, g->nbytes, m.NW));
+        hm.mul(acc, acc, ww);
+    }
+    hostbig::to_be(hm.from_mont(acc), out_be, g->nbytes);
+    return VMN_OK;
+}
+
+extern "C" int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int ebits, uint8_t* out_be) {
+    ARG_CHECK(x && e && out_be, "null argument");
+    ARG_CHECK(x->grp == e->grp && x->n == e->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = g->ctx;
+    VMN_HIP(hipSetDevice(ctx->device));
+    if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
+    DevTmp ew(ctx);
+    VMN_TRY(ew.alloc(std::max<size_t>(x->n, 1) * (size_t)g->Q.NW * sizeof(uint32_t)));
+    VMN_TRY(to_words(ctx, g->Q, e->d, e->n, ew.as<uint32_t>()));
+    return expprod_words(g, x->d, ew.as<uint32_t>(), g->Q.NW, ebits, x->n, out_be);
+}
+extern "C" int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, uint8_t* out_be) {
+    ARG_CHECK(x && out_be && (exps_be || x->n == 0) && ebytes > 0, "null argument");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = g->ctx;
+    VMN_HIP(hipSetDevice(ctx->device));
+    if (ebits <= 0 || (size_t)ebits > 8 * ebytes) ebits = (int)(8 * ebytes);
+    int ewords = (ebits + 31) / 32;
+    std::vector<uint32_t> hw;
+    be_ints_to_words(exps_be, ebytes, x->n, ewords, hw);
+    DevTmp ew(ctx);
+    VMN_TRY(ew.alloc(std::max<size_t>(hw.size(), 1) * sizeof(uint32_t)));
+    if (!hw.empty()) VMN_HIP(hipMemcpy(ew.p, hw.data(), hw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return expprod_words(g, x->d, ew.as<uint32_t>(), ewords, ebits, x->n, out_be);
+}
+
+// ---- membership, partials ----------------------------------------------------------------------------
+extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
+    ARG_CHECK(x && all_members, "null argument");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = g->ctx;
+    VMN_HIP(hipSetDevice(ctx->device));
+    *all_members = 1;
+    if (x->n == 0) return VMN_OK;
+    // x^q == 1 for every element: shared-exponent modpow, then compare with a broadcast of one
+    const vmn_modulus& m = g->P;
+    const size_t Wd = elem_words(m);
+    DevTmp ew(ctx), pw(ctx);
+    VMN_TRY(ew.alloc(m.NW * sizeof(uint32_t)));
+    VMN_HIP(hipMemcpy(ew.p, g->Q.n_words.data(), m.NW * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VMN_TRY(pw.alloc(2 * x->n * Wd * sizeof(uint32_t)));
+    uint32_t* powers = pw.as<uint32_t>();
+    uint32_t* ones = powers + x->n * Wd;
+    VMN_TRY(modpow_words(ctx, m, x->d, ew.as<uint32_t>(), m.NW, 0, g->Q.nbits, x->n, powers));
+    std::vector<uint32_t> idx(x->n, 0xffffffffu);
+    std::vector<uint32_t> one_row(Wd, 0);
+    VMN_HIP(hipMemcpy(one_row.data(), m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    DevTmp fill(ctx);
+    VMN_TRY(fill.alloc(Wd * sizeof(uint32_t)));
+    VMN_HIP(hipMemcpy(fill.p, one_row.data(), Wd * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VMN_TRY(gather_rows(ctx, m, powers, idx, fill.as<uint32_t>(), ones));
+    return compare_arrays(ctx, m, powers, ones, x->n, all_members);
+}
+
+extern "C" int vmn_group_mul_partials(vmn_group* grp, const uint8_t* partials_be, size_t k, uint8_t* out_be) {
+    ARG_CHECK(grp && out_be && (partials_be || k == 0), "null argument");
+    const vmn_modulus& m = grp->P;
+    const hostbig::Mont& hm = *m.hm;
+    Big acc = hm.one;
+    for (size_t i = 0; i < k; ++i) {
+        Big v = hostbig::from_be(partials_be + i * grp->nbytes, grp->nbytes, m.NW);
+        if (hostbig::cmp(v, m.n_words) >= 0) {
+            set_error("partial %zu out of range", i);
+            return VMN_ERR_FORMAT;
+        }
+        hm.mul(acc, acc, hm.to_mont(v));
+    }
+    hostbig::to_be(hm.from_mont(acc), out_be, grp->nbytes);
+    return VMN_OK;
+}
