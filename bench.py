@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native VMN exponentiation core.
+
+Workload (BASELINE.json configs[1]): one *step* = one batched variable-base modular
+exponentiation  out[i] = x[i]^e[i] mod p  over N = 1,000,000 elements, p = RFC 3526 group 14
+(2048-bit safe prime), random bases, random full-length (2047-bit) exponents, inputs and outputs
+resident in HBM (device arrays of the C ABI), through ``vmn_garray_exp_array`` — the call the
+reference makes as ``PGroupElementArray.exp(PRingElementArray)`` (PoSBasicTW.java:1032).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU (torch.distributed / RCCL), every rank holds its own shard of N_per_gpu
+elements (weak scaling, no data-path collective: element-wise op), barrier + synchronize on both
+sides of the timed region, MAX over ranks.
+
+The JSON line carries
+  roofline     : the dominant kernel (k_modpow) against the integer-VALU roofline.  This path is
+                 integer big-number arithmetic: it is bound by VALU issue, not by HBM and not by
+                 MFMA, so bound = "valu-int".  achieved = algorithmic 32x32-bit
+                 multiply-accumulates (SURVEY.md §8d canonical count, 16,422,432 per 2048/2047-bit
+                 modexp) per launch / the kernel's average duration measured with HIP events on
+                 the launch stream; peak = 39.3 TMAC/s = 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz,
+                 the issue rate of v_mad_u64_u32 measured by tools/valu_rate.hip
+                 (profiles/valu_rate_r01.txt) = the FP64-vector FMA rate of MI355X_MICROARCH.md.
+  cpu_baseline : the GMP oracle (mpz_powm, OpenMP over all host cores) on a bounded sample of the
+                 same inputs; the GPU output for that sample is compared bit for bit.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAC_2048_2047 = 16_422_432           # fixed-window modpow, n = 2048, t = 2047, w = 5
+PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3
+HBM_PEAK_GBS = 8000.0
+
+
+def make_inputs(n: int, seed: int, nbytes: int):
+    """n random bases (< 2^2047 < p) and exponents (2047-bit, < q) as big-endian bytes."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+    e = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+    x[:, 0] &= 0x7F
+    e[:, 0] &= 0x7F
+    x[:, -1] |= 1                     # no zero base
+    return x.tobytes(), e.tobytes()
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000, help="elements per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="elements of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    # Build (only if a prebuilt library is missing) BEFORE anything touches the GPU: a process that has
+    # initialised the GPU must not exec children on this pool, and under rocprofv3 it already has.
+    import __graft_entry__ as entry
+    if not (os.path.exists(entry.LIB) and os.path.exists(os.path.join(ROOT, "oracle", "libvmnoracle.so"))):
+        entry.build()
+    vmn = entry.load_package()
+    from oracle import pyref
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    p, q, g = pyref.modp_group(2048)
+    nbytes = 256
+    n = args.n
+    ctx = vmn.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    grp = vmn.ModPGroup(ctx, p, q, g, nbytes=nbytes)
+
+    xb, eb = make_inputs(n, 20260000 + rank, nbytes)
+    X = grp.toElementArray(xb)
+    E = grp.ringArray(eb)
+
+    def step():
+        return X.exp(E)
+
+    for _ in range(args.warmup):
+        step().free()
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        if out is not None:
+            out.free()
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(False)
+    launches, kernel_ms = ctx.timing_get("modpow")
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total = n * world * args.steps
+    value = total / elapsed
+    avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+    achieved = MAC_2048_2047 * n / avg_kernel_s / 1e12
+    # algorithmic HBM bytes of one launch: x, e (packed words), out, plus the per-lane window tables
+    # written once and read once per window (they stay in L2/MALL mostly); SURVEY.md §8d: 768 B/element
+    alg_bytes = 768 * n
+
+    result = {
+        "metric": "modexps/sec (batched variable-base modPow, 2048-bit ModPGroup, full-length exponents)",
+        "value": value,
+        "unit": "modexp/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 limbs (28-bit radix), u64 accumulate",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: batched modPow, RFC 3526 group 14 (2048-bit safe prime), "
+                               "random bases, random 2047-bit exponents, device-resident in/out",
+                   "elements_per_gpu": n, "parallelism": f"shard{world}" if world > 1 else "single"},
+        "roofline": {"bound": "valu-int", "kernel": "k_modpow<74>", "achieved": achieved, "peak": PEAK_TMACS,
+                     "unit": "TMAC/s (32x32->64-bit multiply-accumulate)", "frac": achieved / PEAK_TMACS,
+                     "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                     "traffic": None,
+                     "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                             "achieved_GBs": alg_bytes / avg_kernel_s / 1e9, "peak_GBs": HBM_PEAK_GBS}},
+    }
+
+    if rank == 0 and not args.no_cpu:
+        from oracle.cbind import Oracle
+        orc = Oracle(p, q, nbytes)
+        cores = orc.threads
+        sample = args.cpu_sample or min(n, 3000 * cores)          # ~10-20 s of mpz_powm
+        t1 = time.perf_counter()
+        want = orc.exp_array_bytes(xb[: sample * nbytes], eb[: sample * nbytes], sample, nbytes)
+        cpu_s = time.perf_counter() - t1
+        got = out.copyOfRange(0, sample).toBytes() if sample < n else out.toBytes()
+        result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "modexp/s", "cores": cores, "kind": "port",
+                                  "sample": f"first {sample} of the {n} elements of rank 0 (GMP mpz_powm, OpenMP static chunks)",
+                                  "bit_exact_vs_gpu": got == want}
+        if got != want:
+            result["parity_error"] = "GPU output differs from the GMP oracle on the sample"
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
