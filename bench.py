@@ -166,8 +166,10 @@ def main() -> None:
     if rank == 0 and not args.no_cpu:
         from oracle.cbind import Oracle
         orc = Oracle(p, q, nbytes)
-        cores = orc.threads
-        sample = args.cpu_sample or min(n, 3000 * cores)          # ~10-20 s of mpz_powm
+        # host cores this job may use: the affinity mask, capped at the 16-core share of a one-GPU box
+        cores = min(orc.threads, len(os.sched_getaffinity(0)), 16 * max(1, world))
+        orc.set_threads(cores)
+        sample = args.cpu_sample or min(n, 6000 * cores)          # ~15 s of mpz_powm
         t1 = time.perf_counter()
         want = orc.exp_array_bytes(xb[: sample * nbytes], eb[: sample * nbytes], sample, nbytes)
         cpu_s = time.perf_counter() - t1
