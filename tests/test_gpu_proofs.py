@@ -1,0 +1,203 @@
+"""GPU suite: the HIP-backed PoS / PoSC / CCPoS drivers against the Python-integer restatement on the
+same random tape: every prover message must be identical, verdicts must agree (honest accept,
+tampered reject), for widths 1 and 2, in a 512-bit group (the size of the reference's own unit
+test, TestPoSCBasicTW.java:69-140) and in the 2048-bit group of the benchmark."""
+import pytest
+
+from conftest import load_golden
+from oracle import pyref, pyref_proofs as P
+from tape import Tape
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods(entry, vmn):
+    import importlib.util, os, sys
+    out = {}
+    for name in ("hvzk", "mixnet"):
+        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}",
+                                                      os.path.join(entry.PKG_DIR, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        out[name] = m
+    return out
+
+
+def make_instance(bits, n, width, seed):
+    grp, _ = load_golden(bits)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    t = Tape(seed, q)
+    h = [pow(g, x, p) for x in t.ring_array(n)]
+    y = pow(g, t.ring_element(), p)
+    pkey = [g] * width + [y] * width
+    msgs = [[pow(g, m, p) for m in t.ring_array(n)] for _ in range(width)]
+    enc_r = [t.ring_array(n) for _ in range(width)]
+    w = [pyref.exp_fixed(g, enc_r[c], p) for c in range(width)] + \
+        [pyref.mul(msgs[c], pyref.exp_fixed(y, enc_r[c], p), p) for c in range(width)]
+    return p, q, g, h, pkey, w, t
+
+
+def ints_of(x):
+    return x.toInts() if hasattr(x, "toInts") else x
+
+
+def same_msg(a, b):
+    assert set(a) == set(b)
+    for k in a:
+        va, vb = a[k], b[k]
+        assert ints_of(va) == ints_of(vb), k
+
+
+@pytest.mark.parametrize("bits,n,width,nbits", [(512, 70, 1, (100, 100, 50)), (512, 33, 2, (100, 100, 50)),
+                                                (2048, 300, 1, (256, 256, 100))])
+def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods):
+    NV, NE, NR = nbits
+    p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"pos%d" % bits)
+    pi = t.permutation(n)
+    s = [t.ring_array(n) for _ in range(width)]
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    # oracle run
+    o = P.PoS(p, q, NV, NE, NR, rand=Tape(b"prover", q))
+    o.precompute(g, h, pi)
+    wp_o = P.reencrypt(w, P.reenc_factors(pkey, s, p), pi, p)
+    o.setInstance(pkey, w, wp_o, s)
+    o.setBatchVector(e)
+    com_o = o.commit()
+    rep_o = o.reply(v)
+    # HIP run on the same tape
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H = G.toElementArray(h)
+    W = [G.toElementArray(c) for c in w]
+    S = [G.ringArray(c) for c in s]
+    hv, mx = mods["hvzk"], mods["mixnet"]
+    pr = hv.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prover", q))
+    pr.precompute(g, H, pi)
+    assert pr.u.toInts() == o.u and pr.Ap == o.Ap
+    WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi)
+    assert [c.toInts() for c in WP] == wp_o
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com = pr.commit()
+    same_msg(com, com_o)
+    rep = pr.reply(v)
+    same_msg(rep, rep_o)
+    # verifier on the GPU
+    ver = hv.PoSBasicTW(G, NV, NE, NR)
+    ver.precompute(g, H)
+    ver.setPermutationCommitment(pr.u)
+    ver.setInstance(pkey, W, WP)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep)
+    bad = dict(rep)
+    bad["k_F"] = [(x + 1) % q for x in rep["k_F"]]
+    assert not ver.verify(bad) and ver.verdicts == (True, True, True, True, False)
+    kb = rep["k_B"].toInts()
+    kb[n // 2] = (kb[n // 2] + 1) % q
+    bad = dict(rep)
+    bad["k_B"] = G.ringArray(kb)
+    assert not ver.verify(bad) and ver.verdicts == (True, False, True, True, True)
+    # oracle verifier accepts the GPU prover's messages
+    ov = P.PoS(p, q, NV, NE, NR)
+    ov.precompute(g, h)
+    ov.u = pr.u.toInts()
+    ov.setInstance(pkey, w, wp_o)
+    ov.setBatchVector(e)
+    ov.computeAF()
+    ov.setCommitment({k: ints_of(x) for k, x in com.items()})
+    assert ov.verify({k: ints_of(x) for k, x in rep.items()}, v)
+
+
+def test_posc_and_permutation_commitment(vmn, gpu_ctx, mods):
+    NV, NE, NR = 100, 100, 50
+    n = 100                                   # the reference's unit test size, TestPoSCBasicTW.java
+    p, q, g, h, _, _, t = make_instance(512, n, 1, b"posc")
+    pi = t.permutation(n)
+    r = t.ring_array(n)
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    rho = t.int_array(1, 50)[0]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H = G.toElementArray(h)
+    hv, mx = mods["hvzk"], mods["mixnet"]
+    pc = mx.PermutationCommitment(G, H)
+    U = pc.precompute(r, pi)
+    u_o = P.permutation_commitment(g, h, r, pi, p)
+    assert U.toInts() == u_o
+    assert pc.raise_(rho).toInts() == pyref.exp_scalar(u_o, rho, p)
+    assert mx.raisedGenerators(H, rho).toInts() == pyref.exp_scalar(h, rho, p)
+
+    def run(rr):
+        o = P.PoSC(p, q, NV, NE, NR, rand=Tape(b"poscprover", q))
+        o.setInstance(g, h, u_o, rr, pi)
+        o.setBatchVector(e)
+        com_o, rep_o = o.commit(), o.reply(v)
+        pr = hv.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"poscprover", q))
+        pr.setInstance(g, H, U, G.ringArray(rr), pi)
+        pr.setBatchVector(e)
+        com = pr.commit()
+        rep = pr.reply(v)
+        same_msg(com, com_o)
+        same_msg(rep, rep_o)
+        ver = hv.PoSCBasicTW(G, NV, NE, NR)
+        ver.setInstance(g, H, U)
+        ver.setBatchVector(e)
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        return ver.verify(rep)
+
+    assert run(r)
+    assert not run([(x + x) % q for x in r])          # TestPoSCBasicTW.java:109-111
+
+
+@pytest.mark.parametrize("raised", [False, True])
+def test_ccpos_transcript_matches_oracle(raised, vmn, gpu_ctx, mods):
+    NV, NE, NR = 256, 256, 100
+    n, width = 130, 1
+    p, q, g, h, pkey, w, t = make_instance(2048, n, width, b"ccpos")
+    pi = t.permutation(n)
+    r = t.ring_array(n)
+    s = [t.ring_array(n)]
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    rho = t.int_array(1, 50)[0]
+    u_o = P.permutation_commitment(g, h, r, pi, p)
+    wp_o = P.reencrypt(w, P.reenc_factors(pkey, s, p), pi, p)
+    o = P.CCPoS(p, q, NV, NE, NR, rand=Tape(b"ccprover", q))
+    o.setInstance(g, h, u_o, pkey, w, wp_o, r, pi, s)
+    o.setBatchVector(e)
+    com_o, rep_o = o.commit(), o.reply(v)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    hv, mx = mods["hvzk"], mods["mixnet"]
+    H, U = G.toElementArray(h), G.toElementArray(u_o)
+    W = [G.toElementArray(c) for c in w]
+    WP = [G.toElementArray(c) for c in wp_o]
+    pr = hv.CCPoSBasicW(G, NV, NE, NR, rand=Tape(b"ccprover", q))
+    pr.setInstance(g, H, U, pkey, W, WP, G.ringArray(r), pi, [G.ringArray(s[0])])
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    same_msg(com, com_o)
+    same_msg(rep, rep_o)
+    ver = hv.CCPoSBasicW(G, NV, NE, NR)
+    ver.setInstance(g, H, U, pkey, W, WP)
+    ver.setBatchVector(e)
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    if raised:
+        ver.computeAB(U.exp(rho))
+        RH = H.exp(rho)
+        assert ver.verify(rep, RH, rho)
+        bad = dict(rep)
+        bad["k_A"] = (rep["k_A"] + 1) % q
+        assert not ver.verify(bad, RH, rho)
+    else:
+        ver.computeAB()
+        assert ver.verify(rep)
+        bad = dict(rep)
+        bad["k_B"] = [(x + 1) % q for x in rep["k_B"]]
+        assert not ver.verify(bad)

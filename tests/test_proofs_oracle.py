@@ -1,0 +1,121 @@
+"""CPU suite: the Python restatement of PoS / PoSC / CCPoS is self-consistent the way the reference's own
+unit test checks it (TestPoSCBasicTW.java:147-163): an honest transcript verifies, a tampered witness
+(r <- r + r, :109-111) is rejected."""
+import pytest
+
+from conftest import load_golden
+from oracle import pyref, pyref_proofs as P
+from tape import Tape
+
+NE = NV = 100
+NR = 50
+
+
+def setup(bits, n, width=1, seed=b"proofs"):
+    grp, _ = load_golden(bits)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    t = Tape(seed, q)
+    h = [pow(g, x, p) for x in t.ring_array(n)]
+    xkey = t.ring_element()
+    y = pow(g, xkey, p)
+    pkey = [g] * width + [y] * width
+    msgs = [[pow(g, m, p) for m in t.ring_array(n)] for _ in range(width)]
+    enc_r = [t.ring_array(n) for _ in range(width)]
+    w = [pyref.exp_fixed(g, enc_r[c], p) for c in range(width)] + \
+        [pyref.mul(msgs[c], pyref.exp_fixed(y, enc_r[c], p), p) for c in range(width)]
+    return p, q, g, h, pkey, w, t
+
+
+@pytest.mark.parametrize("width", [1, 2])
+def test_pos_honest_accepts_tampered_rejects(width):
+    n = 12
+    p, q, g, h, pkey, w, t = setup(512, n, width)
+    pi = t.permutation(n)
+    prover = P.PoS(p, q, NV, NE, NR, rand=t)
+    prover.precompute(g, h, pi)
+    s = [t.ring_array(n) for _ in range(width)]
+    wp = P.reencrypt(w, P.reenc_factors(pkey, s, p), pi, p)
+    prover.setInstance(pkey, w, wp, s)
+    e = t.int_array(n, NE)
+    prover.setBatchVector(e)
+    com = prover.commit()
+    v = t.int_array(1, NV)[0]
+    rep = prover.reply(v)
+    ver = P.PoS(p, q, NV, NE, NR)
+    ver.precompute(g, h)
+    ver.u = prover.u
+    ver.setInstance(pkey, w, wp)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    assert ver.verify(rep, v)
+    # wrong re-encryption exponents: only F may fail
+    bad = dict(rep)
+    bad["k_F"] = [(x + 1) % q for x in rep["k_F"]]
+    assert not ver.verify(bad, v) and ver.verdicts == (True, True, True, True, False)
+    # a different output list is rejected
+    wp2 = [list(c) for c in wp]
+    wp2[0][0], wp2[0][1] = wp2[0][1], wp2[0][0]
+    ver.setInstance(pkey, w, wp2)
+    assert not ver.verify(rep, v)
+
+
+def test_posc_honest_accepts_doubled_r_rejects():
+    n = 10
+    p, q, g, h, _, _, t = setup(512, n)
+    pi = t.permutation(n)
+    r = t.ring_array(n)
+    u = P.permutation_commitment(g, h, r, pi, p)
+
+    def run(rr):
+        prover = P.PoSC(p, q, NV, NE, NR, rand=Tape(b"posc", q))
+        prover.setInstance(g, h, u, rr, pi)
+        e = t.int_array(n, NE)
+        prover.setBatchVector(e)
+        com = prover.commit()
+        v = t.int_array(1, NV)[0]
+        rep = prover.reply(v)
+        ver = P.PoSC(p, q, NV, NE, NR)
+        ver.setInstance(g, h, u)
+        ver.setBatchVector(e)
+        ver.setCommitment(com)
+        return ver.verify(rep, v)
+
+    # note: the commitment u = permute(h * g^r, pi) opens with r indexed like h (before permuting)
+    assert run(r)
+    assert not run([(x + x) % q for x in r])
+
+
+@pytest.mark.parametrize("raised", [False, True])
+def test_ccpos_plain_and_raised(raised):
+    n = 9
+    p, q, g, h, pkey, w, t = setup(512, n)
+    pi = t.permutation(n)
+    r = t.ring_array(n)
+    u = P.permutation_commitment(g, h, r, pi, p)
+    s = [t.ring_array(n)]
+    wp = P.reencrypt(w, P.reenc_factors(pkey, s, p), pi, p)
+    prover = P.CCPoS(p, q, NV, NE, NR, rand=t)
+    prover.setInstance(g, h, u, pkey, w, wp, r, pi, s)
+    e = t.int_array(n, NE)
+    prover.setBatchVector(e)
+    com = prover.commit()
+    v = t.int_array(1, NV)[0]
+    rep = prover.reply(v)
+    ver = P.CCPoS(p, q, NV, NE, NR)
+    ver.setInstance(g, h, u, pkey, w, wp)
+    ver.setBatchVector(e)
+    ver.setCommitment(com)
+    if raised:
+        rho = t.int_array(1, 50)[0]
+        ver.computeAB(pyref.exp_scalar(u, rho, p))
+        assert ver.verify(rep, v, pyref.exp_scalar(h, rho, p), rho)
+        bad = dict(rep)
+        bad["k_A"] = (rep["k_A"] + 1) % q
+        assert not ver.verify(bad, v, pyref.exp_scalar(h, rho, p), rho)
+    else:
+        ver.computeAB()
+        assert ver.verify(rep, v)
+        bad = dict(rep)
+        bad["k_B"] = [(x + 1) % q for x in rep["k_B"]]
+        assert not ver.verify(bad, v)
