@@ -53,6 +53,90 @@ def make_inputs(n: int, seed: int, nbytes: int):
     return x.tobytes(), e.tobytes()
 
 
+def load_sub(entry, name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1):
+    """ciphertexts/s of [A0 re-encrypt + PoS prove + PoS verify] (SURVEY.md §8a rows A0 + A1, width 1),
+    device-resident arrays, n_e = n_v = 256, n_r = 100.  The op sequence is the reference's
+    (ShufflerElGamalSession.java:400-409, 273-278; PoSBasicTW.java precompute/commit/reply/computeAF/verify)."""
+    hv, mx = load_sub(entry, "hvzk"), load_sub(entry, "mixnet")
+    NV = NE = 256
+    NR = 100
+    p, q, g = grp.p, grp.q, grp.g
+    rnd = mx.BulkRandomSource(seed, q, grp.nbytes)
+    # synthetic instance (untimed): independent generators h, key y = g^x, honest ciphertexts (g^t, m*y^t)
+    H = grp.exp(g, grp.ringArray(rnd.ring_array(n)))
+    y = pow(g, rnd.ring_element(), p)
+    pkey = [g, y]
+    T = grp.ringArray(rnd.ring_array(n))
+    M = grp.exp(g, grp.ringArray(rnd.ring_array(n)))
+    YT = grp.exp(y, T)
+    W = [grp.exp(g, T), M.mul(YT)]
+    for a in (T, M, YT):
+        a.free()
+    phases = {}
+    best = None
+    for _ in range(steps):
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        sync()
+        t0 = time.perf_counter()
+        # --- A0: re-encryption + permutation
+        pi = rnd.permutation(n)
+        S = [grp.ringArray(rnd.ring_array(n))]
+        prover = hv.PoSBasicTW(grp, NV, NE, NR, rand=rnd)
+        factors = mx.reencFactors(grp, pkey, S)
+        WP = mx.reencrypt(W, factors, pi)
+        for f in factors:
+            f.free()
+        sync()
+        t1 = time.perf_counter()
+        # --- A1 prover
+        prover.precompute(g, H, pi)
+        prover.setInstance(pkey, W, WP, S)
+        e = rnd.int_array(n, NE)
+        prover.setBatchVector(e)
+        com = prover.commit()
+        v = int.from_bytes(rnd.int_array(1, NV), "big")
+        rep = prover.reply(v)
+        sync()
+        t2 = time.perf_counter()
+        # --- A1 verifier
+        ver = hv.PoSBasicTW(grp, NV, NE, NR)
+        ver.precompute(g, H)
+        ver.setPermutationCommitment(prover.u)
+        ver.setInstance(pkey, W, WP)
+        ver.setBatchVector(e)
+        ver.computeAF()
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        ok = ver.verify(rep)
+        sync()
+        t3 = time.perf_counter()
+        ctx.timing_enable(False)
+        fam = ctx.timing_report()
+        cur = {"kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
+               "kernel_launches": sum(v[0] for v in fam.values()),
+               "reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
+               "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok)}
+        if best is None or cur["total_ms"] < best["total_ms"]:
+            best = cur
+        for a in WP + S + [com["B"], com["Bp"], rep["k_B"], rep["k_E"], prover.u, prover.r, prover.e, ver.e]:
+            a.free()
+    best["ciphertexts_per_s"] = n / (best["total_ms"] / 1e3)
+    best["n"] = n
+    # canonical cost, SURVEY.md §8d: ~3280 M(64) = 2.7e7 MAC per ciphertext (PoS path, n = 2048, width 1)
+    best["algorithmic_TMACs"] = 3280 * 8256 * n / (best["total_ms"] / 1e3) / 1e12
+    return best
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +145,7 @@ def main() -> None:
     ap.add_argument("--n", type=int, default=1_000_000, help="elements per GPU")
     ap.add_argument("--cpu-sample", type=int, default=0, help="elements of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mix-n", type=int, default=200_000, help="ciphertexts of the mix+prove leg (0 = skip)")
     args = ap.parse_args()
 
     # Build (only if a prebuilt library is missing) BEFORE anything touches the GPU: a process that has
@@ -162,6 +247,20 @@ def main() -> None:
                      "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                              "achieved_GBs": alg_bytes / avg_kernel_s / 1e9, "peak_GBs": HBM_PEAK_GBS}},
     }
+
+    if args.mix_n > 0:
+        X.free()
+        E.free()
+        ctx.timing_reset()
+        mp = mix_prove(entry, vmn, ctx, grp, args.mix_n, 777 + rank, barrier)
+        if distributed:
+            t = torch.tensor([mp["total_ms"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mp["total_ms"] = float(t.item())
+            mp["ciphertexts_per_s"] = args.mix_n * world / (mp["total_ms"] / 1e3)
+        mp["workload"] = ("re-encrypt + PoS (Terelius-Wikstrom) prove + verify, ModPGroup 2048-bit, width 1, "
+                          "n_e = n_v = 256, n_r = 100, per-GPU shard")
+        result["mix_prove"] = mp
 
     if rank == 0 and not args.no_cpu:
         from oracle.cbind import Oracle

@@ -166,6 +166,8 @@ int vmn_ctx_timing_enable(vmn_ctx* ctx, int on);
 int vmn_ctx_timing_reset(vmn_ctx* ctx);
 /* family: "modpow", "modmul", "fixed", "expprod", ...; returns launches and total ms. */
 int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launches, double* total_ms);
+/* All families as text lines "family launches total_ms\n" into buf (truncated to len-1 bytes). */
+int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,23 @@ import ctypes as C
 import os
 from typing import Optional, Sequence
 
+try:                                    # optional: large index arrays are passed without a Python-level copy
+    import numpy as _np
+except Exception:                       # pragma: no cover
+    _np = None
+
+
+def _u32_array(seq):
+    """ctypes uint32 array (or a numpy-backed pointer) for an index list."""
+    if _np is not None and isinstance(seq, _np.ndarray):
+        arr = _np.ascontiguousarray(seq, dtype=_np.uint32)
+        return arr.ctypes.data_as(C.POINTER(C.c_uint32)), arr
+    if _np is not None and len(seq) > 4096:
+        arr = _np.asarray(seq, dtype=_np.uint32)
+        return arr.ctypes.data_as(C.POINTER(C.c_uint32)), arr
+    arr = (C.c_uint32 * len(seq))(*seq)
+    return arr, arr
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvmnhip.so")
 
@@ -106,6 +123,16 @@ class Context:
 
     def timing_reset(self) -> None:
         _check(lib().vmn_ctx_timing_reset(self._h))
+
+    def timing_report(self) -> dict:
+        """{family: (launches, total_ms)} of every kernel family since the last reset."""
+        buf = C.create_string_buffer(8192)
+        _check(lib().vmn_ctx_timing_report(self._h, buf, C.c_size_t(len(buf))))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
 
     def timing_get(self, family: str):
         n = C.c_long()
@@ -261,7 +288,7 @@ class PGroupElementArray(_ArrayBase):
 
     # K7
     def permute(self, perm: Sequence[int]) -> "PGroupElementArray":
-        arr = (C.c_uint32 * len(perm))(*perm)
+        arr, _keep = _u32_array(perm)
         h = C.c_void_p()
         _check(lib().vmn_garray_permute(self._h, arr, C.byref(h)))
         return self._new(h)
@@ -360,7 +387,7 @@ class PRingElementArray(_ArrayBase):
         return self._scalar("vmn_rarray_prod")
 
     def permute(self, perm: Sequence[int]) -> "PRingElementArray":
-        arr = (C.c_uint32 * len(perm))(*perm)
+        arr, _keep = _u32_array(perm)
         h = C.c_void_p()
         _check(lib().vmn_rarray_permute(self._h, arr, C.byref(h)))
         return self._new(h)

@@ -665,38 +665,66 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts,
         atomicAdd(&counts[((size_t)w << c) + d], 1u);
     }
 }
-// exclusive prefix sum of each window's 2^c counts; one workgroup per window.  offsets has
-// 2^c + 1 entries per window; cursor is a copy of the first 2^c.
-__global__ void __launch_bounds__(BLOCK) k_bucket_offsets(u32* __restrict__ offsets, u32* __restrict__ cursor,
-                                                          const u32* __restrict__ counts, int c) {
+// ---- generic exclusive scan of a u32 array (three tiny kernels; n up to a few million) ----------
+constexpr int SCAN_ITEMS = 16;                         // items per thread
+__global__ void __launch_bounds__(BLOCK) k_u32_blocksum(u32* __restrict__ bsum, const u32* __restrict__ in, size_t n) {
     __shared__ u32 part[BLOCK];
-    const size_t nb = (size_t)1 << c;
-    const u32* cnt = counts + ((size_t)blockIdx.x << c);
-    u32* off = offsets + (size_t)blockIdx.x * (nb + 1);
-    u32* cur = cursor + ((size_t)blockIdx.x << c);
-    size_t per = (nb + BLOCK - 1) / BLOCK;
-    size_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    size_t base = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * SCAN_ITEMS;
     u32 s = 0;
-    for (size_t i = lo; i < hi; ++i) s += cnt[i];
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += base + k < n ? in[base + k] : 0u;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = BLOCK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = part[0];
+}
+__global__ void k_u32_scan_top(u32* __restrict__ bsum, size_t nblocks, u32* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        u32 run = 0;
+        for (size_t i = 0; i < nblocks; ++i) {
+            u32 v = bsum[i];
+            bsum[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+}
+// out[i] = exclusive prefix; out2 (optional) receives a copy (the scatter cursors); out[n] = total
+__global__ void __launch_bounds__(BLOCK) k_u32_scan_apply(u32* __restrict__ out, u32* __restrict__ out2,
+                                                          const u32* __restrict__ in, const u32* __restrict__ bsum, size_t n) {
+    __shared__ u32 part[BLOCK];
+    size_t base = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 s = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0u;
+        s += v[k];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        u32 run = 0;
+        u32 run = bsum[blockIdx.x];
         for (int i = 0; i < BLOCK; ++i) {
-            u32 v = part[i];
+            u32 t = part[i];
             part[i] = run;
-            run += v;
+            run += t;
         }
-        off[nb] = run;
     }
     __syncthreads();
     u32 run = part[threadIdx.x];
-    for (size_t i = lo; i < hi; ++i) {
-        off[i] = run;
-        cur[i] = run;
-        run += cnt[i];
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) {
+            out[base + k] = run;
+            if (out2) out2[base + k] = run;
+        }
+        run += v[k];
+        if (base + k + 1 == n) out[n] = run;
     }
 }
+
+// sorted[cursor[bucket]++] = element index; one thread per (element, window); bucket = w*2^c + digit
 __global__ void __launch_bounds__(BLOCK) k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ cursor,
                                                           const u32* __restrict__ e, int ewords, size_t n, int c, int nwin) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -706,41 +734,79 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_scatter(u32* __restrict__ sort
         int w = (int)(t / n);
         u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
         u32 pos = atomicAdd(&cursor[((size_t)w << c) + d], 1u);
-        sorted[(size_t)w * n + pos] = (u32)i;
+        sorted[pos] = (u32)i;
     }
 }
-// B[win][d] = prod of x[i] over the bucket (one if empty; d = 0 is forced to one).
-template <int S>
+// digit 0 contributes nothing: drop those buckets' items
+__global__ void __launch_bounds__(BLOCK) k_bucket_drop_zero(u32* __restrict__ counts, int c, int nwin) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t < (size_t)nwin) counts[t << c] = 0;
+}
+// cnt_out[b] = ceil(cnt_in[b] / F); maxcnt = max over b
+__global__ void __launch_bounds__(BLOCK) k_task_counts(u32* __restrict__ cnt_out, const u32* __restrict__ cnt_in,
+                                                       size_t nbuckets, u32 F, u32* __restrict__ maxcnt) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    u32 v = 0;
+    if (t < nbuckets) {
+        v = (cnt_in[t] + F - 1) / F;
+        cnt_out[t] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(maxcnt, v);
+}
+
+// One level of the per-bucket product tree.  Bucket b owns cnt_in[b] items at off_in[b]; output item
+// (b, j) = product of its input items [jF, (j+1)F) and lands at off_out[b] + j.  One lane per output
+// item, so a bucket of any size is spread over ceil(size/F) lanes: no lane ever walks a long bucket
+// (skewed digits -- a short top window, equal exponents -- would otherwise serialise on one lane).
+// FIRST: input items are rows of x selected through `sorted`; otherwise rows of `in`.
+template <int S, bool FIRST>
 __global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
-k_bucket_products(u32* __restrict__ B, const u32* __restrict__ x, const u32* __restrict__ sorted,
-                  const u32* __restrict__ offsets, size_t n, int c, int nwin, const u32* __restrict__ nmod, u32 n0inv,
-                  const u32* __restrict__ one_m) {
+k_bucket_level(u32* __restrict__ out, const u32* __restrict__ in, const u32* __restrict__ sorted,
+               const u32* __restrict__ off_in, const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
+               size_t nbuckets, size_t total_out, u32 F, const u32* __restrict__ nmod, u32 n0inv) {
     constexpr int W = stride_for_limbs(S);
     extern __shared__ u32 lds[];
     u32* bl = lds + threadIdx.x;
     u32 nn[S];
     load_modulus<S>(nn, nmod);
-    const size_t nb = (size_t)1 << c;
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool live = t < nb * nwin;
-    size_t tc = live ? t : nb * nwin - 1;
-    size_t w = tc >> c, d = tc & (nb - 1);
-    const u32* off = offsets + w * (nb + 1);
-    u32 lo = off[d], hi = d == 0 ? lo : off[d + 1];
-    const u32* idx = sorted + w * n;
-    u32 acc[S];
-    if (hi > lo) {
-        load_elem<S>(acc, x + (size_t)idx[lo] * W);
-    } else {
-#pragma unroll
-        for (int j = 0; j < S; ++j) acc[j] = one_m[j];
+    bool live = t < total_out;
+    size_t tc = live ? t : total_out - 1;
+    // b = last bucket with off_out[b] <= tc  (empty buckets share their successor's offset)
+    size_t lo = 0, hi = nbuckets;                 // invariant: off_out[lo] <= tc < off_out[hi] (off_out[nbuckets] = total)
+    while (hi - lo > 1) {
+        size_t mid = (lo + hi) >> 1;
+        if (off_out[mid] <= tc) lo = mid; else hi = mid;
     }
-    for (u32 k = lo + 1; k < hi; ++k) {
-        load_elem_to_lds<S>(bl, x + (size_t)idx[k] * W);
+    size_t b = lo;
+    u32 j = (u32)(tc - off_out[b]);
+    u32 start = off_in[b] + j * F;
+    u32 end = off_in[b] + cnt_in[b];
+    if (end > start + F) end = start + F;
+    u32 acc[S];
+    auto row = [&](u32 k) -> const u32* { return FIRST ? in + (size_t)sorted[k] * W : in + (size_t)k * W; };
+    load_elem<S>(acc, row(start));
+    for (u32 k = start + 1; k < end; ++k) {
+        load_elem_to_lds<S>(bl, row(k));
         mont_mul<S>(acc, acc, bl, nn, n0inv);
     }
     canonicalize<S>(acc, nmod);
-    if (live) store_elem<S>(B + t * W, acc);
+    if (live) store_elem<S>(out + t * W, acc);
+}
+// B[b] = the bucket's single remaining item, or one if it is empty
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_bucket_finalize(uint4* __restrict__ B, const uint4* __restrict__ items,
+                                                           const u32* __restrict__ off_in, const u32* __restrict__ cnt_in,
+                                                           size_t nbuckets, const uint4* __restrict__ one_row) {
+    constexpr int CPR = stride_for_limbs(S) / 4;
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t total = nbuckets * CPR;
+    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
+        size_t b = t / CPR;
+        int ch = (int)(t % CPR);
+        B[t] = cnt_in[b] ? items[(size_t)off_in[b] * CPR + ch] : one_row[ch];
+    }
 }
 // overwrite element 0 of every segment with `one` (the d = 0 slot of the suffix products)
 template <int S>

@@ -210,6 +210,21 @@ extern "C" int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launch
     return VMN_OK;
 }
 
+extern "C" int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len) {
+    ARG_CHECK(ctx && buf && len > 0, "null argument");
+    VMN_TRY(timing_collect(ctx));
+    std::string out;
+    for (auto& kv : ctx->timing_acc) {
+        char line[160];
+        snprintf(line, sizeof(line), "%s %ld %.4f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    size_t k = std::min(out.size(), len - 1);
+    memcpy(buf, out.data(), k);
+    buf[k] = 0;
+    return VMN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // moduli and groups
 // ------------------------------------------------------------------------------------------------
@@ -1192,27 +1207,98 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
     const int c = pick_bucket_bits(n, ebits);
     const int nwin = (ebits + c - 1) / c;
     const size_t nb = (size_t)1 << c;
-    DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx);
-    // counts | cursor : nwin*nb each ; offsets : nwin*(nb+1)
-    VMN_TRY(meta.alloc((2 * (size_t)nwin * nb + (size_t)nwin * (nb + 1)) * sizeof(uint32_t)));
+    const size_t nbuckets = (size_t)nwin * nb;
+    const uint32_t F = 8;                              // fan-in of the per-bucket product tree
+    DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx), onerow(ctx);
+    // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | cntA[nb] | cntB[nb] | offA[nb+1] | offB[nb+1] | bsum | misc
+    const size_t scan_blocks = (nbuckets + (size_t)BLOCK * SCAN_ITEMS - 1) / ((size_t)BLOCK * SCAN_ITEMS);
+    VMN_TRY(meta.alloc((7 * (nbuckets + 1) + scan_blocks + 16) * sizeof(uint32_t)));
     uint32_t* counts = meta.as<uint32_t>();
-    uint32_t* cursor = counts + (size_t)nwin * nb;
-    uint32_t* offsets = cursor + (size_t)nwin * nb;
+    uint32_t* cursor = counts + (nbuckets + 1);
+    uint32_t* off0 = cursor + (nbuckets + 1);
+    uint32_t* cntA = off0 + (nbuckets + 1);
+    uint32_t* cntB = cntA + (nbuckets + 1);
+    uint32_t* offA = cntB + (nbuckets + 1);
+    uint32_t* offB = offA + (nbuckets + 1);
+    uint32_t* bsum = offB + (nbuckets + 1);
+    uint32_t* misc = bsum + scan_blocks;             // [0] = total, [1] = max count
     VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
-    VMN_TRY(buckets.alloc(2 * (size_t)nwin * nb * Wd * sizeof(uint32_t)));
+    VMN_TRY(buckets.alloc(2 * nbuckets * Wd * sizeof(uint32_t)));
     VMN_TRY(wres.alloc((size_t)nwin * Wd * sizeof(uint32_t)));
+    VMN_TRY(onerow.alloc(Wd * sizeof(uint32_t)));
+    VMN_HIP(hipMemsetAsync(onerow.p, 0, Wd * sizeof(uint32_t), ctx->stream));
+    VMN_HIP(hipMemcpyAsync(onerow.p, m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     uint32_t* B = buckets.as<uint32_t>();
-    uint32_t* Ssuf = B + (size_t)nwin * nb * Wd;
-    VMN_HIP(hipMemsetAsync(counts, 0, (size_t)nwin * nb * sizeof(uint32_t), ctx->stream));
+    uint32_t* Ssuf = B + nbuckets * Wd;
+    auto scan_u32 = [&](uint32_t* out, uint32_t* out2, const uint32_t* in) -> int {
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_u32_blocksum, (unsigned)scan_blocks, bsum, in, nbuckets));
+        hipLaunchKernelGGL(k_u32_scan_top, dim3(1), dim3(64), 0, ctx->stream, bsum, scan_blocks, misc);
+        VMN_HIP(hipGetLastError());
+        return launch_light(ctx, "expprod_sort", k_u32_scan_apply, (unsigned)scan_blocks, out, out2, in, (const uint32_t*)bsum, nbuckets);
+    };
+    // counting sort of (window, digit)
+    VMN_HIP(hipMemsetAsync(counts, 0, nbuckets * sizeof(uint32_t), ctx->stream));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, light_grid(ctx, n * nwin), counts, e_words, ewords, n, c, nwin));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_offsets, (unsigned)nwin, offsets, cursor, (const uint32_t*)counts, c));
+    VMN_TRY(scan_u32(off0, cursor, counts));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, light_grid(ctx, n * nwin), sorted.as<uint32_t>(), cursor,
                          e_words, ewords, n, c, nwin));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
+    // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item
+    const uint32_t* cnt_in = counts;
+    const uint32_t* off_in = off0;
+    uint32_t* cnt_out = cntA;
+    uint32_t* off_out = offA;
+    const uint32_t* items_in = x;
+    bool first = true;
+    size_t cap = (size_t)nwin * n / F + nbuckets + 1;        // items of level 1 (later levels are smaller)
+    VMN_TRY(itemsA.alloc(cap * Wd * sizeof(uint32_t)));
+    uint32_t* items_out = itemsA.as<uint32_t>();
+    uint32_t* items_other = nullptr;
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                   \
-    if (m.S == S_)                                                                                                   \
-        rc = launch(ctx, "expprod", k_bucket_products<S_>, grid_for(nb * nwin), lds_bytes(S_), B, x,                 \
-                    (const uint32_t*)sorted.as<uint32_t>(), (const uint32_t*)offsets, n, c, nwin, m.d_n, m.n0inv, m.d_one);
+    for (int level = 0; level < 64; ++level) {
+        VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_out, cnt_in, nbuckets, F, misc + 1));
+        VMN_TRY(scan_u32(off_out, (uint32_t*)nullptr, cnt_out));
+        uint32_t hm2[2];
+        VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        VMN_HIP(hipStreamSynchronize(ctx->stream));
+        const size_t total_out = hm2[0];
+        if (total_out > 0) {
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                      \
+    if (m.S == S_) {                                                                                                    \
+        rc = first ? launch(ctx, "expprod", k_bucket_level<S_, true>, grid_for(total_out), lds_bytes(S_), items_out,    \
+                            items_in, (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out, \
+                            nbuckets, total_out, F, m.d_n, m.n0inv)                                                     \
+                   : launch(ctx, "expprod", k_bucket_level<S_, false>, grid_for(total_out), lds_bytes(S_), items_out,   \
+                            items_in, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_out, nbuckets,     \
+                            total_out, F, m.d_n, m.n0inv);                                                              \
+    }
+            VMN_FOR_SIZES(X)
+#undef X
+            VMN_TRY(rc);
+        }
+        // the outputs become the next level's inputs
+        first = false;
+        items_in = items_out;
+        cnt_in = cnt_out;
+        off_in = off_out;
+        if (hm2[1] <= 1) break;
+        if (!items_other) {
+            size_t cap2 = total_out / F + nbuckets + 1;
+            VMN_TRY(itemsB.alloc(cap2 * Wd * sizeof(uint32_t)));
+            items_other = itemsB.as<uint32_t>();
+        }
+        std::swap(items_out, items_other);
+        cnt_out = (cnt_out == cntA) ? cntB : cntA;
+        off_out = (off_out == offA) ? offB : offA;
+    }
+    rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                  \
+    if (m.S == S_)                                                                                                  \
+        rc = launch_light(ctx, "expprod_agg", k_bucket_finalize<S_>, light_grid(ctx, nbuckets * (Wd / 4)),          \
+                          reinterpret_cast<uint4*>(B), reinterpret_cast<const uint4*>(items_in), off_in, cnt_in,    \
+                          nbuckets, reinterpret_cast<const uint4*>(onerow.p));
     VMN_FOR_SIZES(X)
 #undef X
     VMN_TRY(rc);

@@ -33,11 +33,24 @@ from __future__ import annotations
 from typing import List, Optional, Sequence
 
 
-def _inv_perm(pi: Sequence[int]) -> List[int]:
+def _inv_perm(pi):
+    try:
+        import numpy as np
+        if isinstance(pi, np.ndarray) or len(pi) > 4096:
+            a = np.asarray(pi, dtype=np.int64)
+            inv = np.empty(len(a), dtype=np.uint32)
+            inv[a] = np.arange(len(a), dtype=np.uint32)
+            return inv
+    except ImportError:      # pragma: no cover
+        pass
     inv = [0] * len(pi)
     for i, j in enumerate(pi):
         inv[j] = i
     return inv
+
+
+def _is_bytes(x) -> bool:
+    return isinstance(x, (bytes, bytearray))
 
 
 class _Base:
@@ -58,6 +71,12 @@ class _Base:
     def _div(self, a: int, b: int) -> int:
         return a * pow(b, -1, self.p) % self.p
 
+    def _eps_array(self):
+        """epsilon: N integers of ebitlen+vbitlen+rbitlen bits, as field elements (PoSBasicTW.java:470-475).
+        A random source may hand out big-endian bytes of the group's wire width directly (bulk path)."""
+        eps = self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)
+        return self.G.ringArray(eps if _is_bytes(eps) else [x % self.q for x in eps])
+
     def _ciph_expprod(self, w, E, ebits) -> List[int]:
         return [c.expProd(E, ebits) for c in w]
 
@@ -73,7 +92,7 @@ class PoSBasicTW(_Base):
         if pi is None:
             return
         G = self.G
-        self.pi = list(pi)
+        self.pi = pi
         # u_i = g^{r_pi(i)} * h_pi(i)
         self.r = G.ringArray(self.rand.ring_array(self.size))
         tmp1 = G.exp(g, self.r)
@@ -82,8 +101,7 @@ class PoSBasicTW(_Base):
         self.u = tmp2.permute(self.pi)
         tmp2.free()
         self.alpha = self.rand.ring_element()
-        self.epsilon_ints = self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)
-        self.epsilon = G.ringArray([x % self.q for x in self.epsilon_ints])
+        self.epsilon = self._eps_array()
         # A' = g^alpha * prod h_i^eps_i
         self.Ap = self._gexp(g, self.alpha) * h.expProd(self.epsilon, self.eps_bits) % self.p
 
@@ -96,8 +114,7 @@ class PoSBasicTW(_Base):
 
     def setBatchVector(self, e_ints: Sequence[int]):
         """:533-538 — e = first N values of ebitlen bits from the PRG (the values are the input here)."""
-        self.e_ints = list(e_ints)
-        self.e = self.G.ringArray(self.e_ints)
+        self.e = self.G.ringArray(e_ints if _is_bytes(e_ints) else list(e_ints))
 
     # ---- prover -------------------------------------------------------------------------------
     def commit(self):
@@ -199,12 +216,11 @@ class PoSCBasicTW(_Base):
     def setInstance(self, g: int, h, u, r=None, pi: Optional[Sequence[int]] = None):
         """:306-340."""
         self.g, self.h, self.u, self.r = g, h, u, r
-        self.pi = list(pi) if pi is not None else None
+        self.pi = pi
         self.size = h.size()
 
     def setBatchVector(self, e_ints: Sequence[int]):
-        self.e_ints = list(e_ints)
-        self.e = self.G.ringArray(self.e_ints)
+        self.e = self.G.ringArray(e_ints if _is_bytes(e_ints) else list(e_ints))
 
     def commit(self):
         """:363-529.  Returns (B, A', B', C', D')."""
@@ -220,8 +236,7 @@ class PoSCBasicTW(_Base):
         g_exp_x.free()
         h0_exp_y.free()
         self.alpha = self.rand.ring_element()
-        self.epsilon_ints = self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)
-        self.epsilon = G.ringArray([t % self.q for t in self.epsilon_ints])
+        self.epsilon = self._eps_array()
         self.Ap = self._gexp(g, self.alpha) * h.expProd(self.epsilon, self.eps_bits) % self.p
         self.beta = G.ringArray(self.rand.ring_array(self.size))
         xp = x.shiftPush(0)
@@ -293,20 +308,18 @@ class CCPoSBasicW(_Base):
     def setInstance(self, g: int, h, u, pkey: Sequence[int], w, wp, r=None, pi=None, s=None):
         self.g, self.h, self.u, self.pkey, self.w, self.wp = g, h, u, list(pkey), w, wp
         self.r, self.s = r, s
-        self.pi = list(pi) if pi is not None else None
+        self.pi = pi
         self.size = h.size()
 
     def setBatchVector(self, e_ints: Sequence[int]):
-        self.e_ints = list(e_ints)
-        self.e = self.G.ringArray(self.e_ints)
+        self.e = self.G.ringArray(e_ints if _is_bytes(e_ints) else list(e_ints))
 
     def commit(self):
         """:344-396.  Returns (A', B')."""
         G, g, h, p = self.G, self.g, self.h, self.p
         self.ipe = self.e.permute(_inv_perm(self.pi))
         self.alpha = self.rand.ring_element()
-        self.epsilon_ints = self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)
-        self.epsilon = G.ringArray([t % self.q for t in self.epsilon_ints])
+        self.epsilon = self._eps_array()
         self.Ap = self._gexp(g, self.alpha) * h.expProd(self.epsilon, self.eps_bits) % p
         width = len(self.pkey) // 2
         self.beta = [self.rand.ring_element() for _ in range(width)]

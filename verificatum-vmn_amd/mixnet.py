@@ -18,7 +18,16 @@ from typing import List, Sequence
 RAISED_BITLENGTH = 50        # ShufflerElGamalSession.java:75
 
 
-def inv_perm(pi: Sequence[int]) -> List[int]:
+def inv_perm(pi):
+    try:
+        import numpy as np
+        if isinstance(pi, np.ndarray) or len(pi) > 4096:
+            a = np.asarray(pi, dtype=np.int64)
+            inv = np.empty(len(a), dtype=np.uint32)
+            inv[a] = np.arange(len(a), dtype=np.uint32)
+            return inv
+    except ImportError:      # pragma: no cover
+        pass
     inv = [0] * len(pi)
     for i, j in enumerate(pi):
         inv[j] = i
@@ -59,7 +68,7 @@ class PermutationCommitment:
         tmp = G.exp(G.g, self.exponents)                     # pGroup.getg().exp(exponents)   :200
         self.identityCommitment = self.generators.mul(tmp)   # generators.mul(tmp)            :201
         tmp.free()
-        self.permutation = list(permutation)
+        self.permutation = permutation
         self.commitment = self.identityCommitment.permute(self.permutation)   # :215
         return self.commitment
 
@@ -100,3 +109,38 @@ class ShaRandomSource:
     def permutation(self, n: int) -> List[int]:
         keys = self.int_array(n, 64)
         return sorted(range(n), key=lambda i: (keys[i], i))
+
+
+class BulkRandomSource:
+    """numpy-backed random source for large N (benchmark): hands out big-endian byte blocks of the
+    group's wire width instead of Python integers, so that no per-element Python work happens.
+    Ring elements are uniform below 2^(bits(q)-1) <= q (top bit cleared): statistically as good for
+    a throughput run, and always in range."""
+
+    def __init__(self, seed: int, q: int, nbytes: int):
+        import numpy as np
+        self.np = np
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.q, self.nbytes = q, nbytes
+        self.qbits = q.bit_length()
+
+    def _block(self, n: int, bits: int) -> bytes:
+        np = self.np
+        a = np.zeros((n, self.nbytes), dtype=np.uint8)
+        nb = (bits + 7) // 8
+        a[:, self.nbytes - nb:] = self.rng.integers(0, 256, size=(n, nb), dtype=np.uint8)
+        if bits % 8:
+            a[:, self.nbytes - nb] &= (1 << (bits % 8)) - 1
+        return a.tobytes()
+
+    def int_array(self, n: int, bits: int) -> bytes:
+        return self._block(n, min(bits, self.qbits - 1))
+
+    def ring_array(self, n: int) -> bytes:
+        return self._block(n, self.qbits - 1)
+
+    def ring_element(self) -> int:
+        return int.from_bytes(self._block(1, self.qbits - 1), "big")
+
+    def permutation(self, n: int):
+        return self.rng.permutation(n).astype(self.np.uint32)
