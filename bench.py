@@ -62,6 +62,33 @@ def load_sub(entry, name):
     return m
 
 
+class ReplaySource:
+    """Random tape generated BEFORE the timed region and replayed in order.  Random generation (the
+    reference's K9 family: PRG / randomElementArray, VCR code that is not in the reference tree) is an
+    input of the measured path, not part of it."""
+
+    def __init__(self, src, plan):
+        from collections import deque
+        self.q = deque((kind, getattr(src, kind)(*args)) for kind, *args in plan)
+
+    def _next(self, kind):
+        k, v = self.q.popleft()
+        assert k == kind, f"tape out of order: wanted {kind}, recorded {k}"
+        return v
+
+    def permutation(self, n):
+        return self._next("permutation")
+
+    def ring_array(self, n):
+        return self._next("ring_array")
+
+    def ring_element(self):
+        return self._next("ring_element")
+
+    def int_array(self, n, bits):
+        return self._next("int_array")
+
+
 def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1):
     """ciphertexts/s of [A0 re-encrypt + PoS prove + PoS verify] (SURVEY.md §8a rows A0 + A1, width 1),
     device-resident arrays, n_e = n_v = 256, n_r = 100.  The op sequence is the reference's
@@ -83,7 +110,15 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1):
         a.free()
     phases = {}
     best = None
+    bulk = rnd
     for _ in range(steps):
+        EB = NE + NV + NR
+        rnd = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, s
+                                  ("ring_array", n), ("ring_element",), ("int_array", n, EB),   # r, alpha, epsilon
+                                  ("int_array", n, NE),                                         # e (batching vector)
+                                  ("ring_array", n), ("ring_array", n),                         # b, beta
+                                  ("ring_element",), ("ring_element",), ("ring_element",),      # gamma, delta, phi
+                                  ("int_array", 1, NV)])                                        # v (challenge)
         ctx.timing_reset()
         ctx.timing_enable(True)
         sync()

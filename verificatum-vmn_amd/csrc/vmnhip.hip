@@ -98,21 +98,77 @@ static int ensure_scratch(vmn_ctx* ctx, size_t bytes) {
     return VMN_OK;
 }
 
+// ---- stream-ordered caching allocator ------------------------------------------------------------
+static const size_t POOL_LIMIT = (size_t)96 << 30;      // keep at most 96 GB of freed blocks cached
+
+static void pool_release_all(vmn_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool) {
+        for (void* q : kv.second) (void)hipFree(q);
+    }
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+}
+static size_t pool_round(size_t bytes) { return bytes < 256 ? 256 : (bytes + 255) & ~(size_t)255; }
+static int pool_alloc(vmn_ctx* ctx, size_t bytes, void** out) {
+    bytes = pool_round(bytes);
+    auto it = ctx->pool.find(bytes);
+    if (it != ctx->pool.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        ctx->pool_bytes -= bytes;
+        return VMN_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        pool_release_all(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) {
+        set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? VMN_ERR_NOMEM : VMN_ERR_DEVICE;
+    }
+    return VMN_OK;
+}
+static void pool_free(vmn_ctx* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    bytes = pool_round(bytes);
+    if (ctx->pool_bytes + bytes > POOL_LIMIT) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool[bytes].push_back(p);
+    ctx->pool_bytes += bytes;
+}
+
+// Host<->device copies of small host objects, ordered on the context stream (pool blocks are recycled in
+// stream order, so a copy on the null stream could race with kernels still queued on the stream).
+static int h2d(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return VMN_OK;
+    VMN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VMN_HIP(hipStreamSynchronize(ctx->stream));          // src is pageable / may go out of scope
+    return VMN_OK;
+}
+static int d2h(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return VMN_OK;
+    VMN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VMN_HIP(hipStreamSynchronize(ctx->stream));
+    return VMN_OK;
+}
+
 // RAII device temporary on the context stream
 struct DevTmp {
     vmn_ctx* ctx;
     void* p = nullptr;
+    size_t bytes = 0;
     explicit DevTmp(vmn_ctx* c) : ctx(c) {}
-    int alloc(size_t bytes) {
-        VMN_HIP(hipMalloc(&p, bytes ? bytes : 16));
-        return VMN_OK;
+    int alloc(size_t nbytes) {
+        bytes = nbytes ? nbytes : 16;
+        return pool_alloc(ctx, bytes, &p);
     }
-    ~DevTmp() {
-        if (p) {
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipFree(p);
-        }
-    }
+    ~DevTmp() { pool_free(ctx, p, bytes); }
     template <typename T>
     T* as() { return reinterpret_cast<T*>(p); }
 };
@@ -154,6 +210,7 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
+    pool_release_all(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -336,9 +393,9 @@ extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->
 static size_t elem_words(const vmn_modulus& m) { return (size_t)stride_for_limbs(m.S); }
 static unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
-static int alloc_elems(const vmn_modulus& m, size_t n, uint32_t** d) {
-    VMN_HIP(hipMalloc(d, std::max<size_t>(n, 1) * elem_words(m) * sizeof(uint32_t)));
-    return VMN_OK;
+static size_t elems_bytes(const vmn_modulus& m, size_t n) { return std::max<size_t>(n, 1) * elem_words(m) * sizeof(uint32_t); }
+static int alloc_elems(vmn_ctx* ctx, const vmn_modulus& m, size_t n, uint32_t** d) {
+    return pool_alloc(ctx, elems_bytes(m, n), reinterpret_cast<void**>(d));
 }
 
 static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* be, size_t n, uint32_t* d_out,
@@ -383,22 +440,20 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 
 // one element (big-endian) -> device, M28 form
 static int import_one(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* be, uint32_t** d_out) {
-    VMN_TRY(alloc_elems(m, 1, d_out));
+    VMN_TRY(alloc_elems(ctx, m, 1, d_out));
     int ok = 1;
     int rc = import_be(ctx, m, nbytes, be, 1, *d_out, &ok);
-    if (rc != VMN_OK) {
-        (void)hipFree(*d_out);
-        *d_out = nullptr;
-        return rc;
-    }
-    if (!ok) {
-        (void)hipFree(*d_out);
-        *d_out = nullptr;
+    if (rc == VMN_OK && !ok) {
         set_error("scalar operand out of range");
-        return VMN_ERR_FORMAT;
+        rc = VMN_ERR_FORMAT;
     }
-    return VMN_OK;
+    if (rc != VMN_OK) {
+        pool_free(ctx, *d_out, elems_bytes(m, 1));
+        *d_out = nullptr;
+    }
+    return rc;
 }
+static void free_one(vmn_ctx* ctx, const vmn_modulus& m, uint32_t* d) { pool_free(ctx, d, elems_bytes(m, 1)); }
 
 static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, size_t ystride, size_t n,
                       uint32_t* out) {
@@ -476,7 +531,8 @@ static int new_garray(vmn_group* grp, size_t n, vmn_garray** out) {
     std::unique_ptr<vmn_garray> a(new vmn_garray());
     a->grp = grp;
     a->n = n;
-    VMN_TRY(alloc_elems(grp->P, n, &a->d));
+    a->bytes = elems_bytes(grp->P, n);
+    VMN_TRY(alloc_elems(grp->ctx, grp->P, n, &a->d));
     *out = a.release();
     return VMN_OK;
 }
@@ -484,21 +540,20 @@ static int new_rarray(vmn_group* grp, size_t n, vmn_rarray** out) {
     std::unique_ptr<vmn_rarray> a(new vmn_rarray());
     a->grp = grp;
     a->n = n;
-    VMN_TRY(alloc_elems(grp->Q, n, &a->d));
+    a->bytes = elems_bytes(grp->Q, n);
+    VMN_TRY(alloc_elems(grp->ctx, grp->Q, n, &a->d));
     *out = a.release();
     return VMN_OK;
 }
 
 extern "C" void vmn_garray_free(vmn_garray* a) {
     if (!a) return;
-    (void)hipStreamSynchronize(a->grp->ctx->stream);
-    if (a->d) (void)hipFree(a->d);
+    pool_free(a->grp->ctx, a->d, a->bytes);
     delete a;
 }
 extern "C" void vmn_rarray_free(vmn_rarray* a) {
     if (!a) return;
-    (void)hipStreamSynchronize(a->grp->ctx->stream);
-    if (a->d) (void)hipFree(a->d);
+    pool_free(a->grp->ctx, a->d, a->bytes);
     delete a;
 }
 extern "C" size_t vmn_garray_size(const vmn_garray* a) { return a ? a->n : 0; }
@@ -622,11 +677,7 @@ extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, s
     DevTmp ew(ctx);
     int rc = ew.alloc(ewords * sizeof(uint32_t));
     if (rc == VMN_OK) {
-        hipError_t he = hipMemcpy(ew.p, e.data(), ewords * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (he != hipSuccess) {
-            set_error("exponent upload failed: %s", hipGetErrorString(he));
-            rc = VMN_ERR_DEVICE;
-        }
+        rc = h2d(ctx, ew.p, e.data(), ewords * sizeof(uint32_t));
     }
     if (rc == VMN_OK) rc = modpow_words(ctx, g->P, x->d, ew.as<uint32_t>(), ewords, 0, ebits, x->n, r->d);
     if (rc != VMN_OK) {
@@ -715,7 +766,7 @@ static int gather_rows(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* in, c
     if (n_out == 0) return VMN_OK;
     DevTmp didx(ctx);
     VMN_TRY(didx.alloc(n_out * sizeof(uint32_t)));
-    VMN_HIP(hipMemcpy(didx.p, idx.data(), n_out * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VMN_TRY(h2d(ctx, didx.p, idx.data(), n_out * sizeof(uint32_t)));
     int cpr = (int)(elem_words(m) / 4);
     return launch_light(ctx, "gather", k_gather, light_grid(ctx, n_out * cpr), reinterpret_cast<uint4*>(out),
                         reinterpret_cast<const uint4*>(in), didx.as<uint32_t>(), reinterpret_cast<const uint4*>(d_fill),
@@ -759,8 +810,7 @@ extern "C" int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, 
     std::vector<uint32_t> idx(x->n);
     for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
     int rc = arr_gather<vmn_garray>(x, g->P, idx, d_el, new_garray, vmn_garray_free, out);
-    (void)hipStreamSynchronize(g->ctx->stream);
-    (void)hipFree(d_el);
+    free_one(g->ctx, g->P, d_el);
     return rc;
 }
 extern "C" int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out) {
@@ -772,8 +822,7 @@ extern "C" int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, 
     std::vector<uint32_t> idx(x->n);
     for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
     int rc = arr_gather<vmn_rarray>(x, g->Q, idx, d_el, new_rarray, vmn_rarray_free, out);
-    (void)hipStreamSynchronize(g->ctx->stream);
-    (void)hipFree(d_el);
+    free_one(g->ctx, g->Q, d_el);
     return rc;
 }
 extern "C" int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to, vmn_garray** out) {
@@ -820,9 +869,9 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
     if (len == 0) {       // empty product = one, empty sum = zero
         std::vector<uint32_t> row(Wd, 0);
         if (mul) {
-            VMN_HIP(hipMemcpy(row.data(), m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            VMN_TRY(d2h(ctx, row.data(), m.d_one, m.S * sizeof(uint32_t)));
         }
-        for (size_t s = 0; s < nseg; ++s) VMN_HIP(hipMemcpy(d_out + s * Wd, row.data(), Wd * sizeof(uint32_t), hipMemcpyHostToDevice));
+        for (size_t s = 0; s < nseg; ++s) VMN_TRY(h2d(ctx, d_out + s * Wd, row.data(), Wd * sizeof(uint32_t)));
         return VMN_OK;
     }
     const size_t max_lanes = (size_t)ctx->num_cus * blocks_per_cu(m.S) * BLOCK;
@@ -958,8 +1007,7 @@ extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, cons
     vmn_rarray* r = nullptr;
     int rc = new_rarray(g, x->n, &r);
     if (rc == VMN_OK) rc = ring_elementwise(g->ctx, g->Q, x->d, y->d, d_v, 2, x->n, r->d);
-    (void)hipStreamSynchronize(g->ctx->stream);
-    (void)hipFree(d_v);
+    free_one(g->ctx, g->Q, d_v);
     if (rc != VMN_OK) {
         if (r) vmn_rarray_free(r);
         return rc;
@@ -1347,7 +1395,7 @@ extern "C" int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_
     be_ints_to_words(exps_be, ebytes, x->n, ewords, hw);
     DevTmp ew(ctx);
     VMN_TRY(ew.alloc(std::max<size_t>(hw.size(), 1) * sizeof(uint32_t)));
-    if (!hw.empty()) VMN_HIP(hipMemcpy(ew.p, hw.data(), hw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VMN_TRY(h2d(ctx, ew.p, hw.data(), hw.size() * sizeof(uint32_t)));
     return expprod_words(g, x->d, ew.as<uint32_t>(), ewords, ebits, x->n, out_be);
 }
 
@@ -1364,17 +1412,17 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     const size_t Wd = elem_words(m);
     DevTmp ew(ctx), pw(ctx);
     VMN_TRY(ew.alloc(m.NW * sizeof(uint32_t)));
-    VMN_HIP(hipMemcpy(ew.p, g->Q.n_words.data(), m.NW * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VMN_TRY(h2d(ctx, ew.p, g->Q.n_words.data(), m.NW * sizeof(uint32_t)));
     VMN_TRY(pw.alloc(2 * x->n * Wd * sizeof(uint32_t)));
     uint32_t* powers = pw.as<uint32_t>();
     uint32_t* ones = powers + x->n * Wd;
     VMN_TRY(modpow_words(ctx, m, x->d, ew.as<uint32_t>(), m.NW, 0, g->Q.nbits, x->n, powers));
     std::vector<uint32_t> idx(x->n, 0xffffffffu);
     std::vector<uint32_t> one_row(Wd, 0);
-    VMN_HIP(hipMemcpy(one_row.data(), m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    VMN_TRY(d2h(ctx, one_row.data(), m.d_one, m.S * sizeof(uint32_t)));
     DevTmp fill(ctx);
     VMN_TRY(fill.alloc(Wd * sizeof(uint32_t)));
-    VMN_HIP(hipMemcpy(fill.p, one_row.data(), Wd * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VMN_TRY(h2d(ctx, fill.p, one_row.data(), Wd * sizeof(uint32_t)));
     VMN_TRY(gather_rows(ctx, m, powers, idx, fill.as<uint32_t>(), ones));
     return compare_arrays(ctx, m, powers, ones, x->n, all_members);
 }

@@ -47,6 +47,10 @@ struct vmn_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     uint32_t* flags = nullptr;            // small device word array for verdicts / range flags
+    // stream-ordered caching allocator: freed device blocks are kept by size and handed out again
+    // (all work of a context is on one stream, so reuse is ordered after the previous user)
+    std::map<size_t, std::vector<void*>> pool;
+    size_t pool_bytes = 0;
     std::unordered_set<const void*> lds_attr_set;
     bool timing = false;
     std::vector<vmn::TimingRec> recs;
@@ -86,10 +90,12 @@ struct vmn_garray {
     vmn_group* grp = nullptr;
     uint32_t* d = nullptr;     // n * W words, M28 form mod p
     size_t n = 0;
+    size_t bytes = 0;          // allocation size (pool key)
 };
 
 struct vmn_rarray {
     vmn_group* grp = nullptr;
     uint32_t* d = nullptr;     // n * W words, M28 form mod q
     size_t n = 0;
+    size_t bytes = 0;
 };
