@@ -24,10 +24,21 @@ import sys
 
 
 P0REG = 2   # column 0 is pinned to v[2:3]: inline asm cannot name the low half of a 64-bit operand
+SQR_BLK = 8  # rows per block of the squaring schedule
 
 
-def gen(S: int) -> str:
-    # operand numbering
+def _row(S: int, first: bool, j0: int = 0, blk: int = 0):
+    """Instruction list and operand lists of one row.
+
+    blk == 0: general multiplication row, multiplier b for every column.
+    blk  > 0: squaring row of the block of rows [j0, j0+blk): the row's own limb a_i multiplies the
+              columns of its block with b (= a_i) and the columns of later blocks with b2 (= 2 a_i);
+              columns before the block get no product (their cross terms were added, doubled, by the
+              earlier rows).  Every cross product a_i a_j is thus formed once (doubled) when i and j are in
+              different blocks and twice (plain) inside a block; only the multiplications differ from the
+              general row, the reduction half (m * N) is identical.
+    """
+    sqr = blk > 0
     P = lambda j: f"%{j}"                 # 0..S-1      u64 "+v"
     M = f"%{S}"                           # m           u32 "=&v"
     C = f"%{S + 1}"                       # c           u64 "=&v"
@@ -35,53 +46,74 @@ def gen(S: int) -> str:
     B = f"%{2 * S + 2}"                   # b limb      u32 "v"
     N = lambda j: f"%{2 * S + 3 + j}"     # N[j]        u32 "s"
     NI = f"%{3 * S + 3}"                  # n0inv       u32 "s"
+    B2 = f"%{3 * S + 4}"                  # 2*b         u32 "v"  (squaring rows only)
     MASK = "0xfffffff"                    # 2^28-1 as a 32-bit literal (saves an SGPR)
 
-    def body(first: bool):
-        L = []
-        def ab(j):   # pass 1 for column j
-            if first or j == S - 1:
-                L.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {B}, 0")
-            else:
-                L.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {B}, {P(j)}")
-        ab(0)
-        ab(1)
-        L.append(f"v_mul_lo_u32 {M}, v{P0REG}, {NI}")   # low dword of column 0 (operand 0 is pinned to v[P0REG:P0REG+1])
-        ab(2)
-        L.append(f"v_and_b32 {M}, {MASK}, {M}")
-        ab(3)
-        L.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
-        L.append(f"v_mad_u64_u32 {P(0)}, vcc, {M}, {N(1)}, {P(1)}")
-        L.append(f"v_lshrrev_b64 {C}, 28, {C}")
-        ab(4)
-        L.append(f"v_lshl_add_u64 {P(0)}, {P(0)}, 0, {C}")
-        # steady state: a*b for column j+3 is issued three slots before m*N consumes column j
-        for j in range(2, S):
-            if j + 3 < S:
-                ab(j + 3)
-            L.append(f"v_mad_u64_u32 {P(j - 1)}, vcc, {M}, {N(j)}, {P(j)}")
-        return L
+    L = []
+    emitted = set()
 
+    def ab(j):   # pass 1 for column j
+        if j in emitted or j >= S:
+            return
+        emitted.add(j)
+        if sqr and j < j0:
+            return                                    # no product for this column in this block
+        mult = B2 if (sqr and j >= j0 + blk) else B
+        if first or j == S - 1:
+            L.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {mult}, 0")
+        else:
+            L.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {mult}, {P(j)}")
+
+    ab(0)
+    ab(1)
+    L.append(f"v_mul_lo_u32 {M}, v{P0REG}, {NI}")   # low dword of column 0 (operand 0 is pinned to v[P0REG:P0REG+1])
+    ab(2)
+    L.append(f"v_and_b32 {M}, {MASK}, {M}")
+    ab(3)
+    L.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
+    L.append(f"v_mad_u64_u32 {P(0)}, vcc, {M}, {N(1)}, {P(1)}")
+    L.append(f"v_lshrrev_b64 {C}, 28, {C}")
+    ab(4)
+    L.append(f"v_lshl_add_u64 {P(0)}, {P(0)}, 0, {C}")
+    # steady state: a*b for column j+3 is issued three slots before m*N consumes column j
+    for j in range(2, S):
+        ab(j + 3)
+        L.append(f"v_mad_u64_u32 {P(j - 1)}, vcc, {M}, {N(j)}, {P(j)}")
+    return L
+
+
+def _emit(name: str, S: int, lines, first: bool, sqr: bool, tparams: str) -> str:
     out = []
+    extra = ", u32 b2" if sqr else ""
+    out.append(f"template <> __device__ __forceinline__ void {name}<{tparams}>(u64 (&P)[{S}], const u32 (&a)[{S}], u32 b{extra},\n"
+               f"        const u32 (&n)[{S}], u32 n0inv) {{")
+    out.append("    u32 m; u64 c;")
+    out.append("    asm volatile(")
+    for l in lines:
+        out.append(f'        "{l}\\n\\t"')
+    # in a "first" row of a squaring block only the columns that get a product are written before being read
+    cons = lambda j: ("=&" if first else "+") + ("{v[%d:%d]}" % (P0REG, P0REG + 1) if j == 0 else "v")
+    outs = ", ".join([f'"{cons(j)}"(P[{j}])' for j in range(S)] + ['"=&v"(m)', '"=&v"(c)'])
+    ins = ", ".join([f'"v"(a[{j}])' for j in range(S)] + ['"v"(b)'] + [f'"s"(n[{j}])' for j in range(S)]
+                    + ['"s"(n0inv)'] + (['"v"(b2)'] if sqr else []))
+    out.append(f"        : {outs}")
+    out.append(f"        : {ins}")
+    out.append('        : "vcc");')
+    out.append("}")
+    out.append("")
+    return "\n".join(out)
+
+
+def gen(S: int) -> str:
+    parts = []
     for first in (True, False):
         name = f"mont_row_asm_{'first' if first else 'next'}"
-        lines = body(first)
-        out.append(f"template <> __device__ __forceinline__ void {name}<{S}>(u64 (&P)[{S}], const u32 (&a)[{S}], u32 b,\n"
-                   f"        const u32 (&n)[{S}], u32 n0inv) {{")
-        out.append("    u32 m; u64 c;")
-        out.append("    asm volatile(")
-        for l in lines:
-            out.append(f'        "{l}\\n\\t"')
-        cons = lambda j: ("=&" if first else "+") + ("{v[%d:%d]}" % (P0REG, P0REG + 1) if j == 0 else "v")
-        outs = ", ".join([f'"{cons(j)}"(P[{j}])' for j in range(S)] + ['"=&v"(m)', '"=&v"(c)'])
-        ins = ", ".join([f'"v"(a[{j}])' for j in range(S)] + ['"v"(b)'] + [f'"s"(n[{j}])' for j in range(S)]
-                        + ['"s"(n0inv)'])
-        out.append(f"        : {outs}")
-        out.append(f"        : {ins}")
-        out.append('        : "vcc");')
-        out.append("}")
-        out.append("")
-    return "\n".join(out)
+        parts.append(_emit(name, S, _row(S, first), first, False, f"{S}"))
+    # squaring rows: the very first row (all columns fresh), then one variant per block
+    parts.append(_emit("mont_sqr_row_asm_first", S, _row(S, True, 0, SQR_BLK), True, True, f"{S}"))
+    for j0 in range(0, S, SQR_BLK):
+        parts.append(_emit("mont_sqr_row_asm", S, _row(S, False, j0, SQR_BLK), False, True, f"{S}, {j0}"))
+    return "\n".join(parts)
 
 
 def render(sizes) -> str:

@@ -78,6 +78,14 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[S], const u32 (&a)[S], const u
     normalize_columns<S>(r, T);
 }
 
+// r = a^2 / R mod N; the lane's LDS column must hold a copy of a
+template <int S>
+__device__ __forceinline__ void mont_sqr(u32 (&r)[S], const u32 (&a)[S], const u32* bl, const u32 (&n)[S], u32 n0inv) {
+    u64 T[S];
+    mont_sqr_columns<S>(T, a, bl, BLOCK, n, n0inv);
+    normalize_columns<S>(r, T);
+}
+
 // ---------------------------------------------------------------------------------------------
 // radix conversion between packed 32-bit words (NW words, little-endian) and 28-bit limbs
 // ---------------------------------------------------------------------------------------------
@@ -329,7 +337,7 @@ k_modpow(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict
 #pragma unroll 1
             for (int s = 0; s < wbits; ++s) {
                 regs_to_lds<S>(bl, a);
-                mont_mul<S>(a, a, bl, nn, n0inv);
+                mont_sqr<S>(a, a, bl, nn, n0inv);
             }
             d = exp_digit(ep, ewords, wi * wbits, wbits);
             load_elem_to_lds<S>(bl, mytab + (size_t)d * W);
