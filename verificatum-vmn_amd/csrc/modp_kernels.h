@@ -492,9 +492,11 @@ k_ring_elementwise(u32* __restrict__ out, const u32* __restrict__ x, const u32* 
 //   k_scan_apply  : per chunk, replay the recurrence from the incoming value and store x[i]
 // `rev`: element i of a segment is read/written at position seglen-1-i (suffix scans of K3).
 // ---------------------------------------------------------------------------------------------
-template <int S>
+// WANT_X = false: Etot[c] = prod of the chunk's e.   WANT_X = true: Xtot[c] = value reached from 0.
+// (Two launches for recLin: one accumulator per kernel keeps a + columns + accumulator within 256 VGPRs.)
+template <int S, bool WANT_X>
 __global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
-k_scan_totals(u32* __restrict__ Etot, u32* __restrict__ Xtot, const u32* __restrict__ e, const u32* __restrict__ b,
+k_scan_totals(u32* __restrict__ tot, const u32* __restrict__ e, const u32* __restrict__ b,
               size_t n, size_t C, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
               const u32* __restrict__ one_m) {
     constexpr int W = stride_for_limbs(S);
@@ -507,31 +509,24 @@ k_scan_totals(u32* __restrict__ Etot, u32* __restrict__ Xtot, const u32* __restr
     bool live = c < nchunks;
     size_t cc = live ? c : nchunks - 1;
     size_t lo = cc * C, hi = lo + C < n ? lo + C : n;
-    u32 E[S], X[S];
+    u32 A[S];
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-        E[j] = one_m[j];
-        X[j] = 0;
-    }
+    for (int j = 0; j < S; ++j) A[j] = WANT_X ? 0u : one_m[j];
     for (size_t i = lo; i < lo + C; ++i) {          // uniform trip count; short chunks idle at the end
         if (i < hi) {
             size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
             load_elem_to_lds<S>(bl, e + pos * W);
-            mont_mul<S>(E, E, bl, nn, n0inv);
-            if (b) {
-                u32 t[S], bb[S];
-                mont_mul<S>(t, X, bl, nn, n0inv);
-                canonicalize<S>(t, nmod);
+            mont_mul<S>(A, A, bl, nn, n0inv);
+            if constexpr (WANT_X) {
+                canonicalize<S>(A, nmod);
+                u32 bb[S];
                 load_elem<S>(bb, b + pos * W);
-                mod_add<S>(X, t, bb, nmod);
+                mod_add<S>(A, A, bb, nmod);
             }
         }
     }
-    canonicalize<S>(E, nmod);
-    if (live) {
-        store_elem<S>(Etot + c * W, E);
-        if (b) store_elem<S>(Xtot + c * W, X);
-    }
+    canonicalize<S>(A, nmod);
+    if (live) store_elem<S>(tot + c * W, A);
 }
 
 // incoming: per-chunk inclusive results of the level above (chunk c starts from incoming[c-1]),

@@ -1049,10 +1049,14 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     uint32_t* Xtot = Etot + nchunks * Wd;
     uint32_t* inc = Xtot + nchunks * Wd;
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                     \
-    if (m.S == S_)                                                                                                     \
-        rc = launch(ctx, "scan", k_scan_totals<S_>, grid_for(nchunks), lds_bytes(S_), Etot, Xtot, e, b, n, C, seglen, rev, \
-                    m.d_n, m.n0inv, m.d_one);
+#define X(S_, NW_)                                                                                                      \
+    if (m.S == S_) {                                                                                                    \
+        rc = launch(ctx, "scan", k_scan_totals<S_, false>, grid_for(nchunks), lds_bytes(S_), Etot, e, b, n, C, seglen,  \
+                    rev, m.d_n, m.n0inv, m.d_one);                                                                      \
+        if (rc == VMN_OK && b)                                                                                          \
+            rc = launch(ctx, "scan", k_scan_totals<S_, true>, grid_for(nchunks), lds_bytes(S_), Xtot, e, b, n, C,       \
+                        seglen, rev, m.d_n, m.n0inv, m.d_one);                                                          \
+    }
     VMN_FOR_SIZES(X)
 #undef X
     VMN_TRY(rc);
