@@ -139,7 +139,7 @@ void vmn_rarray_free(vmn_rarray* a);
 int vmn_rarray_mul(const vmn_rarray* x, const vmn_rarray* y, vmn_rarray** out);
 int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarray** out);
 int vmn_rarray_neg(const vmn_rarray* x, vmn_rarray** out);
-/* x.mulAdd(v, y): out[i] = x[i]*v + y[i] with scalar v (big-endian, exp_bytes). */
+/* x.mulAdd(v, y): out[i] = x[i]*v + y[i] with scalar v (big-endian, exp_bytes); y == NULL: out[i] = x[i]*v. */
 int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, const vmn_rarray* y, vmn_rarray** out);
 /* b.recLin(e): x[0] = b[0], x[i] = x[i-1]*e[i] + b[i]; last = x[n-1] (may be NULL). */
 int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_rarray** out_x, uint8_t* last_be);
@@ -151,6 +151,8 @@ int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be);
 int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out);
 int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out);
 int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal);
+int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be);
+int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out);
 
 /* ---- partial results for multi-GPU sharding --------------------------------
  * Each rank holds a contiguous shard; expProd/prod partials are single elements that the host

@@ -355,9 +355,21 @@ class PRingElementArray(_ArrayBase):
         _check(lib().vmn_rarray_neg(self._h, C.byref(h)))
         return self._new(h)
 
-    def mulAdd(self, v: int, other: "PRingElementArray") -> "PRingElementArray":
+    def mulAdd(self, v: int, other: Optional["PRingElementArray"]) -> "PRingElementArray":
+        """x.mulAdd(v, y) = x*v + y ; other=None: x*v."""
         h = C.c_void_p()
-        _check(lib().vmn_rarray_mul_add(self._h, int_to_be(v, self.group.nbytes), other._h, C.byref(h)))
+        _check(lib().vmn_rarray_mul_add(self._h, int_to_be(v, self.group.nbytes), other._h if other is not None else None,
+                                        C.byref(h)))
+        return self._new(h)
+
+    def get(self, i: int) -> int:
+        out = C.create_string_buffer(self.group.nbytes)
+        _check(lib().vmn_rarray_get(self._h, C.c_size_t(i), out))
+        return int.from_bytes(out.raw, "big")
+
+    def copyOfRange(self, start: int, end: int) -> "PRingElementArray":
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_copy_range(self._h, C.c_size_t(start), C.c_size_t(end), C.byref(h)))
         return self._new(h)
 
     def recLin(self, e: "PRingElementArray"):

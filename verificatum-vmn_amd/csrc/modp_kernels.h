@@ -439,7 +439,7 @@ k_reduce_strided(u32* __restrict__ out, const u32* __restrict__ x, size_t len, s
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8 element-wise ring kernels:  op 0: x + y   op 1: -x   op 2: x*v + y (v one element, stride 0)
+// K8 element-wise ring kernels:  op 0: x + y   op 1: -x   op 2: x*v + y (v one element)   op 3: x*v
 // ---------------------------------------------------------------------------------------------
 template <int S>
 __global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
@@ -477,8 +477,13 @@ k_ring_elementwise(u32* __restrict__ out, const u32* __restrict__ x, const u32* 
         u32 t[S], b[S];
         mont_mul<S>(t, a, bl, nn, n0inv);
         canonicalize<S>(t, nmod);
-        load_elem<S>(b, y + ec * W);
-        mod_add<S>(r, t, b, nmod);
+        if (op == 2) {
+            load_elem<S>(b, y + ec * W);
+            mod_add<S>(r, t, b, nmod);
+        } else {
+#pragma unroll
+            for (int j = 0; j < S; ++j) r[j] = t[j];
+        }
     }
     if (live) store_elem<S>(out + el * W, r);
 }

@@ -860,6 +860,32 @@ extern "C" int vmn_garray_get(const vmn_garray* x, size_t i, uint8_t* out_be) {
     return export_be(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d + i * elem_words(x->grp->P), 1, out_be);
 }
 
+extern "C" int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be) {
+    ARG_CHECK(x && out_be, "null argument");
+    ARG_CHECK(i < x->n, "index out of range");
+    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    return export_be(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d + i * elem_words(x->grp->Q), 1, out_be);
+}
+extern "C" int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out) {
+    ARG_CHECK(x && out, "null argument");
+    ARG_CHECK(from <= to && to <= x->n, "range out of bounds");
+    vmn_group* g = x->grp;
+    VMN_HIP(hipSetDevice(g->ctx->device));
+    vmn_rarray* r = nullptr;
+    VMN_TRY(new_rarray(g, to - from, &r));
+    if (to > from) {
+        hipError_t he = hipMemcpyAsync(r->d, x->d + from * elem_words(g->Q), (to - from) * elem_words(g->Q) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToDevice, g->ctx->stream);
+        if (he != hipSuccess) {
+            vmn_rarray_free(r);
+            set_error("copy failed: %s", hipGetErrorString(he));
+            return VMN_ERR_DEVICE;
+        }
+    }
+    *out = r;
+    return VMN_OK;
+}
+
 // ---- K5 / reductions -----------------------------------------------------------------------------
 // Reduce nseg segments of len elements each to nseg single elements (d_out: nseg rows).
 // mul = product, else sum.  Work buffers ping-pong inside one temporary.
@@ -998,15 +1024,15 @@ extern "C" int vmn_rarray_neg(const vmn_rarray* x, vmn_rarray** out) {
     return VMN_OK;
 }
 extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, const vmn_rarray* y, vmn_rarray** out) {
-    ARG_CHECK(x && y && v_be && out, "null argument");
-    ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
+    ARG_CHECK(x && v_be && out, "null argument");
+    ARG_CHECK(!y || (x->grp == y->grp && x->n == y->n), "arrays differ in group or size");
     vmn_group* g = x->grp;
     VMN_HIP(hipSetDevice(g->ctx->device));
     uint32_t* d_v = nullptr;
     VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, v_be, &d_v));
     vmn_rarray* r = nullptr;
     int rc = new_rarray(g, x->n, &r);
-    if (rc == VMN_OK) rc = ring_elementwise(g->ctx, g->Q, x->d, y->d, d_v, 2, x->n, r->d);
+    if (rc == VMN_OK) rc = ring_elementwise(g->ctx, g->Q, x->d, y ? y->d : nullptr, d_v, y ? 2 : 3, x->n, r->d);
     free_one(g->ctx, g->Q, d_v);
     if (rc != VMN_OK) {
         if (r) vmn_rarray_free(r);
