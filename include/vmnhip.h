@@ -120,6 +120,9 @@ int vmn_garray_equals(const vmn_garray* x, const vmn_garray* y, int* equal);
  * ref: P/mixnet/ShufflerElGamalSession.java:278, 684-703, 792; P/hvzk/PoSBasicTW.java:451, 637-638, 1031;
  * P/mixnet/PermutationCommitment.java:398-405, 462-469. */
 int vmn_garray_permute(const vmn_garray* x, const uint32_t* perm_host, vmn_garray** out);
+/* General gather: out[i] = X[idx[i]], i < n_out (n_out may differ from the array's size: a shard of a
+ * permuted array is a gather of the replicated input). */
+int vmn_garray_gather(const vmn_garray* x, const uint32_t* idx_host, size_t n_out, vmn_garray** out);
 int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, vmn_garray** out);
 int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to, vmn_garray** out);
 int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host, vmn_garray** out);
@@ -149,6 +152,7 @@ int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* 
 int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be);
 int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be);
 int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out);
+int vmn_rarray_gather(const vmn_rarray* x, const uint32_t* idx_host, size_t n_out, vmn_rarray** out);
 int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out);
 int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal);
 int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be);

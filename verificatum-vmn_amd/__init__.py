@@ -288,9 +288,9 @@ class PGroupElementArray(_ArrayBase):
 
     # K7
     def permute(self, perm: Sequence[int]) -> "PGroupElementArray":
-        arr, _keep = _u32_array(perm)
+        arr, _keep = _u32_array(perm)          # any length: a shard of a permuted array is a gather
         h = C.c_void_p()
-        _check(lib().vmn_garray_permute(self._h, arr, C.byref(h)))
+        _check(lib().vmn_garray_gather(self._h, arr, C.c_size_t(len(perm)), C.byref(h)))
         return self._new(h)
 
     def shiftPush(self, el: int) -> "PGroupElementArray":
@@ -401,7 +401,7 @@ class PRingElementArray(_ArrayBase):
     def permute(self, perm: Sequence[int]) -> "PRingElementArray":
         arr, _keep = _u32_array(perm)
         h = C.c_void_p()
-        _check(lib().vmn_rarray_permute(self._h, arr, C.byref(h)))
+        _check(lib().vmn_rarray_gather(self._h, arr, C.c_size_t(len(perm)), C.byref(h)))
         return self._new(h)
 
     def shiftPush(self, el: int) -> "PRingElementArray":

@@ -787,19 +787,27 @@ static int arr_gather(const Arr* x, const vmn_modulus& m, const std::vector<uint
     return VMN_OK;
 }
 
-extern "C" int vmn_garray_permute(const vmn_garray* x, const uint32_t* perm_host, vmn_garray** out) {
-    ARG_CHECK(x && out && (perm_host || x->n == 0), "null argument");
+extern "C" int vmn_garray_gather(const vmn_garray* x, const uint32_t* idx_host, size_t n_out, vmn_garray** out) {
+    ARG_CHECK(x && out && (idx_host || n_out == 0), "null argument");
     VMN_HIP(hipSetDevice(x->grp->ctx->device));
-    std::vector<uint32_t> idx(perm_host, perm_host + x->n);
-    for (uint32_t v : idx) ARG_CHECK(v < x->n, "permutation index out of range");
+    std::vector<uint32_t> idx(idx_host, idx_host + n_out);
+    for (uint32_t v : idx) ARG_CHECK(v < x->n, "gather index out of range");
     return arr_gather<vmn_garray>(x, x->grp->P, idx, nullptr, new_garray, vmn_garray_free, out);
 }
-extern "C" int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out) {
-    ARG_CHECK(x && out && (perm_host || x->n == 0), "null argument");
+extern "C" int vmn_rarray_gather(const vmn_rarray* x, const uint32_t* idx_host, size_t n_out, vmn_rarray** out) {
+    ARG_CHECK(x && out && (idx_host || n_out == 0), "null argument");
     VMN_HIP(hipSetDevice(x->grp->ctx->device));
-    std::vector<uint32_t> idx(perm_host, perm_host + x->n);
-    for (uint32_t v : idx) ARG_CHECK(v < x->n, "permutation index out of range");
+    std::vector<uint32_t> idx(idx_host, idx_host + n_out);
+    for (uint32_t v : idx) ARG_CHECK(v < x->n, "gather index out of range");
     return arr_gather<vmn_rarray>(x, x->grp->Q, idx, nullptr, new_rarray, vmn_rarray_free, out);
+}
+extern "C" int vmn_garray_permute(const vmn_garray* x, const uint32_t* perm_host, vmn_garray** out) {
+    ARG_CHECK(x, "null argument");
+    return vmn_garray_gather(x, perm_host, x->n, out);
+}
+extern "C" int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out) {
+    ARG_CHECK(x, "null argument");
+    return vmn_rarray_gather(x, perm_host, x->n, out);
 }
 extern "C" int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, vmn_garray** out) {
     ARG_CHECK(x && el_be && out, "null argument");
