@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_${1:-r01}
 N=${2:-262144}
 mkdir -p $OUT
-CMD="python3 bench.py --steps 1 --warmup 1 --n $N --mix-n 0 --no-cpu"
+CMD="python3 bench.py --steps 1 --warmup 1 --elements $N --mix-elements 0 --skip-cpu"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1 &&
