@@ -111,6 +111,11 @@ int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t 
 /* K4  X.mul(Y).  ref: P/mixnet/ShufflerElGamalSession.java:273, 789, 850 (the re-encryption);
  * P/hvzk/PoSBasicTW.java:448, 610, 648, 1029, 1033. */
 int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out);
+/* Element-wise inverse X.inv() by Montgomery's batch inversion (two product scans + one host inversion
+ * of the total + 2N products instead of N exponentiations).  Serves the negative modified Lagrange
+ * coefficients of pGroup.expProd(bases[], integers[], bitLength),
+ * ref: P/elgamal/DistrElGamalSessionBasic.java:487-502 (K3'), :406-452 (coefficients may be negative). */
+int vmn_garray_inv(const vmn_garray* x, vmn_garray** out);
 /* K5  X.prod() -> one element.  ref: P/hvzk/PoSBasicTW.java:1013; P/hvzk/PoSCBasicTW.java:667. */
 int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be);
 /* K6  X.equals(Y).  ref: P/hvzk/PoSBasicTW.java:1035; P/hvzk/PoSCBasicTW.java:697. */

@@ -274,3 +274,58 @@ class CCPoS(_Base):
             t = pyref.exp_prod(pyref.mul(col, raisedh, p), k_E, p)
             ok = ok and (pow(ABc, v, p) * (Bpc * Ap_rho % p) % p) == (pow(pk, (-k_B[c % width]) % q, p) * t % p * g_term % p)
         return ok
+
+
+# ------------------------------------------------------------------------------------------------
+# Verifiable threshold decryption (row A6).  P/elgamal/DistrElGamalSessionBasic.java:318-344 (prodFactor),
+# :358-452 (modified Lagrange integers), :465-503 (combineDecryptionFactors), :524-526, :683-685, :707-709
+# (batching), :693-700, :718-727 (checks); P/elgamal/DistrElGamalSession.java:365-385, :536-538.
+# ------------------------------------------------------------------------------------------------
+_ODD_PRIMES = [3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97]
+
+
+def prod_factor(q: int, k: int) -> int:
+    res, prime, i = 1, 2, 0
+    while prime <= k:
+        a = b = 1
+        while b <= k:
+            a, b = b, b * prime
+        res *= a
+        prime = _ODD_PRIMES[i]
+        i += 1
+    return res * res % q
+
+
+def lagrange_integers(q: int, correct, k: int, threshold: int):
+    pf = prod_factor(q, k)
+    out = []
+    for i in range(1, k + 1):
+        if len(out) >= threshold:
+            break
+        if not correct[i]:
+            continue
+        res, t = pf, 0
+        for l in range(1, k + 1):
+            if t >= threshold:
+                break
+            if correct[l]:
+                if l != i:
+                    res = res * l * pow(l - i, -1, q) % q
+                t += 1
+        out.append(res - q if q - res < res else res)
+    return out
+
+
+def decryption_factors(u, x_j: int, p: int, q: int, k: int):
+    return pyref.exp_scalar(u, (-x_j) * pow(prod_factor(q, k), -1, q) % q, p)
+
+
+def combine_decryption_factors(factors, correct, k: int, threshold: int, p: int, q: int):
+    bases = [factors[i] for i in range(1, k + 1) if correct[i]][:threshold]
+    ints = lagrange_integers(q, correct, k, threshold)
+    n = len(bases[0])
+    out = [1] * n
+    for base, c in zip(bases, ints):
+        for i in range(n):
+            out[i] = out[i] * pow(base[i], c, p) % p          # Python's pow handles negative exponents (inverse)
+    return out

@@ -281,6 +281,12 @@ class PGroupElementArray(_ArrayBase):
         _check(lib().vmn_garray_prod(self._h, out))
         return int.from_bytes(out.raw, "big")
 
+    def inv(self) -> "PGroupElementArray":
+        """Element-wise inverse (batch inversion)."""
+        h = C.c_void_p()
+        _check(lib().vmn_garray_inv(self._h, C.byref(h)))
+        return self._new(h)
+
     def equals(self, other: "PGroupElementArray") -> bool:
         eq = C.c_int()
         _check(lib().vmn_garray_equals(self._h, other._h, C.byref(eq)))

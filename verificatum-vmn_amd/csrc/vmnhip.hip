@@ -1141,6 +1141,78 @@ extern "C" int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out) {
     return VMN_OK;
 }
 
+// ---- batch inversion (serves K3' with negative coefficients) ----------------------------------------
+extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
+    ARG_CHECK(x && out, "null argument");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = g->ctx;
+    const vmn_modulus& m = g->P;
+    const size_t Wd = elem_words(m);
+    const size_t n = x->n;
+    VMN_HIP(hipSetDevice(ctx->device));
+    vmn_garray* r = nullptr;
+    VMN_TRY(new_garray(g, n, &r));
+    if (n == 0) {
+        *out = r;
+        return VMN_OK;
+    }
+    int rc = VMN_OK;
+    {
+        // P[i] = x0..xi, S[i] = xi..x(n-1);  inv(x_i) = P[i-1] * S[i+1] * (P[n-1])^-1
+        DevTmp ps(ctx), sh(ctx), tinv(ctx), onerow(ctx);
+        rc = ps.alloc(2 * n * Wd * sizeof(uint32_t));
+        if (rc == VMN_OK) rc = sh.alloc(2 * n * Wd * sizeof(uint32_t));
+        if (rc == VMN_OK) rc = onerow.alloc(Wd * sizeof(uint32_t));
+        uint32_t* Pf = ps.as<uint32_t>();
+        uint32_t* Sf = Pf + n * Wd;
+        uint32_t* Psh = sh.as<uint32_t>();
+        uint32_t* Ssh = Psh + n * Wd;
+        if (rc == VMN_OK) rc = scan_affine(ctx, m, x->d, nullptr, n, n, 0, Pf);
+        if (rc == VMN_OK) rc = scan_affine(ctx, m, x->d, nullptr, n, n, 1, Sf);
+        // total -> host, invert with the host Montgomery context (x^(p-2)), back to the device
+        std::vector<uint8_t> tbe(g->nbytes);
+        if (rc == VMN_OK) rc = export_be(ctx, m, g->nbytes, Pf + (n - 1) * Wd, 1, tbe.data());
+        if (rc == VMN_OK) {
+            const hostbig::Mont& hm = *m.hm;
+            Big t = hostbig::from_be(tbe.data(), g->nbytes, m.NW);
+            if (hostbig::is_zero(t)) {
+                set_error("vmn_garray_inv: an element is not invertible");
+                rc = VMN_ERR_FORMAT;
+            } else {
+                Big e = m.n_words;                    // p - 2
+                Big two(m.NW, 0);
+                two[0] = 2;
+                hostbig::sub_in(e, two);
+                Big ti = hm.from_mont(hm.pow_m(hm.to_mont(t), e));
+                hostbig::to_be(ti, tbe.data(), g->nbytes);
+                uint32_t* d_t = nullptr;
+                rc = import_one(ctx, m, g->nbytes, tbe.data(), &d_t);
+                if (rc == VMN_OK) {
+                    if (hipMemsetAsync(onerow.p, 0, Wd * sizeof(uint32_t), ctx->stream) != hipSuccess ||
+                        hipMemcpyAsync(onerow.p, m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                        set_error("vmn_garray_inv: device copy failed");
+                        rc = VMN_ERR_DEVICE;
+                    }
+                    std::vector<uint32_t> idx(n);
+                    for (size_t i = 0; i < n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
+                    if (rc == VMN_OK) rc = gather_rows(ctx, m, Pf, idx, onerow.as<uint32_t>(), Psh);
+                    for (size_t i = 0; i < n; ++i) idx[i] = i + 1 == n ? 0xffffffffu : (uint32_t)(i + 1);
+                    if (rc == VMN_OK) rc = gather_rows(ctx, m, Sf, idx, onerow.as<uint32_t>(), Ssh);
+                    if (rc == VMN_OK) rc = mul_arrays(ctx, m, Psh, Ssh, Wd, n, Pf);          // reuse Pf as scratch
+                    if (rc == VMN_OK) rc = mul_arrays(ctx, m, Pf, d_t, 0, n, r->d);
+                    free_one(ctx, m, d_t);
+                }
+            }
+        }
+    }
+    if (rc != VMN_OK) {
+        vmn_garray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
 // ---- K2 fixed base ---------------------------------------------------------------------------------
 static int pick_fixed_window(size_t n, int ebits, size_t row_bytes) {
     int best = 4;
