@@ -116,17 +116,125 @@ def gen(S: int) -> str:
     return "\n".join(parts)
 
 
-def render(sizes) -> str:
+# ------------------------------------------------------------------------------------------------
+# Two lanes per element (moduli > 2072 bits): lane h of a pair (h = lane & 1) holds limbs / columns
+# [h*L, (h+1)*L) of the S = 2L limbs.  One row, executed by both lanes in lockstep:
+#     pass 1:  P[j] = a[j]*b + P[j]                        (local columns; b is the same for both lanes)
+#     m        = (P[0] * n0inv) & mask  taken from the EVEN lane (DPP quad_perm [0,0,2,2])
+#     c        = m*N[0] + P[0]                              even lane: low 28 bits zero, c>>28 carries into new column 0
+#                                                           odd lane : this is the value of global column L, which
+#                                                                      becomes the even lane's new column L-1
+#     pass 2:  P[j-1] = m*N[j] + P[j]   (j = 1..L-1)
+#     P[0]    += (c >> 28) & evenmask                       (only the even lane has a carry)
+#     P[L-1]   = dpp_from_odd(c) & evenmask                 even lane receives the odd lane's c, odd lane gets the
+#                                                           fresh zero of the top column
+# Column 0, column L-1 and c are pinned to fixed register pairs because DPP moves 32-bit halves.
+# A VALU write followed by a DPP read of the same VGPR needs 2 wait states: every DPP below is preceded by
+# "s_nop 1" (hardware does not interlock this hazard).
+# ------------------------------------------------------------------------------------------------
+PAIR_P0, PAIR_PT, PAIR_C = 2, 4, 6      # v[2:3] column 0, v[4:5] column L-1, v[6:7] c
+
+
+def _row_pair(L: int, first: bool):
+    P = lambda j: f"%{j}"                 # 0..L-1      u64
+    M = f"%{L}"                           # m
+    A = lambda j: f"%{L + 2 + j}"         # a[j]
+    B = f"%{2 * L + 2}"                   # b
+    N = lambda j: f"%{2 * L + 3 + j}"     # N[j] (VGPR: differs between the lanes of a pair)
+    NI = f"%{3 * L + 3}"                  # n0inv (SGPR)
+    EM = f"%{3 * L + 4}"                  # even-lane mask (0xffffffff on even lanes, 0 on odd lanes)
+    C = f"%{L + 1}"
+    MASK = "0xfffffff"
+    out = []
+    emitted = set()
+
+    def ab(j):
+        if j in emitted or j >= L:
+            return
+        emitted.add(j)
+        out.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {B}, " + ("0" if first else P(j)))
+
+    ab(0)
+    ab(1)
+    out.append(f"v_mul_lo_u32 {M}, v{PAIR_P0}, {NI}")
+    ab(2)
+    out.append(f"v_and_b32 {M}, {MASK}, {M}")
+    ab(3)
+    ab(4)
+    out.append("s_nop 1")
+    out.append(f"v_mov_b32_dpp {M}, {M} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+    ab(5)
+    ab(6)
+    out.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
+    for j in range(1, L):
+        ab(j + 6)
+        out.append(f"v_mad_u64_u32 {P(j - 1)}, vcc, {M}, {N(j)}, {P(j)}")
+        if j == 2:
+            # hand the odd lane's c to the even lane's column L-1 ... after pass 2 has consumed the old column L-1
+            pass
+    # column L-1 was consumed by the last pass-2 multiply-add; now refill it from c
+    out.append("s_nop 1")
+    out.append(f"v_mov_b32_dpp v{PAIR_PT}, v{PAIR_C} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
+    out.append(f"v_mov_b32_dpp v{PAIR_PT + 1}, v{PAIR_C + 1} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
+    out.append(f"v_lshrrev_b64 {C}, 28, {C}")
+    out.append(f"v_and_b32 v{PAIR_PT}, {EM}, v{PAIR_PT}")
+    out.append(f"v_and_b32 v{PAIR_PT + 1}, {EM}, v{PAIR_PT + 1}")
+    out.append(f"v_and_b32 v{PAIR_C}, {EM}, v{PAIR_C}")
+    out.append(f"v_and_b32 v{PAIR_C + 1}, {EM}, v{PAIR_C + 1}")
+    out.append(f"v_lshl_add_u64 {P(0)}, {P(0)}, 0, {C}")
+    return out
+
+
+def gen_pair(S: int) -> str:
+    L = S // 2
+    assert 2 * L == S and L >= 8
+    parts = []
+    for first in (True, False):
+        name = f"mont_pair_row_asm_{'first' if first else 'next'}"
+        lines = _row_pair(L, first)
+        o = []
+        o.append(f"template <> __device__ __forceinline__ void {name}<{L}>(u64 (&P)[{L}], const u32 (&a)[{L}], u32 b,\n"
+                 f"        const u32 (&n)[{L}], u32 n0inv, u32 evenmask) {{")
+        o.append("    u32 m; u64 c;")
+        o.append("    asm volatile(")
+        for l in lines:
+            o.append(f'        "{l}\\n\\t"')
+
+        def cons(j):
+            pre = "=&" if first else "+"
+            if j == 0:
+                return pre + "{v[%d:%d]}" % (PAIR_P0, PAIR_P0 + 1)
+            if j == L - 1:
+                return pre + "{v[%d:%d]}" % (PAIR_PT, PAIR_PT + 1)
+            return pre + "v"
+        outs = ", ".join([f'"{cons(j)}"(P[{j}])' for j in range(L)] + ['"=&v"(m)', '"=&{v[%d:%d]}"(c)' % (PAIR_C, PAIR_C + 1)])
+        ins = ", ".join([f'"v"(a[{j}])' for j in range(L)] + ['"v"(b)'] + [f'"v"(n[{j}])' for j in range(L)]
+                        + ['"s"(n0inv)', '"v"(evenmask)'])
+        o.append(f"        : {outs}")
+        o.append(f"        : {ins}")
+        o.append('        : "vcc");')
+        o.append("}")
+        o.append("")
+        parts.append("\n".join(o))
+    return "\n".join(parts)
+
+
+def render(sizes, pair_sizes=()) -> str:
     parts = ["// GENERATED by tools/gen_mont_asm.py " + " ".join(map(str, sizes)) + " -- do not edit.",
              "// One Montgomery row as a single asm statement: 2*S v_mad_u64_u32 + 5 VALU, see the generator."]
     for S in sizes:
         parts.append(gen(S))
+    for S in pair_sizes:
+        parts.append(f"// two lanes per element, S = {S} limbs ({S // 2} per lane)")
+        parts.append(gen_pair(S))
     return "\n".join(parts) + "\n"
 
 
 def main():
-    sizes = [int(x) for x in sys.argv[1:]] or [74]
-    sys.stdout.write(render(sizes))
+    args = sys.argv[1:]
+    pair = [int(x[1:]) for x in args if x.startswith("p")]
+    sizes = [int(x) for x in args if not x.startswith("p")] or [74]
+    sys.stdout.write(render(sizes, pair))
 
 
 if __name__ == "__main__":

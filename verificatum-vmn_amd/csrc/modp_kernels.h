@@ -1,13 +1,18 @@
 // modp_kernels.h — gfx950 kernels over arrays of residues in M28 form (see mont28.h).
 //
-// Device array layout ("AoS"): element i occupies W = stride_for_limbs(S) consecutive 32-bit
-// words at base + i*W; limb j (28 bits) in word j, padding words zero.  Elements are contiguous
-// so that gathers / permutations / sharding by contiguous ranges move whole 16-byte-aligned
-// rows, and one lane streams its element with 16-byte loads.
+// Device array layout ("AoS"): element i occupies W consecutive 32-bit words at base + i*W, limb j
+// (28 bits) in one word, padding words zero.  Elements are contiguous so that gathers / permutations /
+// sharding by contiguous ranges move whole 16-byte-aligned rows.
 //
-// Every arithmetic kernel is "one element per lane": the lane's multiplicand sits in VGPRs, its
-// multiplier is staged in LDS as lds[limb*256 + tid] (bank = tid mod 32: conflict-free
-// ds_read_b32 / ds_write_b32), the modulus limbs are wave-uniform SGPRs.
+// Two execution geometries, chosen by the modulus size (struct Cfg):
+//   LPE = 1  one element per lane (moduli up to 2072 bits, S <= 74 limbs): the lane's multiplicand sits
+//            in VGPRs, its multiplier is staged in LDS as lds[limb*256 + tid], the modulus limbs are
+//            wave-uniform SGPRs.
+//   LPE = 2  two lanes per element (3072-bit moduli, S = 110): a lane holds L = S/2 limbs and columns
+//            (a + columns + modulus half = 4L = 220 VGPRs; one lane would need 330 > the 256
+//            architectural VGPRs).  The lanes of a pair exchange the reduction factor and one column
+//            per row through DPP (mont28.h / the generator).  In memory a lane's share is LW = 56
+//            words (16-byte aligned), W = 2*LW.
 #pragma once
 #include "mont28.h"
 
@@ -15,75 +20,219 @@ namespace vmn {
 
 constexpr int BLOCK = 256;   // threads per workgroup: 4 waves, one per SIMD
 
+template <int S_, int LPE_>
+struct Cfg {
+    static constexpr int S = S_;                        // limbs per element
+    static constexpr int LPE = LPE_;                    // lanes per element
+    static constexpr int L = S_ / LPE_;                 // limbs per lane
+    static constexpr int LW = stride_for_limbs(L);      // words of one lane's share in memory
+    static constexpr int W = LPE_ * LW;                 // words per element in memory
+    static constexpr int EPB = BLOCK / LPE_;            // elements per workgroup
+    static constexpr int MINW = 2;                      // waves per SIMD the kernels are built for
+    static_assert(S_ % LPE_ == 0, "limbs must split evenly over the lanes of an element");
+};
+
+// What a lane needs to know about its place: element slot in the workgroup, which half it holds, its
+// LDS column (limb i of the element's multiplier is bl[i*EPB]).
+template <class C>
+struct Lane {
+    int eslot;        // element slot within the workgroup
+    int half;         // 0 .. LPE-1
+    u32 evenmask;     // LPE = 2: 0xffffffff on the even lane of a pair, 0 on the odd lane
+    u32* bl;
+    __device__ __forceinline__ explicit Lane(u32* lds) {
+        eslot = threadIdx.x / C::LPE;
+        half = threadIdx.x % C::LPE;
+        evenmask = half == 0 ? 0xffffffffu : 0u;
+        bl = lds + eslot;
+    }
+};
+
+// value of the even / odd lane of each pair, delivered to both lanes
+__device__ __forceinline__ u32 from_even(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true); }
+__device__ __forceinline__ u32 from_odd(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true); }
+
 // ---------------------------------------------------------------------------------------------
 // element movement helpers
 // ---------------------------------------------------------------------------------------------
-template <int S>
-__device__ __forceinline__ void load_elem(u32 (&a)[S], const u32* __restrict__ p) {
-    constexpr int W = stride_for_limbs(S);
-    const uint4* q = reinterpret_cast<const uint4*>(p);
+template <class C>
+__device__ __forceinline__ void load_elem(u32 (&a)[C::L], const u32* __restrict__ p, const Lane<C>& ln) {
+    const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
 #pragma unroll
-    for (int k = 0; k < W / 4; ++k) {
+    for (int k = 0; k < C::LW / 4; ++k) {
         uint4 v = q[k];
-        if (4 * k + 0 < S) a[4 * k + 0] = v.x;
-        if (4 * k + 1 < S) a[4 * k + 1] = v.y;
-        if (4 * k + 2 < S) a[4 * k + 2] = v.z;
-        if (4 * k + 3 < S) a[4 * k + 3] = v.w;
+        if (4 * k + 0 < C::L) a[4 * k + 0] = v.x;
+        if (4 * k + 1 < C::L) a[4 * k + 1] = v.y;
+        if (4 * k + 2 < C::L) a[4 * k + 2] = v.z;
+        if (4 * k + 3 < C::L) a[4 * k + 3] = v.w;
     }
 }
-template <int S>
-__device__ __forceinline__ void store_elem(u32* __restrict__ p, const u32 (&a)[S]) {
-    constexpr int W = stride_for_limbs(S);
-    uint4* q = reinterpret_cast<uint4*>(p);
+template <class C>
+__device__ __forceinline__ void store_elem(u32* __restrict__ p, const u32 (&a)[C::L], const Lane<C>& ln) {
+    uint4* q = reinterpret_cast<uint4*>(p + ln.half * C::LW);
 #pragma unroll
-    for (int k = 0; k < W / 4; ++k) {
+    for (int k = 0; k < C::LW / 4; ++k) {
         uint4 v;
-        v.x = 4 * k + 0 < S ? a[4 * k + 0] : 0;
-        v.y = 4 * k + 1 < S ? a[4 * k + 1] : 0;
-        v.z = 4 * k + 2 < S ? a[4 * k + 2] : 0;
-        v.w = 4 * k + 3 < S ? a[4 * k + 3] : 0;
+        v.x = 4 * k + 0 < C::L ? a[4 * k + 0] : 0;
+        v.y = 4 * k + 1 < C::L ? a[4 * k + 1] : 0;
+        v.z = 4 * k + 2 < C::L ? a[4 * k + 2] : 0;
+        v.w = 4 * k + 3 < C::L ? a[4 * k + 3] : 0;
         q[k] = v;
     }
 }
-// global element -> this lane's LDS column (multiplier operand)
-template <int S>
-__device__ __forceinline__ void load_elem_to_lds(u32* bl, const u32* __restrict__ p) {
-    constexpr int W = stride_for_limbs(S);
-    const uint4* q = reinterpret_cast<const uint4*>(p);
+// global element -> the element's LDS column (multiplier operand); each lane moves its own share
+template <class C>
+__device__ __forceinline__ void load_elem_to_lds(const Lane<C>& ln, const u32* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
+    u32* dst = ln.bl + ln.half * C::L * C::EPB;
 #pragma unroll
-    for (int k = 0; k < W / 4; ++k) {
+    for (int k = 0; k < C::LW / 4; ++k) {
         uint4 v = q[k];
-        if (4 * k + 0 < S) bl[(4 * k + 0) * BLOCK] = v.x;
-        if (4 * k + 1 < S) bl[(4 * k + 1) * BLOCK] = v.y;
-        if (4 * k + 2 < S) bl[(4 * k + 2) * BLOCK] = v.z;
-        if (4 * k + 3 < S) bl[(4 * k + 3) * BLOCK] = v.w;
+        if (4 * k + 0 < C::L) dst[(4 * k + 0) * C::EPB] = v.x;
+        if (4 * k + 1 < C::L) dst[(4 * k + 1) * C::EPB] = v.y;
+        if (4 * k + 2 < C::L) dst[(4 * k + 2) * C::EPB] = v.z;
+        if (4 * k + 3 < C::L) dst[(4 * k + 3) * C::EPB] = v.w;
     }
 }
-template <int S>
-__device__ __forceinline__ void regs_to_lds(u32* bl, const u32 (&a)[S]) {
+template <class C>
+__device__ __forceinline__ void regs_to_lds(const Lane<C>& ln, const u32 (&a)[C::L]) {
+    u32* dst = ln.bl + ln.half * C::L * C::EPB;
 #pragma unroll
-    for (int j = 0; j < S; ++j) bl[j * BLOCK] = a[j];
+    for (int j = 0; j < C::L; ++j) dst[j * C::EPB] = a[j];
 }
-template <int S>
-__device__ __forceinline__ void load_modulus(u32 (&n)[S], const u32* __restrict__ nmod) {
+// a small constant element (value v < 2^28) into the LDS column: limb 0 = v, the rest 0
+template <class C>
+__device__ __forceinline__ void small_to_lds(const Lane<C>& ln, u32 v) {
+    u32* dst = ln.bl + ln.half * C::L * C::EPB;
 #pragma unroll
-    for (int j = 0; j < S; ++j) n[j] = nmod[j];     // uniform address: scalar loads into SGPRs
+    for (int j = 0; j < C::L; ++j) dst[j * C::EPB] = (j == 0 && ln.half == 0) ? v : 0u;
+}
+// device constant (modulus-like layout) -> LDS column
+template <class C>
+__device__ __forceinline__ void const_to_lds(const Lane<C>& ln, const u32* __restrict__ c) {
+    u32* dst = ln.bl + ln.half * C::L * C::EPB;
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) dst[j * C::EPB] = c[ln.half * C::LW + j];
+}
+// this lane's share of a constant in modulus layout.  LPE = 1: uniform address => scalar loads into SGPRs.
+template <class C>
+__device__ __forceinline__ void load_modulus(u32 (&n)[C::L], const u32* __restrict__ nmod, const Lane<C>& ln) {
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) n[j] = C::LPE == 1 ? nmod[j] : nmod[ln.half * C::LW + j];
 }
 
-// r = a * (lane's LDS column) / R mod N, limbs normalised, value < 2N
-template <int S>
-__device__ __forceinline__ void mont_mul(u32 (&r)[S], const u32 (&a)[S], const u32* bl, const u32 (&n)[S], u32 n0inv) {
-    u64 T[S];
-    mont_mul_columns<S>(T, a, bl, BLOCK, n, n0inv);
-    normalize_columns<S>(r, T);
+// ---------------------------------------------------------------------------------------------
+// carry / borrow chains (within a lane, and across the two lanes of a pair)
+// ---------------------------------------------------------------------------------------------
+// out = limbs of sum_j v[j] 2^(28j) (+ carry-in), v[j] arbitrary 64-bit columns; returns the carry out
+template <int L>
+__device__ __forceinline__ u64 carry_sweep(u32 (&out)[L], const u64 (&v)[L], u64 cin) {
+    u64 c = cin;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        c += v[j];
+        out[j] = (u32)c & LIMB_MASK;
+        c >>= LIMB_BITS;
+    }
+    return c;
+}
+// Resolve lazy columns into 28-bit limbs.  Pair mode: the even lane's carry-out enters the odd lane's
+// column 0 (second sweep; the even lane repeats its sweep with carry 0 = same result).
+template <class C>
+__device__ __forceinline__ void normalize(u32 (&out)[C::L], const u64 (&T)[C::L], const Lane<C>& ln) {
+    u64 c = carry_sweep<C::L>(out, T, 0);
+    if constexpr (C::LPE == 2) {
+        u32 lo = from_even((u32)c) & ~ln.evenmask, hi = from_even((u32)(c >> 32)) & ~ln.evenmask;
+        carry_sweep<C::L>(out, T, ((u64)hi << 32) | lo);
+    }
+}
+// d = x - n (limbs, borrow-in bin = 0 / -1); returns borrow-out (0 / -1)
+template <int L>
+__device__ __forceinline__ int32_t borrow_sweep(u32 (&d)[L], const u32 (&x)[L], const u32 (&n)[L], int32_t bin) {
+    int32_t borrow = bin;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        int32_t v = (int32_t)x[j] - (int32_t)n[j] + borrow;      // limbs < 2^28: no int32 overflow
+        d[j] = (u32)v & LIMB_MASK;
+        borrow = v >> LIMB_BITS;
+    }
+    return borrow;
+}
+// element-wide x - n: d and the final borrow (0: x >= n, -1: x < n), identical on both lanes of a pair
+template <class C>
+__device__ __forceinline__ int32_t sub_full(u32 (&d)[C::L], const u32 (&x)[C::L], const u32 (&n)[C::L], const Lane<C>& ln) {
+    int32_t b = borrow_sweep<C::L>(d, x, n, 0);
+    if constexpr (C::LPE == 2) {
+        int32_t bin = (int32_t)(from_even((u32)b) & ~ln.evenmask);
+        b = borrow_sweep<C::L>(d, x, n, bin);
+        b = (int32_t)from_odd((u32)b);
+    }
+    return b;
+}
+// x (limbs, value < 2N) -> canonical x mod N (< N), branch-free
+template <class C>
+__device__ __forceinline__ void canonicalize(u32 (&x)[C::L], const u32 (&n)[C::L], const Lane<C>& ln) {
+    u32 d[C::L];
+    bool ge = sub_full<C>(d, x, n, ln) == 0;
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) x[j] = ge ? d[j] : x[j];
+}
+// r = a + b mod N (a, b canonical).  32-bit sums (limbs < 2^28, so a[j] + b[j] + carry < 2^30): the 64-bit
+// column sweep would double the live registers, which the pair geometry (modulus half in VGPRs) cannot afford.
+template <class C>
+__device__ __forceinline__ void mod_add(u32 (&r)[C::L], const u32 (&a)[C::L], const u32 (&b)[C::L], const u32 (&n)[C::L],
+                                        const Lane<C>& ln) {
+    // r may alias a or b: the carry of the even lane is computed without storing, then one storing sweep
+    u32 cin = 0;
+    if constexpr (C::LPE == 2) {
+        u32 c = 0;
+#pragma unroll
+        for (int j = 0; j < C::L; ++j) c = (c + a[j] + b[j]) >> LIMB_BITS;
+        cin = from_even(c) & ~ln.evenmask;
+    }
+    u32 c = cin;
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) {
+        c += a[j] + b[j];
+        r[j] = c & LIMB_MASK;
+        c >>= LIMB_BITS;
+    }
+    canonicalize<C>(r, n, ln);
+}
+// r = -a mod N
+template <class C>
+__device__ __forceinline__ void mod_neg(u32 (&r)[C::L], const u32 (&a)[C::L], const u32 (&n)[C::L], const Lane<C>& ln) {
+    u32 d[C::L];
+    sub_full<C>(d, n, a, ln);                    // N - a  (a < N)
+    u32 nz = 0;
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) nz |= a[j];
+    if constexpr (C::LPE == 2) nz = from_even(nz) | from_odd(nz);
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) r[j] = nz ? d[j] : 0u;
 }
 
-// r = a^2 / R mod N; the lane's LDS column must hold a copy of a
-template <int S>
-__device__ __forceinline__ void mont_sqr(u32 (&r)[S], const u32 (&a)[S], const u32* bl, const u32 (&n)[S], u32 n0inv) {
-    u64 T[S];
-    mont_sqr_columns<S>(T, a, bl, BLOCK, n, n0inv);
-    normalize_columns<S>(r, T);
+// r = a * (element's LDS column) / R mod N, limbs normalised, value < 2N
+template <class C>
+__device__ __forceinline__ void mont_mul(u32 (&r)[C::L], const u32 (&a)[C::L], const Lane<C>& ln, const u32 (&n)[C::L], u32 n0inv) {
+    u64 T[C::L];
+    if constexpr (C::LPE == 1) {
+        mont_mul_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
+    } else {
+        mont_mul_columns_pair<C::L>(T, a, ln.bl, C::EPB, n, n0inv, ln.evenmask);
+    }
+    normalize<C>(r, T, ln);
+}
+// r = a^2 / R mod N; the element's LDS column must hold a copy of a
+template <class C>
+__device__ __forceinline__ void mont_sqr(u32 (&r)[C::L], const u32 (&a)[C::L], const Lane<C>& ln, const u32 (&n)[C::L], u32 n0inv) {
+    u64 T[C::L];
+    if constexpr (C::LPE == 1) {
+        mont_sqr_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
+    } else {
+        mont_mul_columns_pair<C::L>(T, a, ln.bl, C::EPB, n, n0inv, ln.evenmask);   // pair mode: general product
+    }
+    normalize<C>(r, T, ln);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -110,6 +259,16 @@ __device__ __forceinline__ void limbs_to_words(u32 (&w)[NW], const u32 (&l)[S]) 
         if (j + 2 < S) acc |= (u64)l[j + 2] << (56 - sh);
         w[k] = (u32)acc;
     }
+}
+// word k of the element whose S limbs sit in the LDS column (any lane of the element may ask for any word)
+template <class C>
+__device__ __forceinline__ u32 word_from_lds(const Lane<C>& ln, int k) {
+    int bit = 32 * k, j = bit / 28, sh = bit % 28;
+    u64 acc = 0;
+    if (j < C::S) acc = (u64)ln.bl[j * C::EPB] >> sh;
+    if (j + 1 < C::S) acc |= (u64)ln.bl[(j + 1) * C::EPB] << (28 - sh);
+    if (j + 2 < C::S) acc |= (u64)ln.bl[(j + 2) * C::EPB] << (56 - sh);
+    return (u32)acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -147,141 +306,152 @@ __device__ __forceinline__ void store_be_word(uint8_t* __restrict__ p, long nbyt
     }
 }
 
+// this lane's limbs of the big-endian integer at src
+template <class C, int NW>
+__device__ __forceinline__ void limbs_from_be(u32 (&a)[C::L], const uint8_t* __restrict__ src, long nbytes, const Lane<C>& ln) {
+    if constexpr (C::LPE == 1) {
+        u32 w[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) w[k] = load_be_word(src, nbytes, k);
+        words_to_limbs<C::L, NW>(a, w);
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < C::L; ++j) {            // the word index depends on the lane's half: read from memory per limb
+            int bit = 28 * (ln.half * C::L + j), k = bit >> 5, sh = bit & 31;
+            u32 lo = k < NW ? load_be_word(src, nbytes, k) : 0u;
+            u32 hi = k + 1 < NW ? load_be_word(src, nbytes, k + 1) : 0u;
+            a[j] = (u32)((((u64)hi << 32) | lo) >> sh) & LIMB_MASK;
+        }
+    }
+}
+
 // flags[0] |= 1 if some value >= N ; flags[0] |= 2 if some value == 0 (only reported).
 // Out-of-range values are replaced by `one` (x = 1) -- the reference substitutes trivial values
 // for malformed input (P/hvzk/PoSBasicTW.java:794-815).
-template <int S, int NW>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C, int NW>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes, size_t n,
             const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ rr, u32* __restrict__ flags) {
-    constexpr int W = stride_for_limbs(S);
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
     const uint8_t* src = be + ec * nbytes;
-    u32 w[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) w[k] = load_be_word(src, (long)nbytes, k);
     u32 extra = 0;                                    // leading bytes beyond NW words must be zero
     for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) extra |= src[o];
-    u32 a[S];
-    words_to_limbs<S, NW>(a, w);
-    // range check: a < N  (borrow of a - N)
-    int32_t borrow = 0;
+    u32 a[C::L];
+    limbs_from_be<C, NW>(a, src, (long)nbytes, ln);
+    u32 d[C::L];
+    bool bad = sub_full<C>(d, a, nn, ln) == 0 || extra != 0;     // a >= N
     u32 nz = 0;
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-        int32_t v = (int32_t)a[j] - (int32_t)nn[j] + borrow;
-        borrow = v >> LIMB_BITS;
-        nz |= a[j];
-    }
-    bool bad = (borrow == 0) || extra != 0;     // a >= N
+    for (int j = 0; j < C::L; ++j) nz |= a[j];
+    if constexpr (C::LPE == 2) nz = from_even(nz) | from_odd(nz);
     if (live && bad) atomicOr(flags, 1u);
     if (live && nz == 0) atomicOr(flags, 2u);
     if (bad) {
 #pragma unroll
-        for (int j = 0; j < S; ++j) a[j] = j == 0 ? 1u : 0u;
+        for (int j = 0; j < C::L; ++j) a[j] = (j == 0 && ln.half == 0) ? 1u : 0u;
     }
-    // to Montgomery form: a * RR / R
-#pragma unroll
-    for (int j = 0; j < S; ++j) bl[j * BLOCK] = rr[j];
-    u32 r[S];
-    mont_mul<S>(r, a, bl, nn, n0inv);
-    canonicalize<S>(r, nmod);
-    if (live) store_elem<S>(out + el * W, r);
+    const_to_lds<C>(ln, rr);                          // to Montgomery form: a * RR / R
+    u32 r[C::L];
+    mont_mul<C>(r, a, ln, nn, n0inv);
+    canonicalize<C>(r, nn, ln);
+    if (live) store_elem<C>(out + el * C::W, r, ln);
 }
 
-template <int S, int NW>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+// r (canonical standard representative, limbs) -> words; pair mode goes through the LDS column
+template <class C, int NW, typename F>
+__device__ __forceinline__ void emit_words(const u32 (&r)[C::L], const Lane<C>& ln, F&& put) {
+    if constexpr (C::LPE == 1) {
+        u32 w[NW];
+        limbs_to_words<C::L, NW>(w, r);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) put(k, w[k]);
+    } else {
+        regs_to_lds<C>(ln, r);
+#pragma unroll 1
+        for (int k = ln.half; k < NW; k += C::LPE) put(k, word_from_lds<C>(ln, k));
+    }
+}
+
+template <class C, int NW>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_export_be(uint8_t* __restrict__ be, size_t nbytes, const u32* __restrict__ in, size_t n,
             const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
-    u32 a[S];
-    load_elem<S>(a, in + ec * W);
-#pragma unroll
-    for (int j = 0; j < S; ++j) bl[j * BLOCK] = j == 0 ? 1u : 0u;       // multiply by 1: leaves the Montgomery domain
-    u32 r[S];
-    mont_mul<S>(r, a, bl, nn, n0inv);
-    canonicalize<S>(r, nmod);
-    u32 w[NW];
-    limbs_to_words<S, NW>(w, r);
-    if (live) {
-        uint8_t* dst = be + el * nbytes;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) store_be_word(dst, (long)nbytes, k, w[k]);
+    u32 a[C::L];
+    load_elem<C>(a, in + ec * C::W, ln);
+    small_to_lds<C>(ln, 1u);                          // multiply by 1: leaves the Montgomery domain
+    u32 r[C::L];
+    mont_mul<C>(r, a, ln, nn, n0inv);
+    canonicalize<C>(r, nn, ln);
+    uint8_t* dst = be + ec * nbytes;
+    emit_words<C, NW>(r, ln, [&](int k, u32 w) { if (live) store_be_word(dst, (long)nbytes, k, w); });
+    if (live && ln.half == 0) {
         for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) dst[o] = 0;
     }
 }
 
 // M28 form -> packed little-endian words of the standard representative (exponent use)
-template <int S, int NW>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C, int NW>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_to_words(u32* __restrict__ out, const u32* __restrict__ in, size_t n, const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
-    u32 a[S];
-    load_elem<S>(a, in + ec * W);
-#pragma unroll
-    for (int j = 0; j < S; ++j) bl[j * BLOCK] = j == 0 ? 1u : 0u;
-    u32 r[S];
-    mont_mul<S>(r, a, bl, nn, n0inv);
-    canonicalize<S>(r, nmod);
-    u32 w[NW];
-    limbs_to_words<S, NW>(w, r);
-    if (live) {
-        uint4* dst = reinterpret_cast<uint4*>(out + el * NW);
-#pragma unroll
-        for (int k = 0; k < NW / 4; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-    }
+    u32 a[C::L];
+    load_elem<C>(a, in + ec * C::W, ln);
+    small_to_lds<C>(ln, 1u);
+    u32 r[C::L];
+    mont_mul<C>(r, a, ln, nn, n0inv);
+    canonicalize<C>(r, nn, ln);
+    u32* dst = out + ec * NW;
+    emit_words<C, NW>(r, ln, [&](int k, u32 w) { if (live) dst[k] = w; });
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4: out[i] = x[i] * y[i]        (ystride = 0: every x[i] times the single element y)
 // ---------------------------------------------------------------------------------------------
-template <int S>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_mul(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ y, size_t ystride, size_t n,
       const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
-    u32 a[S];
-    load_elem<S>(a, x + ec * W);
-    load_elem_to_lds<S>(bl, y + ec * ystride);
-    u32 r[S];
-    mont_mul<S>(r, a, bl, nn, n0inv);
-    canonicalize<S>(r, nmod);
-    if (live) store_elem<S>(out + el * W, r);
+    u32 a[C::L];
+    load_elem<C>(a, x + ec * C::W, ln);
+    load_elem_to_lds<C>(ln, y + ec * ystride);
+    u32 r[C::L];
+    mont_mul<C>(r, a, ln, nn, n0inv);
+    canonicalize<C>(r, nn, ln);
+    if (live) store_elem<C>(out + el * C::W, r, ln);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1a / K1b: out[i] = x[i] ^ e[i]   fixed-window (wbits), left to right, per-lane exponents.
+// K1a / K1b: out[i] = x[i] ^ e[i]   fixed-window (wbits), left to right, per-element exponents.
 //   e: packed little-endian words, element i at e + i*estride (estride = 0: one shared exponent)
-//   tab: scratch of gridDim.x*BLOCK*(2^wbits)*W words: the lane's table of x^0..x^(2^w-1), one
-//        contiguous row per entry (the lane gathers its entry with 16-byte loads).
-// Persistent grid: a workgroup loops over tiles of BLOCK elements.
+//   tab: scratch of gridDim.x*EPB*(2^wbits)*W words: the element's table of x^0..x^(2^w-1), one
+//        contiguous row per entry (gathered with 16-byte loads).
+// Persistent grid: a workgroup loops over tiles of EPB elements.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 exp_digit(const u32* __restrict__ ep, int ewords, int pos, int wbits) {
     int k = pos >> 5, sh = pos & 31;
@@ -291,70 +461,66 @@ __device__ __forceinline__ u32 exp_digit(const u32* __restrict__ ep, int ewords,
     return (u32)(both >> sh) & ((1u << wbits) - 1);
 }
 
-template <int S>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_modpow(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e, int ewords, size_t estride,
          int ebits, int wbits, size_t n, const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ one_m,
          u32* __restrict__ tab) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const size_t ntiles = (n + C::EPB - 1) / C::EPB;
     const int tsize = 1 << wbits;
-    u32* mytab = tab + ((size_t)blockIdx.x * BLOCK + threadIdx.x) * (size_t)tsize * W;
+    u32* mytab = tab + ((size_t)blockIdx.x * C::EPB + ln.eslot) * (size_t)tsize * W;
     const int nwin = (ebits + wbits - 1) / wbits;
 
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        size_t el = t * BLOCK + threadIdx.x;
+        size_t el = t * C::EPB + ln.eslot;
         bool live = el < n;
         size_t ec = live ? el : n - 1;
         const u32* ep = e + ec * estride;
-        u32 a[S];
+        u32 a[C::L];
         // table: tab[0] = 1, tab[1] = x, tab[k] = tab[k-1] * x
-        load_elem<S>(a, x + ec * W);
+        load_elem<C>(a, x + ec * W, ln);
         {
-            u32 o[S];
-#pragma unroll
-            for (int j = 0; j < S; ++j) o[j] = one_m[j];
-            store_elem<S>(mytab, o);
+            u32 o[C::L];
+            load_modulus<C>(o, one_m, ln);
+            store_elem<C>(mytab, o, ln);
         }
-        store_elem<S>(mytab + W, a);
-        regs_to_lds<S>(bl, a);
+        store_elem<C>(mytab + W, a, ln);
+        regs_to_lds<C>(ln, a);
 #pragma unroll 1
         for (int k = 2; k < tsize; ++k) {
-            u32 r[S];
-            mont_mul<S>(r, a, bl, nn, n0inv);          // x * tab[k-1]
-            store_elem<S>(mytab + (size_t)k * W, r);
-            regs_to_lds<S>(bl, r);
+            u32 r[C::L];
+            mont_mul<C>(r, a, ln, nn, n0inv);          // x * tab[k-1]
+            store_elem<C>(mytab + (size_t)k * W, r, ln);
+            regs_to_lds<C>(ln, r);
         }
         // main loop
         u32 d = exp_digit(ep, ewords, (nwin - 1) * wbits, wbits);
-        load_elem<S>(a, mytab + (size_t)d * W);
+        load_elem<C>(a, mytab + (size_t)d * W, ln);
 #pragma unroll 1
         for (int wi = nwin - 2; wi >= 0; --wi) {
 #pragma unroll 1
             for (int s = 0; s < wbits; ++s) {
-                regs_to_lds<S>(bl, a);
-                mont_sqr<S>(a, a, bl, nn, n0inv);
+                regs_to_lds<C>(ln, a);
+                mont_sqr<C>(a, a, ln, nn, n0inv);
             }
             d = exp_digit(ep, ewords, wi * wbits, wbits);
-            load_elem_to_lds<S>(bl, mytab + (size_t)d * W);
-            mont_mul<S>(a, a, bl, nn, n0inv);
+            load_elem_to_lds<C>(ln, mytab + (size_t)d * W);
+            mont_mul<C>(a, a, ln, nn, n0inv);
         }
-        canonicalize<S>(a, nmod);
-        if (live) store_elem<S>(out + el * W, a);
+        canonicalize<C>(a, nn, ln);
+        if (live) store_elem<C>(out + el * W, a, ln);
     }
 }
-
-}  // namespace vmn
 
 // =============================================================================================
 // second part: fixed-base tables (K2), multi-exponentiation (K3), reductions (K5), comparison
 // (K6), data movement (K7) and the ring kernels over Z_q (K8).
 // =============================================================================================
-namespace vmn {
 
 // ---------------------------------------------------------------------------------------------
 // K6: flags[0] |= 1 if x != y anywhere.  One thread per 16-byte chunk (HBM-bound, coalesced).
@@ -392,189 +558,173 @@ __global__ void __launch_bounds__(BLOCK) k_gather(uint4* __restrict__ out, const
 // for j < L.  OP = Montgomery product (MUL = true) or modular sum.  nseg segments of `len`
 // elements each; the output has nseg segments of L elements.
 // ---------------------------------------------------------------------------------------------
-template <int S>
-__device__ __forceinline__ void mod_add(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const u32* __restrict__ nmod) {
-    u32 c = 0;
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-        u32 v = a[j] + b[j] + c;
-        r[j] = v & LIMB_MASK;
-        c = v >> LIMB_BITS;
-    }
-    canonicalize<S>(r, nmod);      // a, b < N  =>  a + b < 2N
-}
-
-template <int S, bool MUL>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
-k_reduce_strided(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t L, size_t nseg,
+template <class C, bool MUL>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_reduce_strided(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t Lout, size_t nseg,
                  const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool live = t < nseg * L;
-    size_t tc = live ? t : nseg * L - 1;
-    size_t seg = tc / L, j = tc % L;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t t = (size_t)blockIdx.x * C::EPB + ln.eslot;
+    bool live = t < nseg * Lout;
+    size_t tc = live ? t : nseg * Lout - 1;
+    size_t seg = tc / Lout, j = tc % Lout;
     const u32* base = x + seg * len * W;
-    u32 acc[S];
-    load_elem<S>(acc, base + j * W);
-    size_t cnt = (len - j + L - 1) / L;            // elements j, j+L, ... < len
-    // every lane of the workgroup runs the same number of rounds (the LDS column is private, so no
-    // barrier is involved; lanes with fewer terms multiply by nothing = skip)
+    u32 acc[C::L];
+    load_elem<C>(acc, base + j * W, ln);
+    size_t cnt = (len - j + Lout - 1) / Lout;            // elements j, j+Lout, ... < len
     for (size_t k = 1; k < cnt; ++k) {
-        const u32* src = base + (j + k * L) * W;
+        const u32* src = base + (j + k * Lout) * W;
         if constexpr (MUL) {
-            load_elem_to_lds<S>(bl, src);
-            mont_mul<S>(acc, acc, bl, nn, n0inv);
+            load_elem_to_lds<C>(ln, src);
+            mont_mul<C>(acc, acc, ln, nn, n0inv);
         } else {
-            u32 b[S];
-            load_elem<S>(b, src);
-            mod_add<S>(acc, acc, b, nmod);
+            u32 b[C::L];
+            load_elem<C>(b, src, ln);
+            mod_add<C>(acc, acc, b, nn, ln);
         }
     }
-    if constexpr (MUL) canonicalize<S>(acc, nmod);
-    if (live) store_elem<S>(out + t * W, acc);
+    if constexpr (MUL) canonicalize<C>(acc, nn, ln);
+    if (live) store_elem<C>(out + t * W, acc, ln);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K8 element-wise ring kernels:  op 0: x + y   op 1: -x   op 2: x*v + y (v one element)   op 3: x*v
 // ---------------------------------------------------------------------------------------------
-template <int S>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_ring_elementwise(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ y, const u32* __restrict__ v,
                    int op, size_t n, const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
-    u32 a[S], r[S];
-    load_elem<S>(a, x + ec * W);
+    u32 a[C::L], r[C::L];
+    load_elem<C>(a, x + ec * W, ln);
     if (op == 0) {
-        u32 b[S];
-        load_elem<S>(b, y + ec * W);
-        mod_add<S>(r, a, b, nmod);
+        u32 b[C::L];
+        load_elem<C>(b, y + ec * W, ln);
+        mod_add<C>(r, a, b, nn, ln);
     } else if (op == 1) {
-        // N - a, and 0 stays 0
-        int32_t borrow = 0;
-        u32 nz = 0;
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-            int32_t d = (int32_t)nmod[j] - (int32_t)a[j] + borrow;
-            r[j] = (u32)d & LIMB_MASK;
-            borrow = d >> LIMB_BITS;
-            nz |= a[j];
-        }
-#pragma unroll
-        for (int j = 0; j < S; ++j) r[j] = nz ? r[j] : 0u;
+        mod_neg<C>(r, a, nn, ln);
     } else {
-        u32 nn[S];
-        load_modulus<S>(nn, nmod);
-        load_elem_to_lds<S>(bl, v);
-        u32 t[S], b[S];
-        mont_mul<S>(t, a, bl, nn, n0inv);
-        canonicalize<S>(t, nmod);
+        load_elem_to_lds<C>(ln, v);
+        u32 t[C::L];
+        mont_mul<C>(t, a, ln, nn, n0inv);
+        canonicalize<C>(t, nn, ln);
         if (op == 2) {
-            load_elem<S>(b, y + ec * W);
-            mod_add<S>(r, t, b, nmod);
+            u32 b[C::L];
+            load_elem<C>(b, y + ec * W, ln);
+            mod_add<C>(r, t, b, nn, ln);
         } else {
 #pragma unroll
-            for (int j = 0; j < S; ++j) r[j] = t[j];
+            for (int j = 0; j < C::L; ++j) r[j] = t[j];
         }
     }
-    if (live) store_elem<S>(out + el * W, r);
+    if (live) store_elem<C>(out + el * W, r, ln);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K8 scans.  An affine recurrence x[i] = x[i-1]*e[i] + b[i] (recLin; b == nullptr: prods,
-// y[i] = y[i-1]*e[i]) over segments of `seglen` elements (seglen % C == 0 or one segment),
-// processed in chunks of C consecutive elements per lane:
+// y[i] = y[i-1]*e[i]) over segments of `seglen` elements (seglen % Cc == 0 or one segment),
+// processed in chunks of Cc consecutive elements per lane (pair):
 //   k_scan_totals : per chunk, the composed map (E = prod e, X = value reached from 0)
 //   (recursion on the totals gives every chunk's incoming value)
 //   k_scan_apply  : per chunk, replay the recurrence from the incoming value and store x[i]
 // `rev`: element i of a segment is read/written at position seglen-1-i (suffix scans of K3).
 // ---------------------------------------------------------------------------------------------
-// WANT_X = false: Etot[c] = prod of the chunk's e.   WANT_X = true: Xtot[c] = value reached from 0.
+// WANT_X = false: tot[c] = prod of the chunk's e.   WANT_X = true: tot[c] = value reached from 0.
 // (Two launches for recLin: one accumulator per kernel keeps a + columns + accumulator within 256 VGPRs.)
-template <int S, bool WANT_X>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C, bool WANT_X>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_scan_totals(u32* __restrict__ tot, const u32* __restrict__ e, const u32* __restrict__ b,
-              size_t n, size_t C, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
+              size_t n, size_t Cc, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
               const u32* __restrict__ one_m) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t nchunks = (n + C - 1) / C;
-    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t nchunks = (n + Cc - 1) / Cc;
+    size_t c = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = c < nchunks;
     size_t cc = live ? c : nchunks - 1;
-    size_t lo = cc * C, hi = lo + C < n ? lo + C : n;
-    u32 A[S];
+    size_t lo = cc * Cc, hi = lo + Cc < n ? lo + Cc : n;
+    u32 A[C::L];
+    if constexpr (WANT_X) {
 #pragma unroll
-    for (int j = 0; j < S; ++j) A[j] = WANT_X ? 0u : one_m[j];
-    for (size_t i = lo; i < lo + C; ++i) {          // uniform trip count; short chunks idle at the end
+        for (int j = 0; j < C::L; ++j) A[j] = 0u;
+    } else {
+        load_modulus<C>(A, one_m, ln);
+    }
+    for (size_t i = lo; i < lo + Cc; ++i) {          // uniform trip count; short chunks idle at the end
         if (i < hi) {
             size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
-            load_elem_to_lds<S>(bl, e + pos * W);
-            mont_mul<S>(A, A, bl, nn, n0inv);
+            load_elem_to_lds<C>(ln, e + pos * W);
+            mont_mul<C>(A, A, ln, nn, n0inv);
             if constexpr (WANT_X) {
-                canonicalize<S>(A, nmod);
-                u32 bb[S];
-                load_elem<S>(bb, b + pos * W);
-                mod_add<S>(A, A, bb, nmod);
+                canonicalize<C>(A, nn, ln);
+                u32 bb[C::L];
+                load_elem<C>(bb, b + pos * W, ln);
+                mod_add<C>(A, A, bb, nn, ln);
             }
         }
     }
-    canonicalize<S>(A, nmod);
-    if (live) store_elem<S>(tot + c * W, A);
+    canonicalize<C>(A, nn, ln);
+    if (live) store_elem<C>(tot + c * W, A, ln);
 }
 
 // incoming: per-chunk inclusive results of the level above (chunk c starts from incoming[c-1]),
 // nullptr = every chunk starts fresh.  A chunk that begins a segment starts fresh (0 / one).
-template <int S>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_scan_apply(u32* __restrict__ out, const u32* __restrict__ e, const u32* __restrict__ b, const u32* __restrict__ incoming,
-             size_t n, size_t C, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
+             size_t n, size_t Cc, size_t seglen, int rev, const u32* __restrict__ nmod, u32 n0inv,
              const u32* __restrict__ one_m) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t nchunks = (n + C - 1) / C;
-    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t nchunks = (n + Cc - 1) / Cc;
+    size_t c = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = c < nchunks;
     size_t cc = live ? c : nchunks - 1;
-    size_t lo = cc * C, hi = lo + C < n ? lo + C : n;
+    size_t lo = cc * Cc, hi = lo + Cc < n ? lo + Cc : n;
     bool fresh = incoming == nullptr || (lo % seglen) == 0;
-    u32 X[S];
+    u32 X[C::L];
     if (fresh) {
+        if (b) {
 #pragma unroll
-        for (int j = 0; j < S; ++j) X[j] = b ? 0u : one_m[j];
+            for (int j = 0; j < C::L; ++j) X[j] = 0u;
+        } else {
+            load_modulus<C>(X, one_m, ln);
+        }
     } else {
-        load_elem<S>(X, incoming + (cc - 1) * W);
+        load_elem<C>(X, incoming + (cc - 1) * W, ln);
     }
-    for (size_t i = lo; i < lo + C; ++i) {
+    for (size_t i = lo; i < lo + Cc; ++i) {
         if (i < hi) {
             size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
-            load_elem_to_lds<S>(bl, e + pos * W);
-            u32 t[S];
-            mont_mul<S>(t, X, bl, nn, n0inv);
-            canonicalize<S>(t, nmod);
+            load_elem_to_lds<C>(ln, e + pos * W);
+            u32 t[C::L];
+            mont_mul<C>(t, X, ln, nn, n0inv);
+            canonicalize<C>(t, nn, ln);
             if (b) {
-                u32 bb[S];
-                load_elem<S>(bb, b + pos * W);
-                mod_add<S>(X, t, bb, nmod);
+                u32 bb[C::L];
+                load_elem<C>(bb, b + pos * W, ln);
+                mod_add<C>(X, t, bb, nn, ln);
             } else {
 #pragma unroll
-                for (int j = 0; j < S; ++j) X[j] = t[j];
+                for (int j = 0; j < C::L; ++j) X[j] = t[j];
             }
-            if (live) store_elem<S>(out + pos * W, X);
+            if (live) store_elem<C>(out + pos * W, X, ln);
         }
     }
 }
@@ -584,11 +734,9 @@ k_scan_apply(u32* __restrict__ out, const u32* __restrict__ e, const u32* __rest
 // (k*2^w + d)*W.  The host supplies sq[j] = base^(2^j) (the sequential squaring chain); level l
 // fills d in (2^l, 2^(l+1)):  T[k][d] = T[k][d - 2^l] * T[k][2^l].
 // ---------------------------------------------------------------------------------------------
-template <int S>
+// one thread per (k, l) plus the d = 0 rows; plain row copies (W words, constants are in row layout)
 __global__ void __launch_bounds__(BLOCK) k_fixed_seed(u32* __restrict__ T, const u32* __restrict__ sq, int w, int nwin,
-                                                      const u32* __restrict__ one_m) {
-    constexpr int W = stride_for_limbs(S);
-    // one thread per (k, l) plus the d = 0 rows
+                                                      const u32* __restrict__ one_row, int W) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t total = (size_t)nwin * (w + 1);
     if (t >= total) return;
@@ -597,69 +745,69 @@ __global__ void __launch_bounds__(BLOCK) k_fixed_seed(u32* __restrict__ T, const
     const u32* src;
     if (l == w) {                          // d = 0: the Montgomery one
         dst = T + ((size_t)k << w) * W;
-        src = one_m;
+        src = one_row;
     } else {
         dst = T + (((size_t)k << w) + ((size_t)1 << l)) * W;
         src = sq + ((size_t)k * w + l) * W;
     }
-    for (int j = 0; j < W; ++j) dst[j] = j < S ? src[j] : 0u;
+    for (int j = 0; j < W; ++j) dst[j] = src[j];
 }
 
-template <int S>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_fixed_level(u32* __restrict__ T, int w, int nwin, int l, const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
     size_t per = ((size_t)1 << l) - 1;                 // d = 2^l + 1 .. 2^(l+1) - 1
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = t < per * nwin;
     size_t tc = live ? t : per * nwin - 1;
     size_t k = tc / per, r = tc % per + 1;             // r = d - 2^l in [1, 2^l)
     u32* row = T + (k << w) * W;
-    u32 a[S];
-    load_elem<S>(a, row + r * W);
-    load_elem_to_lds<S>(bl, row + ((size_t)1 << l) * W);
-    u32 o[S];
-    mont_mul<S>(o, a, bl, nn, n0inv);
-    canonicalize<S>(o, nmod);
-    if (live) store_elem<S>(row + (((size_t)1 << l) + r) * W, o);
+    u32 a[C::L];
+    load_elem<C>(a, row + r * W, ln);
+    load_elem_to_lds<C>(ln, row + ((size_t)1 << l) * W);
+    u32 o[C::L];
+    mont_mul<C>(o, a, ln, nn, n0inv);
+    canonicalize<C>(o, nn, ln);
+    if (live) store_elem<C>(row + (((size_t)1 << l) + r) * W, o, ln);
 }
 
 // out[i] = prod_k T[k][digit_k(e[i])]
-template <int S>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin, const u32* __restrict__ e, int ewords,
             size_t n, const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const size_t ntiles = (n + C::EPB - 1) / C::EPB;
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        size_t el = t * BLOCK + threadIdx.x;
+        size_t el = t * C::EPB + ln.eslot;
         bool live = el < n;
         size_t ec = live ? el : n - 1;
         const u32* ep = e + ec * ewords;
-        u32 a[S];
+        u32 a[C::L];
         u32 d = exp_digit(ep, ewords, 0, w);
-        load_elem<S>(a, T + (size_t)d * W);
+        load_elem<C>(a, T + (size_t)d * W, ln);
 #pragma unroll 1
         for (int k = 1; k < nwin; ++k) {
             d = exp_digit(ep, ewords, k * w, w);
-            load_elem_to_lds<S>(bl, T + (((size_t)k << w) + d) * W);
-            mont_mul<S>(a, a, bl, nn, n0inv);
+            load_elem_to_lds<C>(ln, T + (((size_t)k << w) + d) * W);
+            mont_mul<C>(a, a, ln, nn, n0inv);
         }
-        canonicalize<S>(a, nmod);
-        if (live) store_elem<S>(out + el * W, a);
+        canonicalize<C>(a, nn, ln);
+        if (live) store_elem<C>(out + el * W, a, ln);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 multi-exponentiation (Pippenger): counting sort of (window, digit) then one lane per bucket.
+// K3 multi-exponentiation (Pippenger): counting sort of (window, digit), then a product tree per bucket.
 // ---------------------------------------------------------------------------------------------
 // counts[win][d] += 1 for every element; one thread per (element, window).
 __global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts, const u32* __restrict__ e, int ewords,
@@ -673,6 +821,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts,
         atomicAdd(&counts[((size_t)w << c) + d], 1u);
     }
 }
+
 // ---- generic exclusive scan of a u32 array (three tiny kernels; n up to a few million) ----------
 constexpr int SCAN_ITEMS = 16;                         // items per thread
 __global__ void __launch_bounds__(BLOCK) k_u32_blocksum(u32* __restrict__ bsum, const u32* __restrict__ in, size_t n) {
@@ -764,21 +913,21 @@ __global__ void __launch_bounds__(BLOCK) k_task_counts(u32* __restrict__ cnt_out
 }
 
 // One level of the per-bucket product tree.  Bucket b owns cnt_in[b] items at off_in[b]; output item
-// (b, j) = product of its input items [jF, (j+1)F) and lands at off_out[b] + j.  One lane per output
+// (b, j) = product of its input items [jF, (j+1)F) and lands at off_out[b] + j.  One lane (pair) per output
 // item, so a bucket of any size is spread over ceil(size/F) lanes: no lane ever walks a long bucket
 // (skewed digits -- a short top window, equal exponents -- would otherwise serialise on one lane).
 // FIRST: input items are rows of x selected through `sorted`; otherwise rows of `in`.
-template <int S, bool FIRST>
-__global__ void __launch_bounds__(BLOCK, (S <= 74 ? 2 : 1))
+template <class C, bool FIRST>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
 k_bucket_level(u32* __restrict__ out, const u32* __restrict__ in, const u32* __restrict__ sorted,
                const u32* __restrict__ off_in, const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
                size_t nbuckets, size_t total_out, u32 F, const u32* __restrict__ nmod, u32 n0inv) {
-    constexpr int W = stride_for_limbs(S);
+    constexpr int W = C::W;
     extern __shared__ u32 lds[];
-    u32* bl = lds + threadIdx.x;
-    u32 nn[S];
-    load_modulus<S>(nn, nmod);
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    size_t t = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = t < total_out;
     size_t tc = live ? t : total_out - 1;
     // b = last bucket with off_out[b] <= tc  (empty buckets share their successor's offset)
@@ -792,39 +941,36 @@ k_bucket_level(u32* __restrict__ out, const u32* __restrict__ in, const u32* __r
     u32 start = off_in[b] + j * F;
     u32 end = off_in[b] + cnt_in[b];
     if (end > start + F) end = start + F;
-    u32 acc[S];
+    u32 acc[C::L];
     auto row = [&](u32 k) -> const u32* { return FIRST ? in + (size_t)sorted[k] * W : in + (size_t)k * W; };
-    load_elem<S>(acc, row(start));
+    load_elem<C>(acc, row(start), ln);
     for (u32 k = start + 1; k < end; ++k) {
-        load_elem_to_lds<S>(bl, row(k));
-        mont_mul<S>(acc, acc, bl, nn, n0inv);
+        load_elem_to_lds<C>(ln, row(k));
+        mont_mul<C>(acc, acc, ln, nn, n0inv);
     }
-    canonicalize<S>(acc, nmod);
-    if (live) store_elem<S>(out + t * W, acc);
+    canonicalize<C>(acc, nn, ln);
+    if (live) store_elem<C>(out + t * W, acc, ln);
 }
-// B[b] = the bucket's single remaining item, or one if it is empty
-template <int S>
+// B[b] = the bucket's single remaining item, or one if it is empty (row copies, 16-byte chunks)
 __global__ void __launch_bounds__(BLOCK) k_bucket_finalize(uint4* __restrict__ B, const uint4* __restrict__ items,
                                                            const u32* __restrict__ off_in, const u32* __restrict__ cnt_in,
-                                                           size_t nbuckets, const uint4* __restrict__ one_row) {
-    constexpr int CPR = stride_for_limbs(S) / 4;
+                                                           size_t nbuckets, const uint4* __restrict__ one_row, int cpr) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = nbuckets * CPR;
+    size_t total = nbuckets * cpr;
     for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t b = t / CPR;
-        int ch = (int)(t % CPR);
-        B[t] = cnt_in[b] ? items[(size_t)off_in[b] * CPR + ch] : one_row[ch];
+        size_t b = t / cpr;
+        int ch = (int)(t % cpr);
+        B[t] = cnt_in[b] ? items[(size_t)off_in[b] * cpr + ch] : one_row[ch];
     }
 }
 // overwrite element 0 of every segment with `one` (the d = 0 slot of the suffix products)
-template <int S>
-__global__ void __launch_bounds__(BLOCK) k_set_segment_heads(u32* __restrict__ a, size_t seglen, size_t nseg,
-                                                             const u32* __restrict__ one_m) {
-    constexpr int W = stride_for_limbs(S);
+__global__ void __launch_bounds__(BLOCK) k_set_segment_heads(uint4* __restrict__ a, size_t seglen, size_t nseg,
+                                                             const uint4* __restrict__ one_row, int cpr) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= nseg) return;
-    u32* dst = a + t * seglen * W;
-    for (int j = 0; j < W; ++j) dst[j] = j < S ? one_m[j] : 0u;
+    if (t >= nseg * cpr) return;
+    size_t s = t / cpr;
+    int ch = (int)(t % cpr);
+    a[s * seglen * cpr + ch] = one_row[ch];
 }
 
 }  // namespace vmn

@@ -54,6 +54,9 @@ template <int S> __device__ __forceinline__ void mont_row_asm_next(u64 (&P)[S], 
 constexpr int SQR_BLK = 8;
 template <int S> __device__ __forceinline__ void mont_sqr_row_asm_first(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
 template <int S, int J0> __device__ __forceinline__ void mont_sqr_row_asm(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
+// Two lanes per element (see the generator): L limbs per lane.
+template <int L> __device__ __forceinline__ void mont_pair_row_asm_first(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 evenmask);
+template <int L> __device__ __forceinline__ void mont_pair_row_asm_next(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 evenmask);
 #include "gen/mont_rows.inc"
 
 // T (S lazy columns, value < 2N when a, b < 2N and R > 4N) = a * b / R mod N.
@@ -96,6 +99,22 @@ __device__ __forceinline__ void mont_sqr_columns(u64 (&T)[S], const u32 (&a)[S],
     mont_sqr_row_asm_first<S>(T, a, b0, b0 << 1, n, n0inv);
     mont_sqr_blocks<S, 0>(T, a, a_lds, bstride, n, n0inv);
     T[S - 1] = 0;
+}
+
+// Lane-pair product: each lane holds L of the S = 2L columns; b_lds streams all S limbs of the multiplier
+// (both lanes of a pair read the same word).  n[] = this lane's half of the modulus (VGPRs).
+template <int L>
+__device__ __forceinline__ void mont_mul_columns_pair(u64 (&T)[L], const u32 (&a)[L], const u32* b_lds, int bstride,
+                                                      const u32 (&n)[L], u32 n0inv, u32 evenmask) {
+    u32 bi = b_lds[0];
+    u32 bn = b_lds[bstride];
+    mont_pair_row_asm_first<L>(T, a, bi, n, n0inv, evenmask);
+#pragma unroll 1
+    for (int i = 2; i <= 2 * L; ++i) {
+        bi = bn;
+        bn = b_lds[(i < 2 * L ? i : 0) * bstride];
+        mont_pair_row_asm_next<L>(T, a, bi, n, n0inv, evenmask);
+    }
 }
 
 // Resolve the lazy columns into 28-bit limbs (value unchanged, < 2N < 2^(28*S)).

@@ -40,24 +40,24 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // size dispatch
 // ------------------------------------------------------------------------------------------------
 // (modulus bits) -> (S limbs, NW words).  One template instantiation per supported size.
-// (3072-bit needs 110 limbs: more modulus limbs than there are SGPRs; that size gets its own row
-// generator and is not instantiated yet.)
-#define VMN_FOR_SIZES(X) X(19, 16) X(37, 32) X(74, 64)
+// X(limbs, packed words, lanes per element).  3072-bit moduli (110 limbs) run two lanes per element.
+#define VMN_FOR_SIZES(X) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(110, 96, 2)
 
-static bool size_for_bits(int nbits, int* S, int* NW) {
-    const int sizes[][3] = {{512, 19, 16}, {1024, 37, 32}, {2048, 74, 64}};
+static bool size_for_bits(int nbits, int* S, int* NW, int* LPE) {
+    const int sizes[][4] = {{512, 19, 16, 1}, {1024, 37, 32, 1}, {2048, 74, 64, 1}, {3072, 110, 96, 2}};
     for (auto& s : sizes) {
         if (nbits <= s[0]) {
             *S = s[1];
             *NW = s[2];
+            *LPE = s[3];
             return true;
         }
     }
     return false;
 }
 
-static size_t lds_bytes(int S) { return (size_t)S * BLOCK * sizeof(u32); }
-static int blocks_per_cu(int S) { return S <= 74 ? 2 : 1; }
+static size_t lds_bytes(const vmn_modulus& m) { return (size_t)m.S * (BLOCK / m.LPE) * sizeof(u32); }
+static int blocks_per_cu(const vmn_modulus&) { return 2; }
 
 // ------------------------------------------------------------------------------------------------
 // launch helper: dynamic LDS attribute, stream, optional event timing per kernel family
@@ -286,16 +286,18 @@ extern "C" int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len) {
 // moduli and groups
 // ------------------------------------------------------------------------------------------------
 // words (NW, little-endian 32-bit) -> S limbs of 28 bits
-static std::vector<uint32_t> words_to_limbs_host(const Big& w, int S) {
-    std::vector<uint32_t> l(S, 0);
+// words (NW, little-endian 32-bit) -> one device row: LPE shares of LW words, L limbs each, zero padded
+static std::vector<uint32_t> words_to_row_host(const Big& w, int S, int LPE) {
+    const int L = S / LPE, LW = stride_for_limbs(L);
+    std::vector<uint32_t> row((size_t)LPE * LW, 0);
     for (int j = 0; j < S; ++j) {
         int bit = 28 * j;
         size_t k = bit / 32;
         int sh = bit % 32;
         uint64_t lo = k < w.size() ? w[k] : 0, hi = k + 1 < w.size() ? w[k + 1] : 0;
-        l[j] = (uint32_t)(((hi << 32) | lo) >> sh) & LIMB_MASK;
+        row[(size_t)(j / L) * LW + (j % L)] = (uint32_t)(((hi << 32) | lo) >> sh) & LIMB_MASK;
     }
-    return l;
+    return row;
 }
 
 static int upload_words(vmn_ctx* ctx, uint32_t** dst, const std::vector<uint32_t>& v) {
@@ -314,9 +316,11 @@ static void modulus_destroy(vmn_modulus& m) {
 }
 
 // Set up one odd modulus given as big-endian bytes; S/NW are forced (q shares p's geometry).
-static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t nbytes, int S, int NW) {
+static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t nbytes, int S, int NW, int LPE) {
     m.S = S;
     m.NW = NW;
+    m.LPE = LPE;
+    m.W = LPE * stride_for_limbs(S / LPE);
     m.n_words = hostbig::from_be(be, nbytes, NW);
     // bytes beyond NW words must be zero
     for (size_t i = 0; i + (size_t)NW * 4 < nbytes; ++i) {
@@ -341,9 +345,9 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
     for (int i = 0; i < 28 * S; ++i) hostbig::dbl_mod(r, m.n_words);
     Big rr = r;
     for (int i = 0; i < 28 * S; ++i) hostbig::dbl_mod(rr, m.n_words);
-    VMN_TRY(upload_words(ctx, &m.d_n, words_to_limbs_host(m.n_words, S)));
-    VMN_TRY(upload_words(ctx, &m.d_one, words_to_limbs_host(r, S)));
-    VMN_TRY(upload_words(ctx, &m.d_rr, words_to_limbs_host(rr, S)));
+    VMN_TRY(upload_words(ctx, &m.d_n, words_to_row_host(m.n_words, S, LPE)));
+    VMN_TRY(upload_words(ctx, &m.d_one, words_to_row_host(r, S, LPE)));
+    VMN_TRY(upload_words(ctx, &m.d_rr, words_to_row_host(rr, S, LPE)));
     m.hm = new hostbig::Mont(m.n_words);
     return VMN_OK;
 }
@@ -354,16 +358,16 @@ extern "C" int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const ui
     VMN_HIP(hipSetDevice(ctx->device));
     Big pw = hostbig::from_be(p_be, nbytes, (nbytes + 3) / 4);
     int nbits = hostbig::bit_length(pw);
-    int S, NW;
-    if (!size_for_bits(nbits, &S, &NW)) {
-        set_error("vmn_modp_group_create: %d-bit modulus not supported (max 2048)", nbits);
+    int S, NW, LPE;
+    if (!size_for_bits(nbits, &S, &NW, &LPE)) {
+        set_error("vmn_modp_group_create: %d-bit modulus not supported (max 3072)", nbits);
         return VMN_ERR_UNSUPPORTED;
     }
     std::unique_ptr<vmn_group> g(new vmn_group());
     g->ctx = ctx;
     g->nbytes = nbytes;
-    int rc = modulus_init(ctx, g->P, p_be, nbytes, S, NW);
-    if (rc == VMN_OK) rc = modulus_init(ctx, g->Q, q_be, nbytes, S, NW);
+    int rc = modulus_init(ctx, g->P, p_be, nbytes, S, NW, LPE);
+    if (rc == VMN_OK) rc = modulus_init(ctx, g->Q, q_be, nbytes, S, NW, LPE);
     if (rc != VMN_OK) {
         modulus_destroy(g->P);
         modulus_destroy(g->Q);
@@ -390,8 +394,12 @@ extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->
 // ------------------------------------------------------------------------------------------------
 // generic array plumbing (group arrays are residues mod p, ring arrays residues mod q)
 // ------------------------------------------------------------------------------------------------
-static size_t elem_words(const vmn_modulus& m) { return (size_t)stride_for_limbs(m.S); }
-static unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+static size_t elem_words(const vmn_modulus& m) { return (size_t)m.W; }
+static unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }                      // one thread per item
+static unsigned egrid(const vmn_modulus& m, size_t n) {                                                    // one lane (pair) per element
+    size_t epb = BLOCK / m.LPE;
+    return (unsigned)((n + epb - 1) / epb);
+}
 
 static size_t elems_bytes(const vmn_modulus& m, size_t n) { return std::max<size_t>(n, 1) * elem_words(m) * sizeof(uint32_t); }
 static int alloc_elems(vmn_ctx* ctx, const vmn_modulus& m, size_t n, uint32_t** d) {
@@ -407,9 +415,9 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     VMN_HIP(hipMemcpyAsync(raw.p, be, n * nbytes, hipMemcpyHostToDevice, ctx->stream));
     VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                              \
+#define X(S_, NW_, LPE_)                                                                                              \
     if (m.S == S_)                                                                                              \
-        rc = launch(ctx, "import", k_import_be<S_, NW_>, grid_for(n), lds_bytes(S_), d_out, raw.as<uint8_t>(), \
+        rc = launch(ctx, "import", k_import_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), d_out, raw.as<uint8_t>(), \
                     nbytes, n, m.d_n, m.n0inv, m.d_rr, ctx->flags);
     VMN_FOR_SIZES(X)
 #undef X
@@ -426,9 +434,9 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * nbytes + 8));
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                          \
+#define X(S_, NW_, LPE_)                                                                                          \
     if (m.S == S_)                                                                                          \
-        rc = launch(ctx, "export", k_export_be<S_, NW_>, grid_for(n), lds_bytes(S_), raw.as<uint8_t>(),    \
+        rc = launch(ctx, "export", k_export_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), raw.as<uint8_t>(),    \
                     nbytes, d_in, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
 #undef X
@@ -459,8 +467,8 @@ static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, con
                       uint32_t* out) {
     if (n == 0) return VMN_OK;
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_) \
-    if (m.S == S_) rc = launch(ctx, "modmul", k_mul<S_>, grid_for(n), lds_bytes(S_), out, x, y, ystride, n, m.d_n, m.n0inv);
+#define X(S_, NW_, LPE_) \
+    if (m.S == S_) rc = launch(ctx, "modmul", k_mul<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), out, x, y, ystride, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
 #undef X
     return rc;
@@ -470,8 +478,8 @@ static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, con
 static int to_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* in, size_t n, uint32_t* out_words) {
     if (n == 0) return VMN_OK;
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_) \
-    if (m.S == S_) rc = launch(ctx, "to_words", k_to_words<S_, NW_>, grid_for(n), lds_bytes(S_), out_words, in, n, m.d_n, m.n0inv);
+#define X(S_, NW_, LPE_) \
+    if (m.S == S_) rc = launch(ctx, "to_words", k_to_words<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), out_words, in, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
 #undef X
     return rc;
@@ -497,14 +505,14 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, c
     if (n == 0) return VMN_OK;
     if (ebits < 1) ebits = 1;
     int wbits = pick_window(ebits);
-    unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m.S));
-    unsigned grid = std::min<unsigned>(grid_for(n), max_blocks);
-    size_t tab_bytes = (size_t)grid * BLOCK * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);
+    unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+    unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
+    size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);
     VMN_TRY(ensure_scratch(ctx, tab_bytes));
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                 \
+#define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
-        rc = launch(ctx, "modpow", k_modpow<S_>, grid, lds_bytes(S_), out, x, e_words, ewords, estride, ebits, wbits, \
+        rc = launch(ctx, "modpow", k_modpow<Cfg<S_, LPE_>>, grid, lds_bytes(m), out, x, e_words, ewords, estride, ebits, wbits, \
                     n, m.d_n, m.n0inv, m.d_one, reinterpret_cast<uint32_t*>(ctx->scratch));
     VMN_FOR_SIZES(X)
 #undef X
@@ -903,12 +911,12 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
     if (len == 0) {       // empty product = one, empty sum = zero
         std::vector<uint32_t> row(Wd, 0);
         if (mul) {
-            VMN_TRY(d2h(ctx, row.data(), m.d_one, m.S * sizeof(uint32_t)));
+            VMN_TRY(d2h(ctx, row.data(), m.d_one, Wd * sizeof(uint32_t)));
         }
         for (size_t s = 0; s < nseg; ++s) VMN_TRY(h2d(ctx, d_out + s * Wd, row.data(), Wd * sizeof(uint32_t)));
         return VMN_OK;
     }
-    const size_t max_lanes = (size_t)ctx->num_cus * blocks_per_cu(m.S) * BLOCK;
+    const size_t max_lanes = (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
     // first pass: as many lanes as the machine holds, then halve
     size_t L = std::min(std::max<size_t>(max_lanes / std::max<size_t>(nseg, 1), 1), (len + 1) / 2);
     if (len == 1) L = 1;
@@ -922,11 +930,11 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
     while (true) {
         uint32_t* dst = (L == 1) ? d_out : ping;
         int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                      \
+#define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
-        rc = mul ? launch(ctx, "reduce", k_reduce_strided<S_, true>, grid_for(nseg * L), lds_bytes(S_), dst, src, cur, L, \
+        rc = mul ? launch(ctx, "reduce", k_reduce_strided<Cfg<S_, LPE_>, true>, egrid(m, nseg * L), lds_bytes(m), dst, src, cur, L, \
                           nseg, m.d_n, m.n0inv)                                                                         \
-                 : launch(ctx, "reduce", k_reduce_strided<S_, false>, grid_for(nseg * L), lds_bytes(S_), dst, src, cur, \
+                 : launch(ctx, "reduce", k_reduce_strided<Cfg<S_, LPE_>, false>, egrid(m, nseg * L), lds_bytes(m), dst, src, cur, \
                           L, nseg, m.d_n, m.n0inv);                                                                     \
     }
         VMN_FOR_SIZES(X)
@@ -980,8 +988,8 @@ static int ring_elementwise(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* 
                             int op, size_t n, uint32_t* out) {
     if (n == 0) return VMN_OK;
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_) \
-    if (m.S == S_) rc = launch(ctx, "ring", k_ring_elementwise<S_>, grid_for(n), lds_bytes(S_), out, x, y, v, op, n, m.d_n, m.n0inv);
+#define X(S_, NW_, LPE_) \
+    if (m.S == S_) rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), out, x, y, v, op, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
 #undef X
     return rc;
@@ -1068,9 +1076,9 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
         size_t Cs = seglen;
         int rc = VMN_ERR_ARG;
         size_t nchunks = (n + Cs - 1) / Cs;
-#define X(S_, NW_)                                                                                                        \
+#define X(S_, NW_, LPE_)                                                                                                        \
     if (m.S == S_)                                                                                                        \
-        rc = launch(ctx, "scan", k_scan_apply<S_>, grid_for(nchunks), lds_bytes(S_), out, e, b, (const uint32_t*)nullptr, \
+        rc = launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)nullptr, \
                     n, Cs, seglen, rev, m.d_n, m.n0inv, m.d_one);
         VMN_FOR_SIZES(X)
 #undef X
@@ -1083,12 +1091,12 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     uint32_t* Xtot = Etot + nchunks * Wd;
     uint32_t* inc = Xtot + nchunks * Wd;
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                      \
+#define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
-        rc = launch(ctx, "scan", k_scan_totals<S_, false>, grid_for(nchunks), lds_bytes(S_), Etot, e, b, n, C, seglen,  \
+        rc = launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, false>, egrid(m, nchunks), lds_bytes(m), Etot, e, b, n, C, seglen,  \
                     rev, m.d_n, m.n0inv, m.d_one);                                                                      \
         if (rc == VMN_OK && b)                                                                                          \
-            rc = launch(ctx, "scan", k_scan_totals<S_, true>, grid_for(nchunks), lds_bytes(S_), Xtot, e, b, n, C,       \
+            rc = launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, true>, egrid(m, nchunks), lds_bytes(m), Xtot, e, b, n, C,       \
                         seglen, rev, m.d_n, m.n0inv, m.d_one);                                                          \
     }
     VMN_FOR_SIZES(X)
@@ -1098,9 +1106,9 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     size_t seg_chunks = seglen == n ? nchunks : seglen / C;
     VMN_TRY(scan_affine(ctx, m, Etot, b ? Xtot : nullptr, nchunks, seg_chunks, 0, inc));
     rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                  \
+#define X(S_, NW_, LPE_)                                                                                                  \
     if (m.S == S_)                                                                                                  \
-        rc = launch(ctx, "scan", k_scan_apply<S_>, grid_for(nchunks), lds_bytes(S_), out, e, b, (const uint32_t*)inc, n, \
+        rc = launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)inc, n, \
                     C, seglen, rev, m.d_n, m.n0inv, m.d_one);
     VMN_FOR_SIZES(X)
 #undef X
@@ -1159,10 +1167,9 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
     int rc = VMN_OK;
     {
         // P[i] = x0..xi, S[i] = xi..x(n-1);  inv(x_i) = P[i-1] * S[i+1] * (P[n-1])^-1
-        DevTmp ps(ctx), sh(ctx), tinv(ctx), onerow(ctx);
+        DevTmp ps(ctx), sh(ctx);
         rc = ps.alloc(2 * n * Wd * sizeof(uint32_t));
         if (rc == VMN_OK) rc = sh.alloc(2 * n * Wd * sizeof(uint32_t));
-        if (rc == VMN_OK) rc = onerow.alloc(Wd * sizeof(uint32_t));
         uint32_t* Pf = ps.as<uint32_t>();
         uint32_t* Sf = Pf + n * Wd;
         uint32_t* Psh = sh.as<uint32_t>();
@@ -1188,16 +1195,11 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
                 uint32_t* d_t = nullptr;
                 rc = import_one(ctx, m, g->nbytes, tbe.data(), &d_t);
                 if (rc == VMN_OK) {
-                    if (hipMemsetAsync(onerow.p, 0, Wd * sizeof(uint32_t), ctx->stream) != hipSuccess ||
-                        hipMemcpyAsync(onerow.p, m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
-                        set_error("vmn_garray_inv: device copy failed");
-                        rc = VMN_ERR_DEVICE;
-                    }
                     std::vector<uint32_t> idx(n);
                     for (size_t i = 0; i < n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
-                    if (rc == VMN_OK) rc = gather_rows(ctx, m, Pf, idx, onerow.as<uint32_t>(), Psh);
+                    if (rc == VMN_OK) rc = gather_rows(ctx, m, Pf, idx, m.d_one, Psh);
                     for (size_t i = 0; i < n; ++i) idx[i] = i + 1 == n ? 0xffffffffu : (uint32_t)(i + 1);
-                    if (rc == VMN_OK) rc = gather_rows(ctx, m, Sf, idx, onerow.as<uint32_t>(), Ssh);
+                    if (rc == VMN_OK) rc = gather_rows(ctx, m, Sf, idx, m.d_one, Ssh);
                     if (rc == VMN_OK) rc = mul_arrays(ctx, m, Psh, Ssh, Wd, n, Pf);          // reuse Pf as scratch
                     if (rc == VMN_OK) rc = mul_arrays(ctx, m, Pf, d_t, 0, n, r->d);
                     free_one(ctx, m, d_t);
@@ -1274,16 +1276,12 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     ft.bytes = (size_t)nwin * ((size_t)1 << w) * Wd * sizeof(uint32_t);
     VMN_HIP(hipMalloc(&ft.d_tab, ft.bytes));
     int rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                              \
-    if (m.S == S_)                                                                                              \
-        rc = launch_light(ctx, "fixed_table", k_fixed_seed<S_>, grid_for((size_t)nwin * (w + 1)), ft.d_tab,     \
-                          sq.as<uint32_t>(), w, nwin, m.d_one);
-    VMN_FOR_SIZES(X)
-#undef X
+    rc = launch_light(ctx, "fixed_table", k_fixed_seed, grid_for((size_t)nwin * (w + 1)), ft.d_tab,
+                      (const uint32_t*)sq.as<uint32_t>(), w, nwin, (const uint32_t*)m.d_one, (int)Wd);
     for (int l = 1; l < w && rc == VMN_OK; ++l) {
         size_t lanes = (((size_t)1 << l) - 1) * nwin;
-#define X(S_, NW_) \
-    if (m.S == S_) rc = launch(ctx, "fixed_table", k_fixed_level<S_>, grid_for(lanes), lds_bytes(S_), ft.d_tab, w, nwin, l, m.d_n, m.n0inv);
+#define X(S_, NW_, LPE_) \
+    if (m.S == S_) rc = launch(ctx, "fixed_table", k_fixed_level<Cfg<S_, LPE_>>, egrid(m, lanes), lds_bytes(m), ft.d_tab, w, nwin, l, m.d_n, m.n0inv);
         VMN_FOR_SIZES(X)
 #undef X
     }
@@ -1316,11 +1314,11 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
     if (rc == VMN_OK) rc = to_words(ctx, grp->Q, e->d, n, ew.as<uint32_t>());
     if (rc == VMN_OK) {
         const vmn_modulus& m = grp->P;
-        unsigned grid = std::min<unsigned>(grid_for(n), (unsigned)(ctx->num_cus * blocks_per_cu(m.S)));
+        unsigned grid = std::min<unsigned>(egrid(m, n), (unsigned)(ctx->num_cus * blocks_per_cu(m)));
         rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                 \
+#define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
-        rc = launch(ctx, "fixed", k_fixed_exp<S_>, grid, lds_bytes(S_), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+        rc = launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                     ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, m.d_n, m.n0inv);
         VMN_FOR_SIZES(X)
 #undef X
@@ -1367,7 +1365,7 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
     const size_t nb = (size_t)1 << c;
     const size_t nbuckets = (size_t)nwin * nb;
     const uint32_t F = 8;                              // fan-in of the per-bucket product tree
-    DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx), onerow(ctx);
+    DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx);
     // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | cntA[nb] | cntB[nb] | offA[nb+1] | offB[nb+1] | bsum | misc
     const size_t scan_blocks = (nbuckets + (size_t)BLOCK * SCAN_ITEMS - 1) / ((size_t)BLOCK * SCAN_ITEMS);
     VMN_TRY(meta.alloc((7 * (nbuckets + 1) + scan_blocks + 16) * sizeof(uint32_t)));
@@ -1383,9 +1381,6 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
     VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
     VMN_TRY(buckets.alloc(2 * nbuckets * Wd * sizeof(uint32_t)));
     VMN_TRY(wres.alloc((size_t)nwin * Wd * sizeof(uint32_t)));
-    VMN_TRY(onerow.alloc(Wd * sizeof(uint32_t)));
-    VMN_HIP(hipMemsetAsync(onerow.p, 0, Wd * sizeof(uint32_t), ctx->stream));
-    VMN_HIP(hipMemcpyAsync(onerow.p, m.d_one, m.S * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     uint32_t* B = buckets.as<uint32_t>();
     uint32_t* Ssuf = B + nbuckets * Wd;
     auto scan_u32 = [&](uint32_t* out, uint32_t* out2, const uint32_t* in) -> int {
@@ -1423,12 +1418,12 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
         const size_t total_out = hm2[0];
         if (total_out > 0) {
             rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                      \
+#define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
-        rc = first ? launch(ctx, "expprod", k_bucket_level<S_, true>, grid_for(total_out), lds_bytes(S_), items_out,    \
+        rc = first ? launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, true>, egrid(m, total_out), lds_bytes(m), items_out,    \
                             items_in, (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out, \
                             nbuckets, total_out, F, m.d_n, m.n0inv)                                                     \
-                   : launch(ctx, "expprod", k_bucket_level<S_, false>, grid_for(total_out), lds_bytes(S_), items_out,   \
+                   : launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, false>, egrid(m, total_out), lds_bytes(m), items_out,   \
                             items_in, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_out, nbuckets,     \
                             total_out, F, m.d_n, m.n0inv);                                                              \
     }
@@ -1451,23 +1446,13 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
         cnt_out = (cnt_out == cntA) ? cntB : cntA;
         off_out = (off_out == offA) ? offB : offA;
     }
-    rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                  \
-    if (m.S == S_)                                                                                                  \
-        rc = launch_light(ctx, "expprod_agg", k_bucket_finalize<S_>, light_grid(ctx, nbuckets * (Wd / 4)),          \
-                          reinterpret_cast<uint4*>(B), reinterpret_cast<const uint4*>(items_in), off_in, cnt_in,    \
-                          nbuckets, reinterpret_cast<const uint4*>(onerow.p));
-    VMN_FOR_SIZES(X)
-#undef X
-    VMN_TRY(rc);
+    VMN_TRY(launch_light(ctx, "expprod_agg", k_bucket_finalize, light_grid(ctx, nbuckets * (Wd / 4)),
+                         reinterpret_cast<uint4*>(B), reinterpret_cast<const uint4*>(items_in), off_in, cnt_in,
+                         nbuckets, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
     // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce
     VMN_TRY(scan_affine(ctx, m, B, nullptr, (size_t)nwin * nb, nb, 1, Ssuf));
-    rc = VMN_ERR_ARG;
-#define X(S_, NW_) \
-    if (m.S == S_) rc = launch_light(ctx, "expprod_agg", k_set_segment_heads<S_>, grid_for(nwin), Ssuf, nb, (size_t)nwin, m.d_one);
-    VMN_FOR_SIZES(X)
-#undef X
-    VMN_TRY(rc);
+    VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for((size_t)nwin * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
+                         nb, (size_t)nwin, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
     VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, nwin, true, wres.as<uint32_t>()));
     // Horner over the windows on the host: nwin elements, c squarings each (O(ebits) modmuls)
     std::vector<uint8_t> wbe((size_t)nwin * g->nbytes);
@@ -1528,12 +1513,7 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     uint32_t* ones = powers + x->n * Wd;
     VMN_TRY(modpow_words(ctx, m, x->d, ew.as<uint32_t>(), m.NW, 0, g->Q.nbits, x->n, powers));
     std::vector<uint32_t> idx(x->n, 0xffffffffu);
-    std::vector<uint32_t> one_row(Wd, 0);
-    VMN_TRY(d2h(ctx, one_row.data(), m.d_one, m.S * sizeof(uint32_t)));
-    DevTmp fill(ctx);
-    VMN_TRY(fill.alloc(Wd * sizeof(uint32_t)));
-    VMN_TRY(h2d(ctx, fill.p, one_row.data(), Wd * sizeof(uint32_t)));
-    VMN_TRY(gather_rows(ctx, m, powers, idx, fill.as<uint32_t>(), ones));
+    VMN_TRY(gather_rows(ctx, m, powers, idx, m.d_one, ones));
     return compare_arrays(ctx, m, powers, ones, x->n, all_members);
 }
 

@@ -61,11 +61,13 @@ struct vmn_ctx {
 struct vmn_modulus {
     int S = 0;                 // 28-bit limbs
     int NW = 0;                // 32-bit words of the packed form
+    int LPE = 1;               // lanes per element (2 for 3072-bit moduli)
+    int W = 0;                 // words per element row in device memory
     int nbits = 0;
     uint32_t n0inv = 0;        // -N^{-1} mod 2^28
-    uint32_t* d_n = nullptr;   // S limbs of N
-    uint32_t* d_rr = nullptr;  // R^2 mod N (limbs), R = 2^(28 S)
-    uint32_t* d_one = nullptr; // R mod N (limbs)  == Montgomery form of 1
+    uint32_t* d_n = nullptr;   // N as one device row (W words: per-lane shares, zero padded)
+    uint32_t* d_rr = nullptr;  // R^2 mod N as a row, R = 2^(28 S)
+    uint32_t* d_one = nullptr; // R mod N as a row == Montgomery form of 1
     vmn::hostbig::Big n_words; // NW words
     vmn::hostbig::Mont* hm = nullptr;     // host Montgomery context (32-bit words, R = 2^(32 NW))
 };
