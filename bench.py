@@ -172,6 +172,99 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1):
     return best
 
 
+def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072):
+    """BASELINE.json configs[2]: ElGamal ciphertexts over the 3072-bit ModPGroup (RFC 3526 group 15), width 1:
+    offline  = permutation commitment (A4) + proof of a shuffle of commitments (A2, prove + verify)
+    online   = re-encryption (A0) + commitment-consistent proof of a shuffle (A3, prove + verify, plain form).
+    3072-bit elements run two lanes per element."""
+    from oracle import pyref
+    hv, mx = load_sub(entry, "hvzk"), load_sub(entry, "mixnet")
+    NV = NE = 256
+    NR = 100
+    EB = NE + NV + NR
+    p, q, g = pyref.modp_group(bits)
+    grp = vmn.ModPGroup(ctx, p, q, g, nbytes=bits // 8)
+    bulk = mx.BulkRandomSource(seed, q, grp.nbytes)
+    H = grp.exp(g, grp.ringArray(bulk.ring_array(n)))
+    y = pow(g, bulk.ring_element(), p)
+    pkey = [g, y]
+    T = grp.ringArray(bulk.ring_array(n))
+    M = grp.exp(g, grp.ringArray(bulk.ring_array(n)))
+    YT = grp.exp(y, T)
+    W = [grp.exp(g, T), M.mul(YT)]
+    for a in (T, M, YT):
+        a.free()
+    tape = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, commitment exponents r
+                               ("int_array", n, NE),                                         # PoSC batching vector
+                               ("ring_array", n), ("ring_element",), ("int_array", n, EB), ("ring_array", n),   # b, alpha, eps, beta
+                               ("ring_element",), ("ring_element",), ("int_array", 1, NV),                        # gamma, delta, v
+                               ("ring_array", n),                                            # s
+                               ("int_array", n, NE), ("ring_element",), ("int_array", n, EB), ("ring_element",), # e, alpha, eps, beta
+                               ("int_array", 1, NV)])
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    # ---- offline
+    pi = tape.permutation(n)
+    pc = mx.PermutationCommitment(grp, H)
+    r_bytes = tape.ring_array(n)
+    U = pc.precompute(r_bytes, pi)
+    e1 = tape.int_array(n, NE)
+    pr = hv.PoSCBasicTW(grp, NV, NE, NR, rand=tape)
+    pr.setInstance(g, H, U, pc.exponents, pi)
+    pr.setBatchVector(e1)
+    com = pr.commit()
+    v1 = int.from_bytes(tape.int_array(1, NV), "big")
+    rep = pr.reply(v1)
+    ver = hv.PoSCBasicTW(grp, NV, NE, NR)
+    ver.setInstance(g, H, U)
+    ver.setBatchVector(e1)
+    ver.setCommitment(com)
+    ver.setChallenge(v1)
+    ok_posc = ver.verify(rep)
+    sync()
+    t1 = time.perf_counter()
+    # ---- online
+    S = [grp.ringArray(tape.ring_array(n))]
+    factors = mx.reencFactors(grp, pkey, S)
+    WP = mx.reencrypt(W, factors, pi)
+    for f in factors:
+        f.free()
+    sync()
+    t2 = time.perf_counter()
+    e2 = tape.int_array(n, NE)
+    cp = hv.CCPoSBasicW(grp, NV, NE, NR, rand=tape)
+    cp.setInstance(g, H, U, pkey, W, WP, pc.exponents, pi, S)
+    cp.setBatchVector(e2)
+    com2 = cp.commit()
+    v2 = int.from_bytes(tape.int_array(1, NV), "big")
+    rep2 = cp.reply(v2)
+    sync()
+    t3 = time.perf_counter()
+    cv = hv.CCPoSBasicW(grp, NV, NE, NR)
+    cv.setInstance(g, H, U, pkey, W, WP)
+    cv.setBatchVector(e2)
+    cv.setCommitment(com2)
+    cv.setChallenge(v2)
+    cv.computeAB()
+    ok = cv.verify(rep2)
+    sync()
+    t4 = time.perf_counter()
+    ctx.timing_enable(False)
+    fam = ctx.timing_report()
+    online = t4 - t1
+    return {"workload": f"BASELINE.json configs[2]: ModPGroup {bits}-bit, width 1, CCPoS path; offline = permutation commitment + PoSC "
+                        "prove+verify, online = re-encrypt + CCPoS prove+verify (n_e = n_v = 256, n_r = 100)",
+            "n": n, "accepted": bool(ok and ok_posc),
+            "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3, "ccpos_prove_ms": (t3 - t2) * 1e3,
+            "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
+            "ciphertexts_per_s_online": n / online, "ciphertexts_per_s_total": n / (t4 - t0),
+            # SURVEY.md §8d canonical cost: 1090 M(96) per ciphertext online (M(96) = 18528 MAC)
+            "algorithmic_TMACs_online": 1090 * 18528 * n / online / 1e12,
+            "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+
+
 def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dist, device):
     """The same workload sharded over the ranks: N = n_per_gpu x world ciphertexts, one proof, every
     array split by position (verificatum-vmn_amd/parallel.py); public inputs replicated per GPU; the
@@ -247,6 +340,8 @@ def main() -> None:
     ap.add_argument("--cpu-sample-elements", dest="cpu_sample", type=int, default=0, help="elements of the CPU baseline sample (0 = auto)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--mix-elements", dest="mix_n", type=int, default=200_000, help="ciphertexts of the mix+prove leg (0 = skip)")
+    ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=100_000,
+                    help="ciphertexts of the 3072-bit CCPoS leg (BASELINE configs[2]; 0 = skip; single GPU only)")
     args = ap.parse_args()
 
     # Build (only if a prebuilt library is missing) BEFORE anything touches the GPU: a process that has
@@ -385,6 +480,10 @@ def main() -> None:
                           "n_e = n_v = 256, n_r = 100; N = mix_n x n_gpus ciphertexts, ONE proof sharded by position "
                           "(all-gather of partial products / scan carries only)")
         result["mix_prove"] = mp
+
+    if args.ccpos_n > 0 and not distributed:
+        ctx.timing_reset()
+        result["mix_ccpos_3072"] = mix_ccpos(entry, vmn, ctx, args.ccpos_n, 4242, barrier)
 
     if rank == 0 and not args.no_cpu:
         from oracle.cbind import Oracle

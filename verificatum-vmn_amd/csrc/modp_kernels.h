@@ -182,18 +182,21 @@ __device__ __forceinline__ void canonicalize(u32 (&x)[C::L], const u32 (&n)[C::L
 template <class C>
 __device__ __forceinline__ void mod_add(u32 (&r)[C::L], const u32 (&a)[C::L], const u32 (&b)[C::L], const u32 (&n)[C::L],
                                         const Lane<C>& ln) {
-    // r may alias a or b: the carry of the even lane is computed without storing, then one storing sweep
+    // r may alias a or b: sums first (own registers), then the carry sweep(s), then r is written
+    u32 s[C::L];
+#pragma unroll
+    for (int j = 0; j < C::L; ++j) s[j] = a[j] + b[j];
     u32 cin = 0;
     if constexpr (C::LPE == 2) {
         u32 c = 0;
 #pragma unroll
-        for (int j = 0; j < C::L; ++j) c = (c + a[j] + b[j]) >> LIMB_BITS;
+        for (int j = 0; j < C::L; ++j) c = (c + s[j]) >> LIMB_BITS;
         cin = from_even(c) & ~ln.evenmask;
     }
     u32 c = cin;
 #pragma unroll
     for (int j = 0; j < C::L; ++j) {
-        c += a[j] + b[j];
+        c += s[j];
         r[j] = c & LIMB_MASK;
         c >>= LIMB_BITS;
     }
