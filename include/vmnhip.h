@@ -88,6 +88,19 @@ int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_garray**
 /* array.toByteTree() payload: n * elem_bytes big-endian bytes.  ref: 174 toByteTree call sites, e.g.
  * P/hvzk/PoSBasicTW.java:694-699. */
 int vmn_garray_to_be(const vmn_garray* a, uint8_t* be_out);
+/* The same in the reference's byte-tree framing: node(N leaves of elem_bytes) =
+ * 00 | uint32_be(N) | N x (01 | uint32_be(elem_bytes) | value).  Leaf headers are written / checked on the
+ * GPU.  from_bytetree: expected_n = 0 accepts any size (pGroup.toElementArray(0, reader)); *format_ok = 0
+ * (and no array) when the tree is not a node of leaves of the right width (the reference's
+ * ArithmFormatException / EIOException, which its callers catch: P/hvzk/PoSBasicTW.java:505-513). */
+size_t vmn_garray_bytetree_size(const vmn_garray* a);
+int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out);
+int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_garray** out,
+                             int* format_ok, int* all_in_range);
+size_t vmn_rarray_bytetree_size(const vmn_rarray* a);
+int vmn_rarray_to_bytetree(const vmn_rarray* a, uint8_t* out);
+int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_rarray** out,
+                             int* format_ok, int* all_in_range);
 size_t vmn_garray_size(const vmn_garray* a);
 void vmn_garray_free(vmn_garray* a);                   /* PGroupElementArray.free() */
 

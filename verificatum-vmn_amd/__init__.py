@@ -63,7 +63,8 @@ def lib() -> C.CDLL:
         _lib.vmn_last_error.restype = C.c_char_p
         _lib.vmn_version.restype = C.c_char_p
         _lib.vmn_ctx_get_stream.restype = C.c_void_p
-        for name in ("vmn_group_elem_bytes", "vmn_group_exp_bytes", "vmn_garray_size", "vmn_rarray_size"):
+        for name in ("vmn_group_elem_bytes", "vmn_group_exp_bytes", "vmn_garray_size", "vmn_rarray_size",
+                     "vmn_garray_bytetree_size", "vmn_rarray_bytetree_size"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 
@@ -190,6 +191,26 @@ class ModPGroup:
             raise ValueError("ArithmFormatException: ring element out of range")
         return arr
 
+    def _from_bytetree(self, fn: str, cls, bt: bytes, expected_n: int):
+        h = C.c_void_p()
+        fmt, rng = C.c_int(0), C.c_int(1)
+        _check(getattr(lib(), fn)(self._h, bytes(bt), C.c_size_t(len(bt)), C.c_size_t(expected_n), C.byref(h),
+                                   C.byref(fmt), C.byref(rng)))
+        if not fmt.value:
+            raise ValueError("EIOException: not a byte tree of %d-byte leaves" % self.nbytes)
+        arr = cls(self, h)
+        if not rng.value:
+            arr.free()
+            raise ValueError("ArithmFormatException: element out of range")
+        return arr
+
+    def toElementArrayFromByteTree(self, bt: bytes, size: int = 0) -> "PGroupElementArray":
+        """``pGroup.toElementArray(size, byteTreeReader)`` (size 0 = any), the reference's wire format."""
+        return self._from_bytetree("vmn_garray_from_bytetree", PGroupElementArray, bt, size)
+
+    def ringArrayFromByteTree(self, bt: bytes, size: int = 0) -> "PRingElementArray":
+        return self._from_bytetree("vmn_rarray_from_bytetree", PRingElementArray, bt, size)
+
     def exp(self, base: int, exponents: "PRingElementArray") -> "PGroupElementArray":
         """``g.exp(PRingElementArray)``: fixed base, one exponent per element (K2)."""
         h = C.c_void_p()
@@ -237,6 +258,13 @@ class PGroupElementArray(_ArrayBase):
 
     def toInts(self) -> list:
         return be_to_ints(self.toBytes(), self.group.nbytes)
+
+    def toByteTree(self) -> bytes:
+        """``array.toByteTree()``: node of N fixed-width leaves, framed on the GPU."""
+        size = lib().vmn_garray_bytetree_size(self._h)
+        out = C.create_string_buffer(size)
+        _check(lib().vmn_garray_to_bytetree(self._h, out))
+        return out.raw[:size]
 
     def _new(self, h) -> "PGroupElementArray":
         return PGroupElementArray(self.group, h)
@@ -341,6 +369,12 @@ class PRingElementArray(_ArrayBase):
 
     def toInts(self) -> list:
         return be_to_ints(self.toBytes(), self.group.nbytes)
+
+    def toByteTree(self) -> bytes:
+        size = lib().vmn_rarray_bytetree_size(self._h)
+        out = C.create_string_buffer(size)
+        _check(lib().vmn_rarray_to_bytetree(self._h, out))
+        return out.raw[:size]
 
     def _new(self, h) -> "PRingElementArray":
         return PRingElementArray(self.group, h)

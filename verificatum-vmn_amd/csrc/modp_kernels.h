@@ -333,7 +333,7 @@ __device__ __forceinline__ void limbs_from_be(u32 (&a)[C::L], const uint8_t* __r
 // for malformed input (P/hvzk/PoSBasicTW.java:794-815).
 template <class C, int NW>
 __global__ void __launch_bounds__(BLOCK, C::MINW)
-k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes, size_t n,
+k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes, size_t stride, int leaf_hdr, size_t n,
             const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ rr, u32* __restrict__ flags) {
     extern __shared__ u32 lds[];
     Lane<C> ln(lds);
@@ -342,7 +342,13 @@ k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes
     size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
-    const uint8_t* src = be + ec * nbytes;
+    const uint8_t* src = be + ec * stride;             // stride = nbytes, or nbytes + 5 with byte-tree leaf headers
+    if (leaf_hdr) {                                   // 01 | uint32_be(nbytes) in front of every value
+        bool hdr_ok = src[0] == 1 && src[1] == (uint8_t)(nbytes >> 24) && src[2] == (uint8_t)(nbytes >> 16) &&
+                      src[3] == (uint8_t)(nbytes >> 8) && src[4] == (uint8_t)nbytes;
+        if (live && !hdr_ok) atomicOr(flags, 4u);
+        src += 5;
+    }
     u32 extra = 0;                                    // leading bytes beyond NW words must be zero
     for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) extra |= src[o];
     u32 a[C::L];
@@ -383,7 +389,7 @@ __device__ __forceinline__ void emit_words(const u32 (&r)[C::L], const Lane<C>& 
 
 template <class C, int NW>
 __global__ void __launch_bounds__(BLOCK, C::MINW)
-k_export_be(uint8_t* __restrict__ be, size_t nbytes, const u32* __restrict__ in, size_t n,
+k_export_be(uint8_t* __restrict__ be, size_t nbytes, size_t stride, int leaf_hdr, const u32* __restrict__ in, size_t n,
             const u32* __restrict__ nmod, u32 n0inv) {
     extern __shared__ u32 lds[];
     Lane<C> ln(lds);
@@ -398,7 +404,17 @@ k_export_be(uint8_t* __restrict__ be, size_t nbytes, const u32* __restrict__ in,
     u32 r[C::L];
     mont_mul<C>(r, a, ln, nn, n0inv);
     canonicalize<C>(r, nn, ln);
-    uint8_t* dst = be + ec * nbytes;
+    uint8_t* dst = be + ec * stride;
+    if (leaf_hdr) {
+        if (live && ln.half == 0) {
+            dst[0] = 1;
+            dst[1] = (uint8_t)(nbytes >> 24);
+            dst[2] = (uint8_t)(nbytes >> 16);
+            dst[3] = (uint8_t)(nbytes >> 8);
+            dst[4] = (uint8_t)nbytes;
+        }
+        dst += 5;
+    }
     emit_words<C, NW>(r, ln, [&](int k, u32 w) { if (live) store_be_word(dst, (long)nbytes, k, w); });
     if (live && ln.half == 0) {
         for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) dst[o] = 0;

@@ -406,19 +406,22 @@ static int alloc_elems(vmn_ctx* ctx, const vmn_modulus& m, size_t n, uint32_t** 
     return pool_alloc(ctx, elems_bytes(m, n), reinterpret_cast<void**>(d));
 }
 
+// leaf_hdr: every value is preceded by its 5-byte byte-tree leaf header (checked on the device; *format_ok)
 static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* be, size_t n, uint32_t* d_out,
-                     int* all_in_range) {
+                     int* all_in_range, int leaf_hdr = 0, int* format_ok = nullptr) {
     if (all_in_range) *all_in_range = 1;
+    if (format_ok) *format_ok = 1;
     if (n == 0) return VMN_OK;
+    const size_t stride = nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
-    VMN_TRY(raw.alloc(n * nbytes + 8));
-    VMN_HIP(hipMemcpyAsync(raw.p, be, n * nbytes, hipMemcpyHostToDevice, ctx->stream));
+    VMN_TRY(raw.alloc(n * stride + 8));
+    VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
     VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                              \
     if (m.S == S_)                                                                                              \
         rc = launch(ctx, "import", k_import_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), d_out, raw.as<uint8_t>(), \
-                    nbytes, n, m.d_n, m.n0inv, m.d_rr, ctx->flags);
+                    nbytes, stride, leaf_hdr, n, m.d_n, m.n0inv, m.d_rr, ctx->flags);
     VMN_FOR_SIZES(X)
 #undef X
     VMN_TRY(rc);
@@ -426,23 +429,49 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     VMN_HIP(hipMemcpyAsync(&fl, ctx->flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
     VMN_HIP(hipStreamSynchronize(ctx->stream));
     if (all_in_range) *all_in_range = (fl & 1u) ? 0 : 1;
+    if (format_ok) *format_ok = (fl & 4u) ? 0 : 1;
     return VMN_OK;
 }
 
-static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be) {
+static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be,
+                     int leaf_hdr = 0) {
     if (n == 0) return VMN_OK;
+    const size_t stride = nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
-    VMN_TRY(raw.alloc(n * nbytes + 8));
+    VMN_TRY(raw.alloc(n * stride + 8));
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                          \
     if (m.S == S_)                                                                                          \
         rc = launch(ctx, "export", k_export_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), raw.as<uint8_t>(),    \
-                    nbytes, d_in, n, m.d_n, m.n0inv);
+                    nbytes, stride, leaf_hdr, d_in, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
 #undef X
     VMN_TRY(rc);
-    VMN_HIP(hipMemcpyAsync(be, raw.p, n * nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    VMN_HIP(hipMemcpyAsync(be, raw.p, n * stride, hipMemcpyDeviceToHost, ctx->stream));
     VMN_HIP(hipStreamSynchronize(ctx->stream));
+    return VMN_OK;
+}
+
+// byte tree of an array: node header on the host, leaves framed on the device
+static size_t bytetree_size(size_t n, size_t nbytes) { return 5 + n * (5 + nbytes); }
+static int to_bytetree(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* out) {
+    out[0] = 0;
+    out[1] = (uint8_t)(n >> 24);
+    out[2] = (uint8_t)(n >> 16);
+    out[3] = (uint8_t)(n >> 8);
+    out[4] = (uint8_t)n;
+    return export_be(ctx, m, nbytes, d_in, n, out + 5, 1);
+}
+// returns the element count through *n_out; *format_ok = 0 if the buffer is not node(N leaves of nbytes)
+static int bytetree_header(const uint8_t* bt, size_t len, size_t nbytes, size_t expected_n, size_t* n_out, int* format_ok) {
+    *format_ok = 0;
+    *n_out = 0;
+    if (len < 5 || bt[0] != 0) return VMN_OK;
+    size_t n = ((size_t)bt[1] << 24) | ((size_t)bt[2] << 16) | ((size_t)bt[3] << 8) | bt[4];
+    if (len != bytetree_size(n, nbytes)) return VMN_OK;
+    if (expected_n != 0 && n != expected_n) return VMN_OK;
+    *n_out = n;
+    *format_ok = 1;
     return VMN_OK;
 }
 
@@ -587,6 +616,54 @@ extern "C" int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, v
     VMN_TRY(new_rarray(grp, n, &a));
     int rc = import_be(grp->ctx, grp->Q, grp->nbytes, be, n, a->d, all_in_range);
     if (rc != VMN_OK) {
+        vmn_rarray_free(a);
+        return rc;
+    }
+    *out = a;
+    return VMN_OK;
+}
+extern "C" size_t vmn_garray_bytetree_size(const vmn_garray* a) { return a ? bytetree_size(a->n, a->grp->nbytes) : 0; }
+extern "C" size_t vmn_rarray_bytetree_size(const vmn_rarray* a) { return a ? bytetree_size(a->n, a->grp->nbytes) : 0; }
+extern "C" int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out) {
+    ARG_CHECK(a && out, "null argument");
+    VMN_HIP(hipSetDevice(a->grp->ctx->device));
+    return to_bytetree(a->grp->ctx, a->grp->P, a->grp->nbytes, a->d, a->n, out);
+}
+extern "C" int vmn_rarray_to_bytetree(const vmn_rarray* a, uint8_t* out) {
+    ARG_CHECK(a && out, "null argument");
+    VMN_HIP(hipSetDevice(a->grp->ctx->device));
+    return to_bytetree(a->grp->ctx, a->grp->Q, a->grp->nbytes, a->d, a->n, out);
+}
+extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_garray** out,
+                                        int* format_ok, int* all_in_range) {
+    ARG_CHECK(grp && bt && out && format_ok, "null argument");
+    VMN_HIP(hipSetDevice(grp->ctx->device));
+    *out = nullptr;
+    size_t n = 0;
+    VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
+    if (!*format_ok) return VMN_OK;
+    vmn_garray* a = nullptr;
+    VMN_TRY(new_garray(grp, n, &a));
+    int rc = import_be(grp->ctx, grp->P, grp->nbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
+    if (rc != VMN_OK || !*format_ok) {
+        vmn_garray_free(a);
+        return rc;
+    }
+    *out = a;
+    return VMN_OK;
+}
+extern "C" int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_rarray** out,
+                                        int* format_ok, int* all_in_range) {
+    ARG_CHECK(grp && bt && out && format_ok, "null argument");
+    VMN_HIP(hipSetDevice(grp->ctx->device));
+    *out = nullptr;
+    size_t n = 0;
+    VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
+    if (!*format_ok) return VMN_OK;
+    vmn_rarray* a = nullptr;
+    VMN_TRY(new_rarray(grp, n, &a));
+    int rc = import_be(grp->ctx, grp->Q, grp->nbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
+    if (rc != VMN_OK || !*format_ok) {
         vmn_rarray_free(a);
         return rc;
     }
