@@ -339,8 +339,8 @@ def main() -> None:
     ap.add_argument("--elements", dest="n", type=int, default=1_000_000, help="elements per GPU")
     ap.add_argument("--cpu-sample-elements", dest="cpu_sample", type=int, default=0, help="elements of the CPU baseline sample (0 = auto)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
-    ap.add_argument("--mix-elements", dest="mix_n", type=int, default=200_000, help="ciphertexts of the mix+prove leg (0 = skip)")
-    ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=100_000,
+    ap.add_argument("--mix-elements", dest="mix_n", type=int, default=1_000_000, help="ciphertexts of the mix+prove leg (0 = skip)")
+    ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=400_000,
                     help="ciphertexts of the 3072-bit CCPoS leg (BASELINE configs[2]; 0 = skip; single GPU only)")
     args = ap.parse_args()
 
