@@ -73,6 +73,12 @@ int vmn_ctx_num_cus(vmn_ctx* ctx);
  * Supported modulus sizes: 512, 1024, 2048, 3072, 4096 bits (nbytes*8 rounded up to those). */
 int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const uint8_t* q_be, const uint8_t* g_be,
                           size_t nbytes, vmn_group** out);
+/* ECqPGroup over a named NIST curve ("P-256", "P-384"; a = -3).  ref: the default group of the
+ * reference, demo/mixnet/.conf:153 (P-256); SURVEY.md §2.3 K11.  Group elements cross the boundary as
+ * x || y (elem_bytes = 2 * coordinate width, big-endian; the point at infinity is all 0xff bytes);
+ * exponents are residues mod the group order.  Every vmn_garray_* call works on such groups with the
+ * group operation = point addition ("mul") and exponentiation = scalar multiplication ("exp"). */
+int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_group** out);
 void vmn_group_destroy(vmn_group* grp);
 size_t vmn_group_elem_bytes(const vmn_group* grp);     /* bytes per group element on the wire */
 size_t vmn_group_exp_bytes(const vmn_group* grp);      /* bytes per exponent (ring element) on the wire */

@@ -1,0 +1,121 @@
+"""GPU suite, K11: the elliptic-curve group kernels (one point per lane, Jacobian rows) against the Python
+curve reference — every array operation the proofs use, with the exceptional cases of the addition."""
+import random
+
+import pytest
+
+from oracle.pyref_ec import Curve
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["P-256", "P-384"])
+def ecg(request, vmn, gpu_ctx):
+    return vmn.ECqPGroup(gpu_ctx, request.param), Curve(request.param)
+
+
+def pts(c, seed, n):
+    rnd = random.Random(seed)
+    return [c.mul(rnd.randrange(1, c.n), c.g) for _ in range(n)]
+
+
+def test_import_export_and_curve_check(ecg, vmn):
+    G, c = ecg
+    xs = pts(c, 1, 70) + [None, c.g, c.neg(c.g)]
+    X = G.toElementArray(xs)
+    assert X.toInts() == xs and X.size() == 73
+    bad = (c.g[0], (c.g[1] + 1) % c.p)                     # not on the curve
+    arr = G.toElementArray([c.g, bad, (c.p, 5)], checked=False)
+    assert arr.all_in_range is False
+    assert arr.toInts() == [c.g, None, None]               # offending entries replaced by the identity
+    with pytest.raises(ValueError):
+        G.toElementArray([bad])
+
+
+def test_pointwise_group_operation_with_exceptional_cases(ecg):
+    G, c = ecg
+    a = pts(c, 2, 40)
+    b = pts(c, 3, 40)
+    # equal points (doubling through the addition), opposite points, identity on either side
+    a += [c.g, c.g, None, c.g, None]
+    b += [c.g, c.neg(c.g), c.g, None, None]
+    A, B = G.toElementArray(a), G.toElementArray(b)
+    assert A.mul(B).toInts() == c.mul_arrays(a, b)
+    assert A.inv().toInts() == [c.neg(P) for P in a]
+    assert A.mul(A.inv()).toInts() == [None] * len(a)
+    assert A.prod() == c.prod(a)
+    assert G.toElementArray([]).prod() is None
+
+
+def test_scalar_multiplication_variable_fixed_and_shared(ecg):
+    G, c = ecg
+    rnd = random.Random(4)
+    n = 150
+    xs = pts(c, 5, n)
+    es = [rnd.randrange(c.n) for _ in range(n)]
+    es[0], es[1], es[2], es[3] = 0, 1, c.n - 1, 2
+    X, E = G.toElementArray(xs), G.ringArray(es)
+    assert X.exp(E).toInts() == c.exp_array(xs, es)
+    assert G.exp(c.g, E).toInts() == c.exp_fixed(c.g, es)
+    k = rnd.randrange(1 << 50)
+    assert X.exp(k).toInts() == [c.mul(k, P) for P in xs]
+    assert X.exp(0).toInts() == [None] * n
+    e612 = [rnd.randrange(1 << 612) for _ in range(n)]    # long integer exponents act through their residue mod n
+    assert X.expInts(e612, 612).toInts() == c.exp_array(xs, e612)
+
+
+def test_equality_is_of_group_elements_not_of_representations(ecg):
+    G, c = ecg
+    rnd = random.Random(6)
+    n = 90
+    xs = pts(c, 7, n)
+    a = [rnd.randrange(c.n) for _ in range(n)]
+    b = [rnd.randrange(c.n) for _ in range(n)]
+    X = G.toElementArray(xs)
+    A, B = G.ringArray(a), G.ringArray(b)
+    left = X.exp(A).exp(B)                                 # Jacobian rows with unrelated Z coordinates
+    right = X.exp(A.mul(B))
+    assert left.equals(right)
+    ys = list(xs)
+    ys[n - 1] = c.g
+    assert not X.equals(G.toElementArray(ys))
+    assert X.exp(A).mul(X.exp(B)).equals(X.exp(A.add(B)))
+
+
+def test_multi_exponentiation_and_movement(ecg):
+    G, c = ecg
+    rnd = random.Random(8)
+    for n in (1, 2, 33, 300):
+        xs = pts(c, 100 + n, n)
+        es = [rnd.randrange(c.n) for _ in range(n)]
+        e256 = [rnd.randrange(1 << 128) for _ in range(n)]
+        X = G.toElementArray(xs)
+        assert X.expProd(G.ringArray(es)) == c.exp_prod(xs, es), n
+        assert X.expProd(e256, 128) == c.exp_prod(xs, e256), n
+        perm = list(range(n))
+        rnd.shuffle(perm)
+        assert X.permute(perm).toInts() == [xs[j] for j in perm]
+        assert X.shiftPush(c.g).toInts() == ([c.g] + xs[:-1])
+        assert X.get(n - 1) == xs[n - 1]
+    # all-equal bases and exponents: one bucket per window, equal-point additions inside the tree
+    xs = [c.g] * 64
+    es = [12345] * 64
+    assert G.toElementArray(xs).expProd(G.ringArray(es)) == c.mul(64 * 12345, c.g)
+    assert G.toElementArray([]).expProd(G.ringArray([])) is None
+
+
+def test_scalar_field_arrays(ecg):
+    G, c = ecg
+    rnd = random.Random(9)
+    n = 77
+    a = [rnd.randrange(c.n) for _ in range(n)]
+    b = [rnd.randrange(c.n) for _ in range(n)]
+    A, B = G.ringArray(a), G.ringArray(b)
+    assert A.mul(B).toInts() == [x * y % c.n for x, y in zip(a, b)]
+    assert A.innerProduct(B) == sum(x * y for x, y in zip(a, b)) % c.n
+    x, d = A.recLin(B)
+    want, acc = [], 0
+    for i in range(n):
+        acc = a[i] % c.n if i == 0 else (acc * b[i] + a[i]) % c.n
+        want.append(acc)
+    assert x.toInts() == want and d == want[-1]

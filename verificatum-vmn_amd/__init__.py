@@ -164,6 +164,36 @@ class ModPGroup:
         except Exception:
             pass
 
+    # -- element codec and single-element ("scalar") group operations ---------------------------
+    @property
+    def elem_bytes(self) -> int:
+        return self.nbytes
+
+    @property
+    def ONE(self):
+        return 1
+
+    def enc_el(self, el) -> bytes:
+        return int_to_be(el, self.nbytes)
+
+    def dec_el(self, buf: bytes):
+        return int.from_bytes(buf, "big")
+
+    def enc_els(self, els) -> bytes:
+        return ints_to_be(els, self.nbytes)
+
+    def dec_els(self, buf: bytes) -> list:
+        return be_to_ints(buf, self.nbytes)
+
+    def k_mul(self, a, b):
+        return a * b % self.p
+
+    def k_exp(self, a, e: int):
+        return pow(a, e % self.q, self.p)
+
+    def k_inv(self, a):
+        return pow(a, -1, self.p)
+
     # -- constructors mirroring pGroup.toElementArray / pRing.toElementArray --------------------
     def toElementArray(self, values, checked: bool = True) -> "PGroupElementArray":
         """values: sequence of ints, or bytes of n*nbytes big-endian."""
@@ -211,16 +241,81 @@ class ModPGroup:
     def ringArrayFromByteTree(self, bt: bytes, size: int = 0) -> "PRingElementArray":
         return self._from_bytetree("vmn_rarray_from_bytetree", PRingElementArray, bt, size)
 
-    def exp(self, base: int, exponents: "PRingElementArray") -> "PGroupElementArray":
+    def exp(self, base, exponents: "PRingElementArray") -> "PGroupElementArray":
         """``g.exp(PRingElementArray)``: fixed base, one exponent per element (K2)."""
         h = C.c_void_p()
-        _check(lib().vmn_group_exp_fixed(self._h, int_to_be(base, self.nbytes), exponents._h, C.byref(h)))
+        _check(lib().vmn_group_exp_fixed(self._h, self.enc_el(base), exponents._h, C.byref(h)))
         return PGroupElementArray(self, h)
 
-    def mulPartials(self, partials: Sequence[int]) -> int:
-        out = C.create_string_buffer(self.nbytes)
-        _check(lib().vmn_group_mul_partials(self._h, ints_to_be(partials, self.nbytes), C.c_size_t(len(partials)), out))
-        return int.from_bytes(out.raw, "big")
+    def mulPartials(self, partials):
+        out = C.create_string_buffer(self.elem_bytes)
+        _check(lib().vmn_group_mul_partials(self._h, self.enc_els(partials), C.c_size_t(len(partials)), out))
+        return self.dec_el(out.raw)
+
+
+class ECqPGroup(ModPGroup):
+    """``com.verificatum.arithm.ECqPGroup`` over a NIST curve (the reference's default group is P-256,
+    demo/mixnet/.conf:153).  Elements are affine points ``(x, y)`` (``None`` = infinity); on the wire
+    x || y fixed width; ``mul`` is point addition, ``exp`` scalar multiplication; exponents live in Z_n."""
+
+    def __init__(self, ctx: Context, name: str = "P-256"):
+        from . import ecscalar
+        self._ec = ecscalar
+        c = ecscalar.CURVES[name]
+        self.ctx, self.name = ctx, name
+        self.p, self.q, self.b = c["p"], c["n"], c["b"]
+        self.g = (c["gx"], c["gy"])
+        self.nbytes = (self.p.bit_length() + 7) // 8
+        self._h = C.c_void_p()
+        _check(lib().vmn_ec_group_create(ctx._h, name.encode(), C.byref(self._h)))
+
+    @property
+    def elem_bytes(self) -> int:
+        return 2 * self.nbytes
+
+    @property
+    def ONE(self):
+        return None
+
+    def enc_el(self, el) -> bytes:
+        if el is None:
+            return b"\xff" * (2 * self.nbytes)
+        return int_to_be(el[0], self.nbytes) + int_to_be(el[1], self.nbytes)
+
+    def dec_el(self, buf: bytes):
+        nb = self.nbytes
+        if buf == b"\xff" * (2 * nb):
+            return None
+        return int.from_bytes(buf[:nb], "big"), int.from_bytes(buf[nb:], "big")
+
+    def enc_els(self, els) -> bytes:
+        return b"".join(self.enc_el(e) for e in els)
+
+    def dec_els(self, buf: bytes) -> list:
+        w = 2 * self.nbytes
+        return [self.dec_el(buf[i:i + w]) for i in range(0, len(buf), w)]
+
+    def k_mul(self, a, b):
+        return self._ec.add(a, b, self.p)
+
+    def k_exp(self, a, e: int):
+        return self._ec.mul(e, a, self.p, self.q)
+
+    def k_inv(self, a):
+        return self._ec.neg(a, self.p)
+
+    def toElementArray(self, values, checked: bool = True) -> "PGroupElementArray":
+        buf = values if isinstance(values, (bytes, bytearray)) else self.enc_els(values)
+        n = len(buf) // self.elem_bytes
+        h = C.c_void_p()
+        ok = C.c_int(1)
+        _check(lib().vmn_garray_from_be(self._h, bytes(buf), C.c_size_t(n), C.byref(h), C.byref(ok)))
+        arr = PGroupElementArray(self, h)
+        arr.all_in_range = bool(ok.value)
+        if checked and not ok.value:
+            arr.free()
+            raise ValueError("ArithmFormatException: point not on the curve")
+        return arr
 
 
 class _ArrayBase:
@@ -252,12 +347,13 @@ class PGroupElementArray(_ArrayBase):
         return lib().vmn_garray_size(self._h)
 
     def toBytes(self) -> bytes:
-        out = C.create_string_buffer(max(1, self.size() * self.group.nbytes))
+        out = C.create_string_buffer(max(1, self.size() * self.group.elem_bytes))
         _check(lib().vmn_garray_to_be(self._h, out))
-        return out.raw[: self.size() * self.group.nbytes]
+        return out.raw[: self.size() * self.group.elem_bytes]
 
     def toInts(self) -> list:
-        return be_to_ints(self.toBytes(), self.group.nbytes)
+        """The elements as host values (ints for ModPGroup, affine points for ECqPGroup)."""
+        return self.group.dec_els(self.toBytes())
 
     def toByteTree(self) -> bytes:
         """``array.toByteTree()``: node of N fixed-width leaves, framed on the GPU."""
@@ -289,14 +385,14 @@ class PGroupElementArray(_ArrayBase):
         return self._new(h)
 
     # K3
-    def expProd(self, e, ebits: int = 0) -> int:
-        out = C.create_string_buffer(self.group.nbytes)
+    def expProd(self, e, ebits: int = 0):
+        out = C.create_string_buffer(self.group.elem_bytes)
         if isinstance(e, PRingElementArray):
             _check(lib().vmn_garray_expprod(self._h, e._h, C.c_int(ebits), out))
         else:
             nb = (ebits + 7) // 8
             _check(lib().vmn_garray_expprod_ints(self._h, ints_to_be(e, nb), C.c_size_t(nb), C.c_int(ebits), out))
-        return int.from_bytes(out.raw, "big")
+        return self.group.dec_el(out.raw)
 
     # K4 / K5 / K6
     def mul(self, other: "PGroupElementArray") -> "PGroupElementArray":
@@ -304,10 +400,10 @@ class PGroupElementArray(_ArrayBase):
         _check(lib().vmn_garray_mul(self._h, other._h, C.byref(h)))
         return self._new(h)
 
-    def prod(self) -> int:
-        out = C.create_string_buffer(self.group.nbytes)
+    def prod(self):
+        out = C.create_string_buffer(self.group.elem_bytes)
         _check(lib().vmn_garray_prod(self._h, out))
-        return int.from_bytes(out.raw, "big")
+        return self.group.dec_el(out.raw)
 
     def inv(self) -> "PGroupElementArray":
         """Element-wise inverse (batch inversion)."""
@@ -327,9 +423,9 @@ class PGroupElementArray(_ArrayBase):
         _check(lib().vmn_garray_gather(self._h, arr, C.c_size_t(len(perm)), C.byref(h)))
         return self._new(h)
 
-    def shiftPush(self, el: int) -> "PGroupElementArray":
+    def shiftPush(self, el) -> "PGroupElementArray":
         h = C.c_void_p()
-        _check(lib().vmn_garray_shift_push(self._h, int_to_be(el, self.group.nbytes), C.byref(h)))
+        _check(lib().vmn_garray_shift_push(self._h, self.group.enc_el(el), C.byref(h)))
         return self._new(h)
 
     def copyOfRange(self, start: int, end: int) -> "PGroupElementArray":
@@ -343,10 +439,10 @@ class PGroupElementArray(_ArrayBase):
         _check(lib().vmn_garray_extract(self._h, buf, C.byref(h)))
         return self._new(h)
 
-    def get(self, i: int) -> int:
-        out = C.create_string_buffer(self.group.nbytes)
+    def get(self, i: int):
+        out = C.create_string_buffer(self.group.elem_bytes)
         _check(lib().vmn_garray_get(self._h, C.c_size_t(i), out))
-        return int.from_bytes(out.raw, "big")
+        return self.group.dec_el(out.raw)
 
     def isMember(self) -> bool:
         ok = C.c_int()

@@ -1,0 +1,661 @@
+// ec_kernels.h — elliptic-curve groups (ECqPGroup: NIST P-256 / P-384, a = -3) on gfx950.
+//
+// The reference's code is group-agnostic (every call site of K1-K7 is reached with
+// `pGroup` = ECqPGroup, the default group being P-256, demo/mixnet/.conf:153).  In VCR's multiplicative
+// notation "mul" is point addition and "exp" scalar multiplication; these kernels mirror the modular
+// ones family by family.
+//
+// One point per lane, everything in registers (a field element is S = 10 limbs of 28 bits for P-256,
+// 14 for P-384, in Montgomery form mod p): a field product is a fully unrolled CIOS of 2*S^2
+// v_mad_u64_u32 with lazily reduced operands — no LDS, no carries inside the product (same column
+// argument as mont28.h).  Field values are kept "lazy": limbs normalised to 28 bits, value allowed to be
+// a small multiple of p (products come out < 2p, sums add their bounds, a difference adds 64p);
+// Montgomery products accept operands up to 2^12 p, so no reduction is needed inside a point operation.
+//
+// Device row of a point: Jacobian (X, Y, Z), 3*FW words (FW = S rounded up to 4), the last padding word
+// holds the infinity flag.  Jacobian storage means no inversion anywhere except export.  Exceptional
+// cases of the addition (equal points, opposite points, infinity) are detected by canonical zero tests
+// and handled exactly (rare wave-divergent path), so every result is the true group element.
+#pragma once
+#include "modp_kernels.h"
+
+namespace vmn {
+
+// Curve constants in device memory (wave-uniform: read through scalar loads)
+struct ECDev {
+    const u32* p;      // S limbs of the field prime
+    const u32* one;    // R mod p                  (Montgomery one)
+    const u32* rr;     // R^2 mod p                (to Montgomery form)
+    const u32* b;      // curve coefficient b, Montgomery form
+    const u32* mp;     // 64 * p, normalised limbs (added before a subtraction so the result stays positive)
+    const u32* mp2;    // 256 * p, for the few subtractions whose subtrahend is itself a difference (< 256 p)
+    const u32* pm2;    // p - 2 as packed 32-bit words (Fermat inversion)
+    u32 n0inv;         // -p^{-1} mod 2^28
+    int pwords;        // words of pm2
+};
+
+template <int S>
+struct ECfg {
+    static constexpr int FS = S;
+    static constexpr int FW = stride_for_limbs(S);
+    static constexpr int ROW = 3 * FW;             // words per point row
+    static constexpr int FLAG = ROW - 1;           // infinity flag word
+};
+
+// ---------------------------------------------------------------------------------------------
+// field arithmetic (lazy values, normalised limbs)
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void f_norm(u32 (&r)[S], const u64 (&v)[S]) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        c += v[j];
+        r[j] = (u32)c & LIMB_MASK;
+        c >>= LIMB_BITS;
+    }
+}
+// r = a * b / R  (mod p), result < 2p for operands with a*b < R*p
+template <int S>
+__device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const ECDev& E) {
+    u64 P[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            if (i == 0 || j == S - 1) P[j] = (u64)a[j] * b[i];
+            else P[j] = (u64)a[j] * b[i] + P[j];
+        }
+        u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
+        u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
+#pragma unroll
+        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
+        P[0] += c;
+    }
+    P[S - 1] = 0;
+    f_norm<S>(r, P);
+}
+template <int S>
+__device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) { f_mul<S>(r, a, a, E); }
+
+template <int S>
+__device__ __forceinline__ void f_add(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S]) {
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        c += a[j] + b[j];
+        r[j] = j == S - 1 ? c : (c & LIMB_MASK);      // the top limb keeps the excess (value stays < 2^(28 S))
+        c = j == S - 1 ? 0 : (c >> LIMB_BITS);
+    }
+}
+// r = a - b + 64p  (b must be < 64p);  BIG: r = a - b + 256p (b < 256p).
+// Bounds inside the point formulas (multiples of p): products < 2, small differences < 66, the two
+// differences with a difference as subtrahend (and the negation) use BIG and stay < 264; every product
+// then has operands whose bounds multiply to far less than 2^24 (the Montgomery limit R/p).
+template <int S, bool BIG = false>
+__device__ __forceinline__ void f_sub(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const ECDev& E) {
+    const u32* __restrict__ mp = BIG ? E.mp2 : E.mp;
+    int32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        int32_t v = (int32_t)a[j] + (int32_t)mp[j] - (int32_t)b[j] + c;
+        if (j == S - 1) {
+            r[j] = (u32)v;
+        } else {
+            r[j] = (u32)v & LIMB_MASK;
+            c = v >> LIMB_BITS;
+        }
+    }
+}
+// r = k * a for a small constant k (k * limb < 2^32)
+template <int S, int K>
+__device__ __forceinline__ void f_small(u32 (&r)[S], const u32 (&a)[S]) {
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        u32 v = a[j] * K + c;
+        r[j] = j == S - 1 ? v : (v & LIMB_MASK);
+        c = v >> LIMB_BITS;
+    }
+}
+// canonical representative (< p) of a lazy value
+template <int S>
+__device__ __forceinline__ void f_canon(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
+    u32 one[S], t[S], d[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) one[j] = E.one[j];
+    f_mul<S>(t, a, one, E);                            // a * R / R = a, now < 2p
+    int32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        int32_t v = (int32_t)t[j] - (int32_t)E.p[j] + borrow;
+        d[j] = (u32)v & LIMB_MASK;
+        borrow = v >> LIMB_BITS;
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) r[j] = borrow == 0 ? d[j] : t[j];
+}
+template <int S>
+__device__ __forceinline__ bool f_is_zero(const u32 (&a)[S], const ECDev& E) {
+    u32 t[S];
+    f_canon<S>(t, a, E);
+    u32 nz = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) nz |= t[j];
+    return nz == 0;
+}
+// r = a^(p-2): Fermat inversion, left-to-right binary (uniform exponent: no divergence).  Export only.
+template <int S>
+__device__ void f_inv(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
+    u32 acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = E.one[j];
+    for (int bit = E.pwords * 32 - 1; bit >= 0; --bit) {
+        f_sqr<S>(acc, acc, E);
+        if ((E.pm2[bit >> 5] >> (bit & 31)) & 1) f_mul<S>(acc, acc, a, E);
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) r[j] = acc[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// points
+// ---------------------------------------------------------------------------------------------
+template <int S>
+struct Pt {
+    u32 X[S], Y[S], Z[S];
+    u32 inf;
+};
+
+template <int S>
+__device__ __forceinline__ void pt_set_inf(Pt<S>& P, const ECDev& E) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        P.X[j] = E.one[j];
+        P.Y[j] = E.one[j];
+        P.Z[j] = 0;
+    }
+    P.inf = 1;
+}
+template <int S>
+__device__ __forceinline__ void f_load(u32 (&a)[S], const u32* __restrict__ p) {
+    constexpr int FW = stride_for_limbs(S);
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int k = 0; k < FW / 4; ++k) {
+        uint4 v = q[k];
+        if (4 * k + 0 < S) a[4 * k + 0] = v.x;
+        if (4 * k + 1 < S) a[4 * k + 1] = v.y;
+        if (4 * k + 2 < S) a[4 * k + 2] = v.z;
+        if (4 * k + 3 < S) a[4 * k + 3] = v.w;
+    }
+}
+template <int S>
+__device__ __forceinline__ void pt_load(Pt<S>& P, const u32* __restrict__ row) {
+    constexpr int FW = stride_for_limbs(S);
+    f_load<S>(P.X, row);
+    f_load<S>(P.Y, row + FW);
+    f_load<S>(P.Z, row + 2 * FW);
+    P.inf = row[3 * FW - 1];
+}
+template <int S>
+__device__ __forceinline__ void pt_store(u32* __restrict__ row, const Pt<S>& P) {
+    constexpr int FW = stride_for_limbs(S);
+    auto put = [&](u32* dst, const u32 (&a)[S], u32 last) {
+        uint4* q = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+        for (int k = 0; k < FW / 4; ++k) {
+            uint4 v;
+            v.x = 4 * k + 0 < S ? a[4 * k + 0] : 0;
+            v.y = 4 * k + 1 < S ? a[4 * k + 1] : 0;
+            v.z = 4 * k + 2 < S ? a[4 * k + 2] : 0;
+            v.w = 4 * k + 3 < S ? a[4 * k + 3] : (4 * k + 3 == FW - 1 ? last : 0);
+            q[k] = v;
+        }
+    };
+    put(row, P.X, 0);
+    put(row + FW, P.Y, 0);
+    put(row + 2 * FW, P.Z, P.inf);
+}
+
+// dbl-2001-b (a = -3): 3M + 5S, valid for every input (infinity stays infinity through the flag)
+template <int S>
+__device__ __forceinline__ void pt_dbl(Pt<S>& R, const Pt<S>& P, const ECDev& E) {
+    u32 delta[S], gamma[S], beta[S], alpha[S], t1[S], t2[S], t3[S];
+    f_sqr<S>(delta, P.Z, E);
+    f_sqr<S>(gamma, P.Y, E);
+    f_mul<S>(beta, P.X, gamma, E);
+    f_sub<S>(t1, P.X, delta, E);
+    f_add<S>(t2, P.X, delta);
+    f_mul<S>(t3, t1, t2, E);
+    f_small<S, 3>(alpha, t3);                          // alpha = 3 (X - delta)(X + delta)
+    f_add<S>(t1, P.Y, P.Z);
+    f_sqr<S>(t2, t1, E);
+    f_add<S>(t3, gamma, delta);
+    u32 Z3[S];
+    f_sub<S>(Z3, t2, t3, E);                           // (Y + Z)^2 - gamma - delta
+    f_sqr<S>(t1, alpha, E);
+    f_small<S, 8>(t2, beta);
+    u32 X3[S];
+    f_sub<S>(X3, t1, t2, E);                           // alpha^2 - 8 beta
+    f_small<S, 4>(t1, beta);
+    f_sub<S, true>(t2, t1, X3, E);
+    f_mul<S>(t3, alpha, t2, E);
+    f_sqr<S>(t1, gamma, E);
+    f_small<S, 8>(t2, t1);
+    f_sub<S>(R.Y, t3, t2, E);                          // alpha (4 beta - X3) - 8 gamma^2
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        R.X[j] = X3[j];
+        R.Z[j] = Z3[j];
+    }
+    R.inf = P.inf;
+}
+
+// add-2007-bl: 11M + 5S; exceptional inputs handled exactly
+template <int S>
+__device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q, const ECDev& E) {
+    u32 Z1Z1[S], Z2Z2[S], U1[S], U2[S], S1[S], S2[S], H[S], rr[S], t1[S], t2[S];
+    f_sqr<S>(Z1Z1, P.Z, E);
+    f_sqr<S>(Z2Z2, Q.Z, E);
+    f_mul<S>(U1, P.X, Z2Z2, E);
+    f_mul<S>(U2, Q.X, Z1Z1, E);
+    f_mul<S>(t1, P.Y, Q.Z, E);
+    f_mul<S>(S1, t1, Z2Z2, E);
+    f_mul<S>(t1, Q.Y, P.Z, E);
+    f_mul<S>(S2, t1, Z1Z1, E);
+    f_sub<S>(H, U2, U1, E);
+    f_sub<S>(rr, S2, S1, E);
+    bool hz = f_is_zero<S>(H, E);
+    bool special = P.inf || Q.inf || hz;
+    Pt<S> G;                                           // general-case result
+    {
+        u32 I[S], J[S], r[S], V[S];
+        f_add<S>(t1, H, H);
+        f_sqr<S>(I, t1, E);                            // (2H)^2
+        f_mul<S>(J, H, I, E);
+        f_add<S>(r, rr, rr);
+        f_mul<S>(V, U1, I, E);
+        f_sqr<S>(t1, r, E);
+        f_add<S>(t2, V, V);
+        f_add<S>(t2, t2, J);
+        f_sub<S>(G.X, t1, t2, E);                      // r^2 - J - 2V
+        f_sub<S, true>(t1, V, G.X, E);
+        f_mul<S>(t2, r, t1, E);
+        f_mul<S>(t1, S1, J, E);
+        f_add<S>(t1, t1, t1);
+        f_sub<S>(G.Y, t2, t1, E);                      // r (V - X3) - 2 S1 J
+        f_add<S>(t1, P.Z, Q.Z);
+        f_sqr<S>(t2, t1, E);
+        f_add<S>(t1, Z1Z1, Z2Z2);
+        f_sub<S>(t2, t2, t1, E);
+        f_mul<S>(G.Z, t2, H, E);                       // ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
+        G.inf = 0;
+    }
+    if (special) {                                     // rare: wave-divergent
+        if (P.inf) {
+            G = Q;
+        } else if (Q.inf) {
+            G = P;
+        } else if (f_is_zero<S>(rr, E)) {
+            pt_dbl<S>(G, P, E);                        // P == Q
+        } else {
+            pt_set_inf<S>(G, E);                       // P == -Q
+        }
+    }
+    R = G;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels (one point per lane; no LDS)
+// ---------------------------------------------------------------------------------------------
+// big-endian x || y (nbytes each; all 0xff = infinity) -> rows.  flags |= 1: coordinate >= p or point not on the
+// curve (replaced by the identity, the reference's "trivial value" convention).
+template <int S, int NW>
+__global__ void __launch_bounds__(BLOCK) k_ec_import(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes,
+                                                     size_t stride, size_t n, ECDev E, u32* __restrict__ flags) {
+    using C1 = Cfg<S, 1>;
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (el >= n) return;
+    const uint8_t* src = be + el * stride;
+    u32 allff = 0xff;
+    for (size_t i = 0; i < 2 * nbytes; ++i) allff &= src[i];
+    Pt<S> P;
+    bool bad = false;
+    if (allff == 0xff) {
+        pt_set_inf<S>(P, E);
+    } else {
+        Lane<C1> ln(nullptr);
+        u32 x[S], y[S], pp[S], d[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) pp[j] = E.p[j];
+        limbs_from_be<C1, NW>(x, src, (long)nbytes, ln);
+        limbs_from_be<C1, NW>(y, src + nbytes, (long)nbytes, ln);
+        u32 extra = 0;
+        for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) extra |= src[o] | src[nbytes + o];
+        bad = extra != 0 || borrow_sweep<S>(d, x, pp, 0) == 0 || borrow_sweep<S>(d, y, pp, 0) == 0;
+        u32 rrc[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) rrc[j] = E.rr[j];
+        f_mul<S>(P.X, x, rrc, E);
+        f_mul<S>(P.Y, y, rrc, E);
+#pragma unroll
+        for (int j = 0; j < S; ++j) P.Z[j] = E.one[j];
+        P.inf = 0;
+        // on the curve?  y^2 == x^3 - 3x + b
+        u32 lhs[S], t[S], x3[S], rhs[S], bb[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) bb[j] = E.b[j];
+        f_sqr<S>(lhs, P.Y, E);
+        f_sqr<S>(t, P.X, E);
+        f_mul<S>(x3, t, P.X, E);
+        f_small<S, 3>(t, P.X);
+        f_add<S>(rhs, x3, bb);
+        f_sub<S>(rhs, rhs, t, E);
+        f_sub<S>(t, lhs, rhs, E);
+        bad = bad || !f_is_zero<S>(t, E);
+        if (bad) pt_set_inf<S>(P, E);
+    }
+    if (bad) atomicOr(flags, 1u);
+    pt_store<S>(out + el * ROW, P);
+}
+
+template <int S, int NW>
+__global__ void __launch_bounds__(BLOCK) k_ec_export(uint8_t* __restrict__ be, size_t nbytes, size_t stride,
+                                                     const u32* __restrict__ in, size_t n, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (el >= n) return;
+    Pt<S> P;
+    pt_load<S>(P, in + el * ROW);
+    uint8_t* dst = be + el * stride;
+    if (P.inf) {
+        for (size_t i = 0; i < 2 * nbytes; ++i) dst[i] = 0xff;
+        return;
+    }
+    u32 zi[S], zi2[S], zi3[S], xa[S], ya[S], one1[S], t[S];
+    f_inv<S>(zi, P.Z, E);
+    f_sqr<S>(zi2, zi, E);
+    f_mul<S>(zi3, zi2, zi, E);
+    f_mul<S>(xa, P.X, zi2, E);
+    f_mul<S>(ya, P.Y, zi3, E);
+#pragma unroll
+    for (int j = 0; j < S; ++j) one1[j] = j == 0 ? 1u : 0u;
+    // leave the Montgomery domain (multiply by 1) and canonicalise
+    auto out_coord = [&](const u32 (&v)[S], uint8_t* d) {
+        u32 s[S], c[S], w[NW];
+        f_mul<S>(s, v, one1, E);                       // v / R : standard representative, < 2p
+        int32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            int32_t q = (int32_t)s[j] - (int32_t)E.p[j] + borrow;
+            c[j] = (u32)q & LIMB_MASK;
+            borrow = q >> LIMB_BITS;
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) t[j] = borrow == 0 ? c[j] : s[j];
+        limbs_to_words<S, NW>(w, t);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) store_be_word(d, (long)nbytes, k, w[k]);
+        for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) d[o] = 0;
+    };
+    out_coord(xa, dst);
+    out_coord(ya, dst + nbytes);
+}
+
+// K4: out[i] = x[i] + y[i]   (ystride = 0: one shared point)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_add(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ y,
+                                                  size_t ystride, size_t n, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (el >= n) return;
+    Pt<S> P, Q, R;
+    pt_load<S>(P, x + el * ROW);
+    pt_load<S>(Q, y + el * ystride);
+    pt_add<S>(R, P, Q, E);
+    pt_store<S>(out + el * ROW, R);
+}
+
+// inverse of every element: (X, -Y, Z)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_neg(u32* __restrict__ out, const u32* __restrict__ x, size_t n, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (el >= n) return;
+    Pt<S> P;
+    pt_load<S>(P, x + el * ROW);
+    u32 z[S], y[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) z[j] = 0;
+    f_sub<S, true>(y, z, P.Y, E);
+#pragma unroll
+    for (int j = 0; j < S; ++j) P.Y[j] = y[j];
+    pt_store<S>(out + el * ROW, P);
+}
+
+// K6: flags |= 1 where x[i] != y[i] as group elements (cross-multiplied Jacobian comparison)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_equal(const u32* __restrict__ x, const u32* __restrict__ y, size_t n, ECDev E,
+                                                    u32* __restrict__ flags) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (el >= n) return;
+    Pt<S> P, Q;
+    pt_load<S>(P, x + el * ROW);
+    pt_load<S>(Q, y + el * ROW);
+    bool eq;
+    if (P.inf || Q.inf) {
+        eq = P.inf && Q.inf;
+    } else {
+        u32 a[S], b[S], c[S], d[S], t[S];
+        f_sqr<S>(a, P.Z, E);
+        f_sqr<S>(b, Q.Z, E);
+        f_mul<S>(c, P.X, b, E);
+        f_mul<S>(d, Q.X, a, E);
+        f_sub<S>(t, c, d, E);
+        eq = f_is_zero<S>(t, E);
+        f_mul<S>(c, a, P.Z, E);
+        f_mul<S>(d, b, Q.Z, E);
+        f_mul<S>(a, P.Y, d, E);
+        f_mul<S>(b, Q.Y, c, E);
+        f_sub<S>(t, a, b, E);
+        eq = eq && f_is_zero<S>(t, E);
+    }
+    if (!eq) atomicOr(flags, 1u);
+}
+
+// K1a / K1b: out[i] = e[i] * x[i]  (fixed window, per-lane table of multiples in scratch)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_mulvar(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e,
+                                                     int ewords, size_t estride, int ebits, int wbits, size_t n, ECDev E,
+                                                     u32* __restrict__ tab) {
+    constexpr int ROW = ECfg<S>::ROW;
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    const int tsize = 1 << wbits;
+    u32* mytab = tab + ((size_t)blockIdx.x * BLOCK + threadIdx.x) * (size_t)tsize * ROW;
+    const int nwin = (ebits + wbits - 1) / wbits;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        size_t el = t * BLOCK + threadIdx.x;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        const u32* ep = e + ec * estride;
+        Pt<S> P, A;
+        pt_load<S>(P, x + ec * ROW);
+        pt_set_inf<S>(A, E);
+        pt_store<S>(mytab, A);
+        pt_store<S>(mytab + ROW, P);
+        A = P;
+#pragma unroll 1
+        for (int k = 2; k < tsize; ++k) {
+            pt_add<S>(A, A, P, E);
+            pt_store<S>(mytab + (size_t)k * ROW, A);
+        }
+        u32 d = exp_digit(ep, ewords, (nwin - 1) * wbits, wbits);
+        pt_load<S>(A, mytab + (size_t)d * ROW);
+#pragma unroll 1
+        for (int wi = nwin - 2; wi >= 0; --wi) {
+#pragma unroll 1
+            for (int s = 0; s < wbits; ++s) pt_dbl<S>(A, A, E);
+            d = exp_digit(ep, ewords, wi * wbits, wbits);
+            Pt<S> T;
+            pt_load<S>(T, mytab + (size_t)d * ROW);
+            pt_add<S>(A, A, T, E);
+        }
+        if (live) pt_store<S>(out + el * ROW, A);
+    }
+}
+
+// sq[j] = 2^j * base, j < count: the doubling chain of a fixed-base table, one lane (count ~ 256-400 doublings)
+template <int S>
+__global__ void k_ec_chain(u32* __restrict__ sq, const u32* __restrict__ base, int count, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Pt<S> A;
+    pt_load<S>(A, base);
+    for (int j = 0; j < count; ++j) {
+        pt_store<S>(sq + (size_t)j * ROW, A);
+        pt_dbl<S>(A, A, E);
+    }
+}
+
+// K2 table level l: T[k][2^l + r] = T[k][r] + T[k][2^l]
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_fixed_level(u32* __restrict__ T, int w, int nwin, int l, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t per = ((size_t)1 << l) - 1;
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= per * nwin) return;
+    size_t k = t / per, r = t % per + 1;
+    u32* row = T + (k << w) * ROW;
+    Pt<S> A, B, R;
+    pt_load<S>(A, row + r * ROW);
+    pt_load<S>(B, row + ((size_t)1 << l) * ROW);
+    pt_add<S>(R, A, B, E);
+    pt_store<S>(row + (((size_t)1 << l) + r) * ROW, R);
+}
+
+// K2: out[i] = sum_k T[k][digit_k(e[i])]
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin,
+                                                        const u32* __restrict__ e, int ewords, size_t n, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (el >= n) return;
+    const u32* ep = e + el * ewords;
+    Pt<S> A, B;
+    u32 d = exp_digit(ep, ewords, 0, w);
+    pt_load<S>(A, T + (size_t)d * ROW);
+#pragma unroll 1
+    for (int k = 1; k < nwin; ++k) {
+        d = exp_digit(ep, ewords, k * w, w);
+        pt_load<S>(B, T + (((size_t)k << w) + d) * ROW);
+        pt_add<S>(A, A, B, E);
+    }
+    pt_store<S>(out + el * ROW, A);
+}
+
+// K3 product-tree level (see k_bucket_level)
+template <int S, bool FIRST>
+__global__ void __launch_bounds__(BLOCK) k_ec_bucket_level(u32* __restrict__ out, const u32* __restrict__ in,
+                                                           const u32* __restrict__ sorted, const u32* __restrict__ off_in,
+                                                           const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
+                                                           size_t nbuckets, size_t total_out, u32 F, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= total_out) return;
+    size_t lo = 0, hi = nbuckets;
+    while (hi - lo > 1) {
+        size_t mid = (lo + hi) >> 1;
+        if (off_out[mid] <= t) lo = mid; else hi = mid;
+    }
+    size_t b = lo;
+    u32 j = (u32)(t - off_out[b]);
+    u32 start = off_in[b] + j * F;
+    u32 end = off_in[b] + cnt_in[b];
+    if (end > start + F) end = start + F;
+    auto row = [&](u32 k) -> const u32* { return FIRST ? in + (size_t)sorted[k] * ROW : in + (size_t)k * ROW; };
+    Pt<S> A, B;
+    pt_load<S>(A, row(start));
+    for (u32 k = start + 1; k < end; ++k) {
+        pt_load<S>(B, row(k));
+        pt_add<S>(A, A, B, E);
+    }
+    pt_store<S>(out + t * ROW, A);
+}
+
+// K5: strided sum (see k_reduce_strided)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_reduce(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t Lout,
+                                                     size_t nseg, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nseg * Lout) return;
+    size_t seg = t / Lout, j = t % Lout;
+    const u32* base = x + seg * len * ROW;
+    Pt<S> A, B;
+    pt_load<S>(A, base + j * ROW);
+    size_t cnt = (len - j + Lout - 1) / Lout;
+    for (size_t k = 1; k < cnt; ++k) {
+        pt_load<S>(B, base + (j + k * Lout) * ROW);
+        pt_add<S>(A, A, B, E);
+    }
+    pt_store<S>(out + t * ROW, A);
+}
+
+// running sums (the "prods" scan of the modular kernels with + as the operation)
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_scan_totals(u32* __restrict__ tot, const u32* __restrict__ e, size_t n, size_t Cc,
+                                                          size_t seglen, int rev, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t nchunks = (n + Cc - 1) / Cc;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= nchunks) return;
+    size_t lo = c * Cc, hi = lo + Cc < n ? lo + Cc : n;
+    Pt<S> A, B;
+    pt_set_inf<S>(A, E);
+    for (size_t i = lo; i < hi; ++i) {
+        size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
+        pt_load<S>(B, e + pos * ROW);
+        pt_add<S>(A, A, B, E);
+    }
+    pt_store<S>(tot + c * ROW, A);
+}
+template <int S>
+__global__ void __launch_bounds__(BLOCK) k_ec_scan_apply(u32* __restrict__ out, const u32* __restrict__ e,
+                                                         const u32* __restrict__ incoming, size_t n, size_t Cc, size_t seglen,
+                                                         int rev, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    size_t nchunks = (n + Cc - 1) / Cc;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= nchunks) return;
+    size_t lo = c * Cc, hi = lo + Cc < n ? lo + Cc : n;
+    bool fresh = incoming == nullptr || (lo % seglen) == 0;
+    Pt<S> A, B;
+    if (fresh) pt_set_inf<S>(A, E);
+    else pt_load<S>(A, incoming + (c - 1) * ROW);
+    for (size_t i = lo; i < hi; ++i) {
+        size_t pos = rev ? (i / seglen) * seglen + (seglen - 1 - i % seglen) : i;
+        pt_load<S>(B, e + pos * ROW);
+        pt_add<S>(A, A, B, E);
+        pt_store<S>(out + pos * ROW, A);
+    }
+}
+
+// Horner over the window results of a multi-exponentiation: out = sum_w 2^(c w) W[w], one lane
+template <int S>
+__global__ void k_ec_horner(u32* __restrict__ out, const u32* __restrict__ wres, int nwin, int c, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Pt<S> A, B;
+    pt_set_inf<S>(A, E);
+    for (int w = nwin - 1; w >= 0; --w) {
+        for (int s = 0; s < c; ++s) pt_dbl<S>(A, A, E);
+        pt_load<S>(B, wres + (size_t)w * ROW);
+        pt_add<S>(A, A, B, E);
+    }
+    pt_store<S>(out, A);
+}
+
+}  // namespace vmn

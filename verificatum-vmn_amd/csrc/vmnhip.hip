@@ -9,6 +9,7 @@
 #include <memory>
 #include <utility>
 
+#include "ec_kernels.h"
 #include "modp_kernels.h"
 #include "vmnhip_internal.h"
 
@@ -41,10 +42,14 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // ------------------------------------------------------------------------------------------------
 // (modulus bits) -> (S limbs, NW words).  One template instantiation per supported size.
 // X(limbs, packed words, lanes per element).  3072-bit moduli (110 limbs) run two lanes per element.
-#define VMN_FOR_SIZES(X) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(110, 96, 2)
+#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(110, 96, 2)
+// elliptic curves: X(field limbs, packed words)
+// (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
+#define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
 
 static bool size_for_bits(int nbits, int* S, int* NW, int* LPE) {
-    const int sizes[][4] = {{512, 19, 16, 1}, {1024, 37, 32, 1}, {2048, 74, 64, 1}, {3072, 110, 96, 2}};
+    const int sizes[][4] = {{256, 10, 8, 1}, {384, 14, 12, 1}, {512, 19, 16, 1}, {1024, 37, 32, 1}, {2048, 74, 64, 1},
+                            {3072, 110, 96, 2}};
     for (auto& s : sizes) {
         if (nbits <= s[0]) {
             *S = s[1];
@@ -84,6 +89,38 @@ static int launch(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), un
     }
     return VMN_OK;
 }
+
+static unsigned light_grid(vmn_ctx* ctx, size_t work_items) {
+    size_t blocks = (work_items + BLOCK - 1) / BLOCK;
+    size_t cap = (size_t)ctx->num_cus * 8;
+    return (unsigned)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+// plain (non-LDS) kernel launch with timing
+template <typename... KArgs, typename... Args>
+static int launch_light(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), unsigned grid, Args... args) {
+    TimingRec rec;
+    if (ctx->timing) {
+        rec.family = family;
+        VMN_HIP(hipEventCreate(&rec.start));
+        VMN_HIP(hipEventCreate(&rec.stop));
+        VMN_HIP(hipEventRecord(rec.start, ctx->stream));
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, static_cast<KArgs>(args)...);
+    VMN_HIP(hipGetLastError());
+    if (ctx->timing) {
+        VMN_HIP(hipEventRecord(rec.stop, ctx->stream));
+        ctx->recs.push_back(rec);
+    }
+    return VMN_OK;
+}
+
+static int read_flag(vmn_ctx* ctx, uint32_t* out) {
+    VMN_HIP(hipMemcpyAsync(out, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VMN_HIP(hipStreamSynchronize(ctx->stream));
+    return VMN_OK;
+}
+
 
 static int ensure_scratch(vmn_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return VMN_OK;
@@ -282,6 +319,8 @@ extern "C" int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len) {
     return VMN_OK;
 }
 
+static void curve_destroy(vmn_curve* c);
+
 // ------------------------------------------------------------------------------------------------
 // moduli and groups
 // ------------------------------------------------------------------------------------------------
@@ -384,12 +423,211 @@ extern "C" void vmn_group_destroy(vmn_group* grp) {
     for (auto& kv : grp->fixed) {
         if (kv.second.d_tab) (void)hipFree(kv.second.d_tab);
     }
-    modulus_destroy(grp->P);
+    if (grp->curve) {
+        if (grp->P.d_one) (void)hipFree(grp->P.d_one);
+        grp->P = vmn_modulus();
+        curve_destroy(grp->curve);
+    } else {
+        modulus_destroy(grp->P);
+    }
     modulus_destroy(grp->Q);
     delete grp;
 }
-extern "C" size_t vmn_group_elem_bytes(const vmn_group* grp) { return grp ? grp->nbytes : 0; }
+extern "C" size_t vmn_group_elem_bytes(const vmn_group* grp) { return grp ? (grp->curve ? 2 * grp->nbytes : grp->nbytes) : 0; }
 extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->nbytes : 0; }
+
+
+// ------------------------------------------------------------------------------------------------
+// elliptic-curve groups
+// ------------------------------------------------------------------------------------------------
+static ECDev ecdev(const vmn_curve* c) {
+    ECDev E;
+    E.p = c->d_p;
+    E.one = c->d_one;
+    E.rr = c->d_rr;
+    E.b = c->d_b;
+    E.mp = c->d_mp;
+    E.mp2 = c->d_mp2;
+    E.pm2 = c->d_pm2;
+    E.n0inv = c->n0inv;
+    E.pwords = c->NW;
+    return E;
+}
+
+struct CurveParams {
+    const char* name;
+    int bits;
+    int field_limbs;
+    const char* p;
+    const char* n;
+    const char* b;
+    const char* gx;
+    const char* gy;
+};
+static const CurveParams kCurves[] = {
+    {"P-256", 256, 10, "ffffffff00000001000000000000000000000000ffffffffffffffffffffffff",
+     "ffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551",
+     "5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b",
+     "6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296",
+     "4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5"},
+    {"P-384", 384, 15,
+     "fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffeffffffff0000000000000000ffffffff",
+     "ffffffffffffffffffffffffffffffffffffffffffffffffc7634d81f4372ddf581a0db248b0a77aecec196accc52973",
+     "b3312fa7e23ee7e4988e056be3f82d19181d9c6efe8141120314088f5013875ac656398d8a2ed19d2a85c8edd3ec2aef",
+     "aa87ca22be8b05378eb1c71ef320ad746e1d3b628ba79b9859f741e082542a385502f25dbf55296c3a545e3872760ab7",
+     "3617de4a96262c6f5d9e98bf9292dc29f8f41dbd289a147ce9da3113b5f0b8c00a60b1ce1d7e819d7a431d7c90ea0e5f"},
+};
+
+static std::vector<uint8_t> hex_to_be(const char* h) {
+    size_t n = strlen(h) / 2;
+    std::vector<uint8_t> out(n);
+    auto nib = [](char c) -> int { return c <= '9' ? c - '0' : (c | 32) - 'a' + 10; };
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)(nib(h[2 * i]) * 16 + nib(h[2 * i + 1]));
+    return out;
+}
+// x * 2^k mod n by repeated doubling (x < n)
+static Big shift_mod(Big x, int k, const Big& n) {
+    for (int i = 0; i < k; ++i) hostbig::dbl_mod(x, n);
+    return x;
+}
+// limbs (28-bit) of an arbitrary word vector, S limbs, no reduction
+static std::vector<uint32_t> limbs_of(const Big& w, int S) {
+    std::vector<uint32_t> l(S, 0);
+    for (int j = 0; j < S; ++j) {
+        int bit = 28 * j;
+        size_t k = bit / 32;
+        int sh = bit % 32;
+        uint64_t lo = k < w.size() ? w[k] : 0, hi = k + 1 < w.size() ? w[k + 1] : 0;
+        l[j] = (uint32_t)(((hi << 32) | lo) >> sh) & LIMB_MASK;
+    }
+    return l;
+}
+static Big times_small(const Big& a, uint32_t k, size_t nw) {
+    Big r(nw, 0);
+    uint64_t c = 0;
+    for (size_t i = 0; i < nw; ++i) {
+        c += (uint64_t)(i < a.size() ? a[i] : 0) * k;
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+static void curve_destroy(vmn_curve* c) {
+    if (!c) return;
+    if (c->d_consts) (void)hipFree(c->d_consts);
+    delete c;
+}
+
+static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
+    std::unique_ptr<vmn_curve> c(new vmn_curve());
+    c->name = cp.name;
+    int S, NW, LPE;
+    if (!size_for_bits(cp.bits, &S, &NW, &LPE) || LPE != 1) return VMN_ERR_UNSUPPORTED;
+    S = cp.field_limbs;
+    c->S = S;
+    c->NW = NW;
+    auto pb = hex_to_be(cp.p), bb = hex_to_be(cp.b), gx = hex_to_be(cp.gx), gy = hex_to_be(cp.gy);
+    c->p_words = hostbig::from_be(pb.data(), pb.size(), NW);
+    c->b_words = hostbig::from_be(bb.data(), bb.size(), NW);
+    c->gx_words = hostbig::from_be(gx.data(), gx.size(), NW);
+    c->gy_words = hostbig::from_be(gy.data(), gy.size(), NW);
+    c->n0inv = hostbig::neg_inv_pow2(c->p_words[0] & LIMB_MASK, 28);
+    const Big& pw = c->p_words;
+    Big one(NW, 0);
+    one[0] = 1;
+    Big r1 = shift_mod(one, 28 * S, pw);                 // R mod p
+    Big r2 = shift_mod(r1, 28 * S, pw);                  // R^2 mod p
+    Big bm = shift_mod(c->b_words, 28 * S, pw);          // b R mod p
+    Big pm2 = pw;
+    Big two(NW, 0);
+    two[0] = 2;
+    hostbig::sub_in(pm2, two);
+    const int FW = stride_for_limbs(S);
+    std::vector<uint32_t> blob;
+    auto put = [&](const std::vector<uint32_t>& v, int words) {
+        size_t off = blob.size();
+        blob.insert(blob.end(), v.begin(), v.end());
+        blob.resize(off + words, 0);
+        return off;
+    };
+    size_t o_p = put(limbs_of(pw, S), FW), o_one = put(limbs_of(r1, S), FW), o_rr = put(limbs_of(r2, S), FW);
+    size_t o_b = put(limbs_of(bm, S), FW);
+    size_t o_mp = put(limbs_of(times_small(pw, 64, NW + 1), S), FW);
+    size_t o_mp2 = put(limbs_of(times_small(pw, 256, NW + 1), S), FW);
+    size_t o_pm2 = put(std::vector<uint32_t>(pm2.begin(), pm2.end()), (NW + 3) & ~3);
+    VMN_TRY(upload_words(ctx, &c->d_consts, blob));
+    c->d_p = c->d_consts + o_p;
+    c->d_one = c->d_consts + o_one;
+    c->d_rr = c->d_consts + o_rr;
+    c->d_b = c->d_consts + o_b;
+    c->d_mp = c->d_consts + o_mp;
+    c->d_mp2 = c->d_consts + o_mp2;
+    c->d_pm2 = c->d_consts + o_pm2;
+    *out = c.release();
+    return VMN_OK;
+}
+
+extern "C" int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_group** out) {
+    ARG_CHECK(ctx && curve_name && out, "null argument");
+    VMN_HIP(hipSetDevice(ctx->device));
+    const CurveParams* cp = nullptr;
+    for (auto& k : kCurves) {
+        if (strcmp(k.name, curve_name) == 0) cp = &k;
+    }
+    if (!cp) {
+        set_error("vmn_ec_group_create: unknown curve %s (known: P-256, P-384)", curve_name);
+        return VMN_ERR_UNSUPPORTED;
+    }
+    std::unique_ptr<vmn_group> g(new vmn_group());
+    g->ctx = ctx;
+    g->nbytes = (size_t)cp->bits / 8;
+    vmn_curve* curve = nullptr;
+    VMN_TRY(curve_create(ctx, *cp, &curve));
+    g->curve = curve;
+    // scalars: ordinary residues mod the group order
+    auto nb = hex_to_be(cp->n);
+    int S, NW, LPE;
+    size_for_bits(cp->bits, &S, &NW, &LPE);
+    int rc = modulus_init(ctx, g->Q, nb.data(), nb.size(), S, NW, LPE);
+    if (rc != VMN_OK) {
+        curve_destroy(curve);
+        return rc;
+    }
+    // point rows: 3 field elements; the identity row is (one, one, 0 | flag)
+    vmn_modulus& P = g->P;
+    P.S = curve->S;
+    P.NW = curve->NW;
+    P.LPE = 1;
+    P.W = 3 * stride_for_limbs(curve->S);
+    P.nbits = cp->bits;
+    P.ec = curve;
+    P.n_words = curve->p_words;
+    {
+        const int FW = stride_for_limbs(curve->S);
+        std::vector<uint32_t> one(curve->S), row(P.W, 0);
+        hipError_t he = hipMemcpy(one.data(), curve->d_one, curve->S * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) {
+            set_error("curve constants readback failed: %s", hipGetErrorString(he));
+            modulus_destroy(g->Q);
+            curve_destroy(curve);
+            return VMN_ERR_DEVICE;
+        }
+        for (int j = 0; j < curve->S; ++j) {
+            row[j] = one[j];
+            row[FW + j] = one[j];
+        }
+        row[P.W - 1] = 1;
+        rc = upload_words(ctx, &P.d_one, row);
+        if (rc != VMN_OK) {
+            modulus_destroy(g->Q);
+            curve_destroy(curve);
+            return rc;
+        }
+    }
+    *out = g.release();
+    return VMN_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // generic array plumbing (group arrays are residues mod p, ring arrays residues mod q)
@@ -412,18 +650,31 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (all_in_range) *all_in_range = 1;
     if (format_ok) *format_ok = 1;
     if (n == 0) return VMN_OK;
-    const size_t stride = nbytes + (leaf_hdr ? 5 : 0);
+    if (m.ec && leaf_hdr) {
+        set_error("byte-tree framing of curve points is not implemented");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    const size_t stride = m.ec ? 2 * nbytes : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
     VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
     int rc = VMN_ERR_ARG;
+    if (m.ec) {
+#define X(S_, NW_)                                                                                                   \
+    if (m.ec->S == S_)                                                                                               \
+        rc = launch_light(ctx, "import", k_ec_import<S_, NW_>, grid_for(n), d_out, (const uint8_t*)raw.as<uint8_t>(), \
+                          nbytes, stride, n, ecdev(m.ec), ctx->flags);
+        VMN_FOR_CURVES(X)
+#undef X
+    } else {
 #define X(S_, NW_, LPE_)                                                                                              \
     if (m.S == S_)                                                                                              \
         rc = launch(ctx, "import", k_import_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), d_out, raw.as<uint8_t>(), \
                     nbytes, stride, leaf_hdr, n, m.d_n, m.n0inv, m.d_rr, ctx->flags);
     VMN_FOR_SIZES(X)
 #undef X
+    }
     VMN_TRY(rc);
     uint32_t fl = 0;
     VMN_HIP(hipMemcpyAsync(&fl, ctx->flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
@@ -436,16 +687,29 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be,
                      int leaf_hdr = 0) {
     if (n == 0) return VMN_OK;
-    const size_t stride = nbytes + (leaf_hdr ? 5 : 0);
+    if (m.ec && leaf_hdr) {
+        set_error("byte-tree framing of curve points is not implemented");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    const size_t stride = m.ec ? 2 * nbytes : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     int rc = VMN_ERR_ARG;
+    if (m.ec) {
+#define X(S_, NW_)                                                                                               \
+    if (m.ec->S == S_)                                                                                           \
+        rc = launch_light(ctx, "export", k_ec_export<S_, NW_>, grid_for(n), raw.as<uint8_t>(), nbytes, stride,   \
+                          d_in, n, ecdev(m.ec));
+        VMN_FOR_CURVES(X)
+#undef X
+    } else {
 #define X(S_, NW_, LPE_)                                                                                          \
     if (m.S == S_)                                                                                          \
         rc = launch(ctx, "export", k_export_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), raw.as<uint8_t>(),    \
                     nbytes, stride, leaf_hdr, d_in, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
 #undef X
+    }
     VMN_TRY(rc);
     VMN_HIP(hipMemcpyAsync(be, raw.p, n * stride, hipMemcpyDeviceToHost, ctx->stream));
     VMN_HIP(hipStreamSynchronize(ctx->stream));
@@ -496,6 +760,13 @@ static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, con
                       uint32_t* out) {
     if (n == 0) return VMN_OK;
     int rc = VMN_ERR_ARG;
+    if (m.ec) {
+#define X(S_, NW_) \
+    if (m.ec->S == S_) rc = launch_light(ctx, "modmul", k_ec_add<S_>, grid_for(n), out, x, y, ystride, n, ecdev(m.ec));
+        VMN_FOR_CURVES(X)
+#undef X
+        return rc;
+    }
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = launch(ctx, "modmul", k_mul<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), out, x, y, ystride, n, m.d_n, m.n0inv);
     VMN_FOR_SIZES(X)
@@ -533,6 +804,20 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, c
                         size_t estride, int ebits, size_t n, uint32_t* out) {
     if (n == 0) return VMN_OK;
     if (ebits < 1) ebits = 1;
+    if (m.ec) {
+        int wb = std::min(pick_window(ebits), 5);
+        unsigned grid = std::min<unsigned>(grid_for(n), (unsigned)(ctx->num_cus * 2));
+        size_t tab_bytes = (size_t)grid * BLOCK * ((size_t)1 << wb) * elem_words(m) * sizeof(uint32_t);
+        VMN_TRY(ensure_scratch(ctx, tab_bytes));
+        int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                  \
+    if (m.ec->S == S_)                                                                                              \
+        rc = launch_light(ctx, "modpow", k_ec_mulvar<S_>, grid, out, x, e_words, ewords, estride, ebits, wb, n,      \
+                          ecdev(m.ec), reinterpret_cast<uint32_t*>(ctx->scratch));
+        VMN_FOR_CURVES(X)
+#undef X
+        return rc;
+    }
     int wbits = pick_window(ebits);
     unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
     unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
@@ -777,42 +1062,23 @@ extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, s
 // second part: K2 fixed base, K3 multi-exponentiation, K5 reductions, K6 compare, K7 movement,
 // K8 ring operations
 // ================================================================================================
-static unsigned light_grid(vmn_ctx* ctx, size_t work_items) {
-    size_t blocks = (work_items + BLOCK - 1) / BLOCK;
-    size_t cap = (size_t)ctx->num_cus * 8;
-    return (unsigned)std::max<size_t>(1, std::min(blocks, cap));
-}
-
-// plain (non-LDS) kernel launch with timing
-template <typename... KArgs, typename... Args>
-static int launch_light(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), unsigned grid, Args... args) {
-    TimingRec rec;
-    if (ctx->timing) {
-        rec.family = family;
-        VMN_HIP(hipEventCreate(&rec.start));
-        VMN_HIP(hipEventCreate(&rec.stop));
-        VMN_HIP(hipEventRecord(rec.start, ctx->stream));
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, static_cast<KArgs>(args)...);
-    VMN_HIP(hipGetLastError());
-    if (ctx->timing) {
-        VMN_HIP(hipEventRecord(rec.stop, ctx->stream));
-        ctx->recs.push_back(rec);
-    }
-    return VMN_OK;
-}
-
-static int read_flag(vmn_ctx* ctx, uint32_t* out) {
-    VMN_HIP(hipMemcpyAsync(out, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    VMN_HIP(hipStreamSynchronize(ctx->stream));
-    return VMN_OK;
-}
-
 // ---- K6 ------------------------------------------------------------------------------------------
 static int compare_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, size_t n, int* equal) {
     *equal = 1;
     if (n == 0) return VMN_OK;
     VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    if (m.ec) {                        // Jacobian rows: equality of group elements, not of bytes
+        int rc = VMN_ERR_ARG;
+#define X(S_, NW_) \
+    if (m.ec->S == S_) rc = launch_light(ctx, "compare", k_ec_equal<S_>, grid_for(n), x, y, n, ecdev(m.ec), ctx->flags);
+        VMN_FOR_CURVES(X)
+#undef X
+        VMN_TRY(rc);
+        uint32_t fl = 0;
+        VMN_TRY(read_flag(ctx, &fl));
+        *equal = fl ? 0 : 1;
+        return VMN_OK;
+    }
     size_t nchunks = n * elem_words(m) / 4;
     VMN_TRY(launch_light(ctx, "compare", k_compare, light_grid(ctx, nchunks), reinterpret_cast<const uint4*>(x),
                          reinterpret_cast<const uint4*>(y), nchunks, ctx->flags));
@@ -1007,6 +1273,12 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
     while (true) {
         uint32_t* dst = (L == 1) ? d_out : ping;
         int rc = VMN_ERR_ARG;
+        if (m.ec) {
+#define X(S_, NW_) \
+    if (m.ec->S == S_) rc = launch_light(ctx, "reduce", k_ec_reduce<S_>, grid_for(nseg * L), dst, src, cur, L, nseg, ecdev(m.ec));
+            VMN_FOR_CURVES(X)
+#undef X
+        } else {
 #define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
         rc = mul ? launch(ctx, "reduce", k_reduce_strided<Cfg<S_, LPE_>, true>, egrid(m, nseg * L), lds_bytes(m), dst, src, cur, L, \
@@ -1016,6 +1288,7 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
     }
         VMN_FOR_SIZES(X)
 #undef X
+        }
         VMN_TRY(rc);
         if (L == 1) break;
         src = dst;
@@ -1143,6 +1416,44 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     if (n == 0) return VMN_OK;
     const size_t Wd = elem_words(m);
     if (seglen == 0 || seglen > n) seglen = n;
+    if (m.ec) {                                        // running sums of curve points (b must be null)
+        if (b) return VMN_ERR_ARG;
+        size_t Cc = 16;
+        if (seglen != n) {
+            while (Cc > 1 && seglen % Cc) Cc >>= 1;
+        }
+        if (seglen <= Cc) Cc = seglen;
+        size_t nchunks = (n + Cc - 1) / Cc;
+        int rc = VMN_ERR_ARG;
+        if (seglen <= Cc) {
+#define X(S_, NW_)                                                                                                 \
+    if (m.ec->S == S_)                                                                                             \
+        rc = launch_light(ctx, "scan", k_ec_scan_apply<S_>, grid_for(nchunks), out, e, (const uint32_t*)nullptr, n, \
+                          Cc, seglen, rev, ecdev(m.ec));
+            VMN_FOR_CURVES(X)
+#undef X
+            return rc;
+        }
+        DevTmp tot(ctx);
+        VMN_TRY(tot.alloc(2 * nchunks * Wd * sizeof(uint32_t)));
+        uint32_t* Etot = tot.as<uint32_t>();
+        uint32_t* inc = Etot + nchunks * Wd;
+#define X(S_, NW_) \
+    if (m.ec->S == S_) rc = launch_light(ctx, "scan", k_ec_scan_totals<S_>, grid_for(nchunks), Etot, e, n, Cc, seglen, rev, ecdev(m.ec));
+        VMN_FOR_CURVES(X)
+#undef X
+        VMN_TRY(rc);
+        size_t seg_chunks = seglen == n ? nchunks : seglen / Cc;
+        VMN_TRY(scan_affine(ctx, m, Etot, nullptr, nchunks, seg_chunks, 0, inc));
+        rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                       \
+    if (m.ec->S == S_)                                                                                                   \
+        rc = launch_light(ctx, "scan", k_ec_scan_apply<S_>, grid_for(nchunks), out, e, (const uint32_t*)inc, n, Cc, seglen, \
+                          rev, ecdev(m.ec));
+        VMN_FOR_CURVES(X)
+#undef X
+        return rc;
+    }
     // chunk length: divides seglen when there are several segments
     size_t C = 16;
     if (seglen != n) {
@@ -1241,6 +1552,19 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
         *out = r;
         return VMN_OK;
     }
+    if (m.ec) {
+        int rce = VMN_ERR_ARG;
+#define X(S_, NW_) \
+    if (m.ec->S == S_) rce = launch_light(ctx, "modmul", k_ec_neg<S_>, grid_for(n), r->d, (const uint32_t*)x->d, n, ecdev(m.ec));
+        VMN_FOR_CURVES(X)
+#undef X
+        if (rce != VMN_OK) {
+            vmn_garray_free(r);
+            return rce;
+        }
+        *out = r;
+        return VMN_OK;
+    }
     int rc = VMN_OK;
     {
         // P[i] = x0..xi, S[i] = xi..x(n-1);  inv(x_i) = P[i-1] * S[i+1] * (P[n-1])^-1
@@ -1314,7 +1638,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     vmn_ctx* ctx = g->ctx;
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
-    std::string key(reinterpret_cast<const char*>(base_be), g->nbytes);
+    std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
     int w = pick_fixed_window(n, ebits, Wd * sizeof(uint32_t));
     auto it = g->fixed.find(key);
     if (it != g->fixed.end()) {
@@ -1328,6 +1652,51 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         g->fixed.erase(it);
     }
     int nwin = (ebits + w - 1) / w;
+    if (m.ec) {
+        // doubling chain on one lane, then the same level-by-level table build with point additions
+        const size_t chain = (size_t)nwin * w;
+        uint32_t* d_base = nullptr;
+        VMN_TRY(import_one(ctx, m, g->nbytes, base_be, &d_base));
+        DevTmp sq(ctx);
+        int rc = sq.alloc(chain * Wd * sizeof(uint32_t));
+        vmn_group::FixedTable ft;
+        ft.wbits = w;
+        ft.nwin = nwin;
+        ft.bytes = (size_t)nwin * ((size_t)1 << w) * Wd * sizeof(uint32_t);
+        if (rc == VMN_OK && hipMalloc(&ft.d_tab, ft.bytes) != hipSuccess) {
+            set_error("fixed-base table allocation of %zu bytes failed", ft.bytes);
+            rc = VMN_ERR_NOMEM;
+        }
+        if (rc == VMN_OK) {
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                \
+    if (m.ec->S == S_) {                                                                                          \
+        hipLaunchKernelGGL(k_ec_chain<S_>, dim3(1), dim3(64), 0, ctx->stream, sq.as<uint32_t>(),                  \
+                           (const uint32_t*)d_base, (int)chain, ecdev(m.ec));                                     \
+        rc = hipGetLastError() == hipSuccess ? VMN_OK : VMN_ERR_DEVICE;                                           \
+    }
+            VMN_FOR_CURVES(X)
+#undef X
+        }
+        if (rc == VMN_OK)
+            rc = launch_light(ctx, "fixed_table", k_fixed_seed, grid_for((size_t)nwin * (w + 1)), ft.d_tab,
+                              (const uint32_t*)sq.as<uint32_t>(), w, nwin, (const uint32_t*)m.d_one, (int)Wd);
+        for (int l = 1; l < w && rc == VMN_OK; ++l) {
+            size_t lanes = (((size_t)1 << l) - 1) * nwin;
+#define X(S_, NW_) \
+    if (m.ec->S == S_) rc = launch_light(ctx, "fixed_table", k_ec_fixed_level<S_>, grid_for(lanes), ft.d_tab, w, nwin, l, ecdev(m.ec));
+            VMN_FOR_CURVES(X)
+#undef X
+        }
+        free_one(ctx, m, d_base);
+        if (rc != VMN_OK) {
+            if (ft.d_tab) (void)hipFree(ft.d_tab);
+            return rc;
+        }
+        auto ins = g->fixed.emplace(key, ft);
+        *out = &ins.first->second;
+        return VMN_OK;
+    }
     // host: sq[j] = base^(2^j) mod p, j < nwin*w   (sequential chain, 32-bit-word Montgomery)
     Big base = hostbig::from_be(base_be, g->nbytes, m.NW);
     if (hostbig::cmp(base, m.n_words) >= 0) {
@@ -1393,12 +1762,21 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
         const vmn_modulus& m = grp->P;
         unsigned grid = std::min<unsigned>(egrid(m, n), (unsigned)(ctx->num_cus * blocks_per_cu(m)));
         rc = VMN_ERR_ARG;
+        if (m.ec) {
+#define X(S_, NW_)                                                                                                   \
+    if (m.ec->S == S_)                                                                                               \
+        rc = launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+                          ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, ecdev(m.ec));
+            VMN_FOR_CURVES(X)
+#undef X
+        } else {
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
         rc = launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                     ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, m.d_n, m.n0inv);
         VMN_FOR_SIZES(X)
 #undef X
+        }
     }
     if (rc != VMN_OK) {
         vmn_garray_free(r);
@@ -1429,11 +1807,14 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
     vmn_ctx* ctx = g->ctx;
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
-    const hostbig::Mont& hm = *m.hm;
     if (n == 0) {
-        Big one(m.NW, 0);
-        one[0] = 1;
-        hostbig::to_be(one, out_be, g->nbytes);
+        if (m.ec) {
+            memset(out_be, 0xff, 2 * g->nbytes);      // the identity: point at infinity
+        } else {
+            Big one(m.NW, 0);
+            one[0] = 1;
+            hostbig::to_be(one, out_be, g->nbytes);
+        }
         return VMN_OK;
     }
     if (ebits < 1) ebits = 1;
@@ -1493,7 +1874,21 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
         VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         VMN_HIP(hipStreamSynchronize(ctx->stream));
         const size_t total_out = hm2[0];
-        if (total_out > 0) {
+        if (total_out > 0 && m.ec) {
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                     \
+    if (m.ec->S == S_) {                                                                                               \
+        rc = first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, grid_for(total_out), items_out, items_in, \
+                                  (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out,    \
+                                  nbuckets, total_out, F, ecdev(m.ec))                                                 \
+                   : launch_light(ctx, "expprod", k_ec_bucket_level<S_, false>, grid_for(total_out), items_out,        \
+                                  items_in, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_out,        \
+                                  nbuckets, total_out, F, ecdev(m.ec));                                                \
+    }
+            VMN_FOR_CURVES(X)
+#undef X
+            VMN_TRY(rc);
+        } else if (total_out > 0) {
             rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
@@ -1531,6 +1926,22 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
     VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for((size_t)nwin * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
                          nb, (size_t)nwin, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
     VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, nwin, true, wres.as<uint32_t>()));
+    if (m.ec) {                                        // Horner over the windows on one lane, then export
+        DevTmp res(ctx);
+        VMN_TRY(res.alloc(Wd * sizeof(uint32_t)));
+        rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                \
+    if (m.ec->S == S_) {                                                                                          \
+        hipLaunchKernelGGL(k_ec_horner<S_>, dim3(1), dim3(64), 0, ctx->stream, res.as<uint32_t>(),                \
+                           (const uint32_t*)wres.as<uint32_t>(), nwin, c, ecdev(m.ec));                           \
+        rc = hipGetLastError() == hipSuccess ? VMN_OK : VMN_ERR_DEVICE;                                           \
+    }
+        VMN_FOR_CURVES(X)
+#undef X
+        VMN_TRY(rc);
+        return export_be(ctx, m, g->nbytes, res.as<uint32_t>(), 1, out_be);
+    }
+    const hostbig::Mont& hm = *m.hm;
     // Horner over the windows on the host: nwin elements, c squarings each (O(ebits) modmuls)
     std::vector<uint8_t> wbe((size_t)nwin * g->nbytes);
     VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), nwin, wbe.data()));
@@ -1579,6 +1990,7 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     VMN_HIP(hipSetDevice(ctx->device));
     *all_members = 1;
     if (x->n == 0) return VMN_OK;
+    if (g->P.ec) return VMN_OK;      // prime-order curve: every point that passed the import's curve check is a member
     // x^q == 1 for every element: shared-exponent modpow, then compare with a broadcast of one
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
@@ -1596,6 +2008,15 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
 
 extern "C" int vmn_group_mul_partials(vmn_group* grp, const uint8_t* partials_be, size_t k, uint8_t* out_be) {
     ARG_CHECK(grp && out_be && (partials_be || k == 0), "null argument");
+    if (grp->curve) {
+        vmn_garray* arr = nullptr;
+        int ok = 1;
+        VMN_TRY(vmn_garray_from_be(grp, partials_be, k, &arr, &ok));
+        int rc = ok ? vmn_garray_prod(arr, out_be) : VMN_ERR_FORMAT;
+        if (!ok) set_error("partial out of range");
+        vmn_garray_free(arr);
+        return rc;
+    }
     const vmn_modulus& m = grp->P;
     const hostbig::Mont& hm = *m.hm;
     Big acc = hm.one;

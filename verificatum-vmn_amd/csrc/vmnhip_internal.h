@@ -57,12 +57,29 @@ struct vmn_ctx {
     std::map<std::string, std::pair<long, double>> timing_acc;
 };
 
+// Elliptic-curve group data (ECqPGroup): field constants on the device, see ec_kernels.h.
+struct vmn_curve {
+    std::string name;
+    int S = 0, NW = 0;             // field limbs / packed words
+    vmn::hostbig::Big p_words, b_words, gx_words, gy_words;
+    uint32_t* d_consts = nullptr;  // one allocation holding p | one | rr | b | mp | mp2 | pm2
+    const uint32_t* d_p = nullptr;
+    const uint32_t* d_one = nullptr;
+    const uint32_t* d_rr = nullptr;
+    const uint32_t* d_b = nullptr;
+    const uint32_t* d_mp = nullptr;
+    const uint32_t* d_mp2 = nullptr;
+    const uint32_t* d_pm2 = nullptr;
+    uint32_t n0inv = 0;
+};
+
 // Device-resident constants of one odd modulus in M28 form.
 struct vmn_modulus {
     int S = 0;                 // 28-bit limbs
     int NW = 0;                // 32-bit words of the packed form
     int LPE = 1;               // lanes per element (2 for 3072-bit moduli)
     int W = 0;                 // words per element row in device memory
+    const vmn_curve* ec = nullptr;   // non-null: the "elements" are curve points (rows of 3 field elements)
     int nbits = 0;
     uint32_t n0inv = 0;        // -N^{-1} mod 2^28
     uint32_t* d_n = nullptr;   // N as one device row (W words: per-lane shares, zero padded)
@@ -74,6 +91,7 @@ struct vmn_modulus {
 
 struct vmn_group {
     vmn_ctx* ctx = nullptr;
+    vmn_curve* curve = nullptr;   // EC group: P describes point rows (P.ec), Q the scalar field Z_n
     size_t nbytes = 0;         // wire width of elements and exponents
     vmn_modulus P;             // arithmetic mod p (group elements)
     vmn_modulus Q;             // arithmetic mod q (exponents)
