@@ -34,6 +34,75 @@ def inv_perm(pi: Sequence[int]) -> List[int]:
     return inv
 
 
+class ModPAdapter:
+    """Group operations on Python ints mod p (multiplicative group)."""
+
+    def __init__(self, p: int, q: int):
+        self.p, self.q, self.one = p, q, 1
+
+    def mul(self, a, b):
+        return a * b % self.p
+
+    def exp(self, a, e):
+        return pow(a, e % self.q, self.p)
+
+    def inv(self, a):
+        return pow(a, -1, self.p)
+
+    def exp_fixed(self, base, es):
+        return pyref.exp_fixed(base, es, self.p)
+
+    def exp_array(self, xs, es):
+        return pyref.exp_array(xs, es, self.p)
+
+    def exp_scalar(self, xs, e):
+        return pyref.exp_scalar(xs, e, self.p)
+
+    def exp_prod(self, xs, es):
+        return pyref.exp_prod(xs, es, self.p)
+
+    def mul_arrays(self, xs, ys):
+        return pyref.mul(xs, ys, self.p)
+
+    def prod(self, xs):
+        return pyref.prod(xs, self.p)
+
+
+class ECAdapter:
+    """The same interface over an elliptic curve (oracle/pyref_ec.Curve): mul = point addition, exp = scalar
+    multiplication."""
+
+    def __init__(self, curve):
+        self.c, self.q, self.one = curve, curve.n, None
+
+    def mul(self, a, b):
+        return self.c.add(a, b)
+
+    def exp(self, a, e):
+        return self.c.mul(e % self.q, a)
+
+    def inv(self, a):
+        return self.c.neg(a)
+
+    def exp_fixed(self, base, es):
+        return self.c.exp_fixed(base, es)
+
+    def exp_array(self, xs, es):
+        return self.c.exp_array(xs, es)
+
+    def exp_scalar(self, xs, e):
+        return [self.c.mul(e, P) for P in xs]
+
+    def exp_prod(self, xs, es):
+        return self.c.exp_prod(xs, es)
+
+    def mul_arrays(self, xs, ys):
+        return self.c.mul_arrays(xs, ys)
+
+    def prod(self, xs):
+        return self.c.prod(xs)
+
+
 def reenc_factors(pkey: Sequence[int], s_cols: Sequence[Sequence[int]], p: int):
     width = len(pkey) // 2
     return [pyref.exp_fixed(pk, s_cols[c % width], p) for c, pk in enumerate(pkey)]
@@ -329,3 +398,167 @@ def combine_decryption_factors(factors, correct, k: int, threshold: int, p: int,
         for i in range(n):
             out[i] = out[i] * pow(base[i], c, p) % p          # Python's pow handles negative exponents (inverse)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# Group-generic restatements (adapter K = ModPAdapter or ECAdapter): the same statements as PoS / PoSC / CCPoS
+# above, written against the group interface so that they also cover ECqPGroup (the reference's code is
+# group-agnostic: SURVEY.md §2.3 K11).  tests/test_proofs_oracle.py checks that over a ModPGroup they produce the
+# same transcripts as the integer-only classes above.
+# ------------------------------------------------------------------------------------------------------
+def g_reenc_factors(K, pkey, s_cols):
+    width = len(pkey) // 2
+    return [K.exp_fixed(pk, s_cols[c % width]) for c, pk in enumerate(pkey)]
+
+
+def g_reencrypt(K, w, factors, permutation):
+    inverse = inv_perm(permutation)
+    return [pyref.permute(K.mul_arrays(c, f), inverse) for c, f in zip(w, factors)]
+
+
+def g_permutation_commitment(K, g, generators, exponents, permutation):
+    return pyref.permute(K.mul_arrays(generators, K.exp_fixed(g, exponents)), permutation)
+
+
+class GPoS:
+    def __init__(self, K, vbitlen, ebitlen, rbitlen, rand=None):
+        self.K, self.q = K, K.q
+        self.vbitlen, self.ebitlen, self.rbitlen, self.rand = vbitlen, ebitlen, rbitlen, rand
+
+    def _cx(self, w, E):
+        return [self.K.exp_prod(c, E) for c in w]
+
+    def precompute(self, g, h, pi=None):
+        K, q = self.K, self.q
+        self.size, self.g, self.h = len(h), g, list(h)
+        if pi is None:
+            return
+        self.pi = list(pi)
+        self.r = self.rand.ring_array(self.size)
+        self.u = pyref.permute(K.mul_arrays(h, K.exp_fixed(g, self.r)), self.pi)
+        self.alpha = self.rand.ring_element()
+        self.epsilon = [x % q for x in self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)]
+        self.Ap = K.mul(K.exp(g, self.alpha), K.exp_prod(h, self.epsilon))
+
+    def setInstance(self, pkey, w, wp, s=None):
+        self.pkey, self.w, self.wp, self.s = list(pkey), w, wp, s
+
+    def setBatchVector(self, e):
+        self.e = list(e)
+
+    def commit(self):
+        K, q, g, h = self.K, self.q, self.g, self.h
+        self.ipe = pyref.permute(self.e, inv_perm(self.pi))
+        h0 = h[0]
+        self.b = self.rand.ring_array(self.size)
+        x, self.d = pyref.rec_lin(self.b, self.ipe, q)
+        y = pyref.prods(self.ipe, q)
+        self.B = K.mul_arrays(K.exp_fixed(g, x), K.exp_fixed(h0, y))
+        self.beta = self.rand.ring_array(self.size)
+        xp = pyref.shift_push(x, 0)
+        yp = pyref.shift_push(y, 1)
+        beta_add_prod = [(bt + a * ep) % q for bt, a, ep in zip(self.beta, xp, self.epsilon)]
+        yp_mul_epsilon = [a * ep % q for a, ep in zip(yp, self.epsilon)]
+        self.Bp = K.mul_arrays(K.exp_fixed(g, beta_add_prod), K.exp_fixed(h0, yp_mul_epsilon))
+        self.gamma = self.rand.ring_element()
+        self.Cp = K.exp(g, self.gamma)
+        self.delta = self.rand.ring_element()
+        self.Dp = K.exp(g, self.delta)
+        width = len(self.pkey) // 2
+        self.phi = [self.rand.ring_element() for _ in range(width)]
+        self.Fp = [K.mul(K.exp(pk, -self.phi[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, self._cx(self.wp, self.epsilon)))]
+        return {"B": self.B, "Ap": self.Ap, "Bp": self.Bp, "Cp": self.Cp, "Dp": self.Dp, "Fp": self.Fp}
+
+    def reply(self, v):
+        q = self.q
+        self.v = v
+        a = pyref.inner_product(self.r, self.ipe, q)
+        c = sum(self.r) % q
+        f = [pyref.inner_product(si, self.e, q) for si in self.s]
+        return {"k_A": (a * v + self.alpha) % q, "k_B": pyref.mul_add(self.b, v % q, self.beta, q),
+                "k_C": (c * v + self.gamma) % q, "k_D": (self.d * v + self.delta) % q,
+                "k_E": pyref.mul_add(self.ipe, v % q, self.epsilon, q),
+                "k_F": [(fc * v + ph) % q for fc, ph in zip(f, self.phi)]}
+
+    def computeAF(self):
+        self.A = self.K.exp_prod(self.u, self.e)
+        self.F = self._cx(self.w, self.e)
+
+    def setCommitment(self, msg):
+        self.B, self.Ap, self.Bp = msg["B"], msg["Ap"], msg["Bp"]
+        self.Cp, self.Dp, self.Fp = msg["Cp"], msg["Dp"], msg["Fp"]
+
+    def verify(self, reply, v):
+        K, q, g, h = self.K, self.q, self.g, self.h
+        k_A, k_B, k_C, k_D, k_E, k_F = (reply[k] for k in ("k_A", "k_B", "k_C", "k_D", "k_E", "k_F"))
+        h0 = h[0]
+        C = K.mul(K.prod(self.u), K.inv(K.prod(h)))
+        eprod = 1
+        for t in self.e:
+            eprod = eprod * t % q
+        D = K.mul(self.B[self.size - 1], K.inv(K.exp(h0, eprod)))
+        verdictA = K.mul(K.exp(self.A, v), self.Ap) == K.mul(K.exp(g, k_A), K.exp_prod(h, k_E))
+        left = K.mul_arrays(K.exp_scalar(self.B, v), self.Bp)
+        right = K.mul_arrays(K.exp_fixed(g, k_B), K.exp_array(pyref.shift_push(self.B, h0), k_E))
+        verdictB = left == right
+        verdictC = K.mul(K.exp(C, v), self.Cp) == K.exp(g, k_C)
+        verdictD = K.mul(K.exp(D, v), self.Dp) == K.exp(g, k_D)
+        prods = self._cx(self.wp, k_E)
+        width = len(self.pkey) // 2
+        verdictF = all(K.mul(K.exp(Fc, v), Fpc) == K.mul(K.exp(pk, -k_F[c % width]), t)
+                       for c, (Fc, Fpc, pk, t) in enumerate(zip(self.F, self.Fp, self.pkey, prods)))
+        self.verdicts = (verdictA, verdictB, verdictC, verdictD, verdictF)
+        return all(self.verdicts)
+
+
+class GCCPoS:
+    def __init__(self, K, vbitlen, ebitlen, rbitlen, rand=None):
+        self.K, self.q = K, K.q
+        self.vbitlen, self.ebitlen, self.rbitlen, self.rand = vbitlen, ebitlen, rbitlen, rand
+
+    def _cx(self, w, E):
+        return [self.K.exp_prod(c, E) for c in w]
+
+    def setInstance(self, g, h, u, pkey, w, wp, r=None, pi=None, s=None):
+        self.g, self.h, self.u, self.pkey, self.w, self.wp = g, list(h), list(u), list(pkey), w, wp
+        self.r, self.s = r, s
+        self.pi = list(pi) if pi is not None else None
+        self.size = len(h)
+
+    def setBatchVector(self, e):
+        self.e = list(e)
+
+    def commit(self):
+        K, q, g, h = self.K, self.q, self.g, self.h
+        self.ipe = pyref.permute(self.e, inv_perm(self.pi))
+        self.alpha = self.rand.ring_element()
+        self.epsilon = [t % q for t in self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)]
+        self.Ap = K.mul(K.exp(g, self.alpha), K.exp_prod(h, self.epsilon))
+        width = len(self.pkey) // 2
+        self.beta = [self.rand.ring_element() for _ in range(width)]
+        self.Bp = [K.mul(K.exp(pk, -self.beta[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, self._cx(self.wp, self.epsilon)))]
+        return {"Ap": self.Ap, "Bp": self.Bp}
+
+    def reply(self, v):
+        q = self.q
+        a = pyref.inner_product(self.r, self.ipe, q)
+        b = [pyref.inner_product(si, self.e, q) for si in self.s]
+        return {"k_A": (a * v + self.alpha) % q, "k_B": [(bc * v + bt) % q for bc, bt in zip(b, self.beta)],
+                "k_E": pyref.mul_add(self.ipe, v % q, self.epsilon, q)}
+
+    def setCommitment(self, msg):
+        self.Ap, self.Bp = msg["Ap"], msg["Bp"]
+
+    def computeAB(self):
+        self.A = self.K.exp_prod(self.u, self.e)
+        self.B = self._cx(self.w, self.e)
+
+    def verify(self, reply, v):
+        K, g, h = self.K, self.g, self.h
+        k_A, k_B, k_E = reply["k_A"], reply["k_B"], reply["k_E"]
+        if K.mul(K.exp(self.A, v), self.Ap) != K.mul(K.exp(g, k_A), K.exp_prod(h, k_E)):
+            return False
+        prods = self._cx(self.wp, k_E)
+        width = len(self.pkey) // 2
+        return all(K.mul(K.exp(Bc, v), Bpc) == K.mul(K.exp(pk, -k_B[c % width]), t)
+                   for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, prods)))

@@ -119,3 +119,100 @@ def test_scalar_field_arrays(ecg):
         acc = a[i] % c.n if i == 0 else (acc * b[i] + a[i]) % c.n
         want.append(acc)
     assert x.toInts() == want and d == want[-1]
+
+
+def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(vmn, gpu_ctx, entry):
+    """PoS and CCPoS with ECqPGroup P-256 (the reference's default group): the GPU provers' messages equal the
+    group-generic Python restatement on the same tape; verifiers accept; a tampered reply is rejected."""
+    import importlib.util, os, sys
+    from oracle import pyref_proofs as P
+    from tape import Tape
+    mods = {}
+    for name in ("hvzk", "mixnet"):
+        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    hv, mx = mods["hvzk"], mods["mixnet"]
+    c = Curve("P-256")
+    K = P.ECAdapter(c)
+    G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    NV, NE, NR = 128, 128, 64
+    n, width = 40, 1
+    t = Tape(b"ecgpu", c.n)
+    g = c.g
+    h = [c.mul(x, g) for x in t.ring_array(n)]
+    y = c.mul(t.ring_element(), g)
+    pkey = [g, y]
+    er = t.ring_array(n)
+    w = [c.exp_fixed(g, er), c.mul_arrays([c.mul(m, g) for m in t.ring_array(n)], c.exp_fixed(y, er))]
+    pi = t.permutation(n)
+    s = [t.ring_array(n)]
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    ints = lambda x: x.toInts() if hasattr(x, "toInts") else x
+
+    def same(a, b):
+        assert set(a) == set(b)
+        for k in a:
+            assert ints(a[k]) == ints(b[k]), k
+
+    # ---- PoS
+    o = P.GPoS(K, NV, NE, NR, rand=Tape(b"prover", c.n))
+    o.precompute(g, h, pi)
+    wp_o = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    o.setInstance(pkey, w, wp_o, s)
+    o.setBatchVector(e)
+    com_o, rep_o = o.commit(), o.reply(v)
+    H = G.toElementArray(h)
+    W = [G.toElementArray(col) for col in w]
+    S = [G.ringArray(s[0])]
+    pr = hv.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prover", c.n))
+    pr.precompute(g, H, pi)
+    assert pr.u.toInts() == o.u and pr.Ap == o.Ap
+    WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi)
+    assert [col.toInts() for col in WP] == wp_o
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    same(com, com_o)
+    same(rep, rep_o)
+    ver = hv.PoSBasicTW(G, NV, NE, NR)
+    ver.precompute(g, H)
+    ver.setPermutationCommitment(pr.u)
+    ver.setInstance(pkey, W, WP)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep)
+    bad = dict(rep)
+    bad["k_F"] = [(x + 1) % c.n for x in rep["k_F"]]
+    assert not ver.verify(bad) and ver.verdicts == (True, True, True, True, False)
+    # ---- CCPoS on a permutation commitment
+    r = t.ring_array(n)
+    u_o = P.g_permutation_commitment(K, g, h, r, pi)
+    pc = mx.PermutationCommitment(G, H)
+    U = pc.precompute(r, pi)
+    assert U.toInts() == u_o
+    oc = P.GCCPoS(K, NV, NE, NR, rand=Tape(b"cc", c.n))
+    oc.setInstance(g, h, u_o, pkey, w, wp_o, r, pi, s)
+    oc.setBatchVector(e)
+    cc_o, cr_o = oc.commit(), oc.reply(v)
+    cp = hv.CCPoSBasicW(G, NV, NE, NR, rand=Tape(b"cc", c.n))
+    cp.setInstance(g, H, U, pkey, W, WP, pc.exponents, pi, S)
+    cp.setBatchVector(e)
+    cc, cr = cp.commit(), cp.reply(v)
+    same(cc, cc_o)
+    same(cr, cr_o)
+    cv = hv.CCPoSBasicW(G, NV, NE, NR)
+    cv.setInstance(g, H, U, pkey, W, WP)
+    cv.setBatchVector(e)
+    cv.setCommitment(cc)
+    cv.setChallenge(v)
+    cv.computeAB()
+    assert cv.verify(cr)
+    bad = dict(cr)
+    bad["k_A"] = (cr["k_A"] + 1) % c.n
+    assert not cv.verify(bad)

@@ -119,3 +119,60 @@ def test_ccpos_plain_and_raised(raised):
         bad = dict(rep)
         bad["k_B"] = [(x + 1) % q for x in rep["k_B"]]
         assert not ver.verify(bad, v)
+
+
+def test_group_generic_restatement_equals_integer_restatement():
+    """GPoS / GCCPoS over a ModPGroup adapter produce exactly the transcripts of the integer-only classes."""
+    n, width = 9, 2
+    p, q, g, h, pkey, w, t = setup(512, n, width, seed=b"generic")
+    pi = t.permutation(n)
+    s = [t.ring_array(n) for _ in range(width)]
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    K = P.ModPAdapter(p, q)
+    a = P.PoS(p, q, NV, NE, NR, rand=Tape(b"x", q))
+    b = P.GPoS(K, NV, NE, NR, rand=Tape(b"x", q))
+    for o in (a, b):
+        o.precompute(g, h, pi)
+    wp = P.reencrypt(w, P.reenc_factors(pkey, s, p), pi, p)
+    assert wp == P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    for o in (a, b):
+        o.setInstance(pkey, w, wp, s)
+        o.setBatchVector(e)
+    assert a.commit() == b.commit() and a.reply(v) == b.reply(v)
+
+
+@pytest.mark.parametrize("name", ["P-256"])
+def test_proofs_over_an_elliptic_curve_accept_and_reject(name):
+    from oracle.pyref_ec import Curve
+    c = Curve(name)
+    K = P.ECAdapter(c)
+    n = 6
+    t = Tape(b"ecproof", c.n)
+    g = c.g
+    h = [c.mul(x, g) for x in t.ring_array(n)]
+    y = c.mul(t.ring_element(), g)
+    pkey = [g, y]
+    er = t.ring_array(n)
+    w = [c.exp_fixed(g, er), c.mul_arrays([c.mul(m, g) for m in t.ring_array(n)], c.exp_fixed(y, er))]
+    pi = t.permutation(n)
+    s = [t.ring_array(n)]
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    pr = P.GPoS(K, NV, NE, NR, rand=t)
+    pr.precompute(g, h, pi)
+    wp = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    pr.setInstance(pkey, w, wp, s)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    ver = P.GPoS(K, NV, NE, NR)
+    ver.precompute(g, h)
+    ver.u = pr.u
+    ver.setInstance(pkey, w, wp)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    assert ver.verify(rep, v)
+    bad = dict(rep)
+    bad["k_D"] = (rep["k_D"] + 1) % c.n
+    assert not ver.verify(bad, v) and ver.verdicts == (True, True, True, False, True)

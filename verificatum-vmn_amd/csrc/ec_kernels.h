@@ -352,8 +352,8 @@ __global__ void __launch_bounds__(BLOCK) k_ec_import(u32* __restrict__ out, cons
         f_mul<S>(x3, t, P.X, E);
         f_small<S, 3>(t, P.X);
         f_add<S>(rhs, x3, bb);
-        f_sub<S>(rhs, rhs, t, E);
-        f_sub<S>(t, lhs, rhs, E);
+        f_sub<S>(rhs, rhs, t, E);                       // < 4p + 64p
+        f_sub<S, true>(t, lhs, rhs, E);                 // subtrahend up to 68p: the 256p form
         bad = bad || !f_is_zero<S>(t, E);
         if (bad) pt_set_inf<S>(P, E);
     }

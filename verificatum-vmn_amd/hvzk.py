@@ -64,12 +64,17 @@ class _Base:
         self.eps_bits = min(ebitlen + vbitlen + rbitlen, qbits)
         self.kE_bits = min(ebitlen + vbitlen + rbitlen + 1, qbits)
 
-    # scalar helpers (single group / ring elements: host integers, as VCR's scalar classes)
-    def _gexp(self, base: int, e: int) -> int:
-        return pow(base, e % self.q, self.p)
+    # scalar helpers (single group elements on the host, as VCR's scalar classes): through the group object, so
+    # the same driver serves ModPGroup (integers) and ECqPGroup (affine points)
+    def _gexp(self, base, e: int):
+        return self.G.k_exp(base, e)
 
-    def _div(self, a: int, b: int) -> int:
-        return a * pow(b, -1, self.p) % self.p
+    def _div(self, a, b):
+        return self.G.k_mul(a, self.G.k_inv(b))
+
+    def _expmul(self, a, v: int, b):
+        """``a.expMul(v, b)`` = a^v * b (PoSBasicTW.java:1016-1021)."""
+        return self.G.k_mul(self.G.k_exp(a, v), b)
 
     def _eps_array(self):
         """epsilon: N integers of ebitlen+vbitlen+rbitlen bits, as field elements (PoSBasicTW.java:470-475).
@@ -103,7 +108,7 @@ class PoSBasicTW(_Base):
         self.alpha = self.rand.ring_element()
         self.epsilon = self._eps_array()
         # A' = g^alpha * prod h_i^eps_i
-        self.Ap = self._gexp(g, self.alpha) * h.expProd(self.epsilon, self.eps_bits) % self.p
+        self.Ap = self.G.k_mul(self._gexp(g, self.alpha), h.expProd(self.epsilon, self.eps_bits))
 
     def setInstance(self, pkey: Sequence[int], w, wp, s=None):
         """:421-433 (verifier) / prover variant with the re-encryption exponents s (list of ω ring arrays)."""
@@ -151,7 +156,7 @@ class PoSBasicTW(_Base):
         width = len(self.pkey) // 2
         self.phi = [self.rand.ring_element() for _ in range(width)]      # ciphPRing element: one value per column
         prods = self._ciph_expprod(self.wp, self.epsilon, self.eps_bits)
-        self.Fp = [self._gexp(pk, -self.phi[c % width]) * t % p for c, (pk, t) in enumerate(zip(self.pkey, prods))]
+        self.Fp = [G.k_mul(self._gexp(pk, -self.phi[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, prods))]
         return {"B": self.B, "Ap": self.Ap, "Bp": self.Bp, "Cp": self.Cp, "Dp": self.Dp, "Fp": self.Fp}
 
     def setChallenge(self, v: int):
@@ -190,7 +195,7 @@ class PoSBasicTW(_Base):
         h0 = h.get(0)
         C = self._div(self.u.prod(), h.prod())
         D = self._div(self.B.get(self.size - 1), self._gexp(h0, self.e.prod()))
-        verdictA = (pow(self.A, v, p) * self.Ap % p) == (self._gexp(g, k_A) * h.expProd(k_E, self.kE_bits) % p)
+        verdictA = self._expmul(self.A, v, self.Ap) == G.k_mul(self._gexp(g, k_A), h.expProd(k_E, self.kE_bits))
         B_exp_v = self.B.exp(v)
         leftSide = B_exp_v.mul(self.Bp)
         g_exp_k_B = G.exp(g, k_B)
@@ -200,11 +205,11 @@ class PoSBasicTW(_Base):
         verdictB = leftSide.equals(rightSide)
         for t in (B_exp_v, leftSide, g_exp_k_B, B_shift, B_shift_exp_k_E, rightSide):
             t.free()
-        verdictC = (pow(C, v, p) * self.Cp % p) == self._gexp(g, k_C)
-        verdictD = (pow(D, v, p) * self.Dp % p) == self._gexp(g, k_D)
+        verdictC = self._expmul(C, v, self.Cp) == self._gexp(g, k_C)
+        verdictD = self._expmul(D, v, self.Dp) == self._gexp(g, k_D)
         prods = self._ciph_expprod(self.wp, k_E, self.kE_bits)
         width = len(self.pkey) // 2
-        verdictF = all((pow(Fc, v, p) * Fpc % p) == (self._gexp(pk, -k_F[c % width]) * t % p)
+        verdictF = all(self._expmul(Fc, v, Fpc) == G.k_mul(self._gexp(pk, -k_F[c % width]), t)
                        for c, (Fc, Fpc, pk, t) in enumerate(zip(self.F, self.Fp, self.pkey, prods)))
         self.verdicts = (verdictA, verdictB, verdictC, verdictD, verdictF)
         return all(self.verdicts)
@@ -237,7 +242,7 @@ class PoSCBasicTW(_Base):
         h0_exp_y.free()
         self.alpha = self.rand.ring_element()
         self.epsilon = self._eps_array()
-        self.Ap = self._gexp(g, self.alpha) * h.expProd(self.epsilon, self.eps_bits) % self.p
+        self.Ap = self.G.k_mul(self._gexp(g, self.alpha), h.expProd(self.epsilon, self.eps_bits))
         self.beta = G.ringArray(self.rand.ring_array(self.size))
         xp = x.shiftPush(0)
         yp = y.shiftPush(1)
@@ -282,7 +287,7 @@ class PoSCBasicTW(_Base):
         A = self.u.expProd(self.e, self.e_bits)
         C = self._div(self.u.prod(), h.prod())
         D = self._div(self.B.get(self.size - 1), self._gexp(h0, self.e.prod()))
-        if (pow(A, v, p) * self.Ap % p) != (self._gexp(g, k_A) * h.expProd(k_E, self.kE_bits) % p):
+        if self._expmul(A, v, self.Ap) != G.k_mul(self._gexp(g, k_A), h.expProd(k_E, self.kE_bits)):
             return False
         B_exp_v = self.B.exp(v)
         leftSide = B_exp_v.mul(self.Bp)
@@ -295,9 +300,9 @@ class PoSCBasicTW(_Base):
             t.free()
         if not B_res:
             return False
-        if (pow(C, v, p) * self.Cp % p) != self._gexp(g, k_C):
+        if self._expmul(C, v, self.Cp) != self._gexp(g, k_C):
             return False
-        if (pow(D, v, p) * self.Dp % p) != self._gexp(g, k_D):
+        if self._expmul(D, v, self.Dp) != self._gexp(g, k_D):
             return False
         return True
 
@@ -320,11 +325,11 @@ class CCPoSBasicW(_Base):
         self.ipe = self.e.permute(_inv_perm(self.pi))
         self.alpha = self.rand.ring_element()
         self.epsilon = self._eps_array()
-        self.Ap = self._gexp(g, self.alpha) * h.expProd(self.epsilon, self.eps_bits) % p
+        self.Ap = G.k_mul(self._gexp(g, self.alpha), h.expProd(self.epsilon, self.eps_bits))
         width = len(self.pkey) // 2
         self.beta = [self.rand.ring_element() for _ in range(width)]
         prods = self._ciph_expprod(self.wp, self.epsilon, self.eps_bits)
-        self.Bp = [self._gexp(pk, -self.beta[c % width]) * t % p for c, (pk, t) in enumerate(zip(self.pkey, prods))]
+        self.Bp = [G.k_mul(self._gexp(pk, -self.beta[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, prods))]
         return {"Ap": self.Ap, "Bp": self.Bp}
 
     def setChallenge(self, v: int):
@@ -361,14 +366,15 @@ class CCPoSBasicW(_Base):
         g, h, p, v = self.g, self.h, self.p, self.v
         k_A, k_B, k_E = reply["k_A"], reply["k_B"], reply["k_E"]
         if raisedExponent is None:
-            if (pow(self.A, v, p) * self.Ap % p) != (self._gexp(g, k_A) * h.expProd(k_E, self.kE_bits) % p):
+            if self._expmul(self.A, v, self.Ap) != self.G.k_mul(self._gexp(g, k_A), h.expProd(k_E, self.kE_bits)):
                 return False
             prods = self._ciph_expprod(self.wp, k_E, self.kE_bits)
             width = len(self.pkey) // 2
-            return all((pow(Bc, v, p) * Bpc % p) == (self._gexp(pk, -k_B[c % width]) * t % p)
+            return all(self._expmul(Bc, v, Bpc) == self.G.k_mul(self._gexp(pk, -k_B[c % width]), t)
                        for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, prods)))
         rho = raisedExponent
-        Ap_rho = pow(self.Ap, rho, p)
+        KG = self.G
+        Ap_rho = KG.k_exp(self.Ap, rho)
         g_term = self._gexp(g, k_A * rho)
         ok = True
         width = len(self.pkey) // 2
@@ -376,7 +382,7 @@ class CCPoSBasicW(_Base):
             wp_mul_raisedh = col.mul(raisedh)
             t = wp_mul_raisedh.expProd(k_E, self.kE_bits)
             wp_mul_raisedh.free()
-            lhs = pow(ABc, v, p) * (Bpc * Ap_rho % p) % p
-            rhs = self._gexp(pk, -k_B[c % width]) * t % p * g_term % p
+            lhs = self._expmul(ABc, v, KG.k_mul(Bpc, Ap_rho))
+            rhs = KG.k_mul(KG.k_mul(self._gexp(pk, -k_B[c % width]), t), g_term)
             ok = ok and lhs == rhs
         return ok
