@@ -265,6 +265,80 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072):
             "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
+def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width: int = 3):
+    """BASELINE.json configs[4] on one GPU: ElGamal ciphertexts over ECqPGroup P-256 (the reference's default group),
+    width 3 (a ciphertext = 6 points): offline = permutation commitment; online = re-encryption (A0) +
+    commitment-consistent proof of a shuffle (A3, prove + verify).  Point kernels: csrc/ec_kernels.h."""
+    hv, mx = load_sub(entry, "hvzk"), load_sub(entry, "mixnet")
+    NV = NE = 256
+    NR = 100
+    EB = NE + NV + NR
+    grp = vmn.ECqPGroup(ctx, curve)
+    g, q = grp.g, grp.q
+    bulk = mx.BulkRandomSource(seed, q, grp.nbytes)
+    H = grp.exp(g, grp.ringArray(bulk.ring_array(n)))
+    y = grp.k_exp(g, bulk.ring_element())
+    pkey = [g] * width + [y] * width
+    W = []
+    Ts = [grp.ringArray(bulk.ring_array(n)) for _ in range(width)]
+    for c in range(width):
+        W.append(grp.exp(g, Ts[c]))
+    for c in range(width):
+        M = grp.exp(g, grp.ringArray(bulk.ring_array(n)))
+        YT = grp.exp(y, Ts[c])
+        W.append(M.mul(YT))
+        M.free()
+        YT.free()
+    for t in Ts:
+        t.free()
+    plan = [("permutation", n), ("ring_array", n)] + [("ring_array", n)] * width + \
+           [("int_array", n, NE), ("ring_element",), ("int_array", n, EB)] + [("ring_element",)] * width + [("int_array", 1, NV)]
+    tape = ReplaySource(bulk, plan)
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    pi = tape.permutation(n)
+    pc = mx.PermutationCommitment(grp, H)
+    U = pc.precompute(tape.ring_array(n), pi)
+    sync()
+    t1 = time.perf_counter()
+    S = [grp.ringArray(tape.ring_array(n)) for _ in range(width)]
+    factors = mx.reencFactors(grp, pkey, S)
+    WP = mx.reencrypt(W, factors, pi)
+    for f in factors:
+        f.free()
+    sync()
+    t2 = time.perf_counter()
+    e = tape.int_array(n, NE)
+    cp = hv.CCPoSBasicW(grp, NV, NE, NR, rand=tape)
+    cp.setInstance(g, H, U, pkey, W, WP, pc.exponents, pi, S)
+    cp.setBatchVector(e)
+    com = cp.commit()
+    v = int.from_bytes(tape.int_array(1, NV), "big")
+    rep = cp.reply(v)
+    sync()
+    t3 = time.perf_counter()
+    cv = hv.CCPoSBasicW(grp, NV, NE, NR)
+    cv.setInstance(g, H, U, pkey, W, WP)
+    cv.setBatchVector(e)
+    cv.setCommitment(com)
+    cv.setChallenge(v)
+    cv.computeAB()
+    ok = cv.verify(rep)
+    sync()
+    t4 = time.perf_counter()
+    ctx.timing_enable(False)
+    fam = ctx.timing_report()
+    online = t4 - t1
+    return {"workload": f"BASELINE.json configs[4] on one GPU: ECqPGroup {curve}, width {width}; offline = permutation commitment, "
+                        "online = re-encrypt + CCPoS prove+verify (n_e = n_v = 256, n_r = 100)",
+            "n": n, "accepted": bool(ok), "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3,
+            "ccpos_prove_ms": (t3 - t2) * 1e3, "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
+            "ciphertexts_per_s_online": n / online,
+            "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+
+
 def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dist, device):
     """The same workload sharded over the ranks: N = n_per_gpu x world ciphertexts, one proof, every
     array split by position (verificatum-vmn_amd/parallel.py); public inputs replicated per GPU; the
@@ -340,6 +414,8 @@ def main() -> None:
     ap.add_argument("--cpu-sample-elements", dest="cpu_sample", type=int, default=0, help="elements of the CPU baseline sample (0 = auto)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--mix-elements", dest="mix_n", type=int, default=1_000_000, help="ciphertexts of the mix+prove leg (0 = skip)")
+    ap.add_argument("--ec-elements", dest="ec_n", type=int, default=400_000,
+                    help="ciphertexts of the P-256 width-3 leg (BASELINE configs[4]; 0 = skip; single GPU only)")
     ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=400_000,
                     help="ciphertexts of the 3072-bit CCPoS leg (BASELINE configs[2]; 0 = skip; single GPU only)")
     args = ap.parse_args()
@@ -484,6 +560,10 @@ def main() -> None:
     if args.ccpos_n > 0 and not distributed:
         ctx.timing_reset()
         result["mix_ccpos_3072"] = mix_ccpos(entry, vmn, ctx, args.ccpos_n, 4242, barrier)
+
+    if args.ec_n > 0 and not distributed:
+        ctx.timing_reset()
+        result["mix_ec_p256"] = mix_ec(entry, vmn, ctx, args.ec_n, 555, barrier)
 
     if rank == 0 and not args.no_cpu:
         from oracle.cbind import Oracle
