@@ -33,7 +33,7 @@ def main():
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     device = None
-    if backend == "hip":                       # one GPU per rank, RCCL
+    if backend in ("hip", "hip-ec"):           # one GPU per rank, RCCL
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", device_id=device)
@@ -41,27 +41,38 @@ def main():
         dist.init_process_group("gloo")
     par = load_parallel()
     comm = par.Comm(dist, device)
-    grp, _ = load_golden(bits)
-    p, q, g = grp["p"], grp["q"], grp["g"]
+    ec = backend.endswith("-ec")
+    if ec:
+        from oracle.pyref_ec import Curve
+        curve = Curve("P-256")
+        K = P.ECAdapter(curve)
+        p, q, g = curve.p, curve.n, curve.g
+    else:
+        grp, _ = load_golden(bits)
+        p, q, g = grp["p"], grp["q"], grp["g"]
+        K = P.ModPAdapter(p, q)
     NV, NE, NR = (100, 100, 50) if bits == 512 else (256, 256, 100)
     # public instance + secrets, identical on every rank (deterministic tape)
     t = Tape(b"dist%d" % bits, q)
-    h = [pow(g, x, p) for x in t.ring_array(n)]
-    y = pow(g, t.ring_element(), p)
+    h = K.exp_fixed(g, t.ring_array(n))
+    y = K.exp(g, t.ring_element())
     pkey = [g] * width + [y] * width
-    msgs = [[pow(g, m, p) for m in t.ring_array(n)] for _ in range(width)]
+    msgs = [K.exp_fixed(g, t.ring_array(n)) for _ in range(width)]
     enc_r = [t.ring_array(n) for _ in range(width)]
-    w = [pyref.exp_fixed(g, enc_r[c], p) for c in range(width)] + \
-        [pyref.mul(msgs[c], pyref.exp_fixed(y, enc_r[c], p), p) for c in range(width)]
+    w = [K.exp_fixed(g, enc_r[c]) for c in range(width)] + \
+        [K.mul_arrays(msgs[c], K.exp_fixed(y, enc_r[c])) for c in range(width)]
     pi = t.permutation(n)
     s = [t.ring_array(n) for _ in range(width)]
     e = t.int_array(n, NE)
     v = t.int_array(1, NV)[0]
 
-    if backend in ("hip", "hip-gloo"):
+    if backend.startswith("hip"):
         vmn = entry.load_package()
-        ctx = vmn.Context(int(os.environ.get("LOCAL_RANK", "0")) if backend == "hip" else 0)
-        G = vmn.ModPGroup(ctx, p, q, g)
+        ctx = vmn.Context(int(os.environ.get("LOCAL_RANK", "0")) if backend in ("hip", "hip-ec") else 0)
+        G = vmn.ECqPGroup(ctx, "P-256") if ec else vmn.ModPGroup(ctx, p, q, g)
+    elif ec:
+        from fake_backend import FakeECGroup
+        G = FakeECGroup(curve)
     else:
         from fake_backend import FakeGroup
         G = FakeGroup(p, q, g)
@@ -104,9 +115,9 @@ def main():
     dist.all_gather_object(gathered, mine)
     result = {"pass": True, "why": ""}
     if rank == 0:
-        o = P.PoS(p, q, NV, NE, NR, rand=Tape(b"prover", q))
+        o = P.GPoS(K, NV, NE, NR, rand=Tape(b"prover", q))
         o.precompute(g, h, pi)
-        wp_o = P.reencrypt(w, P.reenc_factors(pkey, s, p), pi, p)
+        wp_o = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
         o.setInstance(pkey, w, wp_o, s)
         o.setBatchVector(e)
         com_o = o.commit()

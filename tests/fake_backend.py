@@ -28,6 +28,25 @@ class FakeGroup:
     def mulPartials(self, partials):
         return pyref.prod(partials, self.p)
 
+    # single-element helpers (same names as the product's group classes)
+    elem_bytes = property(lambda self: self.nbytes)
+    ONE = 1
+
+    def enc_el(self, el):
+        return int(el).to_bytes(self.nbytes, "big")
+
+    def dec_el(self, buf):
+        return int.from_bytes(buf, "big")
+
+    def k_mul(self, a, b):
+        return a * b % self.p
+
+    def k_exp(self, a, e):
+        return pow(a, e % self.q, self.p)
+
+    def k_inv(self, a):
+        return pow(a, -1, self.p)
+
 
 class _Arr:
     def __init__(self, group, v):
@@ -109,3 +128,57 @@ class FakeR(_Arr):
         for t in self.v:
             acc = acc * t % self.group.q
         return acc
+
+
+class FakeECGroup(FakeGroup):
+    """The same stand-in over an elliptic curve (oracle/pyref_ec.Curve); elements are affine points or None."""
+
+    def __init__(self, curve):
+        self.c = curve
+        self.p, self.q, self.g = curve.p, curve.n, curve.g
+        self.nbytes = curve.nbytes
+
+    elem_bytes = property(lambda self: 2 * self.nbytes)
+    ONE = None
+
+    def enc_el(self, el):
+        return self.c.enc(el)
+
+    def dec_el(self, buf):
+        return self.c.dec(buf)
+
+    def k_mul(self, a, b):
+        return self.c.add(a, b)
+
+    def k_exp(self, a, e):
+        return self.c.mul(e % self.q, a)
+
+    def k_inv(self, a):
+        return self.c.neg(a)
+
+    def toElementArray(self, values, checked=True):
+        return FakeECArr(self, list(values))
+
+    def exp(self, base, exponents):
+        return FakeECArr(self, self.c.exp_fixed(base, exponents.v))
+
+    def mulPartials(self, partials):
+        return self.c.prod(partials)
+
+
+class FakeECArr(_Arr):
+    def exp(self, e, ebits=0):
+        c = self.group.c
+        if isinstance(e, FakeR):
+            return FakeECArr(self.group, c.exp_array(self.v, e.v))
+        return FakeECArr(self.group, [c.mul(int(e), P) for P in self.v])
+
+    def expProd(self, e, ebits=0):
+        es = e.v if isinstance(e, FakeR) else list(e)
+        return self.group.c.exp_prod(self.v, es)
+
+    def mul(self, other):
+        return FakeECArr(self.group, self.group.c.mul_arrays(self.v, other.v))
+
+    def prod(self):
+        return self.group.c.prod(self.v)

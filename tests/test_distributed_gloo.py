@@ -50,6 +50,12 @@ def test_sharded_pos_matches_oracle_on_gloo(world, n, width, tmp_path):
     assert res["pass"], res["why"]
 
 
+def test_sharded_pos_over_p256_on_gloo(tmp_path):
+    """The sharded driver is group-agnostic: the same exchanges carry curve points (BASELINE configs[4])."""
+    res = run_world(2, "fake-ec", 256, 7, 1, tmp_path)
+    assert res["pass"], res["why"]
+
+
 def test_more_ranks_than_elements(tmp_path):
     """Ragged extreme: some ranks own an empty shard."""
     res = run_world(3, "fake", 512, 2, 1, tmp_path)
@@ -61,4 +67,10 @@ def test_sharded_pos_real_kernels_two_ranks_one_gpu(tmp_path):
     """The same sharded proof with the HIP library doing the arithmetic: two ranks share the one GPU of
     the test box (gloo carries the small exchanges; on an 8-GPU node the backend is nccl = RCCL)."""
     res = run_world(2, "hip-gloo", 2048, 150, 1, tmp_path, timeout=900)
+    assert res["pass"], res["why"]
+
+
+@pytest.mark.gpu
+def test_sharded_pos_p256_real_kernels_two_ranks_one_gpu(tmp_path):
+    res = run_world(2, "hip-gloo-ec", 256, 60, 1, tmp_path, timeout=900)
     assert res["pass"], res["why"]

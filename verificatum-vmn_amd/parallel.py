@@ -101,20 +101,28 @@ class ShardedPoSBasicTW:
         self.eps_bits = min(ebitlen + vbitlen + rbitlen, qbits)
         self.kE_bits = min(ebitlen + vbitlen + rbitlen + 1, qbits)
 
-    # ---- helpers ------------------------------------------------------------------------------
-    def _gexp(self, base: int, e: int) -> int:
-        return pow(base, e % self.q, self.p)
+    # ---- helpers (single elements through the group object: ModPGroup integers or ECqPGroup points) --------
+    def _gexp(self, base, e: int):
+        return self.G.k_exp(base, e)
 
-    def _div(self, a: int, b: int) -> int:
-        return a * pow(b, -1, self.p) % self.p
+    def _div(self, a, b):
+        return self.G.k_mul(a, self.G.k_inv(b))
 
-    def _prod_all(self, local: Sequence[int]) -> List[int]:
-        """Component-wise product mod p of every rank's partial group elements (all-gather + multiply)."""
-        parts = self.comm.all_gather_ints(local, self.nb)
-        out = []
-        for c in range(len(local)):
-            out.append(self.G.mulPartials([pr[c] for pr in parts]))
-        return out
+    def _expmul(self, a, v: int, b):
+        return self.G.k_mul(self.G.k_exp(a, v), b)
+
+    def _gather_elems(self, local):
+        """All-gather of a few group elements per rank (fixed-width wire encoding); returns per-rank lists."""
+        eb = self.G.elem_bytes
+        as_ints = [int.from_bytes(self.G.enc_el(x), "big") for x in local]
+        parts = self.comm.all_gather_ints(as_ints, eb)
+        return [[self.G.dec_el(v.to_bytes(eb, "big")) for v in pr] for pr in parts]
+
+    def _prod_all(self, local) -> list:
+        """Component-wise group product of every rank's partial elements (all-gather + multiply: modular
+        multiplication / point addition is not an RCCL reduction operator)."""
+        parts = self._gather_elems(local)
+        return [self.G.mulPartials([pr[c] for pr in parts]) for c in range(len(local))]
 
     def _sum_all(self, local: Sequence[int]) -> List[int]:
         parts = self.comm.all_gather_ints(local, self.nb)
@@ -128,6 +136,8 @@ class ShardedPoSBasicTW:
 
     def _ring_rows(self, arr, idx):
         rows = _take_rows(arr, idx, self.nb)
+        if not isinstance(rows, (bytes, bytearray)):
+            rows = [x % self.q for x in rows]        # integers longer than q (epsilon over a 256-bit curve order) act mod q
         return self.G.ringArray(rows)
 
     # ---- setup --------------------------------------------------------------------------------
@@ -158,7 +168,7 @@ class ShardedPoSBasicTW:
             t.free()
         self.epsilon = self._ring_rows(eps_full, self.local)
         part = self.h.expProd(self.epsilon, self.eps_bits)
-        self.Ap = self._gexp(g, self.alpha) * self._prod_all([part])[0] % self.p
+        self.Ap = self.G.k_mul(self._gexp(g, self.alpha), self._prod_all([part])[0])
 
     def reencrypt(self, pkey: Sequence[int], w_full, s_full):
         """This rank's shard of w' = permute(w pk^s, pi^-1): local gathers of the replicated input.
@@ -248,7 +258,7 @@ class ShardedPoSBasicTW:
         self.phi = [self.rand.ring_element() for _ in range(width)]
         parts = [c.expProd(self.epsilon, self.eps_bits) for c in self.wp]
         prods = self._prod_all(parts)
-        self.Fp = [self._gexp(pk, -self.phi[c % width]) * t % p for c, (pk, t) in enumerate(zip(self.pkey, prods))]
+        self.Fp = [self.G.k_mul(self._gexp(pk, -self.phi[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, prods))]
         return {"B": self.B, "Ap": self.Ap, "Bp": self.Bp, "Cp": self.Cp, "Dp": self.Dp, "Fp": self.Fp}
 
     def setChallenge(self, v: int):
@@ -283,10 +293,10 @@ class ShardedPoSBasicTW:
         k_A, k_B, k_C, k_D, k_E, k_F = (reply[k] for k in ("k_A", "k_B", "k_C", "k_D", "k_E", "k_F"))
         n_loc = self.hi - self.lo
         # one exchange for all partial products of this phase + each shard's last B element
-        b_last = self.B.get(n_loc - 1) if n_loc else 1
+        b_last = self.B.get(n_loc - 1) if n_loc else self.G.ONE
         parts = [self.u.prod(), self.h.prod(), self.h.expProd(k_E, self.kE_bits), b_last] + \
                 [c.expProd(k_E, self.kE_bits) for c in self.wp]
-        gathered = self.comm.all_gather_ints(parts, self.nb)
+        gathered = self._gather_elems(parts)
         mulp = lambda idx: self.G.mulPartials([pr[idx] for pr in gathered])
         u_prod, h_prod, h_kE = mulp(0), mulp(1), mulp(2)
         wp_kE = [mulp(4 + c) for c in range(len(self.wp))]
@@ -296,7 +306,7 @@ class ShardedPoSBasicTW:
         B_final = next(b_lasts[k] for k in range(self.comm.world - 1, -1, -1)
                        if shard_bounds(self.size, self.comm.world, k)[1] > shard_bounds(self.size, self.comm.world, k)[0])
         D = self._div(B_final, self._gexp(self.h0, e_prod))
-        verdictA = (pow(self.A, v, p) * self.Ap % p) == (self._gexp(g, k_A) * h_kE % p)
+        verdictA = self._expmul(self.A, v, self.Ap) == self.G.k_mul(self._gexp(g, k_A), h_kE)
         # B check on the shard; the element shifted in is the previous non-empty shard's last B (or h0)
         prev = self.h0
         for k in range(self.comm.rank):
@@ -312,10 +322,10 @@ class ShardedPoSBasicTW:
         verdictB = self.comm.all_true(leftSide.equals(rightSide))
         for t in (B_exp_v, leftSide, g_exp_k_B, B_shift, B_shift_exp_k_E, rightSide):
             t.free()
-        verdictC = (pow(C, v, p) * self.Cp % p) == self._gexp(g, k_C)
-        verdictD = (pow(D, v, p) * self.Dp % p) == self._gexp(g, k_D)
+        verdictC = self._expmul(C, v, self.Cp) == self._gexp(g, k_C)
+        verdictD = self._expmul(D, v, self.Dp) == self._gexp(g, k_D)
         width = len(self.pkey) // 2
-        verdictF = all((pow(Fc, v, p) * Fpc % p) == (self._gexp(pk, -k_F[c % width]) * t % p)
+        verdictF = all(self._expmul(Fc, v, Fpc) == self.G.k_mul(self._gexp(pk, -k_F[c % width]), t)
                        for c, (Fc, Fpc, pk, t) in enumerate(zip(self.F, self.Fp, self.pkey, wp_kE)))
         self.verdicts = (verdictA, verdictB, verdictC, verdictD, verdictF)
         return all(self.verdicts)
