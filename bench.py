@@ -551,7 +551,7 @@ def main() -> None:
             mp["total_ms"] = float(t.item())
             mp["ciphertexts_per_s"] = mp["n"] / (mp["total_ms"] / 1e3)
         else:
-            mp = mix_prove(entry, vmn, ctx, grp, args.mix_n, 777 + rank, barrier)
+            mp = mix_prove(entry, vmn, ctx, grp, args.mix_n, 777 + rank, barrier, steps=2)
         mp["workload"] = ("re-encrypt + PoS (Terelius-Wikstrom) prove + verify, ModPGroup 2048-bit, width 1, "
                           "n_e = n_v = 256, n_r = 100; N = mix_n x n_gpus ciphertexts, ONE proof sharded by position "
                           "(all-gather of partial products / scan carries only)")

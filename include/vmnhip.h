@@ -127,6 +127,10 @@ int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray
  * ref: P/hvzk/PoSBasicTW.java:408, 409, 481, 690, 1021, 1063; P/hvzk/CCPoSBasicW.java:380, 391, 497-503. */
 int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int ebits, uint8_t* out_be);
 int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, uint8_t* out_be);
+/* The same for k arrays under ONE exponent array (the 2*width component arrays of a ciphertext array:
+ * PPGroupElementArray.expProd, ref: P/hvzk/PoSBasicTW.java:409, 690, 1063; P/hvzk/CCPoSBasicW.java:391, 498, 567):
+ * the exponent digits are sorted once; out_be receives k elements. */
+int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, const vmn_rarray* e, int ebits, uint8_t* out_be);
 /* K4  X.mul(Y).  ref: P/mixnet/ShufflerElGamalSession.java:273, 789, 850 (the re-encryption);
  * P/hvzk/PoSBasicTW.java:448, 610, 648, 1029, 1033. */
 int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out);

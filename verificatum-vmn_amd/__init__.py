@@ -450,6 +450,17 @@ class PGroupElementArray(_ArrayBase):
         return bool(ok.value)
 
 
+def expProdMulti(arrays, e: "PRingElementArray", ebits: int = 0) -> list:
+    """``expProd`` of several arrays under one exponent array (a ciphertext array's components): one sort."""
+    grp = arrays[0].group
+    k = len(arrays)
+    hs = (C.c_void_p * k)(*[a._h for a in arrays])
+    out = C.create_string_buffer(k * grp.elem_bytes)
+    _check(lib().vmn_garray_expprod_multi(hs, C.c_size_t(k), e._h, C.c_int(ebits), out))
+    eb = grp.elem_bytes
+    return [grp.dec_el(out.raw[i * eb:(i + 1) * eb]) for i in range(k)]
+
+
 class PRingElementArray(_ArrayBase):
     """Device-resident ``PRingElementArray`` / ``PFieldElementArray`` over Z_q."""
 

@@ -1802,18 +1802,25 @@ static int pick_bucket_bits(size_t n, int ebits) {
 }
 
 // prod_i x[i]^e[i] with packed-word exponents on the device -> big-endian element on the host
-static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_words, int ewords, int ebits, size_t n,
-                         uint8_t* out_be) {
+// k arrays with the SAME exponents (the 2*width components of a ciphertext array, or u / h / w' under one
+// batching vector): the counting sort of the exponent digits and the shape of the product trees are computed
+// once and reused for every array; out_be receives k elements.
+static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, const uint32_t* e_words, int ewords,
+                         int ebits, size_t n, uint8_t* out_be) {
     vmn_ctx* ctx = g->ctx;
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
+    const size_t ebytes_out = m.ec ? 2 * g->nbytes : g->nbytes;
     if (n == 0) {
-        if (m.ec) {
-            memset(out_be, 0xff, 2 * g->nbytes);      // the identity: point at infinity
-        } else {
-            Big one(m.NW, 0);
-            one[0] = 1;
-            hostbig::to_be(one, out_be, g->nbytes);
+        for (size_t a = 0; a < k; ++a) {
+            uint8_t* o = out_be + a * ebytes_out;
+            if (m.ec) {
+                memset(o, 0xff, ebytes_out);          // the identity: point at infinity
+            } else {
+                Big one(m.NW, 0);
+                one[0] = 1;
+                hostbig::to_be(one, o, g->nbytes);
+            }
         }
         return VMN_OK;
     }
@@ -1855,6 +1862,10 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
                          e_words, ewords, n, c, nwin));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
     // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item
+    std::vector<std::pair<uint32_t, uint32_t>> level_cache;      // (total items, max per bucket) per level, from the first array
+    for (size_t arr = 0; arr < k; ++arr) {
+    const uint32_t* x = xs[arr];
+    uint8_t* out_one = out_be + arr * ebytes_out;
     const uint32_t* cnt_in = counts;
     const uint32_t* off_in = off0;
     uint32_t* cnt_out = cntA;
@@ -1862,17 +1873,23 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
     const uint32_t* items_in = x;
     bool first = true;
     size_t cap = (size_t)nwin * n / F + nbuckets + 1;        // items of level 1 (later levels are smaller)
-    VMN_TRY(itemsA.alloc(cap * Wd * sizeof(uint32_t)));
+    if (!itemsA.p) VMN_TRY(itemsA.alloc(cap * Wd * sizeof(uint32_t)));
     uint32_t* items_out = itemsA.as<uint32_t>();
-    uint32_t* items_other = nullptr;
+    uint32_t* items_other = itemsB.p ? itemsB.as<uint32_t>() : nullptr;
     int rc = VMN_ERR_ARG;
     for (int level = 0; level < 64; ++level) {
         VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
         VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_out, cnt_in, nbuckets, F, misc + 1));
         VMN_TRY(scan_u32(off_out, (uint32_t*)nullptr, cnt_out));
         uint32_t hm2[2];
-        VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        VMN_HIP(hipStreamSynchronize(ctx->stream));
+        if ((size_t)level < level_cache.size()) {            // same exponents => same tree shape: no readback
+            hm2[0] = level_cache[level].first;
+            hm2[1] = level_cache[level].second;
+        } else {
+            VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            VMN_HIP(hipStreamSynchronize(ctx->stream));
+            level_cache.emplace_back(hm2[0], hm2[1]);
+        }
         const size_t total_out = hm2[0];
         if (total_out > 0 && m.ec) {
             rc = VMN_ERR_ARG;
@@ -1939,7 +1956,8 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
         VMN_FOR_CURVES(X)
 #undef X
         VMN_TRY(rc);
-        return export_be(ctx, m, g->nbytes, res.as<uint32_t>(), 1, out_be);
+        VMN_TRY(export_be(ctx, m, g->nbytes, res.as<uint32_t>(), 1, out_one));
+        continue;
     }
     const hostbig::Mont& hm = *m.hm;
     // Horner over the windows on the host: nwin elements, c squarings each (O(ebits) modmuls)
@@ -1951,7 +1969,8 @@ static int expprod_words(vmn_group* g, const uint32_t* x, const uint32_t* e_word
         Big ww = hm.to_mont(hostbig::from_be(wbe.data() + (size_t)w * g->nbytes, g->nbytes, m.NW));
         hm.mul(acc, acc, ww);
     }
-    hostbig::to_be(hm.from_mont(acc), out_be, g->nbytes);
+    hostbig::to_be(hm.from_mont(acc), out_one, g->nbytes);
+    }
     return VMN_OK;
 }
 
@@ -1965,7 +1984,8 @@ extern "C" int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int 
     DevTmp ew(ctx);
     VMN_TRY(ew.alloc(std::max<size_t>(x->n, 1) * (size_t)g->Q.NW * sizeof(uint32_t)));
     VMN_TRY(to_words(ctx, g->Q, e->d, e->n, ew.as<uint32_t>()));
-    return expprod_words(g, x->d, ew.as<uint32_t>(), g->Q.NW, ebits, x->n, out_be);
+    const uint32_t* xs[1] = {x->d};
+    return expprod_words(g, xs, 1, ew.as<uint32_t>(), g->Q.NW, ebits, x->n, out_be);
 }
 extern "C" int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, uint8_t* out_be) {
     ARG_CHECK(x && out_be && (exps_be || x->n == 0) && ebytes > 0, "null argument");
@@ -1979,7 +1999,23 @@ extern "C" int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_
     DevTmp ew(ctx);
     VMN_TRY(ew.alloc(std::max<size_t>(hw.size(), 1) * sizeof(uint32_t)));
     VMN_TRY(h2d(ctx, ew.p, hw.data(), hw.size() * sizeof(uint32_t)));
-    return expprod_words(g, x->d, ew.as<uint32_t>(), ewords, ebits, x->n, out_be);
+    const uint32_t* xs[1] = {x->d};
+    return expprod_words(g, xs, 1, ew.as<uint32_t>(), ewords, ebits, x->n, out_be);
+}
+
+extern "C" int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, const vmn_rarray* e, int ebits, uint8_t* out_be) {
+    ARG_CHECK(xs && k > 0 && e && out_be, "null argument");
+    vmn_group* g = e->grp;
+    for (size_t a = 0; a < k; ++a) ARG_CHECK(xs[a] && xs[a]->grp == g && xs[a]->n == e->n, "arrays differ in group or size");
+    vmn_ctx* ctx = g->ctx;
+    VMN_HIP(hipSetDevice(ctx->device));
+    if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
+    DevTmp ew(ctx);
+    VMN_TRY(ew.alloc(std::max<size_t>(e->n, 1) * (size_t)g->Q.NW * sizeof(uint32_t)));
+    VMN_TRY(to_words(ctx, g->Q, e->d, e->n, ew.as<uint32_t>()));
+    std::vector<const uint32_t*> ptrs(k);
+    for (size_t a = 0; a < k; ++a) ptrs[a] = xs[a]->d;
+    return expprod_words(g, ptrs.data(), k, ew.as<uint32_t>(), g->Q.NW, ebits, e->n, out_be);
 }
 
 // ---- membership, partials ----------------------------------------------------------------------------

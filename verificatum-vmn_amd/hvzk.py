@@ -30,6 +30,7 @@ key the matching list of scalars ``[g..g, y..y]`` (ProtocolElGamal.java:785-800)
 """
 from __future__ import annotations
 
+import sys
 from typing import List, Optional, Sequence
 
 
@@ -82,7 +83,11 @@ class _Base:
         eps = self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)
         return self.G.ringArray(eps if _is_bytes(eps) else [x % self.q for x in eps])
 
-    def _ciph_expprod(self, w, E, ebits) -> List[int]:
+    def _ciph_expprod(self, w, E, ebits) -> list:
+        """``w.expProd(E)`` of a ciphertext array = one multi-exponentiation per component, exponents sorted once."""
+        multi = getattr(sys.modules.get("verificatum_vmn_amd"), "expProdMulti", None)
+        if multi is not None and hasattr(w[0], "_h"):
+            return multi(list(w), E, ebits)
         return [c.expProd(E, ebits) for c in w]
 
 
@@ -180,8 +185,8 @@ class PoSBasicTW(_Base):
     # ---- verifier -----------------------------------------------------------------------------
     def computeAF(self):
         """:407-410."""
-        self.A = self.u.expProd(self.e, self.e_bits)
-        self.F = self._ciph_expprod(self.w, self.e, self.e_bits)
+        res = self._ciph_expprod([self.u] + list(self.w), self.e, self.e_bits)      # one sort of e for u and w
+        self.A, self.F = res[0], res[1:]
 
     def setCommitment(self, msg):
         """:780-823 (parsing is out of scope; the parsed objects are handed over)."""
@@ -195,7 +200,8 @@ class PoSBasicTW(_Base):
         h0 = h.get(0)
         C = self._div(self.u.prod(), h.prod())
         D = self._div(self.B.get(self.size - 1), self._gexp(h0, self.e.prod()))
-        verdictA = self._expmul(self.A, v, self.Ap) == G.k_mul(self._gexp(g, k_A), h.expProd(k_E, self.kE_bits))
+        kE_prods = self._ciph_expprod([h] + list(self.wp), k_E, self.kE_bits)         # one sort of k_E for h and w'
+        verdictA = self._expmul(self.A, v, self.Ap) == G.k_mul(self._gexp(g, k_A), kE_prods[0])
         B_exp_v = self.B.exp(v)
         leftSide = B_exp_v.mul(self.Bp)
         g_exp_k_B = G.exp(g, k_B)
@@ -207,7 +213,7 @@ class PoSBasicTW(_Base):
             t.free()
         verdictC = self._expmul(C, v, self.Cp) == self._gexp(g, k_C)
         verdictD = self._expmul(D, v, self.Dp) == self._gexp(g, k_D)
-        prods = self._ciph_expprod(self.wp, k_E, self.kE_bits)
+        prods = kE_prods[1:]
         width = len(self.pkey) // 2
         verdictF = all(self._expmul(Fc, v, Fpc) == G.k_mul(self._gexp(pk, -k_F[c % width]), t)
                        for c, (Fc, Fpc, pk, t) in enumerate(zip(self.F, self.Fp, self.pkey, prods)))
@@ -325,10 +331,11 @@ class CCPoSBasicW(_Base):
         self.ipe = self.e.permute(_inv_perm(self.pi))
         self.alpha = self.rand.ring_element()
         self.epsilon = self._eps_array()
-        self.Ap = G.k_mul(self._gexp(g, self.alpha), h.expProd(self.epsilon, self.eps_bits))
+        eps_prods = self._ciph_expprod([h] + list(self.wp), self.epsilon, self.eps_bits)   # one sort of epsilon
+        self.Ap = G.k_mul(self._gexp(g, self.alpha), eps_prods[0])
         width = len(self.pkey) // 2
         self.beta = [self.rand.ring_element() for _ in range(width)]
-        prods = self._ciph_expprod(self.wp, self.epsilon, self.eps_bits)
+        prods = eps_prods[1:]
         self.Bp = [G.k_mul(self._gexp(pk, -self.beta[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, prods))]
         return {"Ap": self.Ap, "Bp": self.Bp}
 
@@ -352,8 +359,8 @@ class CCPoSBasicW(_Base):
     def computeAB(self, raisedu=None):
         """:493-506.  raisedu = u^rho selects the single-equation ("raised") form."""
         if raisedu is None:
-            self.A = self.u.expProd(self.e, self.e_bits)
-            self.B = self._ciph_expprod(self.w, self.e, self.e_bits)
+            res = self._ciph_expprod([self.u] + list(self.w), self.e, self.e_bits)
+            self.A, self.B = res[0], res[1:]
         else:
             self.AB = []
             for c in self.w:                       # w.mul(raisedu): the base-group array multiplies every component
@@ -366,9 +373,10 @@ class CCPoSBasicW(_Base):
         g, h, p, v = self.g, self.h, self.p, self.v
         k_A, k_B, k_E = reply["k_A"], reply["k_B"], reply["k_E"]
         if raisedExponent is None:
-            if self._expmul(self.A, v, self.Ap) != self.G.k_mul(self._gexp(g, k_A), h.expProd(k_E, self.kE_bits)):
+            kE_prods = self._ciph_expprod([h] + list(self.wp), k_E, self.kE_bits)
+            if self._expmul(self.A, v, self.Ap) != self.G.k_mul(self._gexp(g, k_A), kE_prods[0]):
                 return False
-            prods = self._ciph_expprod(self.wp, k_E, self.kE_bits)
+            prods = kE_prods[1:]
             width = len(self.pkey) // 2
             return all(self._expmul(Bc, v, Bpc) == self.G.k_mul(self._gexp(pk, -k_B[c % width]), t)
                        for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, prods)))

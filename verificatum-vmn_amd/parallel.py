@@ -22,6 +22,7 @@ CPU test suite runs it on two gloo ranks with an integer-backed stand-in for the
 """
 from __future__ import annotations
 
+import sys
 from typing import List, Optional, Sequence
 
 
