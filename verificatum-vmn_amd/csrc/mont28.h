@@ -83,21 +83,23 @@ __device__ __forceinline__ void mont_mul_columns(u64 (&T)[S], const u32 (&a)[S],
 // of a (the row's own limb needs a dynamic index).
 template <int S, int J0>
 __device__ __forceinline__ void mont_sqr_blocks(u64 (&T)[S], const u32 (&a)[S], const u32* a_lds, int bstride,
-                                                const u32 (&n)[S], u32 n0inv) {
+                                                const u32 (&n)[S], u32 n0inv, u32& bn) {
     constexpr int END = J0 + SQR_BLK < S ? J0 + SQR_BLK : S;
 #pragma unroll 1
     for (int i = (J0 == 0 ? 1 : J0); i < END; ++i) {
-        u32 bi = a_lds[i * bstride];
+        u32 bi = bn;
+        bn = a_lds[(i + 1 < S ? i + 1 : 0) * bstride];            // prefetch the next row's limb under this row
         mont_sqr_row_asm<S, J0>(T, a, bi, bi << 1, n, n0inv);
     }
-    if constexpr (END < S) mont_sqr_blocks<S, END>(T, a, a_lds, bstride, n, n0inv);
+    if constexpr (END < S) mont_sqr_blocks<S, END>(T, a, a_lds, bstride, n, n0inv, bn);
 }
 template <int S>
 __device__ __forceinline__ void mont_sqr_columns(u64 (&T)[S], const u32 (&a)[S], const u32* a_lds, int bstride,
                                                  const u32 (&n)[S], u32 n0inv) {
     u32 b0 = a_lds[0];
+    u32 bn = a_lds[bstride];
     mont_sqr_row_asm_first<S>(T, a, b0, b0 << 1, n, n0inv);
-    mont_sqr_blocks<S, 0>(T, a, a_lds, bstride, n, n0inv);
+    mont_sqr_blocks<S, 0>(T, a, a_lds, bstride, n, n0inv, bn);
     T[S - 1] = 0;
 }
 
