@@ -216,3 +216,58 @@ def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(vmn, gpu_ctx, ent
     bad = dict(cr)
     bad["k_A"] = (cr["k_A"] + 1) % c.n
     assert not cv.verify(bad)
+
+
+def test_threshold_decryption_over_p256(vmn, gpu_ctx, entry):
+    """Row A6 over the curve group: factors, Lagrange combination (negative integers = point negation), plaintext
+    recovery and the batched proofs."""
+    import importlib.util, os, sys
+    from tape import Tape
+    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.elgamal", os.path.join(entry.PKG_DIR, "elgamal.py"))
+    eg = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = eg
+    spec.loader.exec_module(eg)
+    c = Curve("P-256")
+    G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    q, g = c.n, c.g
+    n, k, thr = 50, 5, 3
+    t = Tape(b"ecdec", q)
+    coeffs = t.ring_array(thr)
+    share = lambda j: sum(cf * pow(j, d, q) for d, cf in enumerate(coeffs)) % q
+    xs = [None] + [share(j) for j in range(1, k + 1)]
+    ys = [None] + [c.mul(xj, g) for xj in xs[1:]]
+    y = c.mul(coeffs[0], g)
+    msgs = [c.mul(m, g) for m in t.ring_array(n)]
+    rs = t.ring_array(n)
+    u = c.exp_fixed(g, rs)
+    v = c.mul_arrays(msgs, c.exp_fixed(y, rs))
+    correct = [False, True, False, True, True, True]
+    U, V = G.toElementArray(u), G.toElementArray(v)
+    F = [None] + [eg.decryptionFactors(U, xs[j], q, k) for j in range(1, k + 1)]
+    inv_c = pow(eg.prodFactor(q, k), -1, q)
+    for j in range(1, k + 1):
+        assert F[j].toInts() == [c.mul((-xs[j]) * inv_c % q, P) for P in u]
+    assert any(ci < 0 for ci in eg.modifiedLagrangeCoefficients(q, correct, k, thr))
+    comb = eg.combineDecryptionFactors(F, correct, k, thr, q)
+    assert eg.plaintexts(V, comb).toInts() == msgs
+    e = t.int_array(n, 100)
+    chal = t.int_array(1, 100)[0]
+    ver = eg.DistrElGamalSessionBasic(G, 1, k, thr, 100)
+    ver.setInstance(U, ys, F)
+    ver.setBatchVector(e)
+    ver.batchInput()
+    for j in range(1, k + 1):
+        pr = eg.DistrElGamalSessionBasic(G, j, k, thr, 100, rand=Tape(b"p%d" % j, q))
+        pr.setInstance(U, ys, F)
+        pr.setBatchVector(e)
+        pr.batchInput()
+        ver.setCommitment(j, *pr.commit(xs[j]))
+        ver.setReply(j, pr.reply(chal))
+    for j in range(1, k + 1):
+        ver.batch(j)
+        assert ver.verify(j, chal)
+    ver.combine(correct, y, comb)
+    ver.batchCombined()
+    assert ver.verifyCombined(chal)
+    ver.setReply(3, (ver.k_x[3] + 1) % q)
+    assert not ver.verify(3, chal)

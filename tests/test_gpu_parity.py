@@ -170,3 +170,29 @@ def test_properties_at_scale_2048(groups):
     got = XE.toInts()
     for i in (0, 1, n // 2, n - 1):
         assert got[i] == pow(xs[i], es[i], p)
+
+
+def test_properties_at_full_baseline_size(groups):
+    """BASELINE.json configs[1] size (1 000 000 elements, 2048 bits): the CPU oracle would need hours, so the
+    result is pinned through size-independent properties plus spot checks against Python."""
+    import numpy as np
+    G, grp, _ = groups[2048]
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    n = 1_000_000
+    rng = np.random.Generator(np.random.PCG64(99))
+    def block(clear_top_bits):
+        a = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+        a[:, 0] &= 0xFF >> clear_top_bits
+        return a
+    eb, fb = block(2), block(2)                       # exponents < 2^2046: e + f < q, no wrap
+    E, F = G.ringArray(eb.tobytes()), G.ringArray(fb.tobytes())
+    X = G.exp(g, G.ringArray(block(1).tobytes()))     # random subgroup elements
+    XE, XF = X.exp(E), X.exp(F)
+    assert XE.mul(XF).equals(X.exp(E.add(F)))         # x^e x^f = x^(e+f), element-wise over 10^6 elements
+    Gs = G.toElementArray(int(g).to_bytes(256, "big") * n)
+    assert G.exp(g, E).equals(Gs.exp(E))              # fixed-base table path = variable-base path
+    assert X.expProd(E) == XE.prod()                  # Pippenger = product of the individual powers
+    for i in (0, 1, 499_999, 999_999):
+        x = X.get(i)
+        e = int.from_bytes(eb[i].tobytes(), "big")
+        assert XE.get(i) == pow(x, e, p)

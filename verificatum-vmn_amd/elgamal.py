@@ -107,6 +107,8 @@ class DistrElGamalSessionBasic:
     def __init__(self, group, j: int, k: int, threshold: int, ebitlen: int, rand=None):
         self.G, self.j, self.k, self.threshold, self.ebitlen, self.rand = group, j, k, threshold, ebitlen, rand
         self.p, self.q, self.g = group.p, group.q, group.g
+        # single elements through the group object (ModPGroup integers or ECqPGroup points)
+        self._mul, self._exp, self._inv = group.k_mul, group.k_exp, group.k_inv
         self.inverseFactor = pow(prodFactor(self.q, k), -1, self.q)
         self.yp, self.Bp, self.k_x, self.B = {}, {}, {}, {}
 
@@ -125,8 +127,8 @@ class DistrElGamalSessionBasic:
         """:534-540 (prover j).  x = this party's secret share."""
         self.x = x
         self.r = self.rand.ring_element()
-        self.yp[self.j] = pow(self.g, self.r, self.p)
-        self.Bp[self.j] = pow(self.A, self.r, self.p)
+        self.yp[self.j] = self._exp(self.g, self.r)
+        self.Bp[self.j] = self._exp(self.A, self.r)
         return self.yp[self.j], self.Bp[self.j]
 
     def reply(self, v: int) -> int:
@@ -146,26 +148,26 @@ class DistrElGamalSessionBasic:
 
     def verify(self, l: int, v: int) -> bool:
         """:718-727."""
-        p, q = self.p, self.q
-        lhs1 = pow(pow(self.y[l], -1, p), self.inverseFactor * (v % q) % q, p) * self.yp[l] % p
-        ok1 = lhs1 == pow(self.g, self.k_x[l], p)
-        ok2 = pow(self.B[l], v % q, p) * self.Bp[l] % p == pow(self.A, self.k_x[l], p)
+        q = self.q
+        lhs1 = self._mul(self._exp(self._inv(self.y[l]), self.inverseFactor * (v % q) % q), self.yp[l])
+        ok1 = lhs1 == self._exp(self.g, self.k_x[l])
+        ok2 = self._mul(self._exp(self.B[l], v % q), self.Bp[l]) == self._exp(self.A, self.k_x[l])
         return ok1 and ok2
 
     def combine(self, correct: Sequence[bool], combinedy: int, combinedf):
         """:642-678 plus the inputs of verifyCombined (combined public key and combined factors)."""
-        p, q = self.p, self.q
+        q = self.q
         ints = modifiedLagrangeCoefficients(q, correct, self.k, self.threshold)
         exps = [c % q for c in ints]
-        self.combinedyp = self.combinedBp = 1
+        self.combinedyp = self.combinedBp = self.G.ONE
         self.combinedk_x = 0
         t = 0
         for l in range(1, self.k + 1):
             if t >= self.threshold:
                 break
             if correct[l]:
-                self.combinedyp = self.combinedyp * pow(self.yp[l], exps[t], p) % p
-                self.combinedBp = self.combinedBp * pow(self.Bp[l], exps[t], p) % p
+                self.combinedyp = self._mul(self.combinedyp, self._exp(self.yp[l], exps[t]))
+                self.combinedBp = self._mul(self.combinedBp, self._exp(self.Bp[l], exps[t]))
                 self.combinedk_x = (self.combinedk_x + self.k_x[l] * exps[t]) % q
                 t += 1
         self.combinedy, self.combinedf = combinedy, combinedf
@@ -175,7 +177,7 @@ class DistrElGamalSessionBasic:
 
     def verifyCombined(self, v: int) -> bool:
         """:693-700."""
-        p, q = self.p, self.q
-        ok1 = pow(pow(self.combinedy, -1, p), v % q, p) * self.combinedyp % p == pow(self.g, self.combinedk_x, p)
-        ok2 = pow(self.combinedB, v % q, p) * self.combinedBp % p == pow(self.A, self.combinedk_x, p)
+        q = self.q
+        ok1 = self._mul(self._exp(self._inv(self.combinedy), v % q), self.combinedyp) == self._exp(self.g, self.combinedk_x)
+        ok2 = self._mul(self._exp(self.combinedB, v % q), self.combinedBp) == self._exp(self.A, self.combinedk_x)
         return ok1 and ok2
