@@ -196,3 +196,42 @@ def test_properties_at_full_baseline_size(groups):
         x = X.get(i)
         e = int.from_bytes(eb[i].tobytes(), "big")
         assert XE.get(i) == pow(x, e, p)
+
+
+def test_helper_thread_runs_concurrently_with_main_thread(groups):
+    """The reference's one concurrency pattern (ShufflerElGamalSession.java:839-859): a helper thread does
+    mul + permute on arrays while the protocol thread runs a verification.  ctypes drops the GIL during the
+    foreign calls, so the two threads really enter the library together; results must equal the sequential ones."""
+    import threading
+    G, grp, _ = groups[2048]
+    p, q = grp["p"], grp["q"]
+    n = 3000
+    xs, es = _inputs(b"thr", n, p, q)
+    ys, _ = _inputs(b"thr2", n, p, q)
+    perm = sorted(range(n), key=lambda i: (xs[i], i))
+    X, Y, E = G.toElementArray(xs), G.toElementArray(ys), G.ringArray(es)
+    want_main = [pyref.exp_prod(xs, es, p), pyref.exp_prod(ys, es, p)]
+    prod_xy = [a * b % p for a, b in zip(xs, ys)]
+    want_helper = pyref.permute(prod_xy, perm)
+    got_helper, errors = [], []
+
+    def helper():
+        try:
+            for _ in range(12):
+                t = X.mul(Y)
+                r = t.permute(perm)
+                t.free()
+                got_helper.append(r.toInts())
+                r.free()
+        except Exception as exc:      # pragma: no cover
+            errors.append(exc)
+
+    th = threading.Thread(target=helper)
+    th.start()
+    got_main = []
+    for _ in range(6):
+        got_main.append([X.expProd(E), Y.expProd(E)])
+    th.join()
+    assert not errors
+    assert all(g == want_main for g in got_main)
+    assert len(got_helper) == 12 and all(g == want_helper for g in got_helper)

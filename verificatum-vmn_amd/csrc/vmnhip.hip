@@ -256,6 +256,7 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
 
 extern "C" int vmn_ctx_set_stream(vmn_ctx* ctx, void* hip_stream) {
     ARG_CHECK(ctx, "null ctx");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return VMN_OK;
@@ -263,6 +264,7 @@ extern "C" int vmn_ctx_set_stream(vmn_ctx* ctx, void* hip_stream) {
 extern "C" void* vmn_ctx_get_stream(vmn_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 extern "C" int vmn_ctx_synchronize(vmn_ctx* ctx) {
     ARG_CHECK(ctx, "null ctx");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_HIP(hipStreamSynchronize(ctx->stream));
     return VMN_OK;
 }
@@ -285,18 +287,21 @@ static int timing_collect(vmn_ctx* ctx) {
 }
 extern "C" int vmn_ctx_timing_enable(vmn_ctx* ctx, int on) {
     ARG_CHECK(ctx, "null ctx");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_TRY(timing_collect(ctx));
     ctx->timing = on != 0;
     return VMN_OK;
 }
 extern "C" int vmn_ctx_timing_reset(vmn_ctx* ctx) {
     ARG_CHECK(ctx, "null ctx");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_TRY(timing_collect(ctx));
     ctx->timing_acc.clear();
     return VMN_OK;
 }
 extern "C" int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launches, double* total_ms) {
     ARG_CHECK(ctx && family, "null argument");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_TRY(timing_collect(ctx));
     auto it = ctx->timing_acc.find(family);
     if (launches) *launches = it == ctx->timing_acc.end() ? 0 : it->second.first;
@@ -306,6 +311,7 @@ extern "C" int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launch
 
 extern "C" int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len) {
     ARG_CHECK(ctx && buf && len > 0, "null argument");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_TRY(timing_collect(ctx));
     std::string out;
     for (auto& kv : ctx->timing_acc) {
@@ -394,7 +400,7 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
 extern "C" int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const uint8_t* q_be, const uint8_t* g_be,
                                      size_t nbytes, vmn_group** out) {
     ARG_CHECK(ctx && p_be && q_be && g_be && out && nbytes > 0, "null argument");
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     Big pw = hostbig::from_be(p_be, nbytes, (nbytes + 3) / 4);
     int nbits = hostbig::bit_length(pw);
     int S, NW, LPE;
@@ -419,6 +425,7 @@ extern "C" int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const ui
 
 extern "C" void vmn_group_destroy(vmn_group* grp) {
     if (!grp) return;
+    std::lock_guard<std::recursive_mutex> guard__(grp->ctx->mu);
     (void)hipStreamSynchronize(grp->ctx->stream);
     for (auto& kv : grp->fixed) {
         if (kv.second.d_tab) (void)hipFree(kv.second.d_tab);
@@ -570,7 +577,7 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
 
 extern "C" int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_group** out) {
     ARG_CHECK(ctx && curve_name && out, "null argument");
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     const CurveParams* cp = nullptr;
     for (auto& k : kCurves) {
         if (strcmp(k.name, curve_name) == 0) cp = &k;
@@ -870,11 +877,13 @@ static int new_rarray(vmn_group* grp, size_t n, vmn_rarray** out) {
 
 extern "C" void vmn_garray_free(vmn_garray* a) {
     if (!a) return;
+    std::lock_guard<std::recursive_mutex> guard__(a->grp->ctx->mu);
     pool_free(a->grp->ctx, a->d, a->bytes);
     delete a;
 }
 extern "C" void vmn_rarray_free(vmn_rarray* a) {
     if (!a) return;
+    std::lock_guard<std::recursive_mutex> guard__(a->grp->ctx->mu);
     pool_free(a->grp->ctx, a->d, a->bytes);
     delete a;
 }
@@ -883,7 +892,7 @@ extern "C" size_t vmn_rarray_size(const vmn_rarray* a) { return a ? a->n : 0; }
 
 extern "C" int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_garray** out, int* all_in_range) {
     ARG_CHECK(grp && out && (be || n == 0), "null argument");
-    VMN_HIP(hipSetDevice(grp->ctx->device));
+    VMN_ENTER(grp->ctx);
     vmn_garray* a = nullptr;
     VMN_TRY(new_garray(grp, n, &a));
     int rc = import_be(grp->ctx, grp->P, grp->nbytes, be, n, a->d, all_in_range);
@@ -896,7 +905,7 @@ extern "C" int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, v
 }
 extern "C" int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_rarray** out, int* all_in_range) {
     ARG_CHECK(grp && out && (be || n == 0), "null argument");
-    VMN_HIP(hipSetDevice(grp->ctx->device));
+    VMN_ENTER(grp->ctx);
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
     int rc = import_be(grp->ctx, grp->Q, grp->nbytes, be, n, a->d, all_in_range);
@@ -911,18 +920,18 @@ extern "C" size_t vmn_garray_bytetree_size(const vmn_garray* a) { return a ? byt
 extern "C" size_t vmn_rarray_bytetree_size(const vmn_rarray* a) { return a ? bytetree_size(a->n, a->grp->nbytes) : 0; }
 extern "C" int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
-    VMN_HIP(hipSetDevice(a->grp->ctx->device));
+    VMN_ENTER(a->grp->ctx);
     return to_bytetree(a->grp->ctx, a->grp->P, a->grp->nbytes, a->d, a->n, out);
 }
 extern "C" int vmn_rarray_to_bytetree(const vmn_rarray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
-    VMN_HIP(hipSetDevice(a->grp->ctx->device));
+    VMN_ENTER(a->grp->ctx);
     return to_bytetree(a->grp->ctx, a->grp->Q, a->grp->nbytes, a->d, a->n, out);
 }
 extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_garray** out,
                                         int* format_ok, int* all_in_range) {
     ARG_CHECK(grp && bt && out && format_ok, "null argument");
-    VMN_HIP(hipSetDevice(grp->ctx->device));
+    VMN_ENTER(grp->ctx);
     *out = nullptr;
     size_t n = 0;
     VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
@@ -940,7 +949,7 @@ extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_
 extern "C" int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_rarray** out,
                                         int* format_ok, int* all_in_range) {
     ARG_CHECK(grp && bt && out && format_ok, "null argument");
-    VMN_HIP(hipSetDevice(grp->ctx->device));
+    VMN_ENTER(grp->ctx);
     *out = nullptr;
     size_t n = 0;
     VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
@@ -957,12 +966,12 @@ extern "C" int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_
 }
 extern "C" int vmn_garray_to_be(const vmn_garray* a, uint8_t* be_out) {
     ARG_CHECK(a && (be_out || a->n == 0), "null argument");
-    VMN_HIP(hipSetDevice(a->grp->ctx->device));
+    VMN_ENTER(a->grp->ctx);
     return export_be(a->grp->ctx, a->grp->P, a->grp->nbytes, a->d, a->n, be_out);
 }
 extern "C" int vmn_rarray_to_be(const vmn_rarray* a, uint8_t* be_out) {
     ARG_CHECK(a && (be_out || a->n == 0), "null argument");
-    VMN_HIP(hipSetDevice(a->grp->ctx->device));
+    VMN_ENTER(a->grp->ctx);
     return export_be(a->grp->ctx, a->grp->Q, a->grp->nbytes, a->d, a->n, be_out);
 }
 
@@ -970,7 +979,7 @@ extern "C" int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garr
     ARG_CHECK(x && y && out, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(g, x->n, &r));
     int rc = mul_arrays(g->ctx, g->P, x->d, y->d, elem_words(g->P), x->n, r->d);
@@ -987,7 +996,7 @@ extern "C" int vmn_garray_exp_array(const vmn_garray* x, const vmn_rarray* e, in
     ARG_CHECK(x->grp == e->grp && x->n == e->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(g, x->n, &r));
@@ -1007,7 +1016,7 @@ extern "C" int vmn_garray_exp_ints(const vmn_garray* x, const uint8_t* exps_be, 
     ARG_CHECK(x && out && (exps_be || x->n == 0) && ebytes > 0, "null argument");
     vmn_group* g = x->grp;
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     if (ebits <= 0 || (size_t)ebits > 8 * ebytes) ebits = (int)(8 * ebytes);
     int ewords = (ebits + 31) / 32;
     std::vector<uint32_t> hw;
@@ -1037,7 +1046,7 @@ extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, s
     ARG_CHECK(x && e_be && out && ebytes > 0, "null argument");
     vmn_group* g = x->grp;
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     int ewords = (int)((ebytes + 3) / 4);
     Big e = hostbig::from_be(e_be, ebytes, ewords);
     int ebits = std::max(1, hostbig::bit_length(e));
@@ -1091,7 +1100,7 @@ static int compare_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x,
 extern "C" int vmn_garray_equals(const vmn_garray* x, const vmn_garray* y, int* equal) {
     ARG_CHECK(x && y && equal, "null argument");
     ARG_CHECK(x->grp == y->grp, "arrays differ in group");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     if (x->n != y->n) {
         *equal = 0;
         return VMN_OK;
@@ -1101,7 +1110,7 @@ extern "C" int vmn_garray_equals(const vmn_garray* x, const vmn_garray* y, int* 
 extern "C" int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal) {
     ARG_CHECK(x && y && equal, "null argument");
     ARG_CHECK(x->grp == y->grp, "arrays differ in group");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     if (x->n != y->n) {
         *equal = 0;
         return VMN_OK;
@@ -1140,14 +1149,14 @@ static int arr_gather(const Arr* x, const vmn_modulus& m, const std::vector<uint
 
 extern "C" int vmn_garray_gather(const vmn_garray* x, const uint32_t* idx_host, size_t n_out, vmn_garray** out) {
     ARG_CHECK(x && out && (idx_host || n_out == 0), "null argument");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     std::vector<uint32_t> idx(idx_host, idx_host + n_out);
     for (uint32_t v : idx) ARG_CHECK(v < x->n, "gather index out of range");
     return arr_gather<vmn_garray>(x, x->grp->P, idx, nullptr, new_garray, vmn_garray_free, out);
 }
 extern "C" int vmn_rarray_gather(const vmn_rarray* x, const uint32_t* idx_host, size_t n_out, vmn_rarray** out) {
     ARG_CHECK(x && out && (idx_host || n_out == 0), "null argument");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     std::vector<uint32_t> idx(idx_host, idx_host + n_out);
     for (uint32_t v : idx) ARG_CHECK(v < x->n, "gather index out of range");
     return arr_gather<vmn_rarray>(x, x->grp->Q, idx, nullptr, new_rarray, vmn_rarray_free, out);
@@ -1163,7 +1172,7 @@ extern "C" int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host
 extern "C" int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, vmn_garray** out) {
     ARG_CHECK(x && el_be && out, "null argument");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     uint32_t* d_el = nullptr;
     VMN_TRY(import_one(g->ctx, g->P, g->nbytes, el_be, &d_el));
     std::vector<uint32_t> idx(x->n);
@@ -1175,7 +1184,7 @@ extern "C" int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, 
 extern "C" int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out) {
     ARG_CHECK(x && el_be && out, "null argument");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     uint32_t* d_el = nullptr;
     VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, el_be, &d_el));
     std::vector<uint32_t> idx(x->n);
@@ -1188,7 +1197,7 @@ extern "C" int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to
     ARG_CHECK(x && out, "null argument");
     ARG_CHECK(from <= to && to <= x->n, "range out of bounds");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(g, to - from, &r));
     if (to > from) {
@@ -1205,7 +1214,7 @@ extern "C" int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to
 }
 extern "C" int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host, vmn_garray** out) {
     ARG_CHECK(x && out && (keep_host || x->n == 0), "null argument");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     std::vector<uint32_t> idx;
     for (size_t i = 0; i < x->n; ++i) {
         if (keep_host[i]) idx.push_back((uint32_t)i);
@@ -1215,21 +1224,21 @@ extern "C" int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host,
 extern "C" int vmn_garray_get(const vmn_garray* x, size_t i, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     ARG_CHECK(i < x->n, "index out of range");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     return export_be(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d + i * elem_words(x->grp->P), 1, out_be);
 }
 
 extern "C" int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     ARG_CHECK(i < x->n, "index out of range");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     return export_be(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d + i * elem_words(x->grp->Q), 1, out_be);
 }
 extern "C" int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out) {
     ARG_CHECK(x && out, "null argument");
     ARG_CHECK(from <= to && to <= x->n, "range out of bounds");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, to - from, &r));
     if (to > from) {
@@ -1309,24 +1318,24 @@ static int reduce_to_host(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, con
 
 extern "C" int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     return reduce_to_host(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d, x->n, true, out_be);
 }
 extern "C" int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d, x->n, true, out_be);
 }
 extern "C" int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
-    VMN_HIP(hipSetDevice(x->grp->ctx->device));
+    VMN_ENTER(x->grp->ctx);
     return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d, x->n, false, out_be);
 }
 extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* out_be) {
     ARG_CHECK(x && y && out_be, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     DevTmp prod(g->ctx);
     VMN_TRY(prod.alloc(std::max<size_t>(x->n, 1) * elem_words(g->Q) * sizeof(uint32_t)));
     VMN_TRY(mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, prod.as<uint32_t>()));
@@ -1349,7 +1358,7 @@ extern "C" int vmn_rarray_mul(const vmn_rarray* x, const vmn_rarray* y, vmn_rarr
     ARG_CHECK(x && y && out, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, x->n, &r));
     int rc = mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, r->d);
@@ -1364,7 +1373,7 @@ extern "C" int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarr
     ARG_CHECK(x && y && out, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, x->n, &r));
     int rc = ring_elementwise(g->ctx, g->Q, x->d, y->d, nullptr, 0, x->n, r->d);
@@ -1378,7 +1387,7 @@ extern "C" int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarr
 extern "C" int vmn_rarray_neg(const vmn_rarray* x, vmn_rarray** out) {
     ARG_CHECK(x && out, "null argument");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, x->n, &r));
     int rc = ring_elementwise(g->ctx, g->Q, x->d, nullptr, nullptr, 1, x->n, r->d);
@@ -1393,7 +1402,7 @@ extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, cons
     ARG_CHECK(x && v_be && out, "null argument");
     ARG_CHECK(!y || (x->grp == y->grp && x->n == y->n), "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     uint32_t* d_v = nullptr;
     VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, v_be, &d_v));
     vmn_rarray* r = nullptr;
@@ -1507,7 +1516,7 @@ extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_
     ARG_CHECK(b && e && out_x, "null argument");
     ARG_CHECK(b->grp == e->grp && b->n == e->n, "arrays differ in group or size");
     vmn_group* g = b->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, b->n, &r));
     int rc = scan_affine(g->ctx, g->Q, e->d, b->d, b->n, b->n, 0, r->d);
@@ -1525,7 +1534,7 @@ extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_
 extern "C" int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out) {
     ARG_CHECK(e && out, "null argument");
     vmn_group* g = e->grp;
-    VMN_HIP(hipSetDevice(g->ctx->device));
+    VMN_ENTER(g->ctx);
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, e->n, &r));
     int rc = scan_affine(g->ctx, g->Q, e->d, nullptr, e->n, e->n, 0, r->d);
@@ -1545,7 +1554,7 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     const size_t n = x->n;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(g, n, &r));
     if (n == 0) {
@@ -1744,7 +1753,7 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
     ARG_CHECK(grp && base_be && e && out, "null argument");
     ARG_CHECK(e->grp == grp, "exponent array belongs to another group");
     vmn_ctx* ctx = grp->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     const size_t n = e->n;
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(grp, n, &r));
@@ -1979,7 +1988,7 @@ extern "C" int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int 
     ARG_CHECK(x->grp == e->grp && x->n == e->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
     DevTmp ew(ctx);
     VMN_TRY(ew.alloc(std::max<size_t>(x->n, 1) * (size_t)g->Q.NW * sizeof(uint32_t)));
@@ -1991,7 +2000,7 @@ extern "C" int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_
     ARG_CHECK(x && out_be && (exps_be || x->n == 0) && ebytes > 0, "null argument");
     vmn_group* g = x->grp;
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     if (ebits <= 0 || (size_t)ebits > 8 * ebytes) ebits = (int)(8 * ebytes);
     int ewords = (ebits + 31) / 32;
     std::vector<uint32_t> hw;
@@ -2008,7 +2017,7 @@ extern "C" int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, c
     vmn_group* g = e->grp;
     for (size_t a = 0; a < k; ++a) ARG_CHECK(xs[a] && xs[a]->grp == g && xs[a]->n == e->n, "arrays differ in group or size");
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
     DevTmp ew(ctx);
     VMN_TRY(ew.alloc(std::max<size_t>(e->n, 1) * (size_t)g->Q.NW * sizeof(uint32_t)));
@@ -2023,7 +2032,7 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     ARG_CHECK(x && all_members, "null argument");
     vmn_group* g = x->grp;
     vmn_ctx* ctx = g->ctx;
-    VMN_HIP(hipSetDevice(ctx->device));
+    VMN_ENTER(ctx);
     *all_members = 1;
     if (x->n == 0) return VMN_OK;
     if (g->P.ec) return VMN_OK;      // prime-order curve: every point that passed the import's curve check is a member

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -25,6 +26,13 @@ void set_error(const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// Entry-point prologue: calls of all threads on one context are serialised (the reference's protocol thread and
+// its one helper thread, ShufflerElGamalSession.java:839-859, may call concurrently on distinct arrays); the
+// mutex is recursive because entry points compose (permute -> gather, mul_partials -> from_be / prod).
+#define VMN_ENTER(c)                                                \
+    std::lock_guard<std::recursive_mutex> guard__((c)->mu);         \
+    VMN_HIP(hipSetDevice((c)->device))
+
 #define VMN_TRY(expr)                 \
     do {                              \
         int rc__ = (expr);            \
@@ -39,6 +47,7 @@ struct TimingRec {
 }  // namespace vmn
 
 struct vmn_ctx {
+    std::recursive_mutex mu;              // serialises entry points (pool, scratch, flags and the stream are shared)
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
