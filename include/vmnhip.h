@@ -55,6 +55,8 @@ typedef struct vmn_rarray vmn_rarray;   /* PRingElementArray / PFieldElementArra
 const char* vmn_version(void);
 /* Thread-local description of the last failing call in this thread (never NULL). */
 const char* vmn_last_error(void);
+/* for libraries layered on this ABI (vmnproofs.h): record the message vmn_last_error() returns */
+void vmn_report_error(const char* message);
 
 /* device: HIP device ordinal.  Fails with VMN_ERR_DEVICE when no gfx950 GPU is present. */
 int vmn_ctx_create(int device, vmn_ctx** out);
@@ -82,6 +84,13 @@ int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_group** out);
 void vmn_group_destroy(vmn_group* grp);
 size_t vmn_group_elem_bytes(const vmn_group* grp);     /* bytes per group element on the wire */
 size_t vmn_group_exp_bytes(const vmn_group* grp);      /* bytes per exponent (ring element) on the wire */
+/* PGroup accessors used by host-side protocol code: getElementOrder() (P/hvzk/PoSBasicTW.java:470 uses its
+ * bit length), getg() (P/mixnet/PermutationCommitment.java:200), and the modulus / field prime.
+ * kind: 0 = ModPGroup, 1 = ECqPGroup.  order / modulus: exp_bytes big-endian bytes; generator: elem_bytes. */
+int vmn_group_kind(const vmn_group* grp);
+int vmn_group_get_order(const vmn_group* grp, uint8_t* q_be);
+int vmn_group_get_modulus(const vmn_group* grp, uint8_t* p_be);
+int vmn_group_get_generator(const vmn_group* grp, uint8_t* g_be);
 
 /* ---- group element arrays (PGroupElementArray) --------------------------------------------- */
 

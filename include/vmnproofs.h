@@ -1,0 +1,149 @@
+/* vmnproofs.h — proof-level C ABI (seam S1 of SURVEY.md §8b): the sigma-protocol cores and the shuffler's
+ * arithmetic lines of the reference as host-side C++ drivers (verificatum-vmn_amd/csrc/vmnproofs.cpp) that
+ * issue array operations through vmnhip.h.  A Java `PoSGPU / PoSCGPU / CCPoSGPU` triple binds
+ * these entry points one to one; nothing here touches the GPU except through vmnhip.h.
+ *
+ * Classes mirrored (same operation order, same message item order, same verdict rules):
+ *   vmn_pos_*    PoSBasicTW    src/java/com/verificatum/protocol/hvzk/PoSBasicTW.java
+ *                (precompute :436-482 / :394-402, setBatchVector :533-538, commit :546-700, reply :856-888,
+ *                 computeAF :407-410, setCommitment :780-823, setChallenge :840-847, verify :1000-1066)
+ *   vmn_posc_*   PoSCBasicTW   hvzk/PoSCBasicTW.java (setInstance :306-340, commit :363-529, reply :607-636,
+ *                 verify :646-727, short-circuiting)
+ *   vmn_ccpos_*  CCPoSBasicW   hvzk/CCPoSBasicW.java (commit :344-396, reply :462-485, computeAB :493-506,
+ *                 verify :519-584, plain and "raised" form)
+ *   vmn_shuffle_reencrypt        mixnet/ShufflerElGamalSession.java:400-409, 273-278
+ *   vmn_permutation_commitment   mixnet/PermutationCommitment.java:189-215
+ *
+ * Conventions
+ *   * A ciphertext array of width w is 2w component arrays [u_1..u_w, v_1..v_w] (struct of arrays, the way
+ *     PPGroupElementArray.project exposes it, elgamal/DistrElGamalSession.java:377-378); the wide public key is
+ *     the matching 2w group elements [g..g, y..y] (elgamal/ProtocolElGamal.java:785-800), elem_bytes each.
+ *   * Arrays handed IN are borrowed (the caller keeps them alive until the proof object is freed); arrays handed
+ *     OUT inside a vmn_msg belong to the message.
+ *   * Single group elements / ring elements cross as big-endian bytes of vmn_group_elem_bytes / exp_bytes.
+ *   * Status codes are those of vmnhip.h; a failed verification is verdict 0 with status VMN_OK, never an error
+ *     (PoSBasicTW.java:1065).  vmn_last_error() of vmnhip.h holds the message of the last failure.
+ *   * VCR's PRG / randomElementArray sampling is not part of the reference tree: randomness
+ *     and the batching vector are explicit inputs (vmn_random_source, *_set_batch_vector).
+ */
+#ifndef VMNPROOFS_H
+#define VMNPROOFS_H
+
+#include "vmnhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The prover's randomness, at the granularity the reference draws it: PRing.randomElementArray / randomElement
+ * (PoSBasicTW.java:446, 465, 583, 612, 667, 673, 687) and LargeIntegerArray.random (:470-475).  Each callback
+ * sets *rows to n big-endian rows of vmn_group_exp_bytes() bytes, owned by the source and valid until its next
+ * call; integers of `bits` bits are delivered as field elements (reduced mod q when bits exceeds the order).
+ * Return 0 on success. */
+typedef struct vmn_random_source {
+    void* user;
+    int (*ring_elements)(void* user, size_t n, const uint8_t** rows);
+    int (*integers)(void* user, size_t n, int bits, const uint8_t** rows);
+} vmn_random_source;
+
+/* ---- messages: ordered items, each an element array, a ring array, k group elements or k ring elements ----
+ *   PoS  commitment (PoSBasicTW.java:694-699):  B[N], A', B'[N], C', D', F'[2w]
+ *   PoS  reply      (:880-886):                 k_A, k_B[N], k_C, k_D, k_E[N], k_F[w]
+ *   PoSC commitment (PoSCBasicTW.java:524-528): B[N], A', B'[N], C', D'
+ *   PoSC reply      (:629-634):                 k_A, k_B[N], k_C, k_D, k_E[N]
+ *   CCPoS commitment (CCPoSBasicW.java:395):    A', B'[2w]
+ *   CCPoS reply      (:480-483):                k_A, k_B[w], k_E[N]                                           */
+typedef struct vmn_msg vmn_msg;
+enum { VMN_ITEM_GARRAY = 1, VMN_ITEM_RARRAY = 2, VMN_ITEM_ELEMENTS = 3, VMN_ITEM_RING = 4 };
+int vmn_msg_create(vmn_msg** out);
+void vmn_msg_free(vmn_msg* m);                                   /* frees the arrays it owns */
+size_t vmn_msg_items(const vmn_msg* m);
+int vmn_msg_item_kind(const vmn_msg* m, size_t i);
+const vmn_garray* vmn_msg_item_garray(const vmn_msg* m, size_t i);
+const vmn_rarray* vmn_msg_item_rarray(const vmn_msg* m, size_t i);
+int vmn_msg_item_bytes(const vmn_msg* m, size_t i, const uint8_t** data, size_t* count, size_t* width);
+/* receiving side: ownership of the array passes to the message */
+int vmn_msg_push_garray(vmn_msg* m, vmn_garray* a);
+int vmn_msg_push_rarray(vmn_msg* m, vmn_rarray* a);
+int vmn_msg_push_elements(vmn_msg* m, const uint8_t* be, size_t count, size_t width);
+int vmn_msg_push_ring(vmn_msg* m, const uint8_t* be, size_t count, size_t width);
+/* Wire form: node(items); an array item is the array's byte tree, one element a leaf, k > 1
+ * elements of a ciphertext-shaped item node(node(k/2 leaves), node(k/2 leaves)) (k = 2: node(leaf, leaf)), k > 1
+ * ring elements node(k leaves).  ModPGroup only (byte trees of curve points are not built). */
+size_t vmn_msg_bytetree_size(const vmn_msg* m);
+int vmn_msg_to_bytetree(const vmn_msg* m, uint8_t* out);
+/* `layout` lists the expected item kinds (VMN_ITEM_*), `counts[i]` the element count of items of kind 3 / 4 and
+ * the array size of kinds 1 / 2.  *format_ok = 0 (and no message) on malformed input: the caller substitutes
+ * trivial values as the reference does (PoSBasicTW.java:794-815). */
+int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const int* layout, const size_t* counts,
+                          size_t items, vmn_msg** out, int* format_ok);
+
+/* ---- PoSBasicTW --------------------------------------------------------------------------------------------- */
+typedef struct vmn_pos vmn_pos;
+/* rs = NULL for a verifier.  ref: constructor PoSBasicTW.java:300-330 (vbitlen, ebitlen, rbitlen). */
+int vmn_pos_create(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, vmn_pos** out);
+void vmn_pos_free(vmn_pos* p);                                    /* free() :1088-1101 */
+/* prover (pi != NULL, :436-482): draws r, computes u = permute(h g^r, pi), alpha, epsilon, A'.
+ * verifier (pi == NULL, :394-402): records g, h. */
+int vmn_pos_precompute(vmn_pos* p, const uint8_t* g_be, const vmn_garray* h, const uint32_t* pi);
+const vmn_garray* vmn_pos_permutation_commitment(const vmn_pos* p);          /* u, owned by the proof object */
+int vmn_pos_set_permutation_commitment(vmn_pos* p, const vmn_garray* u);     /* verifier :780-792 */
+/* setInstance :421-433; s = the w arrays of re-encryption exponents (prover) or NULL (verifier) */
+int vmn_pos_set_instance(vmn_pos* p, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,
+                         const vmn_garray* const* wp, const vmn_rarray* const* s);
+int vmn_pos_set_batch_vector(vmn_pos* p, const uint8_t* e_be);    /* N rows of exp_bytes; :533-538 */
+int vmn_pos_commit(vmn_pos* p, vmn_msg** commitment);             /* :546-700 */
+int vmn_pos_reply(vmn_pos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);   /* :856-888 */
+int vmn_pos_compute_af(vmn_pos* p);                               /* :407-410 */
+int vmn_pos_set_commitment(vmn_pos* p, const vmn_msg* commitment);/* :780-823 (parsed form) */
+int vmn_pos_set_challenge(vmn_pos* p, const uint8_t* v_be, size_t vbytes);            /* :840-847 */
+/* :1000-1066; all five checks are evaluated; verdicts5 (may be NULL) = A, B, C, D, F */
+int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts5);
+
+/* ---- PoSCBasicTW -------------------------------------------------------------------------------------------- */
+typedef struct vmn_posc vmn_posc;
+int vmn_posc_create(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, vmn_posc** out);
+void vmn_posc_free(vmn_posc* p);
+/* setInstance :306-340; r, pi = NULL for a verifier */
+int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u,
+                          const vmn_rarray* r, const uint32_t* pi);
+int vmn_posc_set_batch_vector(vmn_posc* p, const uint8_t* e_be);
+int vmn_posc_commit(vmn_posc* p, vmn_msg** commitment);           /* :363-529 */
+int vmn_posc_reply(vmn_posc* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :607-636 */
+int vmn_posc_set_commitment(vmn_posc* p, const vmn_msg* commitment);
+int vmn_posc_set_challenge(vmn_posc* p, const uint8_t* v_be, size_t vbytes);
+int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict);                 /* :646-727 */
+
+/* ---- CCPoSBasicW -------------------------------------------------------------------------------------------- */
+typedef struct vmn_ccpos vmn_ccpos;
+int vmn_ccpos_create(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, vmn_ccpos** out);
+void vmn_ccpos_free(vmn_ccpos* p);
+/* setInstance :290-330; r, pi, s = NULL for a verifier */
+int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u,
+                           const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,
+                           const vmn_garray* const* wp, const vmn_rarray* r, const uint32_t* pi,
+                           const vmn_rarray* const* s);
+int vmn_ccpos_set_batch_vector(vmn_ccpos* p, const uint8_t* e_be);
+int vmn_ccpos_commit(vmn_ccpos* p, vmn_msg** commitment);         /* :344-396 */
+int vmn_ccpos_reply(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :462-485 */
+int vmn_ccpos_set_commitment(vmn_ccpos* p, const vmn_msg* commitment);
+int vmn_ccpos_set_challenge(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes);
+/* computeAB :493-506; raisedu = u^rho selects the single-equation form (NULL = plain) */
+int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu);
+/* verify :519-584; raisedh / rho_be = NULL for the plain form */
+int vmn_ccpos_verify(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be,
+                     size_t rho_bytes, int* verdict);
+
+/* ---- shuffler lines ----------------------------------------------------------------------------------------- */
+/* w' = permute(w * pk^s, pi^-1): ShufflerElGamalSession.java:400-409 (widePublicKey.exp(reencExponents)), :273-278
+ * (input.mul(reencFactors), permute(inverse), reencFactors.free()).  wp_out receives 2w new arrays. */
+int vmn_shuffle_reencrypt(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,
+                          const vmn_rarray* const* s, const uint32_t* pi, vmn_garray** wp_out);
+/* u = permute(h * g^r, pi): PermutationCommitment.java:189-215 (:200 g.exp(exponents), :201 generators.mul, :215). */
+int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h, const vmn_rarray* r,
+                               const uint32_t* pi, vmn_garray** u_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMNPROOFS_H */

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def mods(entry, vmn):
     import importlib.util, os, sys
     out = {}
-    for name in ("hvzk", "mixnet"):
+    for name in ("hvzk", "mixnet", "native"):
         spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}",
                                                       os.path.join(entry.PKG_DIR, f"{name}.py"))
         m = importlib.util.module_from_spec(spec)
@@ -23,6 +23,13 @@ def mods(entry, vmn):
         spec.loader.exec_module(m)
         out[name] = m
     return out
+
+
+@pytest.fixture(params=["python", "native"])
+def hv(request, mods):
+    """The proof drivers under test: the Python mirror (hvzk.py) or the C++ drivers behind include/vmnproofs.h
+    (native.py); both expose the reference's method names."""
+    return mods["hvzk"] if request.param == "python" else mods["native"]
 
 
 def make_instance(bits, n, width, seed):
@@ -52,7 +59,7 @@ def same_msg(a, b):
 
 @pytest.mark.parametrize("bits,n,width,nbits", [(512, 70, 1, (100, 100, 50)), (512, 33, 2, (100, 100, 50)),
                                                 (2048, 300, 1, (256, 256, 100))])
-def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods):
+def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods, hv):
     NV, NE, NR = nbits
     p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"pos%d" % bits)
     pi = t.permutation(n)
@@ -72,11 +79,14 @@ def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods
     H = G.toElementArray(h)
     W = [G.toElementArray(c) for c in w]
     S = [G.ringArray(c) for c in s]
-    hv, mx = mods["hvzk"], mods["mixnet"]
+    mx = mods["mixnet"]
     pr = hv.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prover", q))
     pr.precompute(g, H, pi)
-    assert pr.u.toInts() == o.u and pr.Ap == o.Ap
-    WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi)
+    assert pr.u.toInts() == o.u and getattr(pr, "Ap", o.Ap) == o.Ap        # A' is part of the commitment (checked below)
+    if hv is mods["native"]:
+        WP = hv.reencrypt_native(G, pkey, W, S, pi)
+    else:
+        WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi)
     assert [c.toInts() for c in WP] == wp_o
     pr.setInstance(pkey, W, WP, S)
     pr.setBatchVector(e)
@@ -113,7 +123,7 @@ def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods
     assert ov.verify({k: ints_of(x) for k, x in rep.items()}, v)
 
 
-def test_posc_and_permutation_commitment(vmn, gpu_ctx, mods):
+def test_posc_and_permutation_commitment(vmn, gpu_ctx, mods, hv):
     NV, NE, NR = 100, 100, 50
     n = 100                                   # the reference's unit test size, TestPoSCBasicTW.java
     p, q, g, h, _, _, t = make_instance(512, n, 1, b"posc")
@@ -124,11 +134,12 @@ def test_posc_and_permutation_commitment(vmn, gpu_ctx, mods):
     rho = t.int_array(1, 50)[0]
     G = vmn.ModPGroup(gpu_ctx, p, q, g)
     H = G.toElementArray(h)
-    hv, mx = mods["hvzk"], mods["mixnet"]
+    mx = mods["mixnet"]
     pc = mx.PermutationCommitment(G, H)
     U = pc.precompute(r, pi)
     u_o = P.permutation_commitment(g, h, r, pi, p)
     assert U.toInts() == u_o
+    assert mods["native"].permutation_commitment_native(G, g, H, G.ringArray(r), pi).toInts() == u_o
     assert pc.raise_(rho).toInts() == pyref.exp_scalar(u_o, rho, p)
     assert mx.raisedGenerators(H, rho).toInts() == pyref.exp_scalar(h, rho, p)
 
@@ -156,7 +167,7 @@ def test_posc_and_permutation_commitment(vmn, gpu_ctx, mods):
 
 
 @pytest.mark.parametrize("raised", [False, True])
-def test_ccpos_transcript_matches_oracle(raised, vmn, gpu_ctx, mods):
+def test_ccpos_transcript_matches_oracle(raised, vmn, gpu_ctx, mods, hv):
     NV, NE, NR = 256, 256, 100
     n, width = 130, 1
     p, q, g, h, pkey, w, t = make_instance(2048, n, width, b"ccpos")
@@ -173,7 +184,6 @@ def test_ccpos_transcript_matches_oracle(raised, vmn, gpu_ctx, mods):
     o.setBatchVector(e)
     com_o, rep_o = o.commit(), o.reply(v)
     G = vmn.ModPGroup(gpu_ctx, p, q, g)
-    hv, mx = mods["hvzk"], mods["mixnet"]
     H, U = G.toElementArray(h), G.toElementArray(u_o)
     W = [G.toElementArray(c) for c in w]
     WP = [G.toElementArray(c) for c in wp_o]

@@ -1,0 +1,39 @@
+"""CPU suite: the host-side big-number code of the C++ proof drivers (csrc/hostnum64.h: Montgomery arithmetic on
+64-bit limbs for the O(1) scalars of a proof) against Python integers."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from oracle import pyref
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("hostnum") / "hostnum_harness")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tests", "hostnum_harness.cpp")], check=True)
+    return exe
+
+
+def run(exe, n, a, b, e):
+    out = subprocess.run([exe] + ["%x" % v for v in (n, a, b, e)], check=True, capture_output=True, text=True).stdout.split()
+    return [int(x, 16) for x in out]
+
+
+@pytest.mark.parametrize("bits", [2048, 3072])
+def test_modp_scalars(bits, harness):
+    p, q, g = pyref.modp_group(bits)
+    vals = pyref.stream_ints(b"hostnum%d" % bits, 6, p)
+    for k in range(3):
+        a, b = 1 + vals[2 * k] % (p - 1), vals[2 * k + 1]
+        e = pyref.stream_ints(b"hostnum-e%d" % k, 1, q)[0] if k else (1 << 612) + 12345      # also a wide exponent mod small n
+        got = run(harness, p, a, b, e)
+        assert got == [a * b % p, pow(a, e, p), pow(a, -1, p), e % p, (a + b) % p, (-a) % p]
+
+
+def test_order_of_p256_and_edge_values(harness):
+    n = 0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551
+    for a, b, e in [(1, 0, 0), (n - 1, n - 1, n - 1), (2, 3, (1 << 612) - 1), (12345, n - 2, 1 << 300)]:
+        got = run(harness, n, a, b, e)
+        assert got == [a * b % n, pow(a, e, n), pow(a, -1, n), e % n, (a + b) % n, (-a) % n]

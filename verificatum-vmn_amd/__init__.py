@@ -325,10 +325,12 @@ class _ArrayBase:
         self.group = group
         self._h = handle
 
+    _borrowed = False      # True: the handle belongs to a vmn_msg / proof object (native.py); free() is a no-op
+
     def free(self) -> None:
-        if self._h:
+        if self._h and not self._borrowed:
             getattr(lib(), self._free_fn)(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

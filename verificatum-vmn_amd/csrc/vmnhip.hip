@@ -27,6 +27,7 @@ void vmn::set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vmn_last_error(void) { return g_err; }
+extern "C" void vmn_report_error(const char* message) { vmn::set_error("%s", message ? message : ""); }
 extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^28 lazy-carry Montgomery)"; }
 
 #define ARG_CHECK(cond, msg)             \
@@ -442,6 +443,27 @@ extern "C" void vmn_group_destroy(vmn_group* grp) {
 }
 extern "C" size_t vmn_group_elem_bytes(const vmn_group* grp) { return grp ? (grp->curve ? 2 * grp->nbytes : grp->nbytes) : 0; }
 extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->nbytes : 0; }
+extern "C" int vmn_group_kind(const vmn_group* grp) { return grp && grp->curve ? 1 : 0; }
+extern "C" int vmn_group_get_order(const vmn_group* grp, uint8_t* q_be) {
+    ARG_CHECK(grp && q_be, "null argument");
+    hostbig::to_be(grp->Q.n_words, q_be, grp->nbytes);
+    return VMN_OK;
+}
+extern "C" int vmn_group_get_modulus(const vmn_group* grp, uint8_t* p_be) {
+    ARG_CHECK(grp && p_be, "null argument");
+    hostbig::to_be(grp->curve ? grp->curve->p_words : grp->P.n_words, p_be, grp->nbytes);
+    return VMN_OK;
+}
+extern "C" int vmn_group_get_generator(const vmn_group* grp, uint8_t* g_be) {
+    ARG_CHECK(grp && g_be, "null argument");
+    if (grp->curve) {
+        hostbig::to_be(grp->curve->gx_words, g_be, grp->nbytes);
+        hostbig::to_be(grp->curve->gy_words, g_be + grp->nbytes, grp->nbytes);
+    } else {
+        hostbig::to_be(grp->g_words, g_be, grp->nbytes);
+    }
+    return VMN_OK;
+}
 
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,1293 @@
+// vmnproofs.cpp — host-side drivers of include/vmnproofs.h: PoSBasicTW, PoSCBasicTW, CCPoSBasicW and the
+// shuffler's arithmetic lines, written against the array-level C ABI (include/vmnhip.h) only.  Plain C++ (g++),
+// no HIP here: every per-element operation is a vmn_* call that runs on the GPU; what stays on the host are the
+// O(1) scalars of a proof, as in the reference (VCR scalar classes).
+//
+// Ordering note.  Calls of one context are stream-ordered and a call that returns a scalar blocks the host until
+// everything queued before it has run.  Each method therefore (1) draws its randomness in the reference's
+// order, (2) issues the calls that return scalars, (3) queues the long element-wise work, (4) does the host
+// exponentiations of single elements while the GPU is busy, (5) returns without waiting (messages own arrays
+// that may still be in flight; any later call is ordered behind them).  The VALUES are those of the reference's
+// statement order; only independent statements were moved.
+#include "../../include/vmnproofs.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hostnum64.h"
+
+using vmn::num64::Bytes;
+using vmn::num64::Mod;
+using vmn::num64::Num;
+
+namespace vmnp {
+
+int fail(int code, const char* fmt, ...) {
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    vmn_report_error(buf);
+    return code;
+}
+
+#define TRY(expr)                           \
+    do {                                    \
+        int rc__ = (expr);                  \
+        if (rc__ != VMN_OK) return rc__;    \
+    } while (0)
+#define REQUIRE(cond, msg)                                                   \
+    do {                                                                     \
+        if (!(cond)) return fail(VMN_ERR_ARG, "%s: %s", __func__, msg);      \
+    } while (0)
+
+// ---- owning handles --------------------------------------------------------------------------------------
+struct GA {
+    vmn_garray* p = nullptr;
+    GA() {}
+    GA(const GA&) = delete;
+    GA& operator=(const GA&) = delete;
+    ~GA() { reset(); }
+    void reset() {
+        if (p) vmn_garray_free(p);
+        p = nullptr;
+    }
+    vmn_garray** out() {
+        reset();
+        return &p;
+    }
+    vmn_garray* release() {
+        vmn_garray* r = p;
+        p = nullptr;
+        return r;
+    }
+    operator const vmn_garray*() const { return p; }
+};
+struct RA {
+    vmn_rarray* p = nullptr;
+    RA() {}
+    RA(const RA&) = delete;
+    RA& operator=(const RA&) = delete;
+    ~RA() { reset(); }
+    void reset() {
+        if (p) vmn_rarray_free(p);
+        p = nullptr;
+    }
+    vmn_rarray** out() {
+        reset();
+        return &p;
+    }
+    vmn_rarray* release() {
+        vmn_rarray* r = p;
+        p = nullptr;
+        return r;
+    }
+    operator const vmn_rarray*() const { return p; }
+};
+
+std::vector<uint32_t> inverse_permutation(const uint32_t* pi, size_t n) {
+    std::vector<uint32_t> inv(n);
+    for (size_t i = 0; i < n; ++i) inv[pi[i]] = (uint32_t)i;
+    return inv;
+}
+bool is_permutation(const uint32_t* pi, size_t n) {
+    std::vector<uint8_t> seen(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (pi[i] >= n || seen[pi[i]]) return false;
+        seen[pi[i]] = 1;
+    }
+    return true;
+}
+
+// ---- the group as the host sees it: sizes, Z_q scalars, single group elements ---------------------------------
+struct HostGroup {
+    vmn_group* grp = nullptr;
+    bool ec = false;
+    size_t eb = 0, xb = 0;            // element / exponent bytes
+    size_t ql = 0;                    // limbs of q
+    Mod Zq, Zp;                       // Zp only for ModPGroup
+    int qbits = 0;
+    Bytes g;
+
+    int init(vmn_group* g_) {
+        grp = g_;
+        ec = vmn_group_kind(grp) == 1;
+        eb = vmn_group_elem_bytes(grp);
+        xb = vmn_group_exp_bytes(grp);
+        ql = (xb + 7) / 8;
+        Bytes qb(xb), pb(xb);
+        TRY(vmn_group_get_order(grp, qb.data()));
+        TRY(vmn_group_get_modulus(grp, pb.data()));
+        Zq = Mod(vmn::num64::from_be(qb.data(), xb, ql));
+        qbits = vmn::num64::bit_length(Zq.n);
+        if (!ec) Zp = Mod(vmn::num64::from_be(pb.data(), xb, ql));
+        g.resize(eb);
+        TRY(vmn_group_get_generator(grp, g.data()));
+        return VMN_OK;
+    }
+    // ---- ring scalars
+    Num ring_from(const uint8_t* be) const { return vmn::num64::from_be(be, xb, ql); }
+    Bytes ring_bytes(const Num& a) const { return vmn::num64::to_bytes(a, xb); }
+    Num reduce(const uint8_t* be, size_t n) const { return Zq.reduce(be, n); }
+    Num mul_add(const Num& a, const Num& v, const Num& b) const { return Zq.add(Zq.mul(a, v), b); }   // a v + b
+
+    // ---- single group elements (big-endian bytes, canonical => equality is memcmp)
+    Bytes one() const {
+        Bytes o(eb, ec ? 0xff : 0);               // EC: the point at infinity is all 0xff on the wire
+        if (!ec) o[eb - 1] = 1;
+        return o;
+    }
+    int el_exp(const Bytes& base, const uint8_t* e_be, size_t ebytes, Bytes& out) const {
+        if (!ec) {
+            Num b = vmn::num64::from_be(base.data(), eb, ql);
+            out = vmn::num64::to_bytes(Zp.pow(b, e_be, ebytes), eb);
+            return VMN_OK;
+        }
+        GA x, r;
+        int ok = 1;
+        TRY(vmn_garray_from_be(grp, base.data(), 1, x.out(), &ok));
+        if (!ok) return fail(VMN_ERR_FORMAT, "group element not on the curve");
+        Bytes zero(1, 0);
+        bool any = false;
+        for (size_t i = 0; i < ebytes; ++i) any = any || e_be[i];
+        TRY(vmn_garray_exp_scalar(x, any ? e_be : zero.data(), any ? ebytes : 1, r.out()));
+        out.resize(eb);
+        return vmn_garray_get(r, 0, out.data());
+    }
+    int el_exp(const Bytes& base, const Num& e, Bytes& out) const {
+        Bytes eb_ = ring_bytes(e);
+        return el_exp(base, eb_.data(), eb_.size(), out);
+    }
+    int el_mul(const Bytes& a, const Bytes& b, Bytes& out) const {
+        if (!ec) {
+            out = vmn::num64::to_bytes(Zp.mul(vmn::num64::from_be(a.data(), eb, ql), vmn::num64::from_be(b.data(), eb, ql)), eb);
+            return VMN_OK;
+        }
+        Bytes both(a);
+        both.insert(both.end(), b.begin(), b.end());
+        GA x;
+        int ok = 1;
+        TRY(vmn_garray_from_be(grp, both.data(), 2, x.out(), &ok));
+        if (!ok) return fail(VMN_ERR_FORMAT, "group element not on the curve");
+        out.resize(eb);
+        return vmn_garray_prod(x, out.data());
+    }
+    int el_inv(const Bytes& a, Bytes& out) const {
+        if (!ec) {
+            out = vmn::num64::to_bytes(Zp.inv(vmn::num64::from_be(a.data(), eb, ql)), eb);
+            return VMN_OK;
+        }
+        GA x, r;
+        int ok = 1;
+        TRY(vmn_garray_from_be(grp, a.data(), 1, x.out(), &ok));
+        if (!ok) return fail(VMN_ERR_FORMAT, "group element not on the curve");
+        TRY(vmn_garray_inv(x, r.out()));
+        out.resize(eb);
+        return vmn_garray_get(r, 0, out.data());
+    }
+    int el_div(const Bytes& a, const Bytes& b, Bytes& out) const {
+        Bytes bi;
+        TRY(el_inv(b, bi));
+        return el_mul(a, bi, out);
+    }
+    // a^v * b  (a.expMul(v, b), PoSBasicTW.java:1016-1021)
+    int el_expmul(const Bytes& a, const Bytes& v_be, const Bytes& b, Bytes& out) const {
+        Bytes t;
+        TRY(el_exp(a, v_be.data(), v_be.size(), t));
+        return el_mul(t, b, out);
+    }
+};
+
+}  // namespace vmnp
+using namespace vmnp;
+
+// ---- messages ------------------------------------------------------------------------------------------------
+struct vmn_msg {
+    struct Item {
+        int kind = 0;
+        vmn_garray* ga = nullptr;
+        vmn_rarray* ra = nullptr;
+        Bytes bytes;
+        size_t count = 0, width = 0;
+    };
+    std::vector<Item> items;
+    ~vmn_msg() {
+        for (auto& it : items) {
+            if (it.ga) vmn_garray_free(it.ga);
+            if (it.ra) vmn_rarray_free(it.ra);
+        }
+    }
+    void push(GA& a) {
+        Item it;
+        it.kind = VMN_ITEM_GARRAY;
+        it.ga = a.release();
+        items.push_back(std::move(it));
+    }
+    void push(RA& a) {
+        Item it;
+        it.kind = VMN_ITEM_RARRAY;
+        it.ra = a.release();
+        items.push_back(std::move(it));
+    }
+    void push_bytes(int kind, const std::vector<Bytes>& els) {
+        Item it;
+        it.kind = kind;
+        it.count = els.size();
+        it.width = els.empty() ? 0 : els[0].size();
+        for (auto& e : els) it.bytes.insert(it.bytes.end(), e.begin(), e.end());
+        items.push_back(std::move(it));
+    }
+    void push_element(const Bytes& e) { push_bytes(VMN_ITEM_ELEMENTS, {e}); }
+    void push_ring(const Bytes& e) { push_bytes(VMN_ITEM_RING, {e}); }
+};
+
+namespace vmnp {
+
+const vmn_msg::Item* item_of(const vmn_msg* m, size_t i, int kind) {
+    if (!m || i >= m->items.size() || m->items[i].kind != kind) return nullptr;
+    return &m->items[i];
+}
+std::vector<Bytes> split(const vmn_msg::Item& it) {
+    std::vector<Bytes> out;
+    for (size_t k = 0; k < it.count; ++k) out.emplace_back(it.bytes.begin() + k * it.width, it.bytes.begin() + (k + 1) * it.width);
+    return out;
+}
+
+// ---- what the three proofs share -----------------------------------------------------------------------------
+struct ProofBase {
+    HostGroup G;
+    int vbitlen, ebitlen, rbitlen;
+    int e_bits, eps_bits, kE_bits;
+    bool has_rs = false;
+    vmn_random_source rs{};
+    size_t N = 0;
+    Bytes v_be;                        // the challenge as handed in (exponent of single elements)
+    Num v;                             // ... and reduced mod q
+
+    int init(vmn_group* grp, int vb, int ebl, int rb, const vmn_random_source* r) {
+        TRY(G.init(grp));
+        vbitlen = vb;
+        ebitlen = ebl;
+        rbitlen = rb;
+        e_bits = std::min(ebl, G.qbits);
+        eps_bits = std::min(ebl + vb + rb, G.qbits);
+        kE_bits = std::min(ebl + vb + rb + 1, G.qbits);
+        if (r) {
+            if (!r->ring_elements || !r->integers) return fail(VMN_ERR_ARG, "random source lacks a callback");
+            rs = *r;
+            has_rs = true;
+        }
+        return VMN_OK;
+    }
+    int need_rs() const { return has_rs ? VMN_OK : fail(VMN_ERR_ARG, "this proof object was created without a random source (verifier)"); }
+    int draw_ring_array(size_t n, RA& out) {
+        TRY(need_rs());
+        const uint8_t* rows = nullptr;
+        if (rs.ring_elements(rs.user, n, &rows) != 0 || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
+        int ok = 1;
+        TRY(vmn_rarray_from_be(G.grp, rows, n, out.out(), &ok));
+        return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+    }
+    int draw_integers(size_t n, int bits, RA& out) {
+        TRY(need_rs());
+        const uint8_t* rows = nullptr;
+        if (rs.integers(rs.user, n, bits, &rows) != 0 || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
+        int ok = 1;
+        TRY(vmn_rarray_from_be(G.grp, rows, n, out.out(), &ok));
+        return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+    }
+    int draw_ring_element(Num& out) {
+        TRY(need_rs());
+        const uint8_t* rows = nullptr;
+        if (rs.ring_elements(rs.user, 1, &rows) != 0 || !rows) return fail(VMN_ERR_ARG, "random source failed");
+        out = G.ring_from(rows);
+        if (vmn::num64::cmp(out, G.Zq.n) >= 0) return fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+        return VMN_OK;
+    }
+    int set_challenge(const uint8_t* vb, size_t n) {
+        if (!vb || !n) return fail(VMN_ERR_ARG, "null challenge");
+        v_be.assign(vb, vb + n);
+        v = G.reduce(vb, n);
+        return VMN_OK;
+    }
+    int batch_vector(const uint8_t* e_be, RA& e) {
+        if (!e_be && N) return fail(VMN_ERR_ARG, "null batching vector");
+        int ok = 1;
+        TRY(vmn_rarray_from_be(G.grp, e_be, N, e.out(), &ok));
+        return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "batching vector entry >= q");
+    }
+    // g^a for a ring scalar; through the cached fixed-base table when the group is a curve (one launch), on the
+    // host for ModPGroup
+    int gexp(const Bytes& base, const Num& e, Bytes& out) const { return G.el_exp(base, e, out); }
+
+    // the commitments B, B' of PoS and PoSC (PoSBasicTW.java:583-648, PoSCBasicTW.java:400-470): x, y are consumed
+    int bridging_commitments(const Bytes& g, const Bytes& h0, RA& x, RA& y, const RA& beta, const RA& epsilon, GA& B, GA& Bp) {
+        GA g_exp_x, h0_exp_y;
+        TRY(vmn_group_exp_fixed(G.grp, g.data(), x, g_exp_x.out()));
+        TRY(vmn_group_exp_fixed(G.grp, h0.data(), y, h0_exp_y.out()));
+        TRY(vmn_garray_mul(g_exp_x, h0_exp_y, B.out()));
+        g_exp_x.reset();
+        h0_exp_y.reset();
+        Bytes zero(G.xb, 0), one(G.xb, 0);
+        one[G.xb - 1] = 1;
+        RA xp, yp, xp_mul_eps, beta_add_prod, yp_mul_eps;
+        TRY(vmn_rarray_shift_push(x, zero.data(), xp.out()));
+        TRY(vmn_rarray_shift_push(y, one.data(), yp.out()));
+        x.reset();
+        y.reset();
+        TRY(vmn_rarray_mul(xp, epsilon, xp_mul_eps.out()));
+        TRY(vmn_rarray_add(beta, xp_mul_eps, beta_add_prod.out()));
+        GA g_exp_beta_add_prod, h0_exp_yp_mul_eps;
+        TRY(vmn_group_exp_fixed(G.grp, g.data(), beta_add_prod, g_exp_beta_add_prod.out()));
+        TRY(vmn_rarray_mul(yp, epsilon, yp_mul_eps.out()));
+        TRY(vmn_group_exp_fixed(G.grp, h0.data(), yp_mul_eps, h0_exp_yp_mul_eps.out()));
+        TRY(vmn_garray_mul(g_exp_beta_add_prod, h0_exp_yp_mul_eps, Bp.out()));
+        return VMN_OK;
+    }
+    // check (B): B_i^v B'_i == g^{k_B,i} B_{i-1}^{k_E,i}, B_{-1} = h0 (PoSBasicTW.java:1023-1042).  Queues the
+    // element-wise work and returns the two sides; the comparison (which blocks) is left to the caller.
+    int bridging_sides(const Bytes& g, const Bytes& h0, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
+                       const vmn_rarray* k_E, GA& left, GA& right) {
+        GA B_exp_v, g_exp_k_B, B_shift, B_shift_exp_k_E;
+        TRY(vmn_garray_exp_scalar(B, v_be.data(), v_be.size(), B_exp_v.out()));
+        TRY(vmn_garray_mul(B_exp_v, Bp, left.out()));
+        B_exp_v.reset();
+        TRY(vmn_group_exp_fixed(G.grp, g.data(), k_B, g_exp_k_B.out()));
+        TRY(vmn_garray_shift_push(B, h0.data(), B_shift.out()));
+        TRY(vmn_garray_exp_array(B_shift, k_E, kE_bits, B_shift_exp_k_E.out()));
+        TRY(vmn_garray_mul(g_exp_k_B, B_shift_exp_k_E, right.out()));
+        return VMN_OK;
+    }
+    // pk_c^{-k_c mod width} * t_c for the 2w components of a ciphertext-shaped value
+    int pk_side(const std::vector<Bytes>& pkey, const std::vector<Num>& k, const std::vector<Bytes>& t, std::vector<Bytes>& out) const {
+        const size_t width = pkey.size() / 2;
+        out.resize(pkey.size());
+        for (size_t c = 0; c < pkey.size(); ++c) {
+            Bytes pw;
+            TRY(G.el_exp(pkey[c], G.Zq.neg(k[c % width]), pw));
+            TRY(G.el_mul(pw, t[c], out[c]));
+        }
+        return VMN_OK;
+    }
+    int expprod_multi(const std::vector<const vmn_garray*>& xs, const vmn_rarray* e, int bits, std::vector<Bytes>& out) const {
+        Bytes flat(xs.size() * G.eb);
+        TRY(vmn_garray_expprod_multi(xs.data(), xs.size(), e, bits, flat.data()));
+        out.clear();
+        for (size_t k = 0; k < xs.size(); ++k) out.emplace_back(flat.begin() + k * G.eb, flat.begin() + (k + 1) * G.eb);
+        return VMN_OK;
+    }
+    int check_arrays(const vmn_garray* const* arr, size_t k, const char* what) const {
+        if (!arr) return fail(VMN_ERR_ARG, "%s: null", what);
+        for (size_t c = 0; c < k; ++c) {
+            if (!arr[c] || vmn_garray_size(arr[c]) != N) return fail(VMN_ERR_ARG, "%s: component %zu is null or not of size N", what, c);
+        }
+        return VMN_OK;
+    }
+};
+
+}  // namespace vmnp
+
+// ================================================================================================================
+// PoSBasicTW
+// ================================================================================================================
+struct vmn_pos : ProofBase {
+    Bytes g;
+    const vmn_garray* h = nullptr;
+    std::vector<uint32_t> pi, piinv;
+    bool prover = false;
+    RA r, epsilon, e, ipe, b, beta;
+    GA u_own;
+    const vmn_garray* u = nullptr;
+    Num alpha, gamma, delta, d;
+    std::vector<Num> phi;
+    Bytes Ap;
+    size_t width = 0;
+    std::vector<Bytes> pkey;
+    std::vector<const vmn_garray*> w, wp;
+    std::vector<const vmn_rarray*> s;
+    // verifier
+    Bytes A;
+    std::vector<Bytes> F;
+    const vmn_garray* cB = nullptr;
+    const vmn_garray* cBp = nullptr;
+    Bytes cAp, cCp, cDp;
+    std::vector<Bytes> cFp;
+
+    int precompute(const uint8_t* g_be, const vmn_garray* h_, const uint32_t* pi_) {
+        REQUIRE(g_be && h_, "null argument");
+        N = vmn_garray_size(h_);
+        REQUIRE(N > 0, "empty generator array");
+        g.assign(g_be, g_be + G.eb);
+        h = h_;
+        prover = pi_ != nullptr;
+        if (!prover) return VMN_OK;                              // verifier :394-402
+        REQUIRE(is_permutation(pi_, N), "pi is not a permutation of [0, N)");
+        pi.assign(pi_, pi_ + N);
+        piinv = inverse_permutation(pi_, N);
+        // :446-465  u_i = g^{r_pi(i)} h_pi(i)
+        TRY(draw_ring_array(N, r));
+        TRY(draw_ring_element(alpha));
+        TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
+        TRY(vmn_permutation_commitment(G.grp, g.data(), h, r, pi.data(), u_own.out()));
+        u = u_own;
+        // :481  A' = g^alpha prod h_i^eps_i
+        Bytes hp(G.eb), ga;
+        TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        TRY(gexp(g, alpha, ga));
+        return G.el_mul(ga, hp, Ap);
+    }
+    int set_instance(const uint8_t* pkey_be, size_t width_, const vmn_garray* const* w_, const vmn_garray* const* wp_,
+                     const vmn_rarray* const* s_) {
+        REQUIRE(pkey_be && width_ > 0 && N > 0, "null argument or precompute not called");
+        width = width_;
+        TRY(check_arrays(w_, 2 * width, "w"));
+        TRY(check_arrays(wp_, 2 * width, "w'"));
+        pkey.clear();
+        for (size_t c = 0; c < 2 * width; ++c) pkey.emplace_back(pkey_be + c * G.eb, pkey_be + (c + 1) * G.eb);
+        w.assign(w_, w_ + 2 * width);
+        wp.assign(wp_, wp_ + 2 * width);
+        s.clear();
+        if (s_) {
+            for (size_t c = 0; c < width; ++c) {
+                REQUIRE(s_[c] && vmn_rarray_size(s_[c]) == N, "re-encryption exponents: null or not of size N");
+                s.push_back(s_[c]);
+            }
+        }
+        return VMN_OK;
+    }
+    int commit(vmn_msg** out) {
+        REQUIRE(out && prover && e.p && width, "commit needs a prover with instance and batching vector set");
+        // randomness in the reference's order: b :583, beta :612, gamma :667, delta :673, phi :687
+        TRY(draw_ring_array(N, b));
+        TRY(draw_ring_array(N, beta));
+        TRY(draw_ring_element(gamma));
+        TRY(draw_ring_element(delta));
+        phi.resize(width);
+        for (auto& ph : phi) TRY(draw_ring_element(ph));
+        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :552-554
+        Bytes h0(G.eb), dbytes(G.xb);
+        TRY(vmn_garray_get(h, 0, h0.data()));
+        RA x, y;
+        TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dbytes.data()));                  // :583-598
+        d = G.ring_from(dbytes.data());
+        TRY(vmn_rarray_prods(ipe, y.out()));                                      // :600-604
+        std::vector<Bytes> prods;
+        TRY(expprod_multi(wp, epsilon, eps_bits, prods));                         // :690
+        GA B, Bp;
+        TRY(bridging_commitments(g, h0, x, y, beta, epsilon, B, Bp));             // :606-648 (queued)
+        Bytes Cp, Dp;
+        TRY(gexp(g, gamma, Cp));                                                  // :667-679
+        TRY(gexp(g, delta, Dp));
+        std::vector<Bytes> Fp;
+        TRY(pk_side(pkey, phi, prods, Fp));                                       // :687-690
+        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        m->push(B);
+        m->push_element(Ap);
+        m->push(Bp);
+        m->push_element(Cp);
+        m->push_element(Dp);
+        m->push_bytes(VMN_ITEM_ELEMENTS, Fp);
+        *out = m.release();
+        return VMN_OK;
+    }
+    int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
+        REQUIRE(out && prover && ipe.p && s.size() == width, "reply needs commit() and the re-encryption exponents");
+        TRY(set_challenge(vb, vbytes));
+        Bytes a(G.xb), c(G.xb), f(G.xb);
+        TRY(vmn_rarray_inner_product(r, ipe, a.data()));
+        TRY(vmn_rarray_sum(r, c.data()));
+        std::vector<Bytes> kF;
+        for (size_t col = 0; col < width; ++col) {                               // product-ring inner product: per column
+            TRY(vmn_rarray_inner_product(s[col], e, f.data()));
+            kF.push_back(G.ring_bytes(G.mul_add(G.ring_from(f.data()), v, phi[col])));
+        }
+        Bytes vq = G.ring_bytes(v);
+        RA k_B, k_E;
+        TRY(vmn_rarray_mul_add(b, vq.data(), beta, k_B.out()));
+        TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
+        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(a.data()), v, alpha)));
+        m->push(k_B);
+        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(c.data()), v, gamma)));
+        m->push_ring(G.ring_bytes(G.mul_add(d, v, delta)));
+        m->push(k_E);
+        m->push_bytes(VMN_ITEM_RING, kF);
+        *out = m.release();
+        return VMN_OK;
+    }
+    int compute_af() {
+        REQUIRE(u && e.p && width, "computeAF needs u, the instance and the batching vector");
+        std::vector<const vmn_garray*> xs{u};
+        xs.insert(xs.end(), w.begin(), w.end());
+        std::vector<Bytes> res;
+        TRY(expprod_multi(xs, e, e_bits, res));                                   // one sort of e for u and w
+        A = res[0];
+        F.assign(res.begin() + 1, res.end());
+        return VMN_OK;
+    }
+    int set_commitment(const vmn_msg* m) {
+        const vmn_msg::Item *iB = item_of(m, 0, VMN_ITEM_GARRAY), *iAp = item_of(m, 1, VMN_ITEM_ELEMENTS),
+                            *iBp = item_of(m, 2, VMN_ITEM_GARRAY), *iCp = item_of(m, 3, VMN_ITEM_ELEMENTS),
+                            *iDp = item_of(m, 4, VMN_ITEM_ELEMENTS), *iFp = item_of(m, 5, VMN_ITEM_ELEMENTS);
+        REQUIRE(m && m->items.size() == 6 && iB && iAp && iBp && iCp && iDp && iFp, "commitment is not (B, A', B', C', D', F')");
+        REQUIRE(vmn_garray_size(iB->ga) == N && vmn_garray_size(iBp->ga) == N, "B / B' not of size N");
+        REQUIRE(iAp->count == 1 && iCp->count == 1 && iDp->count == 1 && iFp->count == 2 * width && iAp->width == G.eb &&
+                    iFp->width == G.eb, "commitment scalars have the wrong shape");
+        cB = iB->ga;
+        cBp = iBp->ga;
+        cAp = iAp->bytes;
+        cCp = iCp->bytes;
+        cDp = iDp->bytes;
+        cFp = split(*iFp);
+        return VMN_OK;
+    }
+    int verify(const vmn_msg* rep, int* verdict, int* five) {
+        REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
+        const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
+                            *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
+                            *ikE = item_of(rep, 4, VMN_ITEM_RARRAY), *ikF = item_of(rep, 5, VMN_ITEM_RING);
+        REQUIRE(rep && rep->items.size() == 6 && ikA && ikB && ikC && ikD && ikE && ikF, "reply is not (k_A, k_B, k_C, k_D, k_E, k_F)");
+        REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikF->count == width && ikA->width == G.xb,
+                "reply items have the wrong shape");
+        Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
+        std::vector<Num> k_F;
+        for (auto& bts : split(*ikF)) k_F.push_back(G.ring_from(bts.data()));
+        // scalars that come back from the GPU first (each blocks on the stream) ...
+        Bytes h0(G.eb), uprod(G.eb), hprod(G.eb), Blast(G.eb), eprod(G.xb);
+        TRY(vmn_garray_get(h, 0, h0.data()));
+        TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
+        TRY(vmn_garray_prod(h, hprod.data()));
+        TRY(vmn_garray_get(cB, N - 1, Blast.data()));
+        TRY(vmn_rarray_prod(e, eprod.data()));                                    // :1014
+        std::vector<const vmn_garray*> xs{h};
+        xs.insert(xs.end(), wp.begin(), wp.end());
+        std::vector<Bytes> kE_prods;
+        TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));                       // :1021, :1063 — one sort of k_E
+        // ... then the element-wise work of check (B) is queued ...
+        GA left, right;
+        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, left, right));       // :1023-1042
+        // ... and the single-element checks run on the host while the GPU works
+        Bytes C, D, t, lhs, rhs;
+        TRY(G.el_div(uprod, hprod, C));
+        TRY(G.el_exp(h0, eprod.data(), eprod.size(), t));
+        TRY(G.el_div(Blast, t, D));
+        TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :1016-1021
+        TRY(gexp(g, k_A, t));
+        TRY(G.el_mul(t, kE_prods[0], rhs));
+        const int vA = lhs == rhs;
+        TRY(G.el_expmul(C, v_be, cCp, lhs));                                      // (C) :1045-1048
+        TRY(gexp(g, k_C, rhs));
+        const int vC = lhs == rhs;
+        TRY(G.el_expmul(D, v_be, cDp, lhs));                                      // (D) :1051-1054
+        TRY(gexp(g, k_D, rhs));
+        const int vD = lhs == rhs;
+        std::vector<Bytes> prods(kE_prods.begin() + 1, kE_prods.end()), rF;
+        TRY(pk_side(pkey, k_F, prods, rF));                                       // (F) :1057-1063
+        int vF = 1;
+        for (size_t c = 0; c < 2 * width; ++c) {
+            TRY(G.el_expmul(F[c], v_be, cFp[c], lhs));
+            vF = vF && lhs == rF[c];
+        }
+        int vB = 0;
+        TRY(vmn_garray_equals(left, right, &vB));
+        if (five) {
+            five[0] = vA;
+            five[1] = vB;
+            five[2] = vC;
+            five[3] = vD;
+            five[4] = vF;
+        }
+        *verdict = vA && vB && vC && vD && vF;                                    // no short-circuit :1065
+        return VMN_OK;
+    }
+};
+
+// ================================================================================================================
+// PoSCBasicTW
+// ================================================================================================================
+struct vmn_posc : ProofBase {
+    Bytes g;
+    const vmn_garray* h = nullptr;
+    const vmn_garray* u = nullptr;
+    const vmn_rarray* r = nullptr;
+    std::vector<uint32_t> piinv;
+    RA epsilon, e, ipe, b, beta;
+    Num alpha, gamma, delta, d;
+    const vmn_garray* cB = nullptr;
+    const vmn_garray* cBp = nullptr;
+    Bytes cAp, cCp, cDp;
+
+    int set_instance(const uint8_t* g_be, const vmn_garray* h_, const vmn_garray* u_, const vmn_rarray* r_, const uint32_t* pi_) {
+        REQUIRE(g_be && h_ && u_, "null argument");
+        N = vmn_garray_size(h_);
+        REQUIRE(N > 0 && vmn_garray_size(u_) == N, "h / u empty or of different size");
+        g.assign(g_be, g_be + G.eb);
+        h = h_;
+        u = u_;
+        r = r_;
+        piinv.clear();
+        if (pi_) {
+            REQUIRE(r_ && vmn_rarray_size(r_) == N, "prover needs the commitment exponents r");
+            REQUIRE(is_permutation(pi_, N), "pi is not a permutation of [0, N)");
+            piinv = inverse_permutation(pi_, N);
+        }
+        return VMN_OK;
+    }
+    int commit(vmn_msg** out) {
+        REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
+        // randomness in the reference's order: b, alpha, epsilon, beta, gamma, delta (PoSCBasicTW.java:400-500)
+        TRY(draw_ring_array(N, b));
+        TRY(draw_ring_element(alpha));
+        TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
+        TRY(draw_ring_array(N, beta));
+        TRY(draw_ring_element(gamma));
+        TRY(draw_ring_element(delta));
+        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));
+        Bytes h0(G.eb), dbytes(G.xb), hp(G.eb);
+        TRY(vmn_garray_get(h, 0, h0.data()));
+        RA x, y;
+        TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dbytes.data()));
+        d = G.ring_from(dbytes.data());
+        TRY(vmn_rarray_prods(ipe, y.out()));
+        TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        GA B, Bp;
+        TRY(bridging_commitments(g, h0, x, y, beta, epsilon, B, Bp));
+        Bytes ga, Ap, Cp, Dp;
+        TRY(gexp(g, alpha, ga));
+        TRY(G.el_mul(ga, hp, Ap));
+        TRY(gexp(g, gamma, Cp));
+        TRY(gexp(g, delta, Dp));
+        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        m->push(B);
+        m->push_element(Ap);
+        m->push(Bp);
+        m->push_element(Cp);
+        m->push_element(Dp);
+        *out = m.release();
+        return VMN_OK;
+    }
+    int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
+        REQUIRE(out && ipe.p && r, "reply needs commit()");
+        TRY(set_challenge(vb, vbytes));
+        Bytes a(G.xb), c(G.xb);
+        TRY(vmn_rarray_inner_product(r, ipe, a.data()));
+        TRY(vmn_rarray_sum(r, c.data()));
+        Bytes vq = G.ring_bytes(v);
+        RA k_B, k_E;
+        TRY(vmn_rarray_mul_add(b, vq.data(), beta, k_B.out()));
+        TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
+        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(a.data()), v, alpha)));
+        m->push(k_B);
+        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(c.data()), v, gamma)));
+        m->push_ring(G.ring_bytes(G.mul_add(d, v, delta)));
+        m->push(k_E);
+        *out = m.release();
+        return VMN_OK;
+    }
+    int set_commitment(const vmn_msg* m) {
+        const vmn_msg::Item *iB = item_of(m, 0, VMN_ITEM_GARRAY), *iAp = item_of(m, 1, VMN_ITEM_ELEMENTS),
+                            *iBp = item_of(m, 2, VMN_ITEM_GARRAY), *iCp = item_of(m, 3, VMN_ITEM_ELEMENTS),
+                            *iDp = item_of(m, 4, VMN_ITEM_ELEMENTS);
+        REQUIRE(m && m->items.size() == 5 && iB && iAp && iBp && iCp && iDp, "commitment is not (B, A', B', C', D')");
+        REQUIRE(vmn_garray_size(iB->ga) == N && vmn_garray_size(iBp->ga) == N && iAp->count == 1 && iCp->count == 1 &&
+                    iDp->count == 1 && iAp->width == G.eb, "commitment items have the wrong shape");
+        cB = iB->ga;
+        cBp = iBp->ga;
+        cAp = iAp->bytes;
+        cCp = iCp->bytes;
+        cDp = iDp->bytes;
+        return VMN_OK;
+    }
+    int verify(const vmn_msg* rep, int* verdict) {
+        REQUIRE(verdict && cB && e.p && !v_be.empty(), "verify needs the batching vector, setCommitment and setChallenge");
+        const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
+                            *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
+                            *ikE = item_of(rep, 4, VMN_ITEM_RARRAY);
+        REQUIRE(rep && rep->items.size() == 5 && ikA && ikB && ikC && ikD && ikE, "reply is not (k_A, k_B, k_C, k_D, k_E)");
+        REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
+        *verdict = 0;
+        Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
+        Bytes h0(G.eb), A(G.eb), uprod(G.eb), hprod(G.eb), Blast(G.eb), eprod(G.xb), hk(G.eb);
+        TRY(vmn_garray_get(h, 0, h0.data()));
+        TRY(vmn_garray_expprod(u, e, e_bits, A.data()));                          // :660
+        TRY(vmn_garray_prod(u, uprod.data()));
+        TRY(vmn_garray_prod(h, hprod.data()));
+        TRY(vmn_garray_get(cB, N - 1, Blast.data()));
+        TRY(vmn_rarray_prod(e, eprod.data()));
+        TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, hk.data()));
+        Bytes t, lhs, rhs, C, D;
+        TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :676-682
+        TRY(gexp(g, k_A, t));
+        TRY(G.el_mul(t, hk, rhs));
+        if (lhs != rhs) return VMN_OK;                                            // short-circuit :682
+        GA left, right;
+        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, left, right));       // (B) :685-715
+        TRY(G.el_div(uprod, hprod, C));
+        TRY(G.el_exp(h0, eprod.data(), eprod.size(), t));
+        TRY(G.el_div(Blast, t, D));
+        TRY(G.el_expmul(C, v_be, cCp, lhs));                                      // (C) :718-723
+        TRY(gexp(g, k_C, rhs));
+        const int vC = lhs == rhs;
+        TRY(G.el_expmul(D, v_be, cDp, lhs));                                      // (D) :724-727
+        TRY(gexp(g, k_D, rhs));
+        const int vD = lhs == rhs;
+        int vB = 0;
+        TRY(vmn_garray_equals(left, right, &vB));
+        *verdict = vB && vC && vD;
+        return VMN_OK;
+    }
+};
+
+// ================================================================================================================
+// CCPoSBasicW
+// ================================================================================================================
+struct vmn_ccpos : ProofBase {
+    Bytes g;
+    const vmn_garray* h = nullptr;
+    const vmn_garray* u = nullptr;
+    const vmn_rarray* r = nullptr;
+    std::vector<uint32_t> piinv;
+    size_t width = 0;
+    std::vector<Bytes> pkey;
+    std::vector<const vmn_garray*> w, wp;
+    std::vector<const vmn_rarray*> s;
+    RA epsilon, e, ipe;
+    Num alpha;
+    std::vector<Num> beta;
+    Bytes cAp;
+    std::vector<Bytes> cBp;
+    bool have_commitment = false;
+    Bytes A;
+    std::vector<Bytes> B, AB;
+    bool raised = false, have_ab = false;
+
+    int set_instance(const uint8_t* g_be, const vmn_garray* h_, const vmn_garray* u_, const uint8_t* pkey_be, size_t width_,
+                     const vmn_garray* const* w_, const vmn_garray* const* wp_, const vmn_rarray* r_, const uint32_t* pi_,
+                     const vmn_rarray* const* s_) {
+        REQUIRE(g_be && h_ && u_ && pkey_be && width_ > 0, "null argument");
+        N = vmn_garray_size(h_);
+        REQUIRE(N > 0 && vmn_garray_size(u_) == N, "h / u empty or of different size");
+        width = width_;
+        TRY(check_arrays(w_, 2 * width, "w"));
+        TRY(check_arrays(wp_, 2 * width, "w'"));
+        g.assign(g_be, g_be + G.eb);
+        h = h_;
+        u = u_;
+        r = r_;
+        pkey.clear();
+        for (size_t c = 0; c < 2 * width; ++c) pkey.emplace_back(pkey_be + c * G.eb, pkey_be + (c + 1) * G.eb);
+        w.assign(w_, w_ + 2 * width);
+        wp.assign(wp_, wp_ + 2 * width);
+        piinv.clear();
+        s.clear();
+        if (pi_) {
+            REQUIRE(r_ && vmn_rarray_size(r_) == N && s_, "prover needs r and s");
+            REQUIRE(is_permutation(pi_, N), "pi is not a permutation of [0, N)");
+            piinv = inverse_permutation(pi_, N);
+            for (size_t c = 0; c < width; ++c) {
+                REQUIRE(s_[c] && vmn_rarray_size(s_[c]) == N, "re-encryption exponents: null or not of size N");
+                s.push_back(s_[c]);
+            }
+        }
+        return VMN_OK;
+    }
+    int commit(vmn_msg** out) {
+        REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
+        TRY(draw_ring_element(alpha));                                            // :360-375
+        TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
+        beta.resize(width);
+        for (auto& bt : beta) TRY(draw_ring_element(bt));
+        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :350
+        std::vector<const vmn_garray*> xs{h};
+        xs.insert(xs.end(), wp.begin(), wp.end());
+        std::vector<Bytes> eps_prods;
+        TRY(expprod_multi(xs, epsilon, eps_bits, eps_prods));                     // :377, :391 — one sort of epsilon
+        Bytes ga, Ap;
+        TRY(gexp(g, alpha, ga));
+        TRY(G.el_mul(ga, eps_prods[0], Ap));
+        std::vector<Bytes> prods(eps_prods.begin() + 1, eps_prods.end()), Bp;
+        TRY(pk_side(pkey, beta, prods, Bp));
+        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        m->push_element(Ap);
+        m->push_bytes(VMN_ITEM_ELEMENTS, Bp);
+        *out = m.release();
+        return VMN_OK;
+    }
+    int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
+        REQUIRE(out && ipe.p && r && s.size() == width, "reply needs commit()");
+        TRY(set_challenge(vb, vbytes));
+        Bytes a(G.xb), bsum(G.xb);
+        TRY(vmn_rarray_inner_product(r, ipe, a.data()));
+        std::vector<Bytes> kB;
+        for (size_t col = 0; col < width; ++col) {
+            TRY(vmn_rarray_inner_product(s[col], e, bsum.data()));
+            kB.push_back(G.ring_bytes(G.mul_add(G.ring_from(bsum.data()), v, beta[col])));
+        }
+        Bytes vq = G.ring_bytes(v);
+        RA k_E;
+        TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
+        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(a.data()), v, alpha)));
+        m->push_bytes(VMN_ITEM_RING, kB);
+        m->push(k_E);
+        *out = m.release();
+        return VMN_OK;
+    }
+    int set_commitment(const vmn_msg* m) {
+        const vmn_msg::Item *iAp = item_of(m, 0, VMN_ITEM_ELEMENTS), *iBp = item_of(m, 1, VMN_ITEM_ELEMENTS);
+        REQUIRE(m && m->items.size() == 2 && iAp && iBp && iAp->count == 1 && iBp->count == 2 * width && iAp->width == G.eb &&
+                    iBp->width == G.eb, "commitment is not (A', B')");
+        cAp = iAp->bytes;
+        cBp = split(*iBp);
+        have_commitment = true;
+        return VMN_OK;
+    }
+    int compute_ab(const vmn_garray* raisedu) {
+        REQUIRE(u && e.p && width, "computeAB needs the instance and the batching vector");
+        raised = raisedu != nullptr;
+        if (!raised) {
+            std::vector<const vmn_garray*> xs{u};
+            xs.insert(xs.end(), w.begin(), w.end());
+            std::vector<Bytes> res;
+            TRY(expprod_multi(xs, e, e_bits, res));
+            A = res[0];
+            B.assign(res.begin() + 1, res.end());
+        } else {
+            REQUIRE(vmn_garray_size(raisedu) == N, "raised commitment not of size N");
+            // w.mul(raisedu): the base-group array multiplies every component (:502); then one sort of e
+            std::vector<GA> tmp(2 * width);
+            std::vector<const vmn_garray*> xs;
+            for (size_t c = 0; c < 2 * width; ++c) {
+                TRY(vmn_garray_mul(w[c], raisedu, tmp[c].out()));
+                xs.push_back(tmp[c]);
+            }
+            TRY(expprod_multi(xs, e, e_bits, AB));
+        }
+        have_ab = true;
+        return VMN_OK;
+    }
+    int verify(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes, int* verdict) {
+        REQUIRE(verdict && have_commitment && have_ab && !v_be.empty(), "verify needs computeAB, setCommitment and setChallenge");
+        const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RING),
+                            *ikE = item_of(rep, 2, VMN_ITEM_RARRAY);
+        REQUIRE(rep && rep->items.size() == 3 && ikA && ikB && ikE, "reply is not (k_A, k_B, k_E)");
+        REQUIRE(ikB->count == width && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
+        REQUIRE(raised == (raisedh != nullptr) && raised == (rho_be != nullptr), "raised / plain form must match computeAB");
+        *verdict = 0;
+        Num k_A = G.ring_from(ikA->bytes.data());
+        std::vector<Num> k_B;
+        for (auto& bts : split(*ikB)) k_B.push_back(G.ring_from(bts.data()));
+        Bytes t, lhs, rhs;
+        if (!raised) {                                                            // :554-570
+            std::vector<const vmn_garray*> xs{h};
+            xs.insert(xs.end(), wp.begin(), wp.end());
+            std::vector<Bytes> kE_prods;
+            TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));
+            TRY(G.el_expmul(A, v_be, cAp, lhs));
+            TRY(gexp(g, k_A, t));
+            TRY(G.el_mul(t, kE_prods[0], rhs));
+            if (lhs != rhs) return VMN_OK;
+            std::vector<Bytes> prods(kE_prods.begin() + 1, kE_prods.end()), rB;
+            TRY(pk_side(pkey, k_B, prods, rB));
+            int ok = 1;
+            for (size_t c = 0; c < 2 * width; ++c) {
+                TRY(G.el_expmul(B[c], v_be, cBp[c], lhs));
+                ok = ok && lhs == rB[c];
+            }
+            *verdict = ok;
+            return VMN_OK;
+        }
+        // raised, single-equation form :571-580:  AB^v (B' A'^rho) = pk^{-k_B} prod (w'_i h_i^rho)^{k_E,i} g^{k_A rho}
+        REQUIRE(vmn_garray_size(raisedh) == N && rho_bytes > 0, "raised generators not of size N");
+        std::vector<GA> tmp(2 * width);
+        std::vector<const vmn_garray*> xs;
+        for (size_t c = 0; c < 2 * width; ++c) {
+            TRY(vmn_garray_mul(wp[c], raisedh, tmp[c].out()));
+            xs.push_back(tmp[c]);
+        }
+        std::vector<Bytes> prods, rB;
+        TRY(expprod_multi(xs, ikE->ra, kE_bits, prods));
+        Num rho = G.reduce(rho_be, rho_bytes);
+        Bytes Ap_rho, g_term;
+        TRY(G.el_exp(cAp, rho_be, rho_bytes, Ap_rho));
+        TRY(gexp(g, G.Zq.mul(k_A, rho), g_term));
+        TRY(pk_side(pkey, k_B, prods, rB));
+        int ok = 1;
+        for (size_t c = 0; c < 2 * width; ++c) {
+            TRY(G.el_mul(cBp[c], Ap_rho, t));
+            TRY(G.el_expmul(AB[c], v_be, t, lhs));
+            TRY(G.el_mul(rB[c], g_term, rhs));
+            ok = ok && lhs == rhs;
+        }
+        *verdict = ok;
+        return VMN_OK;
+    }
+};
+
+// ================================================================================================================
+// C entry points
+// ================================================================================================================
+extern "C" {
+
+int vmn_msg_create(vmn_msg** out) {
+    if (!out) return fail(VMN_ERR_ARG, "vmn_msg_create: null argument");
+    *out = new vmn_msg();
+    return VMN_OK;
+}
+void vmn_msg_free(vmn_msg* m) { delete m; }
+size_t vmn_msg_items(const vmn_msg* m) { return m ? m->items.size() : 0; }
+int vmn_msg_item_kind(const vmn_msg* m, size_t i) { return m && i < m->items.size() ? m->items[i].kind : 0; }
+const vmn_garray* vmn_msg_item_garray(const vmn_msg* m, size_t i) {
+    const vmn_msg::Item* it = item_of(m, i, VMN_ITEM_GARRAY);
+    return it ? it->ga : nullptr;
+}
+const vmn_rarray* vmn_msg_item_rarray(const vmn_msg* m, size_t i) {
+    const vmn_msg::Item* it = item_of(m, i, VMN_ITEM_RARRAY);
+    return it ? it->ra : nullptr;
+}
+int vmn_msg_item_bytes(const vmn_msg* m, size_t i, const uint8_t** data, size_t* count, size_t* width) {
+    if (!m || i >= m->items.size() || (m->items[i].kind != VMN_ITEM_ELEMENTS && m->items[i].kind != VMN_ITEM_RING))
+        return fail(VMN_ERR_ARG, "vmn_msg_item_bytes: item %zu is not a scalar item", i);
+    if (data) *data = m->items[i].bytes.data();
+    if (count) *count = m->items[i].count;
+    if (width) *width = m->items[i].width;
+    return VMN_OK;
+}
+int vmn_msg_push_garray(vmn_msg* m, vmn_garray* a) {
+    if (!m || !a) return fail(VMN_ERR_ARG, "vmn_msg_push_garray: null argument");
+    vmn_msg::Item it;
+    it.kind = VMN_ITEM_GARRAY;
+    it.ga = a;
+    m->items.push_back(std::move(it));
+    return VMN_OK;
+}
+int vmn_msg_push_rarray(vmn_msg* m, vmn_rarray* a) {
+    if (!m || !a) return fail(VMN_ERR_ARG, "vmn_msg_push_rarray: null argument");
+    vmn_msg::Item it;
+    it.kind = VMN_ITEM_RARRAY;
+    it.ra = a;
+    m->items.push_back(std::move(it));
+    return VMN_OK;
+}
+static int push_scalar_item(vmn_msg* m, int kind, const uint8_t* be, size_t count, size_t width) {
+    if (!m || (!be && count) || !width) return fail(VMN_ERR_ARG, "vmn_msg_push: null argument");
+    vmn_msg::Item it;
+    it.kind = kind;
+    it.count = count;
+    it.width = width;
+    it.bytes.assign(be, be + count * width);
+    m->items.push_back(std::move(it));
+    return VMN_OK;
+}
+int vmn_msg_push_elements(vmn_msg* m, const uint8_t* be, size_t count, size_t width) {
+    return push_scalar_item(m, VMN_ITEM_ELEMENTS, be, count, width);
+}
+int vmn_msg_push_ring(vmn_msg* m, const uint8_t* be, size_t count, size_t width) {
+    return push_scalar_item(m, VMN_ITEM_RING, be, count, width);
+}
+
+// ---- wire form -------------------------------------------------------------------------------------------------
+static void put_header(uint8_t*& o, uint8_t tag, size_t n) {
+    *o++ = tag;
+    *o++ = (uint8_t)(n >> 24);
+    *o++ = (uint8_t)(n >> 16);
+    *o++ = (uint8_t)(n >> 8);
+    *o++ = (uint8_t)n;
+}
+static size_t scalar_item_size(const vmn_msg::Item& it) {
+    const size_t leaf = 5 + it.width;
+    if (it.count == 1) return leaf;
+    if (it.kind == VMN_ITEM_RING) return 5 + it.count * leaf;
+    if (it.count == 2) return 5 + 2 * leaf;
+    return 5 + 2 * (5 + (it.count / 2) * leaf);
+}
+size_t vmn_msg_bytetree_size(const vmn_msg* m) {
+    if (!m) return 0;
+    size_t total = 5;
+    for (auto& it : m->items) {
+        if (it.kind == VMN_ITEM_GARRAY) total += vmn_garray_bytetree_size(it.ga);
+        else if (it.kind == VMN_ITEM_RARRAY) total += vmn_rarray_bytetree_size(it.ra);
+        else total += scalar_item_size(it);
+    }
+    return total;
+}
+int vmn_msg_to_bytetree(const vmn_msg* m, uint8_t* out) {
+    if (!m || !out) return fail(VMN_ERR_ARG, "vmn_msg_to_bytetree: null argument");
+    uint8_t* o = out;
+    put_header(o, 0, m->items.size());
+    for (auto& it : m->items) {
+        if (it.kind == VMN_ITEM_GARRAY) {
+            TRY(vmn_garray_to_bytetree(it.ga, o));
+            o += vmn_garray_bytetree_size(it.ga);
+            continue;
+        }
+        if (it.kind == VMN_ITEM_RARRAY) {
+            TRY(vmn_rarray_to_bytetree(it.ra, o));
+            o += vmn_rarray_bytetree_size(it.ra);
+            continue;
+        }
+        auto leaf = [&](size_t k) {
+            put_header(o, 1, it.width);
+            memcpy(o, it.bytes.data() + k * it.width, it.width);
+            o += it.width;
+        };
+        if (it.count == 1) {
+            leaf(0);
+        } else if (it.kind == VMN_ITEM_RING || it.count == 2) {
+            put_header(o, 0, it.count);
+            for (size_t k = 0; k < it.count; ++k) leaf(k);
+        } else {
+            put_header(o, 0, 2);
+            for (size_t half = 0; half < 2; ++half) {
+                put_header(o, 0, it.count / 2);
+                for (size_t k = 0; k < it.count / 2; ++k) leaf(half * (it.count / 2) + k);
+            }
+        }
+    }
+    return VMN_OK;
+}
+
+namespace {
+struct Reader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool header(uint8_t tag, size_t* n) {
+        if (end - p < 5 || p[0] != tag) return false;
+        *n = ((size_t)p[1] << 24) | ((size_t)p[2] << 16) | ((size_t)p[3] << 8) | p[4];
+        p += 5;
+        return true;
+    }
+    bool leaf(size_t width, Bytes& sink) {
+        size_t n;
+        if (!header(1, &n) || n != width || (size_t)(end - p) < width) return false;
+        sink.insert(sink.end(), p, p + width);
+        p += width;
+        return true;
+    }
+};
+}  // namespace
+
+int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const int* layout, const size_t* counts, size_t items,
+                          vmn_msg** out, int* format_ok) {
+    if (!grp || !bt || !layout || !counts || !out || !format_ok) return fail(VMN_ERR_ARG, "vmn_msg_from_bytetree: null argument");
+    *format_ok = 0;
+    *out = nullptr;
+    const size_t eb = vmn_group_elem_bytes(grp), xb = vmn_group_exp_bytes(grp);
+    Reader rd{bt, bt + len};
+    size_t n;
+    if (!rd.header(0, &n) || n != items) return VMN_OK;
+    std::unique_ptr<vmn_msg> m(new vmn_msg());
+    for (size_t i = 0; i < items; ++i) {
+        if (layout[i] == VMN_ITEM_GARRAY || layout[i] == VMN_ITEM_RARRAY) {
+            const size_t width = layout[i] == VMN_ITEM_GARRAY ? eb : xb;
+            const size_t need = 5 + counts[i] * (5 + width);
+            if ((size_t)(rd.end - rd.p) < need) return VMN_OK;
+            int ok = 0, in_range = 1;
+            if (layout[i] == VMN_ITEM_GARRAY) {
+                vmn_garray* a = nullptr;
+                TRY(vmn_garray_from_bytetree(grp, rd.p, need, counts[i], &a, &ok, &in_range));
+                if (a) vmn_msg_push_garray(m.get(), a);
+            } else {
+                vmn_rarray* a = nullptr;
+                TRY(vmn_rarray_from_bytetree(grp, rd.p, need, counts[i], &a, &ok, &in_range));
+                if (a) vmn_msg_push_rarray(m.get(), a);
+            }
+            if (!ok || !in_range) return VMN_OK;
+            rd.p += need;
+            continue;
+        }
+        vmn_msg::Item it;
+        it.kind = layout[i];
+        it.count = counts[i];
+        it.width = layout[i] == VMN_ITEM_ELEMENTS ? eb : xb;
+        bool good = true;
+        if (it.count == 1) {
+            good = rd.leaf(it.width, it.bytes);
+        } else if (it.kind == VMN_ITEM_RING || it.count == 2) {
+            good = rd.header(0, &n) && n == it.count;
+            for (size_t k = 0; good && k < it.count; ++k) good = rd.leaf(it.width, it.bytes);
+        } else {
+            good = rd.header(0, &n) && n == 2;
+            for (size_t half = 0; good && half < 2; ++half) {
+                good = rd.header(0, &n) && n == it.count / 2;
+                for (size_t k = 0; good && k < it.count / 2; ++k) good = rd.leaf(it.width, it.bytes);
+            }
+        }
+        if (!good) return VMN_OK;
+        m->items.push_back(std::move(it));
+    }
+    if (rd.p != rd.end) return VMN_OK;
+    *format_ok = 1;
+    *out = m.release();
+    return VMN_OK;
+}
+
+// ---- shuffler lines --------------------------------------------------------------------------------------------
+int vmn_shuffle_reencrypt(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,
+                          const vmn_rarray* const* s, const uint32_t* pi, vmn_garray** wp_out) {
+    if (!grp || !pkey_be || !width || !w || !s || !pi || !wp_out) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt: null argument");
+    const size_t eb = vmn_group_elem_bytes(grp);
+    const size_t n = vmn_garray_size(w[0]);
+    if (!is_permutation(pi, n)) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt: pi is not a permutation of [0, N)");
+    std::vector<uint32_t> inv = inverse_permutation(pi, n);
+    std::vector<GA> res(2 * width);
+    for (size_t c = 0; c < 2 * width; ++c) {
+        GA factors, reenc;                                                        // freed right after use (:274)
+        TRY(vmn_group_exp_fixed(grp, pkey_be + c * eb, s[c % width], factors.out()));     // widePublicKey.exp(reencExponents) :407
+        TRY(vmn_garray_mul(w[c], factors, reenc.out()));                          // input.mul(reencFactors) :273
+        TRY(vmn_garray_permute(reenc, inv.data(), res[c].out()));                 // permute(permutation.inv()) :278
+    }
+    for (size_t c = 0; c < 2 * width; ++c) wp_out[c] = res[c].release();
+    return VMN_OK;
+}
+
+int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h, const vmn_rarray* r, const uint32_t* pi,
+                               vmn_garray** u_out) {
+    if (!grp || !g_be || !h || !r || !pi || !u_out) return fail(VMN_ERR_ARG, "vmn_permutation_commitment: null argument");
+    if (!is_permutation(pi, vmn_garray_size(h))) return fail(VMN_ERR_ARG, "vmn_permutation_commitment: pi is not a permutation of [0, N)");
+    GA tmp1, tmp2;
+    TRY(vmn_group_exp_fixed(grp, g_be, r, tmp1.out()));                           // g.exp(exponents) :200
+    TRY(vmn_garray_mul(h, tmp1, tmp2.out()));                                     // generators.mul(tmp) :201
+    tmp1.reset();
+    return vmn_garray_permute(tmp2, pi, u_out);                                   // :215
+}
+
+// ---- proof objects ---------------------------------------------------------------------------------------------
+#define CREATE(T, name)                                                                                              \
+    int name(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, T** out) {          \
+        if (!grp || !out || vbitlen <= 0 || ebitlen <= 0 || rbitlen < 0) return fail(VMN_ERR_ARG, #name ": bad argument"); \
+        std::unique_ptr<T> p(new T());                                                                               \
+        TRY(p->init(grp, vbitlen, ebitlen, rbitlen, rs));                                                            \
+        *out = p.release();                                                                                          \
+        return VMN_OK;                                                                                               \
+    }
+CREATE(vmn_pos, vmn_pos_create)
+CREATE(vmn_posc, vmn_posc_create)
+CREATE(vmn_ccpos, vmn_ccpos_create)
+#undef CREATE
+#define NONNULL(p) \
+    if (!(p)) return fail(VMN_ERR_ARG, "%s: null proof object", __func__)
+
+void vmn_pos_free(vmn_pos* p) { delete p; }
+int vmn_pos_precompute(vmn_pos* p, const uint8_t* g_be, const vmn_garray* h, const uint32_t* pi) {
+    NONNULL(p);
+    return p->precompute(g_be, h, pi);
+}
+const vmn_garray* vmn_pos_permutation_commitment(const vmn_pos* p) { return p ? p->u : nullptr; }
+int vmn_pos_set_permutation_commitment(vmn_pos* p, const vmn_garray* u) {
+    NONNULL(p);
+    if (!u || vmn_garray_size(u) != p->N) return fail(VMN_ERR_ARG, "vmn_pos_set_permutation_commitment: u null or not of size N");
+    p->u = u;
+    return VMN_OK;
+}
+int vmn_pos_set_instance(vmn_pos* p, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w, const vmn_garray* const* wp,
+                         const vmn_rarray* const* s) {
+    NONNULL(p);
+    return p->set_instance(pkey_be, width, w, wp, s);
+}
+int vmn_pos_set_batch_vector(vmn_pos* p, const uint8_t* e_be) {
+    NONNULL(p);
+    return p->batch_vector(e_be, p->e);
+}
+int vmn_pos_commit(vmn_pos* p, vmn_msg** commitment) {
+    NONNULL(p);
+    return p->commit(commitment);
+}
+int vmn_pos_reply(vmn_pos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply) {
+    NONNULL(p);
+    return p->reply(v_be, vbytes, reply);
+}
+int vmn_pos_compute_af(vmn_pos* p) {
+    NONNULL(p);
+    return p->compute_af();
+}
+int vmn_pos_set_commitment(vmn_pos* p, const vmn_msg* commitment) {
+    NONNULL(p);
+    return p->set_commitment(commitment);
+}
+int vmn_pos_set_challenge(vmn_pos* p, const uint8_t* v_be, size_t vbytes) {
+    NONNULL(p);
+    return p->set_challenge(v_be, vbytes);
+}
+int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts5) {
+    NONNULL(p);
+    return p->verify(reply, verdict, verdicts5);
+}
+
+void vmn_posc_free(vmn_posc* p) { delete p; }
+int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u, const vmn_rarray* r,
+                          const uint32_t* pi) {
+    NONNULL(p);
+    return p->set_instance(g_be, h, u, r, pi);
+}
+int vmn_posc_set_batch_vector(vmn_posc* p, const uint8_t* e_be) {
+    NONNULL(p);
+    return p->batch_vector(e_be, p->e);
+}
+int vmn_posc_commit(vmn_posc* p, vmn_msg** commitment) {
+    NONNULL(p);
+    return p->commit(commitment);
+}
+int vmn_posc_reply(vmn_posc* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply) {
+    NONNULL(p);
+    return p->reply(v_be, vbytes, reply);
+}
+int vmn_posc_set_commitment(vmn_posc* p, const vmn_msg* commitment) {
+    NONNULL(p);
+    return p->set_commitment(commitment);
+}
+int vmn_posc_set_challenge(vmn_posc* p, const uint8_t* v_be, size_t vbytes) {
+    NONNULL(p);
+    return p->set_challenge(v_be, vbytes);
+}
+int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict) {
+    NONNULL(p);
+    return p->verify(reply, verdict);
+}
+
+void vmn_ccpos_free(vmn_ccpos* p) { delete p; }
+int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u, const uint8_t* pkey_be,
+                           size_t width, const vmn_garray* const* w, const vmn_garray* const* wp, const vmn_rarray* r,
+                           const uint32_t* pi, const vmn_rarray* const* s) {
+    NONNULL(p);
+    return p->set_instance(g_be, h, u, pkey_be, width, w, wp, r, pi, s);
+}
+int vmn_ccpos_set_batch_vector(vmn_ccpos* p, const uint8_t* e_be) {
+    NONNULL(p);
+    return p->batch_vector(e_be, p->e);
+}
+int vmn_ccpos_commit(vmn_ccpos* p, vmn_msg** commitment) {
+    NONNULL(p);
+    return p->commit(commitment);
+}
+int vmn_ccpos_reply(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply) {
+    NONNULL(p);
+    return p->reply(v_be, vbytes, reply);
+}
+int vmn_ccpos_set_commitment(vmn_ccpos* p, const vmn_msg* commitment) {
+    NONNULL(p);
+    return p->set_commitment(commitment);
+}
+int vmn_ccpos_set_challenge(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes) {
+    NONNULL(p);
+    return p->set_challenge(v_be, vbytes);
+}
+int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu) {
+    NONNULL(p);
+    return p->compute_ab(raisedu);
+}
+int vmn_ccpos_verify(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes,
+                     int* verdict) {
+    NONNULL(p);
+    return p->verify(reply, raisedh, rho_be, rho_bytes, verdict);
+}
+
+}  // extern "C"

@@ -1,0 +1,393 @@
+"""native.py — ctypes binding of the proof-level C ABI (``include/vmnproofs.h``, ``libvmnproofs.so``): the C++
+drivers ``vmn_pos_* / vmn_posc_* / vmn_ccpos_*`` and the shuffler lines, under the method names of the reference
+classes so that the same tests drive them and the Python mirror in ``hvzk.py`` / ``mixnet.py``.
+
+ref: src/java/com/verificatum/protocol/hvzk/{PoSBasicTW,PoSCBasicTW,CCPoSBasicW}.java,
+     mixnet/ShufflerElGamalSession.java:400-409, 273-278, mixnet/PermutationCommitment.java:189-215.
+
+Messages are dicts with the keys of ``hvzk.py`` (arrays are views into the native message, scalars host values);
+the native message travels along as the ``native`` attribute of the dict (``MsgDict``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+from . import (PGroupElementArray, PRingElementArray, VmnError, _check, _u32_array, int_to_be, lib)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmnproofs.so")
+_plib: Optional[C.CDLL] = None
+
+GARRAY, RARRAY, ELEMENTS, RING = 1, 2, 3, 4
+_ROWS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p))
+_INTS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p))
+
+
+class _RandomSourceStruct(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("ring_elements", _ROWS_CB), ("integers", _INTS_CB)]
+
+
+def plib() -> C.CDLL:
+    """Load ``libvmnproofs.so`` (g++, built by ``__graft_entry__.build()``); it links against ``libvmnhip.so``."""
+    global _plib
+    if _plib is None:
+        lib()                                   # the HIP library first: fails loudly when it is missing
+        if not os.path.exists(LIB_PATH):
+            raise VmnError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        _plib = C.CDLL(LIB_PATH)
+        for name in ("vmn_msg_items", "vmn_msg_bytetree_size"):
+            getattr(_plib, name).restype = C.c_size_t
+        for name in ("vmn_msg_item_garray", "vmn_msg_item_rarray", "vmn_pos_permutation_commitment"):
+            getattr(_plib, name).restype = C.c_void_p
+    return _plib
+
+
+class RandomSource:
+    """Adapter from a tape object (``ring_array(n)``, ``ring_element()``, ``int_array(n, bits)``; ints or
+    big-endian blocks) to ``vmn_random_source``.  Buffers stay alive until the next call, as the ABI requires."""
+
+    def __init__(self, group, tape):
+        self.group, self.tape = group, tape
+        self._keep = None
+        self.error = None
+
+        def hand_over(vals, out):
+            if isinstance(vals, (bytes, bytearray)):
+                rows = bytes(vals)                     # big-endian block of the wire width (bulk sources): no copy
+            else:
+                q = group.q
+                rows = b"".join(int(x % q).to_bytes(group.nbytes, "big") for x in vals)
+            self._keep = rows                          # valid until the next call
+            out[0] = C.cast(C.c_char_p(rows), C.c_void_p).value
+
+        def ring_cb(_user, n, out):
+            try:
+                hand_over([self.tape.ring_element()] if n == 1 else self.tape.ring_array(n), out)
+                return 0
+            except Exception as exc:       # pragma: no cover - re-raised by the caller
+                self.error = exc
+                return 1
+
+        def ints_cb(_user, n, bits, out):
+            try:
+                hand_over(self.tape.int_array(n, bits), out)
+                return 0
+            except Exception as exc:       # pragma: no cover
+                self.error = exc
+                return 1
+
+        self._cbs = (_ROWS_CB(ring_cb), _INTS_CB(ints_cb))
+        self.struct = _RandomSourceStruct(None, self._cbs[0], self._cbs[1])
+
+
+class Message:
+    """Owner of a ``vmn_msg``; arrays handed out are borrowed views that keep the message alive."""
+
+    def __init__(self, group, handle):
+        self.group, self._h = group, handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                plib().vmn_msg_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def items(self) -> int:
+        return plib().vmn_msg_items(self._h)
+
+    def item(self, i: int):
+        kind = plib().vmn_msg_item_kind(self._h, C.c_size_t(i))
+        if kind in (GARRAY, RARRAY):
+            fn, cls = ("vmn_msg_item_garray", PGroupElementArray) if kind == GARRAY else ("vmn_msg_item_rarray", PRingElementArray)
+            arr = cls(self.group, C.c_void_p(getattr(plib(), fn)(self._h, C.c_size_t(i))))
+            arr._borrowed, arr._keep = True, self
+            return arr
+        data, count, width = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(plib().vmn_msg_item_bytes(self._h, C.c_size_t(i), C.byref(data), C.byref(count), C.byref(width)))
+        raw = C.string_at(data, count.value * width.value)
+        rows = [raw[k * width.value:(k + 1) * width.value] for k in range(count.value)]
+        if kind == ELEMENTS:
+            return [self.group.dec_el(r) for r in rows]
+        return [int.from_bytes(r, "big") for r in rows]
+
+    def toByteTree(self) -> bytes:
+        size = plib().vmn_msg_bytetree_size(self._h)
+        out = C.create_string_buffer(size)
+        _check(plib().vmn_msg_to_bytetree(self._h, out))
+        return out.raw
+
+    @staticmethod
+    def fromByteTree(group, bt: bytes, layout: Sequence[int], counts: Sequence[int]) -> Optional["Message"]:
+        """None when the bytes are not a message of that layout (the caller substitutes trivial values)."""
+        h, ok = C.c_void_p(), C.c_int(0)
+        lay = (C.c_int * len(layout))(*layout)
+        cnt = (C.c_size_t * len(counts))(*counts)
+        _check(plib().vmn_msg_from_bytetree(group._h, bytes(bt), C.c_size_t(len(bt)), lay, cnt, C.c_size_t(len(layout)),
+                                            C.byref(h), C.byref(ok)))
+        return Message(group, h) if ok.value else None
+
+    @staticmethod
+    def build(group, parts) -> "Message":
+        """parts: arrays (copied handles are NOT taken: the array is duplicated) or ('el', [..]) / ('ring', [..])."""
+        h = C.c_void_p()
+        _check(plib().vmn_msg_create(C.byref(h)))
+        m = Message(group, h)
+        for part in parts:
+            if isinstance(part, PGroupElementArray):
+                dup = part.copyOfRange(0, part.size())
+                _check(plib().vmn_msg_push_garray(h, dup._h))
+                dup._borrowed = True
+            elif isinstance(part, PRingElementArray):
+                dup = part.copyOfRange(0, part.size())
+                _check(plib().vmn_msg_push_rarray(h, dup._h))
+                dup._borrowed = True
+            elif part[0] == "el":
+                buf = group.enc_els(part[1])
+                _check(plib().vmn_msg_push_elements(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.elem_bytes)))
+            else:
+                buf = b"".join(int_to_be(x % group.q, group.nbytes) for x in part[1])
+                _check(plib().vmn_msg_push_ring(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.nbytes)))
+        return m
+
+
+class MsgDict(dict):
+    """A message in the shape of hvzk.py's dicts, plus the native ``vmn_msg`` it was read from."""
+    native: Optional[Message] = None
+
+
+def _one(x):
+    return x[0]
+
+
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a._h.value if isinstance(a._h, C.c_void_p) else a._h for a in arrs])
+
+
+def _be(x: int) -> bytes:
+    return int(x).to_bytes(max(1, (int(x).bit_length() + 7) // 8), "big")
+
+
+class _NativeProof:
+    _prefix = ""
+    _com_keys: Sequence[str] = ()
+    _rep_keys: Sequence[str] = ()
+    _com_scalar = ()          # keys whose value is ONE element (not a list)
+    _rep_scalar = ()
+
+    def __init__(self, group, vbitlen: int, ebitlen: int, rbitlen: int, rand=None):
+        self.G = group
+        self.q = group.q
+        self._rs = RandomSource(group, rand) if rand is not None else None
+        self._h = C.c_void_p()
+        rs = C.byref(self._rs.struct) if self._rs else None
+        _check(self._fn("create")(group._h, C.c_int(vbitlen), C.c_int(ebitlen), C.c_int(rbitlen), rs, C.byref(self._h)))
+        self._keep = []
+
+    def _fn(self, name):
+        return getattr(plib(), f"vmn_{self._prefix}_{name}")
+
+    def _call(self, name, *args):
+        rc = self._fn(name)(self._h, *args)
+        if rc != 0 and self._rs is not None and self._rs.error is not None:
+            raise self._rs.error
+        _check(rc)
+
+    def free(self):
+        if self._h:
+            self._fn("free")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def _msg_dict(self, h, keys, scalar_keys):
+        m = Message(self.G, h)
+        out = MsgDict()
+        out.native = m
+        for i, k in enumerate(keys):
+            val = m.item(i)
+            out[k] = _one(val) if k in scalar_keys else val
+        return out
+
+    def _as_msg(self, d, keys, scalar_keys, kinds) -> Message:
+        """A dict produced here travels with its native message; a hand-made (e.g. tampered) one is rebuilt."""
+        m = getattr(d, "native", None)
+        if m is not None and all(self._same(d[k], m.item(i), k in scalar_keys) for i, k in enumerate(keys)):
+            return m
+        parts = []
+        for k, kind in zip(keys, kinds):
+            val = d[k]
+            if kind in (GARRAY, RARRAY):
+                parts.append(val)
+            else:
+                vals = [val] if k in scalar_keys else list(val)
+                parts.append(("el" if kind == ELEMENTS else "ring", vals))
+        return Message.build(self.G, parts)
+
+    @staticmethod
+    def _same(val, item, scalar):
+        if hasattr(val, "_h"):
+            return hasattr(item, "_h") and val._h.value == item._h.value
+        return ([val] if scalar else list(val)) == item
+
+    def setBatchVector(self, e_ints):
+        buf = bytes(e_ints) if isinstance(e_ints, (bytes, bytearray)) else b"".join(int_to_be(x, self.G.nbytes) for x in e_ints)
+        self._call("set_batch_vector", buf)
+
+    def setChallenge(self, v: int):
+        b = _be(v)
+        self._call("set_challenge", b, C.c_size_t(len(b)))
+
+    def _commit(self):
+        h = C.c_void_p()
+        self._call("commit", C.byref(h))
+        return self._msg_dict(h, self._com_keys, self._com_scalar)
+
+    def reply(self, v: int):
+        b = _be(v)
+        h = C.c_void_p()
+        self._call("reply", b, C.c_size_t(len(b)), C.byref(h))
+        return self._msg_dict(h, self._rep_keys, self._rep_scalar)
+
+
+class PoSBasicTW(_NativeProof):
+    """``vmn_pos_*`` — ref: hvzk/PoSBasicTW.java."""
+    _prefix = "pos"
+    _com_keys = ("B", "Ap", "Bp", "Cp", "Dp", "Fp")
+    _com_scalar = ("Ap", "Cp", "Dp")
+    _com_kinds = (GARRAY, ELEMENTS, GARRAY, ELEMENTS, ELEMENTS, ELEMENTS)
+    _rep_keys = ("k_A", "k_B", "k_C", "k_D", "k_E", "k_F")
+    _rep_scalar = ("k_A", "k_C", "k_D")
+    _rep_kinds = (RING, RARRAY, RING, RING, RARRAY, RING)
+
+    def precompute(self, g, h, pi=None):
+        self.h = h
+        if pi is None:
+            self._call("precompute", self.G.enc_el(g), h._h, None)
+            return
+        ptr, keep = _u32_array(pi)
+        self._call("precompute", self.G.enc_el(g), h._h, ptr)
+        # a view of the proof object's u: valid while this object lives (no back-reference: a cycle would let the
+        # garbage collector finalise the group before the proof object)
+        self.u = PGroupElementArray(self.G, C.c_void_p(plib().vmn_pos_permutation_commitment(self._h)))
+        self.u._borrowed = True
+
+    def setPermutationCommitment(self, u):
+        self.u = u
+        self._call("set_permutation_commitment", u._h)
+
+    def setInstance(self, pkey, w, wp, s=None):
+        width = len(pkey) // 2
+        self._keep = [w, wp, s]
+        self._call("set_instance", self.G.enc_els(pkey), C.c_size_t(width), _ptr_array(w), _ptr_array(wp),
+                   _ptr_array(s) if s is not None else None)
+
+    def commit(self):
+        return self._commit()
+
+    def computeAF(self):
+        self._call("compute_af")
+
+    def setCommitment(self, msg):
+        self._com = self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
+        self._call("set_commitment", self._com._h)
+
+    def verify(self, reply) -> bool:
+        m = self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
+        verdict = C.c_int(0)
+        five = (C.c_int * 5)()
+        self._call("verify", m._h, C.byref(verdict), five)
+        self.verdicts = tuple(bool(x) for x in five)
+        return bool(verdict.value)
+
+
+class PoSCBasicTW(_NativeProof):
+    """``vmn_posc_*`` — ref: hvzk/PoSCBasicTW.java."""
+    _prefix = "posc"
+    _com_keys = ("B", "Ap", "Bp", "Cp", "Dp")
+    _com_scalar = ("Ap", "Cp", "Dp")
+    _com_kinds = (GARRAY, ELEMENTS, GARRAY, ELEMENTS, ELEMENTS)
+    _rep_keys = ("k_A", "k_B", "k_C", "k_D", "k_E")
+    _rep_scalar = ("k_A", "k_C", "k_D")
+    _rep_kinds = (RING, RARRAY, RING, RING, RARRAY)
+
+    def setInstance(self, g, h, u, r=None, pi=None):
+        self._keep = [h, u, r]
+        ptr, keep = _u32_array(pi) if pi is not None else (None, None)
+        self._call("set_instance", self.G.enc_el(g), h._h, u._h, r._h if r is not None else None, ptr)
+
+    def commit(self):
+        return self._commit()
+
+    def setCommitment(self, msg):
+        self._com = self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
+        self._call("set_commitment", self._com._h)
+
+    def verify(self, reply) -> bool:
+        m = self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
+        verdict = C.c_int(0)
+        self._call("verify", m._h, C.byref(verdict))
+        return bool(verdict.value)
+
+
+class CCPoSBasicW(_NativeProof):
+    """``vmn_ccpos_*`` — ref: hvzk/CCPoSBasicW.java."""
+    _prefix = "ccpos"
+    _com_keys = ("Ap", "Bp")
+    _com_scalar = ("Ap",)
+    _com_kinds = (ELEMENTS, ELEMENTS)
+    _rep_keys = ("k_A", "k_B", "k_E")
+    _rep_scalar = ("k_A",)
+    _rep_kinds = (RING, RING, RARRAY)
+
+    def setInstance(self, g, h, u, pkey, w, wp, r=None, pi=None, s=None):
+        width = len(pkey) // 2
+        self._keep = [h, u, w, wp, r, s]
+        ptr, keep = _u32_array(pi) if pi is not None else (None, None)
+        self._call("set_instance", self.G.enc_el(g), h._h, u._h, self.G.enc_els(pkey), C.c_size_t(width), _ptr_array(w),
+                   _ptr_array(wp), r._h if r is not None else None, ptr, _ptr_array(s) if s is not None else None)
+
+    def commit(self):
+        return self._commit()
+
+    def setCommitment(self, msg):
+        self._com = self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
+        self._call("set_commitment", self._com._h)
+
+    def computeAB(self, raisedu=None):
+        self._call("compute_ab", raisedu._h if raisedu is not None else None)
+
+    def verify(self, reply, raisedh=None, raisedExponent: Optional[int] = None) -> bool:
+        m = self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
+        verdict = C.c_int(0)
+        if raisedExponent is None:
+            self._call("verify", m._h, None, None, C.c_size_t(0), C.byref(verdict))
+        else:
+            rho = _be(raisedExponent)
+            self._call("verify", m._h, raisedh._h, rho, C.c_size_t(len(rho)), C.byref(verdict))
+        return bool(verdict.value)
+
+
+# ---- shuffler lines (the signatures of mixnet.py) -----------------------------------------------------------------
+def reencrypt_native(group, pkey, w, s, pi):
+    """``vmn_shuffle_reencrypt``: w' = permute(w * pk^s, pi^-1) in one call (factors are freed inside)."""
+    width = len(pkey) // 2
+    out = (C.c_void_p * (2 * width))()
+    ptr, keep = _u32_array(pi)
+    _check(plib().vmn_shuffle_reencrypt(group._h, group.enc_els(pkey), C.c_size_t(width), _ptr_array(w), _ptr_array(s), ptr, out))
+    return [PGroupElementArray(group, C.c_void_p(h)) for h in out]
+
+
+def permutation_commitment_native(group, g, h, r, pi):
+    """``vmn_permutation_commitment``: u = permute(h * g^r, pi)."""
+    out = C.c_void_p()
+    ptr, keep = _u32_array(pi)
+    _check(plib().vmn_permutation_commitment(group._h, group.enc_el(g), h._h, r._h, ptr, C.byref(out)))
+    return PGroupElementArray(group, out)
