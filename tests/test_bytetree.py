@@ -88,3 +88,68 @@ def test_arrays_cross_the_boundary_as_byte_trees(bits, width, vmn, gpu_ctx, eio)
     with pytest.raises(ValueError):
         G.toElementArrayFromByteTree(bytes(bad))
     assert G.toElementArrayFromByteTree(eio.encode([])).size() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [1, 2])
+def test_proof_messages_cross_the_wire_as_byte_trees(width, vmn, gpu_ctx, eio, entry):
+    """The C++ PoS prover's commitment and reply in the reference's order and framing (PoSBasicTW.java:694-699,
+    880-886): the native byte tree equals the one built on the host from the same values; parsed back, the verifier
+    accepts it; malformed bytes are reported (format_ok = 0), not fatal."""
+    from tape import Tape
+    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.native", os.path.join(entry.PKG_DIR, "native.py"))
+    nat = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = nat
+    spec.loader.exec_module(nat)
+    grp, _ = load_golden(512)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    nb = 65                                                   # Java width (sign byte) as in the fixture
+    G = vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=nb)
+    n, NV, NE, NR = 21, 100, 100, 50
+    t = Tape(b"wire", q)
+    h = [pow(g, x, p) for x in t.ring_array(n)]
+    y = pow(g, t.ring_element(), p)
+    pkey = [g] * width + [y] * width
+    w = [[pow(g, x, p) for x in t.ring_array(n)] for _ in range(2 * width)]
+    pi = t.permutation(n)
+    s = [t.ring_array(n) for _ in range(width)]
+    e = t.int_array(n, NE)
+    v = t.int_array(1, NV)[0]
+    H, W, S = G.toElementArray(h), [G.toElementArray(c) for c in w], [G.ringArray(c) for c in s]
+    pr = nat.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"wire-prover", q))
+    pr.precompute(g, H, pi)
+    WP = nat.reencrypt_native(G, pkey, W, S, pi)
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    el = lambda x: eio.int_leaf(x, nb)
+    arr = lambda a: [el(x) for x in a.toInts()]
+    ciph = lambda xs: [el(xs[0]), el(xs[1])] if width == 1 else [[el(x) for x in xs[:width]], [el(x) for x in xs[width:]]]
+    ring = lambda xs: el(xs[0]) if width == 1 else [el(x) for x in xs]
+    want_com = eio.encode([arr(com["B"]), el(com["Ap"]), arr(com["Bp"]), el(com["Cp"]), el(com["Dp"]), ciph(com["Fp"])])
+    want_rep = eio.encode([el(rep["k_A"]), arr(rep["k_B"]), el(rep["k_C"]), el(rep["k_D"]), arr(rep["k_E"]), ring(rep["k_F"])])
+    com_bt, rep_bt = com.native.toByteTree(), rep.native.toByteTree()
+    assert com_bt == want_com and rep_bt == want_rep
+    # receiving side: parse, verify
+    com_in = nat.Message.fromByteTree(G, com_bt, nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width])
+    rep_in = nat.Message.fromByteTree(G, rep_bt, nat.PoSBasicTW._rep_kinds, [1, n, 1, 1, n, width])
+    assert com_in is not None and rep_in is not None
+    ver = nat.PoSBasicTW(G, NV, NE, NR)
+    ver.precompute(g, H)
+    ver.setPermutationCommitment(pr.u)
+    ver.setInstance(pkey, W, WP)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver._com = com_in
+    ver._call("set_commitment", com_in._h)
+    ver.setChallenge(v)
+    verdict = __import__("ctypes").c_int(0)
+    ver._call("verify", rep_in._h, __import__("ctypes").byref(verdict), None)
+    assert verdict.value == 1
+    # malformed input: truncated, wrong layout, an element >= p
+    assert nat.Message.fromByteTree(G, com_bt[:-1], nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width]) is None
+    assert nat.Message.fromByteTree(G, com_bt, nat.PoSBasicTW._com_kinds, [n + 1, 1, n, 1, 1, 2 * width]) is None
+    assert nat.Message.fromByteTree(G, rep_bt, nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width]) is None
+    bad = bytearray(com_bt)
+    bad[5 + 5 + 5:5 + 5 + 5 + nb] = eio.int_leaf(p, nb)         # B_0 := p
+    assert nat.Message.fromByteTree(G, bytes(bad), nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width]) is None

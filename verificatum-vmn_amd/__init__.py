@@ -154,9 +154,15 @@ class ModPGroup:
                                            int_to_be(g, self.nbytes), C.c_size_t(self.nbytes), C.byref(self._h)))
 
     def close(self) -> None:
-        if self._h:
+        # the garbage collector may finalise a context before the groups / arrays that were created on it
+        # (cycles, interpreter shutdown): native objects of a closed context are gone with it, never touch them
+        if self._h and self.ctx._h:
             lib().vmn_group_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
+
+    @property
+    def alive(self) -> bool:
+        return bool(self._h) and bool(self.ctx._h)
 
     def __del__(self):
         try:
@@ -328,7 +334,7 @@ class _ArrayBase:
     _borrowed = False      # True: the handle belongs to a vmn_msg / proof object (native.py); free() is a no-op
 
     def free(self) -> None:
-        if self._h and not self._borrowed:
+        if self._h and not self._borrowed and self.group.alive:
             getattr(lib(), self._free_fn)(self._h)
         self._h = C.c_void_p()
 

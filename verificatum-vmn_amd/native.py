@@ -49,37 +49,45 @@ class RandomSource:
     big-endian blocks) to ``vmn_random_source``.  Buffers stay alive until the next call, as the ABI requires."""
 
     def __init__(self, group, tape):
-        self.group, self.tape = group, tape
-        self._keep = None
-        self.error = None
+        # the callbacks close over this small state object only (no reference back to the RandomSource or to the
+        # group: a reference cycle would hand finalisation order to the garbage collector)
+        class _State:
+            keep = None
+            error = None
+        st = self._state = _State()
+        st.tape = tape
+        q, nbytes = group.q, group.nbytes
 
         def hand_over(vals, out):
             if isinstance(vals, (bytes, bytearray)):
                 rows = bytes(vals)                     # big-endian block of the wire width (bulk sources): no copy
             else:
-                q = group.q
-                rows = b"".join(int(x % q).to_bytes(group.nbytes, "big") for x in vals)
-            self._keep = rows                          # valid until the next call
+                rows = b"".join(int(x % q).to_bytes(nbytes, "big") for x in vals)
+            st.keep = rows                             # valid until the next call
             out[0] = C.cast(C.c_char_p(rows), C.c_void_p).value
 
         def ring_cb(_user, n, out):
             try:
-                hand_over([self.tape.ring_element()] if n == 1 else self.tape.ring_array(n), out)
+                hand_over([st.tape.ring_element()] if n == 1 else st.tape.ring_array(n), out)
                 return 0
             except Exception as exc:       # pragma: no cover - re-raised by the caller
-                self.error = exc
+                st.error = exc
                 return 1
 
         def ints_cb(_user, n, bits, out):
             try:
-                hand_over(self.tape.int_array(n, bits), out)
+                hand_over(st.tape.int_array(n, bits), out)
                 return 0
             except Exception as exc:       # pragma: no cover
-                self.error = exc
+                st.error = exc
                 return 1
 
         self._cbs = (_ROWS_CB(ring_cb), _INTS_CB(ints_cb))
         self.struct = _RandomSourceStruct(None, self._cbs[0], self._cbs[1])
+
+    @property
+    def error(self):
+        return self._state.error
 
 
 class Message:
@@ -90,9 +98,9 @@ class Message:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and self.group.alive:
                 plib().vmn_msg_free(self._h)
-                self._h = None
+            self._h = None
         except Exception:
             pass
 
@@ -197,9 +205,9 @@ class _NativeProof:
         _check(rc)
 
     def free(self):
-        if self._h:
+        if self._h and self.G.alive:
             self._fn("free")(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
