@@ -38,6 +38,21 @@ def _u32_array(seq):
     arr = (C.c_uint32 * len(seq))(*seq)
     return arr, arr
 
+def host_block(values):
+    """(pointer argument, byte length, keep-alive) of a block of big-endian rows handed in as ``bytes`` or as a
+    host buffer object (a pinned ``torch`` tensor or a numpy array of uint8): the latter cross without a copy and,
+    when page-locked, upload asynchronously at PCIe speed."""
+    if isinstance(values, (bytes, bytearray)):
+        b = bytes(values)
+        return b, len(b), b
+    if hasattr(values, "data_ptr"):                          # torch tensor (host)
+        return C.c_void_p(values.data_ptr()), values.numel() * values.element_size(), values
+    if _np is not None and isinstance(values, _np.ndarray) and values.dtype == _np.uint8:
+        arr = _np.ascontiguousarray(values)
+        return C.c_void_p(arr.ctypes.data), arr.size, arr
+    return None
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvmnhip.so")
 
@@ -202,12 +217,12 @@ class ModPGroup:
 
     # -- constructors mirroring pGroup.toElementArray / pRing.toElementArray --------------------
     def toElementArray(self, values, checked: bool = True) -> "PGroupElementArray":
-        """values: sequence of ints, or bytes of n*nbytes big-endian."""
-        buf = values if isinstance(values, (bytes, bytearray)) else ints_to_be(values, self.nbytes)
-        n = len(buf) // self.nbytes
+        """values: sequence of ints, or a block of n*nbytes big-endian bytes (bytes / pinned tensor / uint8 array)."""
+        blk = host_block(values) or host_block(ints_to_be(values, self.nbytes))
+        n = blk[1] // self.nbytes
         h = C.c_void_p()
         ok = C.c_int(1)
-        _check(lib().vmn_garray_from_be(self._h, bytes(buf), C.c_size_t(n), C.byref(h), C.byref(ok)))
+        _check(lib().vmn_garray_from_be(self._h, blk[0], C.c_size_t(n), C.byref(h), C.byref(ok)))
         arr = PGroupElementArray(self, h)
         arr.all_in_range = bool(ok.value)
         if checked and not ok.value:
@@ -216,11 +231,11 @@ class ModPGroup:
         return arr
 
     def ringArray(self, values, checked: bool = True) -> "PRingElementArray":
-        buf = values if isinstance(values, (bytes, bytearray)) else ints_to_be(values, self.nbytes)
-        n = len(buf) // self.nbytes
+        blk = host_block(values) or host_block(ints_to_be(values, self.nbytes))
+        n = blk[1] // self.nbytes
         h = C.c_void_p()
         ok = C.c_int(1)
-        _check(lib().vmn_rarray_from_be(self._h, bytes(buf), C.c_size_t(n), C.byref(h), C.byref(ok)))
+        _check(lib().vmn_rarray_from_be(self._h, blk[0], C.c_size_t(n), C.byref(h), C.byref(ok)))
         arr = PRingElementArray(self, h)
         if checked and not ok.value:
             arr.free()
@@ -311,11 +326,11 @@ class ECqPGroup(ModPGroup):
         return self._ec.neg(a, self.p)
 
     def toElementArray(self, values, checked: bool = True) -> "PGroupElementArray":
-        buf = values if isinstance(values, (bytes, bytearray)) else self.enc_els(values)
-        n = len(buf) // self.elem_bytes
+        blk = host_block(values) or host_block(self.enc_els(values))
+        n = blk[1] // self.elem_bytes
         h = C.c_void_p()
         ok = C.c_int(1)
-        _check(lib().vmn_garray_from_be(self._h, bytes(buf), C.c_size_t(n), C.byref(h), C.byref(ok)))
+        _check(lib().vmn_garray_from_be(self._h, blk[0], C.c_size_t(n), C.byref(h), C.byref(ok)))
         arr = PGroupElementArray(self, h)
         arr.all_in_range = bool(ok.value)
         if checked and not ok.value:

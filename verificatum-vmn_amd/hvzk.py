@@ -51,7 +51,8 @@ def _inv_perm(pi):
 
 
 def _is_bytes(x) -> bool:
-    return isinstance(x, (bytes, bytearray))
+    """A block of big-endian rows (bytes, or a host buffer object such as a pinned tensor) rather than integers."""
+    return isinstance(x, (bytes, bytearray)) or hasattr(x, "data_ptr") or hasattr(x, "ctypes")
 
 
 class _Base:

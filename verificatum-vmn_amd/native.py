@@ -14,7 +14,7 @@ import ctypes as C
 import os
 from typing import Optional, Sequence
 
-from . import (PGroupElementArray, PRingElementArray, VmnError, _check, _u32_array, int_to_be, lib)
+from . import (PGroupElementArray, PRingElementArray, VmnError, _check, _u32_array, host_block, int_to_be, lib)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvmnproofs.so")
@@ -59,12 +59,11 @@ class RandomSource:
         q, nbytes = group.q, group.nbytes
 
         def hand_over(vals, out):
-            if isinstance(vals, (bytes, bytearray)):
-                rows = bytes(vals)                     # big-endian block of the wire width (bulk sources): no copy
-            else:
-                rows = b"".join(int(x % q).to_bytes(nbytes, "big") for x in vals)
-            st.keep = rows                             # valid until the next call
-            out[0] = C.cast(C.c_char_p(rows), C.c_void_p).value
+            blk = host_block(vals)                     # a block of rows of the wire width (bulk sources): no copy
+            if blk is None:
+                blk = host_block(b"".join(int(x % q).to_bytes(nbytes, "big") for x in vals))
+            st.keep = blk[2]                           # valid until the next call
+            out[0] = blk[0].value if isinstance(blk[0], C.c_void_p) else C.cast(C.c_char_p(blk[0]), C.c_void_p).value
 
         def ring_cb(_user, n, out):
             try:
@@ -246,8 +245,8 @@ class _NativeProof:
         return ([val] if scalar else list(val)) == item
 
     def setBatchVector(self, e_ints):
-        buf = bytes(e_ints) if isinstance(e_ints, (bytes, bytearray)) else b"".join(int_to_be(x, self.G.nbytes) for x in e_ints)
-        self._call("set_batch_vector", buf)
+        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
+        self._call("set_batch_vector", blk[0])
 
     def setChallenge(self, v: int):
         b = _be(v)
