@@ -6,7 +6,7 @@
 
 #include <string>
 
-#include "../verificatum-vmn_amd/csrc/hostnum64.h"
+#include "../verificatum-vmn_amd/csrc/hostcurve.h"
 
 using namespace vmn::num64;
 
@@ -23,7 +23,28 @@ static void print(const Num& a, size_t nbytes) {
     printf("\n");
 }
 
+static void print_bytes(const Bytes& b) {
+    for (uint8_t c : b) printf("%02x", c);
+    printf("\n");
+}
+
+// "ec p a b e": a, b = points as x||y hex (all ff = infinity); prints a^e, a*b, a^-1 in the same encoding
+static int ec_main(char** argv) {
+    Bytes pb = from_hex(argv[2]), a = from_hex(argv[3]), b = from_hex(argv[4]), e = from_hex(argv[5]);
+    size_t nl = (pb.size() + 7) / 8;
+    Mod F(from_be(pb.data(), pb.size(), nl));
+    HostCurve C;
+    C.F = &F;
+    C.cb = pb.size();
+    C.fl = nl;
+    print_bytes(C.exp(a, e.data(), e.size()));
+    print_bytes(C.add(a, b));
+    print_bytes(C.negate(a));
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 6 && !strcmp(argv[1], "ec")) return ec_main(argv);
     if (argc != 5) return 2;
     Bytes nb = from_hex(argv[1]), ab = from_hex(argv[2]), bb = from_hex(argv[3]), eb = from_hex(argv[4]);
     size_t nl = (nb.size() + 7) / 8, nbytes = nb.size();

@@ -37,3 +37,25 @@ def test_order_of_p256_and_edge_values(harness):
     for a, b, e in [(1, 0, 0), (n - 1, n - 1, n - 1), (2, 3, (1 << 612) - 1), (12345, n - 2, 1 << 300)]:
         got = run(harness, n, a, b, e)
         assert got == [a * b % n, pow(a, e, n), pow(a, -1, n), e % n, (a + b) % n, (-a) % n]
+
+
+@pytest.mark.parametrize("name", ["P-256", "P-384"])
+def test_host_curve_points_against_the_affine_reference(name, harness):
+    """csrc/hostcurve.h (single points of the C++ proof drivers) against oracle/pyref_ec.py, with the exceptional
+    cases: infinity operands, P + P, P + (-P), exponents 0, n, above n."""
+    from oracle.pyref_ec import Curve
+    c = Curve(name)
+    nb = (c.p.bit_length() + 7) // 8
+    enc = lambda P: "ff" * (2 * nb) if P is None else "%0*x%0*x" % (2 * nb, P[0], 2 * nb, P[1])
+
+    def run_ec(A, B, e):
+        out = subprocess.run([harness, "ec", "%x" % c.p, enc(A), enc(B), "%x" % e], check=True, capture_output=True, text=True).stdout.split()
+        return out
+
+    ks = pyref.stream_ints(b"hostcurve" + name.encode(), 4, c.n)
+    P, Q = c.mul(ks[0], c.g), c.mul(ks[1], c.g)
+    cases = [(P, Q, ks[2]), (P, P, 0), (P, c.neg(P), c.n), (None, Q, ks[3]), (P, None, c.n + 5), (c.g, c.g, (1 << 612) + 77),
+             (P, Q, (c.n + 1) // 2), (P, Q, c.n - 1)]
+    for A, B, e in cases:
+        got = run_ec(A, B, e)
+        assert got == [enc(c.mul(e % c.n, A) if A is not None else None), enc(c.add(A, B)), enc(c.neg(A) if A is not None else None)], (A, B, e)

@@ -20,11 +20,14 @@
 #include <string>
 #include <vector>
 
+#include "hostcurve.h"
 #include "hostnum64.h"
 
 using vmn::num64::Bytes;
 using vmn::num64::Mod;
 using vmn::num64::Num;
+
+using vmn::num64::HostCurve;
 
 namespace vmnp {
 
@@ -112,7 +115,8 @@ struct HostGroup {
     bool ec = false;
     size_t eb = 0, xb = 0;            // element / exponent bytes
     size_t ql = 0;                    // limbs of q
-    Mod Zq, Zp;                       // Zp only for ModPGroup
+    Mod Zq, Zp;                       // Z_q scalars; Z_p = the modulus (ModPGroup) or the coordinate field (curves)
+    HostCurve curve;
     int qbits = 0;
     Bytes g;
 
@@ -127,7 +131,10 @@ struct HostGroup {
         TRY(vmn_group_get_modulus(grp, pb.data()));
         Zq = Mod(vmn::num64::from_be(qb.data(), xb, ql));
         qbits = vmn::num64::bit_length(Zq.n);
-        if (!ec) Zp = Mod(vmn::num64::from_be(pb.data(), xb, ql));
+        Zp = Mod(vmn::num64::from_be(pb.data(), xb, ql));
+        curve.F = &Zp;                 // (HostGroup objects are not copied after init)
+        curve.cb = xb;
+        curve.fl = ql;
         g.resize(eb);
         TRY(vmn_group_get_generator(grp, g.data()));
         return VMN_OK;
@@ -145,52 +152,42 @@ struct HostGroup {
         return o;
     }
     int el_exp(const Bytes& base, const uint8_t* e_be, size_t ebytes, Bytes& out) const {
-        if (!ec) {
-            Num b = vmn::num64::from_be(base.data(), eb, ql);
-            out = vmn::num64::to_bytes(Zp.pow(b, e_be, ebytes), eb);
+        if (ec) {
+            out = curve.exp(base, e_be, ebytes);
             return VMN_OK;
         }
-        GA x, r;
-        int ok = 1;
-        TRY(vmn_garray_from_be(grp, base.data(), 1, x.out(), &ok));
-        if (!ok) return fail(VMN_ERR_FORMAT, "group element not on the curve");
-        Bytes zero(1, 0);
-        bool any = false;
-        for (size_t i = 0; i < ebytes; ++i) any = any || e_be[i];
-        TRY(vmn_garray_exp_scalar(x, any ? e_be : zero.data(), any ? ebytes : 1, r.out()));
-        out.resize(eb);
-        return vmn_garray_get(r, 0, out.data());
+        Num b = vmn::num64::from_be(base.data(), eb, ql);
+        out = vmn::num64::to_bytes(Zp.pow(b, e_be, ebytes), eb);
+        return VMN_OK;
     }
     int el_exp(const Bytes& base, const Num& e, Bytes& out) const {
         Bytes eb_ = ring_bytes(e);
         return el_exp(base, eb_.data(), eb_.size(), out);
     }
     int el_mul(const Bytes& a, const Bytes& b, Bytes& out) const {
-        if (!ec) {
-            out = vmn::num64::to_bytes(Zp.mul(vmn::num64::from_be(a.data(), eb, ql), vmn::num64::from_be(b.data(), eb, ql)), eb);
+        if (ec) {
+            out = curve.add(a, b);
             return VMN_OK;
         }
-        Bytes both(a);
-        both.insert(both.end(), b.begin(), b.end());
-        GA x;
-        int ok = 1;
-        TRY(vmn_garray_from_be(grp, both.data(), 2, x.out(), &ok));
-        if (!ok) return fail(VMN_ERR_FORMAT, "group element not on the curve");
-        out.resize(eb);
-        return vmn_garray_prod(x, out.data());
+        out = vmn::num64::to_bytes(Zp.mul(vmn::num64::from_be(a.data(), eb, ql), vmn::num64::from_be(b.data(), eb, ql)), eb);
+        return VMN_OK;
     }
     int el_inv(const Bytes& a, Bytes& out) const {
-        if (!ec) {
-            out = vmn::num64::to_bytes(Zp.inv(vmn::num64::from_be(a.data(), eb, ql)), eb);
+        if (ec) {
+            out = curve.negate(a);
             return VMN_OK;
         }
-        GA x, r;
-        int ok = 1;
-        TRY(vmn_garray_from_be(grp, a.data(), 1, x.out(), &ok));
-        if (!ok) return fail(VMN_ERR_FORMAT, "group element not on the curve");
-        TRY(vmn_garray_inv(x, r.out()));
-        out.resize(eb);
-        return vmn_garray_get(r, 0, out.data());
+        out = vmn::num64::to_bytes(Zp.inv(vmn::num64::from_be(a.data(), eb, ql)), eb);
+        return VMN_OK;
+    }
+    // Single elements that arrive from outside (a commitment's A', C', ...) are validated by the GPU import:
+    // range / on-curve.  *ok = 0 when one of them is not a group element encoding.
+    int check_elements(const std::vector<const Bytes*>& els, int* ok) const {
+        Bytes flat;
+        for (const Bytes* e : els) flat.insert(flat.end(), e->begin(), e->end());
+        GA x;
+        *ok = 1;
+        return vmn_garray_from_be(grp, flat.data(), els.size(), x.out(), ok);
     }
     int el_div(const Bytes& a, const Bytes& b, Bytes& out) const {
         Bytes bi;
@@ -546,6 +543,14 @@ struct vmn_pos : ProofBase {
         cCp = iCp->bytes;
         cDp = iDp->bytes;
         cFp = split(*iFp);
+        std::vector<const Bytes*> els{&cAp, &cCp, &cDp};
+        for (auto& f : cFp) els.push_back(&f);
+        int ok = 1;
+        TRY(G.check_elements(els, &ok));
+        if (!ok) {
+            cB = nullptr;
+            return fail(VMN_ERR_FORMAT, "commitment holds a value that is not a group element");
+        }
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, int* verdict, int* five) {
@@ -704,6 +709,12 @@ struct vmn_posc : ProofBase {
         cAp = iAp->bytes;
         cCp = iCp->bytes;
         cDp = iDp->bytes;
+        int ok = 1;
+        TRY(G.check_elements({&cAp, &cCp, &cDp}, &ok));
+        if (!ok) {
+            cB = nullptr;
+            return fail(VMN_ERR_FORMAT, "commitment holds a value that is not a group element");
+        }
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, int* verdict) {
@@ -847,6 +858,11 @@ struct vmn_ccpos : ProofBase {
                     iBp->width == G.eb, "commitment is not (A', B')");
         cAp = iAp->bytes;
         cBp = split(*iBp);
+        std::vector<const Bytes*> els{&cAp};
+        for (auto& f : cBp) els.push_back(&f);
+        int ok = 1;
+        TRY(G.check_elements(els, &ok));
+        if (!ok) return fail(VMN_ERR_FORMAT, "commitment holds a value that is not a group element");
         have_commitment = true;
         return VMN_OK;
     }
