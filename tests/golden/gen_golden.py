@@ -100,7 +100,7 @@ def cases_for(bits, sizes):
 
 
 def main():
-    plan = {512: [1, 2, 7, 65], 1024: [5, 64], 2048: [1, 2, 5, 63, 64], 3072: [1, 5, 33]}
+    plan = {512: [1, 2, 7, 65], 1024: [5, 64], 2048: [1, 2, 5, 63, 64], 3072: [1, 5, 33], 4096: [1, 5, 19]}
     for bits, sizes in plan.items():
         rec = cases_for(bits, sizes)
         path = os.path.join(HERE, f"modp{bits}.json")

@@ -54,11 +54,11 @@ def test_unsupported_modulus_size_is_a_status_not_a_crash(vmn, gpu_ctx, eio):
     p, q, g, _, width = eio.unmarshal_modpgroup(fixture_bytes())
     with pytest.raises(vmn.VmnError) as ei:
         vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=width)
-    assert ei.value.status == -5                                   # VMN_ERR_UNSUPPORTED (15 492 bits > 3072)
+    assert ei.value.status == -5                                   # VMN_ERR_UNSUPPORTED (15 492 bits > 4096)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bits,width", [(512, 65), (2048, 257), (3072, 385)])
+@pytest.mark.parametrize("bits,width", [(512, 65), (2048, 257), (3072, 385), (4096, 513)])
 def test_arrays_cross_the_boundary_as_byte_trees(bits, width, vmn, gpu_ctx, eio):
     """Width = Java's BigInteger.toByteArray length of the modulus (sign byte included), as in the fixture."""
     grp, _ = load_golden(bits)

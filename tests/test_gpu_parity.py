@@ -11,13 +11,13 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def groups(vmn, gpu_ctx):
     out = {}
-    for bits in (512, 1024, 2048, 3072):
+    for bits in (512, 1024, 2048, 3072, 4096):
         grp, cases = load_golden(bits)
         out[bits] = (vmn.ModPGroup(gpu_ctx, grp["p"], grp["q"], grp["g"]), grp, cases)
     return out
 
 
-@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072])
+@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072, 4096])
 def test_golden_vectors_through_c_abi(bits, groups):
     G, grp, cases = groups[bits]
     for c in cases:
@@ -68,10 +68,10 @@ def _inputs(tag, n, p, q):
     return xs, es
 
 
-@pytest.mark.parametrize("bits,n", [(2048, 257), (2048, 5000), (3072, 129), (3072, 1500)])
+@pytest.mark.parametrize("bits,n", [(2048, 257), (2048, 5000), (3072, 129), (3072, 1500), (4096, 131), (4096, 700)])
 def test_seeded_arrays_against_gmp_oracle(bits, n, groups, oracle_for):
     """Ragged sizes (not multiples of the workgroup tile) against the GMP oracle, element for element;
-    3072 bits exercises the two-lanes-per-element kernels."""
+    3072 bits exercises the two-lanes-per-element kernels, 4096 bits the four-lane ones."""
     G, grp, _ = groups[bits]
     p, q, g = grp["p"], grp["q"], grp["g"]
     orc = oracle_for(p, q)

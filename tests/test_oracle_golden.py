@@ -5,7 +5,7 @@ from conftest import ints, load_golden
 from oracle import pyref
 
 
-@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072])
+@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072, 4096])
 def test_groups_are_safe_prime_groups(bits):
     grp, _ = load_golden(bits)
     p, q, g = grp["p"], grp["q"], grp["g"]
@@ -20,7 +20,7 @@ def test_rfc3526_group14_constant_matches_pi_formula():
     assert pyref.rfc_modp_prime(2048) == pyref.RFC3526_14_P
 
 
-@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072])
+@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072, 4096])
 def test_c_oracle_matches_golden(bits, oracle_for):
     grp, cases = load_golden(bits)
     p, q = grp["p"], grp["q"]

@@ -135,14 +135,21 @@ def gen(S: int) -> str:
 PAIR_P0, PAIR_PT, PAIR_C = 2, 4, 6      # v[2:3] column 0, v[4:5] column L-1, v[6:7] c
 
 
-def _row_pair(L: int, first: bool):
+def _row_pair(L: int, first: bool, lanes: int = 2):
+    """lanes = 2: the pair row described above.  lanes = 4 (moduli > 3080 bits): lane h = lane & 3 holds columns
+    [h*L, (h+1)*L); m is taken from lane 0 of the quad (quad_perm [0,0,0,0]); every lane hands its c to the lane
+    below (quad_perm [1,2,3,3]; the top lane receives the fresh zero); only lane 0 carries c >> 28 into its new
+    column 0.  Two masks: LOW = all ones on lane 0 of the element, NOTTOP = all ones on every lane but the last."""
     P = lambda j: f"%{j}"                 # 0..L-1      u64
     M = f"%{L}"                           # m
     A = lambda j: f"%{L + 2 + j}"         # a[j]
     B = f"%{2 * L + 2}"                   # b
     N = lambda j: f"%{2 * L + 3 + j}"     # N[j] (VGPR: differs between the lanes of a pair)
     NI = f"%{3 * L + 3}"                  # n0inv (SGPR)
-    EM = f"%{3 * L + 4}"                  # even-lane mask (0xffffffff on even lanes, 0 on odd lanes)
+    EM = f"%{3 * L + 4}"                  # LOW mask: 0xffffffff on lane 0 of the element (pair: the even lane)
+    NT = f"%{3 * L + 5}"                  # NOTTOP mask: 0xffffffff on all lanes but the last (pair: the even lane)
+    bcast = "[0,0,2,2]" if lanes == 2 else "[0,0,0,0]"
+    from_above = "[1,1,3,3]" if lanes == 2 else "[1,2,3,3]"
     C = f"%{L + 1}"
     MASK = "0xfffffff"
     out = []
@@ -162,7 +169,7 @@ def _row_pair(L: int, first: bool):
     ab(3)
     ab(4)
     out.append("s_nop 1")
-    out.append(f"v_mov_b32_dpp {M}, {M} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+    out.append(f"v_mov_b32_dpp {M}, {M} quad_perm:{bcast} row_mask:0xf bank_mask:0xf")
     ab(5)
     ab(6)
     out.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
@@ -174,27 +181,27 @@ def _row_pair(L: int, first: bool):
             pass
     # column L-1 was consumed by the last pass-2 multiply-add; now refill it from c
     out.append("s_nop 1")
-    out.append(f"v_mov_b32_dpp v{PAIR_PT}, v{PAIR_C} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
-    out.append(f"v_mov_b32_dpp v{PAIR_PT + 1}, v{PAIR_C + 1} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
+    out.append(f"v_mov_b32_dpp v{PAIR_PT}, v{PAIR_C} quad_perm:{from_above} row_mask:0xf bank_mask:0xf")
+    out.append(f"v_mov_b32_dpp v{PAIR_PT + 1}, v{PAIR_C + 1} quad_perm:{from_above} row_mask:0xf bank_mask:0xf")
     out.append(f"v_lshrrev_b64 {C}, 28, {C}")
-    out.append(f"v_and_b32 v{PAIR_PT}, {EM}, v{PAIR_PT}")
-    out.append(f"v_and_b32 v{PAIR_PT + 1}, {EM}, v{PAIR_PT + 1}")
+    out.append(f"v_and_b32 v{PAIR_PT}, {NT}, v{PAIR_PT}")
+    out.append(f"v_and_b32 v{PAIR_PT + 1}, {NT}, v{PAIR_PT + 1}")
     out.append(f"v_and_b32 v{PAIR_C}, {EM}, v{PAIR_C}")
     out.append(f"v_and_b32 v{PAIR_C + 1}, {EM}, v{PAIR_C + 1}")
     out.append(f"v_lshl_add_u64 {P(0)}, {P(0)}, 0, {C}")
     return out
 
 
-def gen_pair(S: int) -> str:
-    L = S // 2
-    assert 2 * L == S and L >= 8
+def gen_pair(S: int, lanes: int = 2) -> str:
+    L = S // lanes
+    assert lanes * L == S and L >= 8
     parts = []
     for first in (True, False):
-        name = f"mont_pair_row_asm_{'first' if first else 'next'}"
-        lines = _row_pair(L, first)
+        name = f"mont_lanes_row_asm_{'first' if first else 'next'}"
+        lines = _row_pair(L, first, lanes)
         o = []
-        o.append(f"template <> __device__ __forceinline__ void {name}<{L}>(u64 (&P)[{L}], const u32 (&a)[{L}], u32 b,\n"
-                 f"        const u32 (&n)[{L}], u32 n0inv, u32 evenmask) {{")
+        o.append(f"template <> __device__ __forceinline__ void {name}<{L}, {lanes}>(u64 (&P)[{L}], const u32 (&a)[{L}], u32 b,\n"
+                 f"        const u32 (&n)[{L}], u32 n0inv, u32 lowmask, u32 nottopmask) {{")
         o.append("    u32 m; u64 c;")
         o.append("    asm volatile(")
         for l in lines:
@@ -209,7 +216,7 @@ def gen_pair(S: int) -> str:
             return pre + "v"
         outs = ", ".join([f'"{cons(j)}"(P[{j}])' for j in range(L)] + ['"=&v"(m)', '"=&{v[%d:%d]}"(c)' % (PAIR_C, PAIR_C + 1)])
         ins = ", ".join([f'"v"(a[{j}])' for j in range(L)] + ['"v"(b)'] + [f'"v"(n[{j}])' for j in range(L)]
-                        + ['"s"(n0inv)', '"v"(evenmask)'])
+                        + ['"s"(n0inv)', '"v"(lowmask)', '"v"(nottopmask)'])
         o.append(f"        : {outs}")
         o.append(f"        : {ins}")
         o.append('        : "vcc");')
@@ -219,7 +226,7 @@ def gen_pair(S: int) -> str:
     return "\n".join(parts)
 
 
-def render(sizes, pair_sizes=()) -> str:
+def render(sizes, pair_sizes=(), quad_sizes=()) -> str:
     parts = ["// GENERATED by tools/gen_mont_asm.py " + " ".join(map(str, sizes)) + " -- do not edit.",
              "// One Montgomery row as a single asm statement: 2*S v_mad_u64_u32 + 5 VALU, see the generator."]
     for S in sizes:
@@ -227,14 +234,18 @@ def render(sizes, pair_sizes=()) -> str:
     for S in pair_sizes:
         parts.append(f"// two lanes per element, S = {S} limbs ({S // 2} per lane)")
         parts.append(gen_pair(S))
+    for S in quad_sizes:
+        parts.append(f"// four lanes per element, S = {S} limbs ({S // 4} per lane)")
+        parts.append(gen_pair(S, 4))
     return "\n".join(parts) + "\n"
 
 
 def main():
     args = sys.argv[1:]
     pair = [int(x[1:]) for x in args if x.startswith("p")]
-    sizes = [int(x) for x in args if not x.startswith("p")] or [74]
-    sys.stdout.write(render(sizes, pair))
+    quad = [int(x[1:]) for x in args if x.startswith("q")]
+    sizes = [int(x) for x in args if x[0].isdigit()] or [74]
+    sys.stdout.write(render(sizes, pair, quad))
 
 
 if __name__ == "__main__":

@@ -13,6 +13,9 @@
 //            architectural VGPRs).  The lanes of a pair exchange the reduction factor and one column
 //            per row through DPP (mont28.h / the generator).  In memory a lane's share is LW = 56
 //            words (16-byte aligned), W = 2*LW.
+//   LPE = 4  four lanes per element (4096-bit moduli, S = 148, L = 37: two lanes would need 4*74 = 296
+//            VGPRs).  Same scheme inside a quad of lanes (quad_perm DPP); carries / borrows cross the
+//            three lane boundaries by repeated sweeps.
 #pragma once
 #include "mont28.h"
 
@@ -37,20 +40,35 @@ struct Cfg {
 template <class C>
 struct Lane {
     int eslot;        // element slot within the workgroup
-    int half;         // 0 .. LPE-1
-    u32 evenmask;     // LPE = 2: 0xffffffff on the even lane of a pair, 0 on the odd lane
+    int half;         // 0 .. LPE-1: which share of the element this lane holds
+    u32 lowmask;      // LPE > 1: 0xffffffff on lane 0 of the element, 0 elsewhere
+    u32 nottopmask;   // LPE > 1: 0xffffffff on every lane of the element but the last
     u32* bl;
     __device__ __forceinline__ explicit Lane(u32* lds) {
         eslot = threadIdx.x / C::LPE;
         half = threadIdx.x % C::LPE;
-        evenmask = half == 0 ? 0xffffffffu : 0u;
+        lowmask = half == 0 ? 0xffffffffu : 0u;
+        nottopmask = half == C::LPE - 1 ? 0u : 0xffffffffu;
         bl = lds + eslot;
     }
 };
 
-// value of the even / odd lane of each pair, delivered to both lanes
-__device__ __forceinline__ u32 from_even(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true); }
-__device__ __forceinline__ u32 from_odd(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true); }
+// Cross-lane moves inside an element (DPP quad_perm; elements are aligned groups of 2 or 4 lanes).
+// from_below: the value of lane h-1 (lane 0 gets its own: mask with ~lowmask); from_top: the last lane's value on all
+// lanes; or_all: OR over the element's lanes, on all lanes.
+template <int LPE>
+__device__ __forceinline__ u32 from_below(u32 x) { return lane_below<LPE>(x); }
+template <int LPE>
+__device__ __forceinline__ u32 from_top(u32 x) {
+    if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
+    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);                        // [3,3,3,3]
+}
+template <int LPE>
+__device__ __forceinline__ u32 or_all(u32 x) {
+    x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);                               // [1,0,3,2]
+    if constexpr (LPE == 4) x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);       // [2,3,0,1]
+    return x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // element movement helpers
@@ -136,14 +154,18 @@ __device__ __forceinline__ u64 carry_sweep(u32 (&out)[L], const u64 (&v)[L], u64
     }
     return c;
 }
-// Resolve lazy columns into 28-bit limbs.  Pair mode: the even lane's carry-out enters the odd lane's
-// column 0 (second sweep; the even lane repeats its sweep with carry 0 = same result).
+// Resolve lazy columns into 28-bit limbs.  Several lanes per element: a lane's carry-out enters column 0 of the
+// lane above; after sweep t the lanes 0..t are final (lane 0 repeats its sweep with carry 0 = same result), so
+// LPE sweeps settle the element.
 template <class C>
 __device__ __forceinline__ void normalize(u32 (&out)[C::L], const u64 (&T)[C::L], const Lane<C>& ln) {
     u64 c = carry_sweep<C::L>(out, T, 0);
-    if constexpr (C::LPE == 2) {
-        u32 lo = from_even((u32)c) & ~ln.evenmask, hi = from_even((u32)(c >> 32)) & ~ln.evenmask;
-        carry_sweep<C::L>(out, T, ((u64)hi << 32) | lo);
+    if constexpr (C::LPE > 1) {
+#pragma unroll
+        for (int t = 1; t < C::LPE; ++t) {
+            u32 lo = from_below<C::LPE>((u32)c) & ~ln.lowmask, hi = from_below<C::LPE>((u32)(c >> 32)) & ~ln.lowmask;
+            c = carry_sweep<C::L>(out, T, ((u64)hi << 32) | lo);
+        }
     }
 }
 // d = x - n (limbs, borrow-in bin = 0 / -1); returns borrow-out (0 / -1)
@@ -158,14 +180,17 @@ __device__ __forceinline__ int32_t borrow_sweep(u32 (&d)[L], const u32 (&x)[L], 
     }
     return borrow;
 }
-// element-wide x - n: d and the final borrow (0: x >= n, -1: x < n), identical on both lanes of a pair
+// element-wide x - n: d and the final borrow (0: x >= n, -1: x < n), identical on all lanes of the element
 template <class C>
 __device__ __forceinline__ int32_t sub_full(u32 (&d)[C::L], const u32 (&x)[C::L], const u32 (&n)[C::L], const Lane<C>& ln) {
     int32_t b = borrow_sweep<C::L>(d, x, n, 0);
-    if constexpr (C::LPE == 2) {
-        int32_t bin = (int32_t)(from_even((u32)b) & ~ln.evenmask);
-        b = borrow_sweep<C::L>(d, x, n, bin);
-        b = (int32_t)from_odd((u32)b);
+    if constexpr (C::LPE > 1) {
+#pragma unroll
+        for (int t = 1; t < C::LPE; ++t) {
+            int32_t bin = (int32_t)(from_below<C::LPE>((u32)b) & ~ln.lowmask);
+            b = borrow_sweep<C::L>(d, x, n, bin);
+        }
+        b = (int32_t)from_top<C::LPE>((u32)b);
     }
     return b;
 }
@@ -187,11 +212,14 @@ __device__ __forceinline__ void mod_add(u32 (&r)[C::L], const u32 (&a)[C::L], co
 #pragma unroll
     for (int j = 0; j < C::L; ++j) s[j] = a[j] + b[j];
     u32 cin = 0;
-    if constexpr (C::LPE == 2) {
-        u32 c = 0;
+    if constexpr (C::LPE > 1) {
 #pragma unroll
-        for (int j = 0; j < C::L; ++j) c = (c + s[j]) >> LIMB_BITS;
-        cin = from_even(c) & ~ln.evenmask;
+        for (int t = 1; t < C::LPE; ++t) {              // carry into this lane, settled from lane 0 upwards
+            u32 c = cin;
+#pragma unroll
+            for (int j = 0; j < C::L; ++j) c = (c + s[j]) >> LIMB_BITS;
+            cin = from_below<C::LPE>(c) & ~ln.lowmask;
+        }
     }
     u32 c = cin;
 #pragma unroll
@@ -210,7 +238,7 @@ __device__ __forceinline__ void mod_neg(u32 (&r)[C::L], const u32 (&a)[C::L], co
     u32 nz = 0;
 #pragma unroll
     for (int j = 0; j < C::L; ++j) nz |= a[j];
-    if constexpr (C::LPE == 2) nz = from_even(nz) | from_odd(nz);
+    if constexpr (C::LPE > 1) nz = or_all<C::LPE>(nz);
 #pragma unroll
     for (int j = 0; j < C::L; ++j) r[j] = nz ? d[j] : 0u;
 }
@@ -222,7 +250,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[C::L], const u32 (&a)[C::L], c
     if constexpr (C::LPE == 1) {
         mont_mul_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
     } else {
-        mont_mul_columns_pair<C::L>(T, a, ln.bl, C::EPB, n, n0inv, ln.evenmask);
+        mont_mul_columns_lanes<C::L, C::LPE>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);
     }
     normalize<C>(r, T, ln);
 }
@@ -233,7 +261,7 @@ __device__ __forceinline__ void mont_sqr(u32 (&r)[C::L], const u32 (&a)[C::L], c
     if constexpr (C::LPE == 1) {
         mont_sqr_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
     } else {
-        mont_mul_columns_pair<C::L>(T, a, ln.bl, C::EPB, n, n0inv, ln.evenmask);   // pair mode: general product
+        mont_mul_columns_lanes<C::L, C::LPE>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);   // general product
     }
     normalize<C>(r, T, ln);
 }
@@ -358,7 +386,7 @@ k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes
     u32 nz = 0;
 #pragma unroll
     for (int j = 0; j < C::L; ++j) nz |= a[j];
-    if constexpr (C::LPE == 2) nz = from_even(nz) | from_odd(nz);
+    if constexpr (C::LPE > 1) nz = or_all<C::LPE>(nz);
     if (live && bad) atomicOr(flags, 1u);
     if (live && nz == 0) atomicOr(flags, 2u);
     if (bad) {

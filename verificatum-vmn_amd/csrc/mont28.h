@@ -54,9 +54,10 @@ template <int S> __device__ __forceinline__ void mont_row_asm_next(u64 (&P)[S], 
 constexpr int SQR_BLK = 8;
 template <int S> __device__ __forceinline__ void mont_sqr_row_asm_first(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
 template <int S, int J0> __device__ __forceinline__ void mont_sqr_row_asm(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
-// Two lanes per element (see the generator): L limbs per lane.
-template <int L> __device__ __forceinline__ void mont_pair_row_asm_first(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 evenmask);
-template <int L> __device__ __forceinline__ void mont_pair_row_asm_next(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 evenmask);
+// LPE = 2 or 4 lanes per element (see the generator): L limbs per lane; lowmask = all ones on lane 0 of the
+// element, nottopmask = all ones on every lane of the element but the last.
+template <int L, int LPE> __device__ __forceinline__ void mont_lanes_row_asm_first(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask);
+template <int L, int LPE> __device__ __forceinline__ void mont_lanes_row_asm_next(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask);
 #include "gen/mont_rows.inc"
 
 // T (S lazy columns, value < 2N when a, b < 2N and R > 4N) = a * b / R mod N.
@@ -103,19 +104,56 @@ __device__ __forceinline__ void mont_sqr_columns(u64 (&T)[S], const u32 (&a)[S],
     T[S - 1] = 0;
 }
 
-// Lane-pair product: each lane holds L of the S = 2L columns; b_lds streams all S limbs of the multiplier
-// (both lanes of a pair read the same word).  n[] = this lane's half of the modulus (VGPRs).
-template <int L>
-__device__ __forceinline__ void mont_mul_columns_pair(u64 (&T)[L], const u32 (&a)[L], const u32* b_lds, int bstride,
-                                                      const u32 (&n)[L], u32 n0inv, u32 evenmask) {
+// Value of the same register on the lane below within the element (lane h-1; lane 0 receives its own value: mask it).
+template <int LPE>
+__device__ __forceinline__ u32 lane_below(u32 x) {
+    static_assert(LPE == 2 || LPE == 4, "lanes per element");
+    if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true);     // quad_perm [0,0,2,2]
+    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x90, 0xf, 0xf, true);                        // quad_perm [0,0,1,2]
+}
+
+// Multi-lane product: each lane holds L of the S = LPE*L columns; b_lds streams all S limbs of the multiplier
+// (all lanes of an element read the same word).  n[] = this lane's share of the modulus (VGPRs).
+// A column collects 2 products < 2^56 per row: 2 S <= 256 rows fit 64 bits (S = 110); for S = 148 the columns are
+// relieved once, half way (carry of each column into the next, across lanes through DPP) -- the value is
+// unchanged, only its spread over the columns.
+template <int L, int LPE>
+__device__ __forceinline__ void relieve_columns(u64 (&T)[L], u32 lowmask, u32 nottopmask) {
+#pragma unroll
+    for (int j = 0; j + 1 < L; ++j) {
+        T[j + 1] += T[j] >> LIMB_BITS;
+        T[j] &= (u64)LIMB_MASK;
+    }
+    const u64 top = T[L - 1];
+    const u64 cout = top >> LIMB_BITS;
+    const u64 nt = ((u64)nottopmask << 32) | nottopmask;
+    T[L - 1] = (top & (u64)LIMB_MASK & nt) | (top & ~nt);           // the element's last lane keeps its top column whole
+    const u32 lo = lane_below<LPE>((u32)cout) & ~lowmask, hi = lane_below<LPE>((u32)(cout >> 32)) & ~lowmask;
+    T[0] += ((u64)hi << 32) | lo;
+}
+template <int L, int LPE>
+__device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&a)[L], const u32* b_lds, int bstride,
+                                                       const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask) {
+    constexpr int S = LPE * L;
+    constexpr int HALF = 2 * S > 256 ? S / 2 : S;       // rows before the relief (S: none)
+    static_assert(S <= 256, "one relief is not enough beyond 256 limbs");
     u32 bi = b_lds[0];
     u32 bn = b_lds[bstride];
-    mont_pair_row_asm_first<L>(T, a, bi, n, n0inv, evenmask);
+    mont_lanes_row_asm_first<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
 #pragma unroll 1
-    for (int i = 2; i <= 2 * L; ++i) {
+    for (int i = 2; i <= HALF; ++i) {
         bi = bn;
-        bn = b_lds[(i < 2 * L ? i : 0) * bstride];
-        mont_pair_row_asm_next<L>(T, a, bi, n, n0inv, evenmask);
+        bn = b_lds[(i < S ? i : 0) * bstride];
+        mont_lanes_row_asm_next<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
+    }
+    if constexpr (HALF < S) {
+        relieve_columns<L, LPE>(T, lowmask, nottopmask);
+#pragma unroll 1
+        for (int i = HALF + 1; i <= S; ++i) {
+            bi = bn;
+            bn = b_lds[(i < S ? i : 0) * bstride];
+            mont_lanes_row_asm_next<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
+        }
     }
 }
 

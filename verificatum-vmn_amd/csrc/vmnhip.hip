@@ -42,15 +42,16 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // size dispatch
 // ------------------------------------------------------------------------------------------------
 // (modulus bits) -> (S limbs, NW words).  One template instantiation per supported size.
-// X(limbs, packed words, lanes per element).  3072-bit moduli (110 limbs) run two lanes per element.
-#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(110, 96, 2)
+// X(limbs, packed words, lanes per element).  3072-bit moduli (110 limbs) run two lanes per element, 4096-bit
+// moduli (148 limbs: R = 2^4144) four.
+#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(110, 96, 2) X(148, 128, 4)
 // elliptic curves: X(field limbs, packed words)
 // (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
 #define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
 
 static bool size_for_bits(int nbits, int* S, int* NW, int* LPE) {
     const int sizes[][4] = {{256, 10, 8, 1}, {384, 14, 12, 1}, {512, 19, 16, 1}, {1024, 37, 32, 1}, {2048, 74, 64, 1},
-                            {3072, 110, 96, 2}};
+                            {3072, 110, 96, 2}, {4096, 148, 128, 4}};
     for (auto& s : sizes) {
         if (nbits <= s[0]) {
             *S = s[1];
@@ -406,7 +407,7 @@ extern "C" int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const ui
     int nbits = hostbig::bit_length(pw);
     int S, NW, LPE;
     if (!size_for_bits(nbits, &S, &NW, &LPE)) {
-        set_error("vmn_modp_group_create: %d-bit modulus not supported (max 3072)", nbits);
+        set_error("vmn_modp_group_create: %d-bit modulus not supported (max 4096)", nbits);
         return VMN_ERR_UNSUPPORTED;
     }
     std::unique_ptr<vmn_group> g(new vmn_group());
