@@ -235,3 +235,20 @@ def test_helper_thread_runs_concurrently_with_main_thread(groups):
     assert not errors
     assert all(g == want_main for g in got_main)
     assert len(got_helper) == 12 and all(g == want_helper for g in got_helper)
+
+
+def test_fixed_base_table_cache_is_bounded(vmn, gpu_ctx, monkeypatch):
+    """Every proof brings a new fixed base (h_0): the per-group table cache drops least-recently-used tables beyond
+    its byte bound instead of growing for ever.  With a bound below one table, every call rebuilds; results stay
+    bit-exact and a dropped base is rebuilt on demand."""
+    grp, _ = load_golden(1024)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    monkeypatch.setenv("VMN_FIXED_CACHE_BYTES", str(3 << 20))          # < two tables at this size
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    n = 300
+    es = pyref.stream_ints(b"cache/e", n, q)
+    E = G.ringArray(es)
+    bases = [pow(g, k, p) for k in pyref.stream_ints(b"cache/b", 4, q)]
+    for rnd in range(2):
+        for b in bases + [bases[0]]:
+            assert G.exp(b, E).toInts() == pyref.exp_fixed(b, es, p), rnd

@@ -1665,6 +1665,40 @@ static int pick_fixed_window(size_t n, int ebits, size_t row_bytes) {
     return best;
 }
 
+// Bound on the cached fixed-base tables of a group.  g and the public key stay hot; the per-proof base h_0 brings
+// a new 2.5 GB table (2048 bits, w = 16) with every proof, so the least recently used tables are dropped.
+static size_t fixed_cache_limit() {
+    const char* env = getenv("VMN_FIXED_CACHE_BYTES");       // operational override (and the eviction test)
+    if (env && *env) return (size_t)strtoull(env, nullptr, 10);
+    return (size_t)32 << 30;
+}
+
+static void fixed_drop(vmn_group* g, std::map<std::string, vmn_group::FixedTable>::iterator it) {
+    (void)hipStreamSynchronize(g->ctx->stream);              // kernels reading the table may still be queued
+    if (it->second.d_tab) (void)hipFree(it->second.d_tab);
+    g->fixed_bytes -= it->second.bytes;
+    g->fixed.erase(it);
+}
+static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
+    for (;;) {
+        bool over = g->fixed_bytes + bytes > fixed_cache_limit();
+        hipError_t e = over && !g->fixed.empty() ? hipErrorOutOfMemory : hipMalloc(reinterpret_cast<void**>(out), bytes);
+        if (e == hipSuccess) return VMN_OK;
+        (void)hipGetLastError();
+        if (g->fixed.empty()) {
+            if (over && hipMalloc(reinterpret_cast<void**>(out), bytes) == hipSuccess) return VMN_OK;   // one table larger than the bound
+            (void)hipGetLastError();
+            set_error("fixed-base table allocation of %zu bytes failed", bytes);
+            return VMN_ERR_NOMEM;
+        }
+        auto lru = g->fixed.begin();
+        for (auto it = g->fixed.begin(); it != g->fixed.end(); ++it) {
+            if (it->second.last_use < lru->second.last_use) lru = it;
+        }
+        fixed_drop(g, lru);
+    }
+}
+
 // Table for (base, window) cached in the group; built on the GPU from the host squaring chain.
 static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out) {
     vmn_ctx* ctx = g->ctx;
@@ -1676,12 +1710,11 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     if (it != g->fixed.end()) {
         vmn_group::FixedTable& ft = it->second;
         if (ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
+            ft.last_use = ++g->fixed_clock;
             *out = &ft;
             return VMN_OK;
         }
-        VMN_HIP(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ft.d_tab);
-        g->fixed.erase(it);
+        fixed_drop(g, it);
     }
     int nwin = (ebits + w - 1) / w;
     if (m.ec) {
@@ -1695,10 +1728,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         ft.wbits = w;
         ft.nwin = nwin;
         ft.bytes = (size_t)nwin * ((size_t)1 << w) * Wd * sizeof(uint32_t);
-        if (rc == VMN_OK && hipMalloc(&ft.d_tab, ft.bytes) != hipSuccess) {
-            set_error("fixed-base table allocation of %zu bytes failed", ft.bytes);
-            rc = VMN_ERR_NOMEM;
-        }
+        if (rc == VMN_OK) rc = fixed_alloc(g, ft.bytes, &ft.d_tab);
         if (rc == VMN_OK) {
             rc = VMN_ERR_ARG;
 #define X(S_, NW_)                                                                                                \
@@ -1725,6 +1755,8 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
             if (ft.d_tab) (void)hipFree(ft.d_tab);
             return rc;
         }
+        ft.last_use = ++g->fixed_clock;
+        g->fixed_bytes += ft.bytes;
         auto ins = g->fixed.emplace(key, ft);
         *out = &ins.first->second;
         return VMN_OK;
@@ -1752,7 +1784,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     ft.wbits = w;
     ft.nwin = nwin;
     ft.bytes = (size_t)nwin * ((size_t)1 << w) * Wd * sizeof(uint32_t);
-    VMN_HIP(hipMalloc(&ft.d_tab, ft.bytes));
+    VMN_TRY(fixed_alloc(g, ft.bytes, &ft.d_tab));
     int rc = VMN_ERR_ARG;
     rc = launch_light(ctx, "fixed_table", k_fixed_seed, grid_for((size_t)nwin * (w + 1)), ft.d_tab,
                       (const uint32_t*)sq.as<uint32_t>(), w, nwin, (const uint32_t*)m.d_one, (int)Wd);
@@ -1767,6 +1799,8 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         (void)hipFree(ft.d_tab);
         return rc;
     }
+    ft.last_use = ++g->fixed_clock;
+    g->fixed_bytes += ft.bytes;
     auto ins = g->fixed.emplace(key, ft);
     *out = &ins.first->second;
     return VMN_OK;
