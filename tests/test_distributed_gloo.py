@@ -44,6 +44,27 @@ def test_shard_bounds_cover_everything(entry):
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
 
 
+def test_host_row_blocks_of_every_kind_are_sliced_alike(entry):
+    """The shared tape may hand out rows as bytes, as a (page-locked) host tensor or as a uint8 array: a shard takes
+    the same rows from each."""
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("par_rows", os.path.join(entry.PKG_DIR, "parallel.py"))
+    par = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(par)
+    nb, n = 32, 50
+    raw = bytes(range(256)) * (nb * n // 256 + 1)
+    raw = raw[: nb * n]
+    kinds = [raw, torch.frombuffer(bytearray(raw), dtype=torch.uint8), np.frombuffer(raw, dtype=np.uint8)]
+    idx = [7, 3, 49, 0, 3]
+    for block in kinds:
+        assert par._take_rows(block, range(10, 20), nb) == raw[10 * nb:20 * nb]
+        assert par._take_rows(block, idx, nb) == b"".join(raw[i * nb:(i + 1) * nb] for i in idx)
+    ints = [int.from_bytes(raw[i * nb:(i + 1) * nb], "big") for i in range(n)]
+    assert par._take_rows(ints, idx, nb) == [ints[i] for i in idx]
+
+
 @pytest.mark.parametrize("world,n,width", [(2, 21, 1), (3, 10, 2)])
 def test_sharded_pos_matches_oracle_on_gloo(world, n, width, tmp_path):
     res = run_world(world, "fake", 512, n, width, tmp_path)

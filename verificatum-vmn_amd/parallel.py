@@ -75,10 +75,23 @@ def _take(arr, idx):
     return [arr[int(i)] for i in idx]
 
 
-def _take_rows(arr, idx, nbytes: int):
+def _as_row_matrix(arr, nbytes: int):
+    """A block of big-endian rows (bytes, a pinned torch tensor, a uint8 array) as an (n, nbytes) uint8 view;
+    None when ``arr`` is a list of integers."""
+    import numpy as np
     if isinstance(arr, (bytes, bytearray)):
+        return np.frombuffer(arr, dtype=np.uint8).reshape(-1, nbytes)
+    if hasattr(arr, "data_ptr") and hasattr(arr, "numpy"):
+        return arr.numpy().reshape(-1, nbytes)               # host tensor: shares memory
+    if isinstance(arr, np.ndarray) and arr.dtype == np.uint8:
+        return arr.reshape(-1, nbytes)
+    return None
+
+
+def _take_rows(arr, idx, nbytes: int):
+    a = _as_row_matrix(arr, nbytes)
+    if a is not None:
         import numpy as np
-        a = np.frombuffer(arr, dtype=np.uint8).reshape(-1, nbytes)
         if isinstance(idx, range):
             return a[idx.start:idx.stop].tobytes()
         return a[np.asarray(idx, dtype=np.int64)].tobytes()
