@@ -195,6 +195,24 @@ int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal);
 int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be);
 int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out);
 
+/* ---- pseudo-random derivations ---------------------------------------------
+ * VCR's PRGHeuristic and RandomOracle over SHA-256, restated from their published definition (the classes are not
+ * in the reference tree): PRG(seed) = H(seed || uint32_be(0)) || H(seed || uint32_be(1)) || ...;
+ * RO_nout(d) = first ceil(nout/8) bytes of PRG(H(uint32_be(nout) || d)) with the superfluous leading bits cleared.
+ * Seeds are 32 bytes (PRGHeuristic.minNoSeedBytes of SHA-256).  Both constructions are pinned by the published
+ * known-answer vectors (tests/test_prg.py). */
+int vmn_prg_bytes(const uint8_t* seed, size_t seedlen, uint8_t* out, size_t nbytes);              /* host */
+int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits, uint8_t* out);            /* host, small inputs */
+/* The random vector of a proof, generated on the device: prg.setSeed(seed); LargeIntegerArray.random(n, bits, prg)
+ * as field elements.  ref: P/hvzk/PoSBasicTW.java:533-538, PoSCBasicTW.java:350-355, CCPoSBasicW.java:330-335.
+ * Value i = the i-th ceil(bits/8) bytes of the stream, leading bits cleared; reduced mod q when it can reach q. */
+int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out);
+/* Independent generators: pGroup.randomElementArray(n, prg, rbitlen) of a safe-prime ModPGroup, generated on the
+ * device.  ref: P/distr/IndependentGeneratorsRO.java:117-130 (seed = RO(globalPrefix || bytetree(sid))).
+ * t_i = the i-th ceil((bits(p) + rbitlen)/8) bytes, leading bits cleared; h_i = t_i^((p-1)/q) = t_i^2 mod p.
+ * The derivation follows the specification's text; it is not pinned by a vector of the reference. */
+int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int rbitlen, vmn_garray** out);
+
 /* ---- partial results for multi-GPU sharding --------------------------------
  * Each rank holds a contiguous shard; expProd/prod partials are single elements that the host
  * side exchanges (RCCL all-gather of G x elem_bytes) and multiplies.  This multiplies k partials

@@ -92,6 +92,9 @@ int vmn_pos_set_permutation_commitment(vmn_pos* p, const vmn_garray* u);     /* 
 int vmn_pos_set_instance(vmn_pos* p, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,
                          const vmn_garray* const* wp, const vmn_rarray* const* s);
 int vmn_pos_set_batch_vector(vmn_pos* p, const uint8_t* e_be);    /* N rows of exp_bytes; :533-538 */
+/* setBatchVector(byte[] prgSeed) as the reference has it (:533-538): e is derived on the GPU from the 32-byte seed
+ * (vmn_rarray_from_prg: PRGHeuristic over SHA-256, N integers of ebitlen bits).  Same for PoSC / CCPoS below. */
+int vmn_pos_set_batch_vector_seed(vmn_pos* p, const uint8_t* seed, size_t seedlen);
 int vmn_pos_commit(vmn_pos* p, vmn_msg** commitment);             /* :546-700 */
 int vmn_pos_reply(vmn_pos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);   /* :856-888 */
 int vmn_pos_compute_af(vmn_pos* p);                               /* :407-410 */
@@ -108,6 +111,7 @@ void vmn_posc_free(vmn_posc* p);
 int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u,
                           const vmn_rarray* r, const uint32_t* pi);
 int vmn_posc_set_batch_vector(vmn_posc* p, const uint8_t* e_be);
+int vmn_posc_set_batch_vector_seed(vmn_posc* p, const uint8_t* seed, size_t seedlen);    /* :350-355 */
 int vmn_posc_commit(vmn_posc* p, vmn_msg** commitment);           /* :363-529 */
 int vmn_posc_reply(vmn_posc* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :607-636 */
 int vmn_posc_set_commitment(vmn_posc* p, const vmn_msg* commitment);
@@ -124,6 +128,7 @@ int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* 
                            const vmn_garray* const* wp, const vmn_rarray* r, const uint32_t* pi,
                            const vmn_rarray* const* s);
 int vmn_ccpos_set_batch_vector(vmn_ccpos* p, const uint8_t* e_be);
+int vmn_ccpos_set_batch_vector_seed(vmn_ccpos* p, const uint8_t* seed, size_t seedlen);  /* :330-335 */
 int vmn_ccpos_commit(vmn_ccpos* p, vmn_msg** commitment);         /* :344-396 */
 int vmn_ccpos_reply(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :462-485 */
 int vmn_ccpos_set_commitment(vmn_ccpos* p, const vmn_msg* commitment);

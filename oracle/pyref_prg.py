@@ -1,0 +1,46 @@
+"""pyref_prg.py — TEST INFRASTRUCTURE (oracle): VCR's PRGHeuristic / RandomOracle and the two derivations the
+reference makes from them, restated from their published definition (the Verificatum verifier specification
+describes both constructions and gives known-answer vectors; the classes themselves live in verificatum-vcr, which
+is not in the reference tree):
+
+  PRG(seed):          block_i = H(seed || uint32_be(i)), i = 0, 1, ...            (PRGHeuristic)
+  RO_nout(data):      first ceil(nout/8) bytes of PRG(H(uint32_be(nout) || data)), superfluous leading bits cleared
+  random vector:      e_i = the i-th ceil(n_e/8) bytes of PRG(seed), leading bits cleared   (PoSBasicTW.java:533-538)
+  generators (ModP):  t_i = the i-th ceil((n_p + n_r)/8) bytes, leading bits cleared; h_i = t_i^((p-1)/q) mod p
+                      (IndependentGeneratorsRO.java:117-130 -> pGroup.randomElementArray(n, prg, rbitlen))
+
+The PRG / RO constructions are pinned by the published vectors in tests/test_prg.py; the two derivations follow the
+specification's text and are not pinned by vectors (the header of DESIGN.md §2 says so).
+"""
+import hashlib
+from typing import List
+
+
+def prg_bytes(seed: bytes, nbytes: int, hashname: str = "sha256") -> bytes:
+    out = bytearray()
+    ctr = 0
+    while len(out) < nbytes:
+        out += hashlib.new(hashname, seed + ctr.to_bytes(4, "big")).digest()
+        ctr += 1
+    return bytes(out[:nbytes])
+
+
+def random_oracle(data: bytes, nout: int, hashname: str = "sha256") -> bytes:
+    seed = hashlib.new(hashname, nout.to_bytes(4, "big") + data).digest()
+    nb = (nout + 7) // 8
+    out = bytearray(prg_bytes(seed, nb, hashname))
+    if nout % 8:
+        out[0] &= (1 << (nout % 8)) - 1
+    return bytes(out)
+
+
+def random_integers(seed: bytes, n: int, bits: int) -> List[int]:
+    vb = (bits + 7) // 8
+    stream = prg_bytes(seed, n * vb)
+    mask = (1 << bits) - 1
+    return [int.from_bytes(stream[i * vb:(i + 1) * vb], "big") & mask for i in range(n)]
+
+
+def modp_generators(seed: bytes, n: int, p: int, q: int, rbitlen: int) -> List[int]:
+    cof = (p - 1) // q
+    return [pow(t % p, cof, p) for t in random_integers(seed, n, p.bit_length() + rbitlen)]

@@ -1,0 +1,123 @@
+"""N1: PRGHeuristic / RandomOracle over SHA-256, the random vector of a proof and the independent
+generators.
+
+CPU: the Python restatement (oracle/pyref_prg.py) and the library's host functions against the known-answer vectors
+published for these two constructions (Verificatum verifier specification, test vectors for PRGHeuristic and
+RandomOracle with SHA-256).  GPU: the device generators against the Python restatement."""
+import ctypes
+import os
+
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import pyref_prg
+
+SEED = bytes(range(32))
+# PRGHeuristic(SHA-256), seed 000102...1f: the first 128 output bytes
+PRG_SHA256 = ("70f4003d52b6eb03da852e93256b5986b5d4883098bb7973bc5318cc66637a84"
+              "04a6950a06d3e3308ad7d3606ef810eb124e3943404ca746a12c51c7bf776839"
+              "0f8d842ac9cb62349779a7537a78327d545aaeb33b2d42c7d1dc3680a4b23628"
+              "627e9db8ad47bfe76dbe653d03d2c0a35999ed28a5023924150d72508668d244")
+# RandomOracle(SHA-256, 65 bits) of the same 32 bytes: 9 bytes, 7 leading bits cleared
+RO_SHA256_65 = "001a8d6b6f65899ba5"
+
+
+def test_python_restatement_reproduces_the_published_vectors():
+    assert pyref_prg.prg_bytes(SEED, 128).hex() == PRG_SHA256
+    assert pyref_prg.random_oracle(SEED, 65).hex() == RO_SHA256_65
+    assert pyref_prg.random_oracle(SEED, 261)[0] < 32 and len(pyref_prg.random_oracle(SEED, 261)) == 33
+
+
+def test_library_host_functions_reproduce_the_published_vectors(entry):
+    lib = ctypes.CDLL(os.path.join(ROOT, "verificatum-vmn_amd", "libvmnhip.so"))
+    out = ctypes.create_string_buffer(128)
+    assert lib.vmn_prg_bytes(SEED, ctypes.c_size_t(32), out, ctypes.c_size_t(128)) == 0
+    assert out.raw.hex() == PRG_SHA256
+    for nout in (65, 261, 519, 1024):
+        nb = (nout + 7) // 8
+        out = ctypes.create_string_buffer(nb)
+        assert lib.vmn_random_oracle(SEED, ctypes.c_size_t(32), ctypes.c_int(nout), out) == 0
+        assert out.raw == pyref_prg.random_oracle(SEED, nout)
+    out = ctypes.create_string_buffer(9)
+    lib.vmn_random_oracle(SEED, ctypes.c_size_t(32), ctypes.c_int(65), out)
+    assert out.raw.hex() == RO_SHA256_65
+    big = bytes(range(256)) * 5                       # multi-block input through the host SHA-256
+    out = ctypes.create_string_buffer(32)
+    assert lib.vmn_random_oracle(big, ctypes.c_size_t(len(big)), ctypes.c_int(256), out) == 0
+    assert out.raw == pyref_prg.random_oracle(big, 256)
+    assert lib.vmn_prg_bytes(SEED, ctypes.c_size_t(31), out, ctypes.c_size_t(32)) == -5          # VMN_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [512, 2048, 3072])
+def test_device_random_vector_and_generators(bits, vmn, gpu_ctx):
+    grp, _ = load_golden(bits)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    seed = pyref_prg.random_oracle(b"generators" + bytes([bits % 251]), 256)
+    for n, ebits in ((1, 256), (77, 256), (300, 100), (33, 37)):
+        assert G.ringArrayFromPRG(seed, n, ebits).toInts() == pyref_prg.random_integers(seed, n, ebits)
+    full = q.bit_length()                              # integers that can reach q are reduced
+    assert G.ringArrayFromPRG(seed, 50, full).toInts() == [x % q for x in pyref_prg.random_integers(seed, 50, full)]
+    for n, rbitlen in ((1, 100), (130, 100), (64, 0), (9, 3)):
+        H = G.elementArrayFromPRG(seed, n, rbitlen)
+        want = pyref_prg.modp_generators(seed, n, p, q, rbitlen)
+        assert H.toInts() == want
+        assert H.isMember()                            # squares: in the order-q subgroup
+
+
+@pytest.mark.gpu
+def test_random_vector_over_a_curve_order(vmn, gpu_ctx):
+    G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    seed = pyref_prg.random_oracle(b"curve", 256)
+    assert G.ringArrayFromPRG(seed, 200, 128).toInts() == pyref_prg.random_integers(seed, 200, 128)
+    assert G.ringArrayFromPRG(seed, 200, 256).toInts() == [x % G.q for x in pyref_prg.random_integers(seed, 200, 256)]
+    with pytest.raises(vmn.VmnError):
+        G.elementArrayFromPRG(seed, 4, 100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_proof_with_the_batching_vector_derived_from_a_seed(impl, vmn, gpu_ctx, entry):
+    """setBatchVector(byte[] prgSeed) as the reference calls it: both drivers derive e on the GPU and produce the
+    transcript of the oracle run on e = the PRG integers."""
+    import importlib.util, sys
+    from oracle import pyref_proofs as P
+    from tape import Tape
+    mods = {}
+    for name in ("hvzk", "native"):
+        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    hv = mods["hvzk" if impl == "python" else "native"]
+    grp, _ = load_golden(512)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    NV, NE, NR, n = 100, 100, 50, 40
+    seed = pyref_prg.random_oracle(b"posc-seed", 256)
+    h = pyref_prg.modp_generators(pyref_prg.random_oracle(b"gens", 256), n, p, q, NR)
+    t = Tape(b"seeded", q)
+    pi, r, v = t.permutation(n), t.ring_array(n), t.int_array(1, NV)[0]
+    e = pyref_prg.random_integers(seed, n, NE)
+    u = P.permutation_commitment(g, h, r, pi, p)
+    o = P.PoSC(p, q, NV, NE, NR, rand=Tape(b"pr", q))
+    o.setInstance(g, h, u, r, pi)
+    o.setBatchVector(e)
+    com_o, rep_o = o.commit(), o.reply(v)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H = G.elementArrayFromPRG(pyref_prg.random_oracle(b"gens", 256), n, NR)
+    assert H.toInts() == h
+    U = G.toElementArray(u)
+    pr = hv.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"pr", q))
+    pr.setInstance(g, H, U, G.ringArray(r), pi)
+    pr.setBatchVectorSeed(seed)
+    com, rep = pr.commit(), pr.reply(v)
+    ints = lambda x: x.toInts() if hasattr(x, "toInts") else x
+    assert {k: ints(x) for k, x in com.items()} == com_o and {k: ints(x) for k, x in rep.items()} == rep_o
+    ver = hv.PoSCBasicTW(G, NV, NE, NR)
+    ver.setInstance(g, H, U)
+    ver.setBatchVectorSeed(seed)
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep)

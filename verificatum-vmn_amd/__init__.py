@@ -262,6 +262,20 @@ class ModPGroup:
     def ringArrayFromByteTree(self, bt: bytes, size: int = 0) -> "PRingElementArray":
         return self._from_bytetree("vmn_rarray_from_bytetree", PRingElementArray, bt, size)
 
+    def ringArrayFromPRG(self, seed: bytes, n: int, bits: int) -> "PRingElementArray":
+        """``prg.setSeed(seed); LargeIntegerArray.random(n, bits, prg)`` as field elements, generated on the GPU
+        (the random vector of a proof, PoSBasicTW.java:533-538)."""
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_from_prg(self._h, bytes(seed), C.c_size_t(len(seed)), C.c_size_t(n), C.c_int(bits), C.byref(h)))
+        return PRingElementArray(self, h)
+
+    def elementArrayFromPRG(self, seed: bytes, n: int, rbitlen: int) -> "PGroupElementArray":
+        """``pGroup.randomElementArray(n, prg, rbitlen)``: independent generators derived on the GPU
+        (IndependentGeneratorsRO.java:117-130; safe-prime ModPGroup)."""
+        h = C.c_void_p()
+        _check(lib().vmn_garray_from_prg(self._h, bytes(seed), C.c_size_t(len(seed)), C.c_size_t(n), C.c_int(rbitlen), C.byref(h)))
+        return PGroupElementArray(self, h)
+
     def exp(self, base, exponents: "PRingElementArray") -> "PGroupElementArray":
         """``g.exp(PRingElementArray)``: fixed base, one exponent per element (K2)."""
         h = C.c_void_p()

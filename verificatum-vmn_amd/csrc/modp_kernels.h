@@ -361,8 +361,12 @@ __device__ __forceinline__ void limbs_from_be(u32 (&a)[C::L], const uint8_t* __r
 // for malformed input (P/hvzk/PoSBasicTW.java:794-815).
 template <class C, int NW>
 __global__ void __launch_bounds__(BLOCK, C::MINW)
-k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes, size_t stride, int leaf_hdr, size_t n,
+k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes, size_t stride, int mode, size_t n,
             const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ rr, u32* __restrict__ flags) {
+    // mode bit 0: every value is preceded by a byte-tree leaf header; bit 1: values >= N are REDUCED mod N instead of
+    // being reported and replaced (pseudo-random integers wider than the modulus: a * RR / R is a mod N for every a < R)
+    const int leaf_hdr = mode & 1;
+    const bool reduce = (mode & 2) != 0;
     extern __shared__ u32 lds[];
     Lane<C> ln(lds);
     u32 nn[C::L];
@@ -382,7 +386,7 @@ k_import_be(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes
     u32 a[C::L];
     limbs_from_be<C, NW>(a, src, (long)nbytes, ln);
     u32 d[C::L];
-    bool bad = sub_full<C>(d, a, nn, ln) == 0 || extra != 0;     // a >= N
+    bool bad = !reduce && (sub_full<C>(d, a, nn, ln) == 0 || extra != 0);     // a >= N
     u32 nz = 0;
 #pragma unroll
     for (int j = 0; j < C::L; ++j) nz |= a[j];

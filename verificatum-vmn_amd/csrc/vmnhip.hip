@@ -12,6 +12,7 @@
 #include "ec_kernels.h"
 #include "modp_kernels.h"
 #include "vmnhip_internal.h"
+#include "sha256.h"
 
 using namespace vmn;
 using vmn::hostbig::Big;
@@ -1640,6 +1641,204 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
             }
         }
     }
+    if (rc != VMN_OK) {
+        vmn_garray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
+// ================================================================================================
+// N1: PRGHeuristic(SHA-256) on the device, the random vector of a proof and independent generators
+// ================================================================================================
+// Row i = bytes [part_off, part_off + part_len) of the i-th val_bytes-byte value of the PRG stream (value i =
+// stream bytes [i*val_bytes, (i+1)*val_bytes), first byte masked with top_mask), right-aligned in row_bytes bytes.
+// One lane per row; a lane hashes the 32-byte blocks its value overlaps (<= val_bytes/32 + 2 compressions).
+__global__ void __launch_bounds__(256) k_prg_rows(uint8_t* __restrict__ out, size_t row_bytes, size_t val_bytes, uint32_t top_mask,
+                                                  size_t part_off, size_t part_len, const uint32_t* __restrict__ seed_words,
+                                                  size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t seed[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) seed[k] = seed_words[k];
+    uint8_t* row = out + i * row_bytes;
+    const size_t pad = row_bytes - part_len;
+    for (size_t k = 0; k < pad; ++k) row[k] = 0;
+    const size_t v0 = i * val_bytes;                       // stream offset of the value
+    const size_t lo = v0 + part_off, hi = lo + part_len;   // stream range wanted
+    for (size_t blk = lo / 32; blk * 32 < hi; ++blk) {
+        uint32_t dg[8];
+        sha256::prg_block(dg, seed, (uint32_t)blk);
+        for (int b = 0; b < 32; ++b) {
+            size_t pos = blk * 32 + b;
+            if (pos < lo || pos >= hi) continue;
+            uint8_t byte = (uint8_t)(dg[b >> 2] >> (24 - 8 * (b & 3)));
+            if (pos == v0) byte &= (uint8_t)top_mask;
+            row[pad + (pos - lo)] = byte;
+        }
+    }
+}
+
+static int prg_seed_words(const uint8_t* seed, size_t seedlen, uint32_t (&w)[8]) {
+    if (!seed || seedlen != 32) {
+        set_error("PRG seed must be 32 bytes (a SHA-256 digest; PRGHeuristic.minNoSeedBytes)");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    for (int i = 0; i < 8; ++i) w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+    return VMN_OK;
+}
+// device rows of one part of the PRG values (see k_prg_rows)
+static int prg_rows(vmn_ctx* ctx, const uint32_t (&seedw)[8], size_t n, size_t val_bytes, int val_bits, size_t part_off, size_t part_len,
+                    size_t row_bytes, DevTmp& rows) {
+    DevTmp dseed(ctx);
+    VMN_TRY(dseed.alloc(32));
+    VMN_TRY(h2d(ctx, dseed.p, seedw, 32));
+    VMN_TRY(rows.alloc(n * row_bytes + 8));
+    uint32_t top_mask = val_bits % 8 ? (1u << (val_bits % 8)) - 1 : 0xffu;
+    return launch_light(ctx, "prg", k_prg_rows, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
+                        (const uint32_t*)dseed.as<uint32_t>(), n);
+}
+// rows already on the device -> residues (mode: see k_import_be)
+static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* d_rows, int mode, size_t n, uint32_t* d_out,
+                      int* all_in_range) {
+    if (all_in_range) *all_in_range = 1;
+    if (n == 0) return VMN_OK;
+    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                               \
+    if (m.S == S_)                                                                                                     \
+        rc = launch(ctx, "import", k_import_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), d_out, d_rows, nbytes, nbytes, mode, n, \
+                    m.d_n, m.n0inv, m.d_rr, ctx->flags);
+    VMN_FOR_SIZES(X)
+#undef X
+    VMN_TRY(rc);
+    if (all_in_range) {
+        uint32_t fl = 0;
+        VMN_TRY(d2h(ctx, &fl, ctx->flags, sizeof(fl)));
+        *all_in_range = (fl & 1u) ? 0 : 1;
+    }
+    return VMN_OK;
+}
+
+extern "C" int vmn_prg_bytes(const uint8_t* seed, size_t seedlen, uint8_t* out, size_t nbytes) {
+    ARG_CHECK(out || nbytes == 0, "null argument");
+    uint32_t w[8];
+    VMN_TRY(prg_seed_words(seed, seedlen, w));
+    for (size_t blk = 0; blk * 32 < nbytes; ++blk) {
+        uint32_t dg[8];
+        sha256::prg_block(dg, w, (uint32_t)blk);
+        for (size_t b = 0; b < 32 && blk * 32 + b < nbytes; ++b) out[blk * 32 + b] = (uint8_t)(dg[b >> 2] >> (24 - 8 * (b & 3)));
+    }
+    return VMN_OK;
+}
+
+extern "C" int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits, uint8_t* out) {
+    ARG_CHECK((data || len == 0) && out && nout_bits > 0, "bad argument");
+    std::vector<uint8_t> msg(4 + len);
+    msg[0] = (uint8_t)((uint32_t)nout_bits >> 24);
+    msg[1] = (uint8_t)((uint32_t)nout_bits >> 16);
+    msg[2] = (uint8_t)((uint32_t)nout_bits >> 8);
+    msg[3] = (uint8_t)nout_bits;
+    if (len) memcpy(msg.data() + 4, data, len);
+    uint8_t seed[32];
+    sha256::hash(msg.data(), msg.size(), seed);
+    size_t nb = ((size_t)nout_bits + 7) / 8;
+    VMN_TRY(vmn_prg_bytes(seed, 32, out, nb));
+    if (nout_bits % 8) out[0] &= (uint8_t)((1u << (nout_bits % 8)) - 1);
+    return VMN_OK;
+}
+
+extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out) {
+    ARG_CHECK(grp && out && bits > 0, "bad argument");
+    vmn_ctx* ctx = grp->ctx;
+    VMN_ENTER(ctx);
+    uint32_t w[8];
+    VMN_TRY(prg_seed_words(seed, seedlen, w));
+    const size_t vb = ((size_t)bits + 7) / 8;
+    if (vb > grp->nbytes || bits > 28 * grp->Q.S) {
+        set_error("vmn_rarray_from_prg: %d-bit integers do not fit the %zu-byte exponent rows", bits, grp->nbytes);
+        return VMN_ERR_UNSUPPORTED;
+    }
+    vmn_rarray* a = nullptr;
+    VMN_TRY(new_rarray(grp, n, &a));
+    DevTmp rows(ctx);
+    int rc = n ? prg_rows(ctx, w, n, vb, bits, 0, vb, grp->nbytes, rows) : VMN_OK;
+    // integers that may reach the order (bits >= bits of q) act as field elements: reduced
+    if (rc == VMN_OK) rc = import_dev(ctx, grp->Q, grp->nbytes, rows.as<uint8_t>(), bits >= grp->Q.nbits ? 2 : 0, n, a->d, nullptr);
+    if (rc != VMN_OK) {
+        vmn_rarray_free(a);
+        return rc;
+    }
+    *out = a;
+    return VMN_OK;
+}
+
+extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int rbitlen, vmn_garray** out) {
+    ARG_CHECK(grp && out && rbitlen >= 0, "bad argument");
+    vmn_ctx* ctx = grp->ctx;
+    VMN_ENTER(ctx);
+    if (grp->curve) {
+        set_error("vmn_garray_from_prg: random curve points (ECqPGroup.randomElementArray) are not implemented");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    const vmn_modulus& m = grp->P;
+    {   // the cofactor (p-1)/q must be 2 (safe-prime groups: the elements are squared)
+        Big twoq = grp->Q.n_words;
+        hostbig::dbl_mod(twoq, m.n_words);          // 2q mod p = p - 1 for a safe prime
+        Big pm1 = m.n_words;
+        pm1[0] -= 1;                                // p is odd
+        if (hostbig::cmp(twoq, pm1) != 0) {
+            set_error("vmn_garray_from_prg: only safe-prime groups (p = 2q + 1) are supported");
+            return VMN_ERR_UNSUPPORTED;
+        }
+    }
+    uint32_t w[8];
+    VMN_TRY(prg_seed_words(seed, seedlen, w));
+    const int vbits = m.nbits + rbitlen;
+    const size_t vb = ((size_t)vbits + 7) / 8, pb = ((size_t)m.nbits + 7) / 8;
+    if (vb - pb > grp->nbytes || pb > grp->nbytes) {
+        set_error("vmn_garray_from_prg: rbitlen too large");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    vmn_garray* r = nullptr;
+    VMN_TRY(new_garray(grp, n, &r));
+    if (n == 0) {
+        *out = r;
+        return VMN_OK;
+    }
+    const size_t Wd = elem_words(m);
+    DevTmp rows(ctx), lo(ctx), hi(ctx), cdev(ctx);
+    int rc = lo.alloc(n * Wd * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = hi.alloc(n * Wd * sizeof(uint32_t));
+    // t = hi * 2^(8 pb) + lo:  lo may exceed p (reduced by the import), hi < 2^(rbitlen + 7) << p
+    if (rc == VMN_OK) rc = prg_rows(ctx, w, n, vb, vbits, vb - pb, pb, grp->nbytes, rows);
+    if (rc == VMN_OK) rc = import_dev(ctx, m, grp->nbytes, rows.as<uint8_t>(), 2, n, lo.as<uint32_t>(), nullptr);
+    if (rc == VMN_OK && vb > pb) {
+        rc = prg_rows(ctx, w, n, vb, vbits, 0, vb - pb, grp->nbytes, rows);
+        if (rc == VMN_OK) rc = import_dev(ctx, m, grp->nbytes, rows.as<uint8_t>(), 0, n, hi.as<uint32_t>(), nullptr);
+        // c = 2^(8 pb) mod p as one element (Montgomery form)
+        Big c(m.NW, 0);
+        c[0] = 1;
+        for (size_t k = 0; k < 8 * pb; ++k) hostbig::dbl_mod(c, m.n_words);
+        std::vector<uint8_t> cbe(grp->nbytes);
+        hostbig::to_be(c, cbe.data(), grp->nbytes);
+        if (rc == VMN_OK) rc = cdev.alloc(Wd * sizeof(uint32_t));
+        int ok = 1;
+        if (rc == VMN_OK) rc = import_be(ctx, m, grp->nbytes, cbe.data(), 1, cdev.as<uint32_t>(), &ok);
+        if (rc == VMN_OK) {                                  // lo := hi * c + lo   (ring op 2 with the modulus p)
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                                      \
+    if (m.S == S_)                                                                                                            \
+        rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), lo.as<uint32_t>(), (const uint32_t*)hi.as<uint32_t>(), \
+                    (const uint32_t*)lo.as<uint32_t>(), (const uint32_t*)cdev.as<uint32_t>(), 2, n, m.d_n, m.n0inv);
+            VMN_FOR_SIZES(X)
+#undef X
+        }
+    }
+    // h_i = t_i^2  (cofactor 2)
+    if (rc == VMN_OK) rc = mul_arrays(ctx, m, lo.as<uint32_t>(), lo.as<uint32_t>(), Wd, n, r->d);
     if (rc != VMN_OK) {
         vmn_garray_free(r);
         return rc;

@@ -314,6 +314,10 @@ struct ProofBase {
         v = G.reduce(vb, n);
         return VMN_OK;
     }
+    int batch_vector_seed(const uint8_t* seed, size_t seedlen, RA& e) {
+        if (!N) return fail(VMN_ERR_ARG, "batching vector before the instance (size unknown)");
+        return vmn_rarray_from_prg(G.grp, seed, seedlen, N, ebitlen, e.out());
+    }
     int batch_vector(const uint8_t* e_be, RA& e) {
         if (!e_be && N) return fail(VMN_ERR_ARG, "null batching vector");
         int ok = 1;
@@ -1213,6 +1217,10 @@ int vmn_pos_set_batch_vector(vmn_pos* p, const uint8_t* e_be) {
     NONNULL(p);
     return p->batch_vector(e_be, p->e);
 }
+int vmn_pos_set_batch_vector_seed(vmn_pos* p, const uint8_t* seed, size_t seedlen) {
+    NONNULL(p);
+    return p->batch_vector_seed(seed, seedlen, p->e);
+}
 int vmn_pos_commit(vmn_pos* p, vmn_msg** commitment) {
     NONNULL(p);
     return p->commit(commitment);
@@ -1248,6 +1256,10 @@ int vmn_posc_set_batch_vector(vmn_posc* p, const uint8_t* e_be) {
     NONNULL(p);
     return p->batch_vector(e_be, p->e);
 }
+int vmn_posc_set_batch_vector_seed(vmn_posc* p, const uint8_t* seed, size_t seedlen) {
+    NONNULL(p);
+    return p->batch_vector_seed(seed, seedlen, p->e);
+}
 int vmn_posc_commit(vmn_posc* p, vmn_msg** commitment) {
     NONNULL(p);
     return p->commit(commitment);
@@ -1279,6 +1291,10 @@ int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* 
 int vmn_ccpos_set_batch_vector(vmn_ccpos* p, const uint8_t* e_be) {
     NONNULL(p);
     return p->batch_vector(e_be, p->e);
+}
+int vmn_ccpos_set_batch_vector_seed(vmn_ccpos* p, const uint8_t* seed, size_t seedlen) {
+    NONNULL(p);
+    return p->batch_vector_seed(seed, seedlen, p->e);
 }
 int vmn_ccpos_commit(vmn_ccpos* p, vmn_msg** commitment) {
     NONNULL(p);

@@ -78,6 +78,11 @@ class _Base:
         """``a.expMul(v, b)`` = a^v * b (PoSBasicTW.java:1016-1021)."""
         return self.G.k_mul(self.G.k_exp(a, v), b)
 
+    def setBatchVectorSeed(self, seed: bytes):
+        """``setBatchVector(byte[] prgSeed)`` (PoSBasicTW.java:533-538): prg.setSeed(seed); e = N integers of ebitlen
+        bits from the PRG, derived on the GPU."""
+        self.e = self.G.ringArrayFromPRG(seed, self.size, self.ebitlen)
+
     def _eps_array(self):
         """epsilon: N integers of ebitlen+vbitlen+rbitlen bits, as field elements (PoSBasicTW.java:470-475).
         A random source may hand out big-endian bytes of the group's wire width directly (bulk path)."""

@@ -248,6 +248,10 @@ class _NativeProof:
         blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
         self._call("set_batch_vector", blk[0])
 
+    def setBatchVectorSeed(self, seed: bytes):
+        """``setBatchVector(byte[] prgSeed)``: e derived on the GPU from the seed (PoSBasicTW.java:533-538)."""
+        self._call("set_batch_vector_seed", bytes(seed), C.c_size_t(len(seed)))
+
     def setChallenge(self, v: int):
         b = _be(v)
         self._call("set_challenge", b, C.c_size_t(len(b)))
