@@ -442,6 +442,47 @@ def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dis
             "algorithmic_TMACs": 3280 * 8256 * n / (t3 - t0) / 1e12}
 
 
+def cpu_mix_prove(p, q, g, n: int, cores: int):
+    """CPU baseline of the mix + prove leg (test infrastructure, never the product): the reference's op sequence
+    (oracle/pyref_proofs.py: re-encrypt, PoS prove, PoS verify) with every array operation in the C + GMP oracle over
+    `cores` OpenMP threads.  Every exponentiation is an mpz_powm (VCR's fixed-base tables are not modelled), the
+    multi-exponentiations are a Pippenger on GMP; single elements are Python integers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyref_proofs as P
+    from oracle.cbind import GmpAdapter, Oracle
+    from tape import Tape
+    orc = Oracle(p, q)
+    orc.set_threads(cores)
+    K = GmpAdapter(orc, pippenger_c=max(4, min(12, n.bit_length() - 3)))
+    NV = NE = 256
+    NR = 100
+    t = Tape(b"cpu-mix", q)
+    h = orc.exp_fixed(g, t.ring_array(n))
+    y = pow(g, t.ring_element(), p)
+    pkey = [g, y]
+    w = [orc.exp_fixed(g, t.ring_array(n)), orc.exp_fixed(y, t.ring_array(n))]
+    pi, s, e, v = t.permutation(n), [t.ring_array(n)], t.int_array(n, NE), t.int_array(1, NV)[0]
+    t0 = time.perf_counter()
+    wp = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    pr = P.GPoS(K, NV, NE, NR, rand=Tape(b"cpu-prover", q))
+    pr.precompute(g, h, pi)
+    pr.setInstance(pkey, w, wp, s)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    ver = P.GPoS(K, NV, NE, NR)
+    ver.precompute(g, h)
+    ver.u = pr.u
+    ver.setInstance(pkey, w, wp)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    ok = ver.verify(rep, v)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "ciphertexts/s", "cores": cores, "kind": "port", "accepted": bool(ok),
+            "sample": f"{n} ciphertexts, 2048-bit group, width 1: re-encrypt + PoS prove + verify, GMP mpz_powm for every "
+                      "exponentiation (no fixed-base tables), Pippenger on GMP, OpenMP static chunks"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -625,6 +666,8 @@ def main() -> None:
                                   "bit_exact_vs_gpu": got == want}
         if got != want:
             result["parity_error"] = "GPU output differs from the GMP oracle on the sample"
+        if "mix_prove" in result and not distributed:
+            result["mix_prove"]["cpu_baseline"] = cpu_mix_prove(p, q, g, 3000, cores)
     if rank == 0:
         print(json.dumps(result))
     if distributed:

@@ -126,3 +126,42 @@ class Oracle:
         self.lib.orc_ring_reduce(out, self.enc(xs), self.enc(ys if ys is not None else xs), C.c_size_t(len(xs)),
                                  C.c_size_t(self.nb), C.c_int(what), self.q_be)
         return int.from_bytes(out.raw, "big")
+
+
+class GmpAdapter:
+    """The group interface of oracle/pyref_proofs.py (GPoS / GCCPoS) on top of the C + GMP oracle: every array
+    operation runs in ``libvmnoracle.so`` over all host cores (OpenMP), single elements stay Python integers.
+    Used by the CPU tests and by bench.py's ``cpu_baseline`` of the mix + prove leg: the reference's op sequence
+    with GMP underneath, i.e. what VCR + VMGJ bottoms out in, minus VCR's fixed-base tables (every exponentiation
+    is an ``mpz_powm``)."""
+
+    def __init__(self, orc: Oracle, pippenger_c: int = 8):
+        self.o, self.p, self.q, self.one, self.c = orc, orc.p, orc.q, 1, pippenger_c
+
+    def mul(self, a, b):
+        return a * b % self.p
+
+    def exp(self, a, e):
+        return pow(a, e % self.q, self.p)
+
+    def inv(self, a):
+        return pow(a, -1, self.p)
+
+    def exp_fixed(self, base, es):
+        return self.o.exp_fixed(base, es)
+
+    def exp_array(self, xs, es):
+        return self.o.exp_array(xs, es)
+
+    def exp_scalar(self, xs, e):
+        return self.o.exp_scalar(xs, e)
+
+    def exp_prod(self, xs, es):
+        bits = max(1, max((int(e).bit_length() for e in es), default=1))
+        return self.o.exp_prod(xs, es, ebits=8 * ((bits + 7) // 8), pippenger_c=self.c)
+
+    def mul_arrays(self, xs, ys):
+        return self.o.mul(xs, ys)
+
+    def prod(self, xs):
+        return self.o.prod(xs)
