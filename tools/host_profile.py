@@ -1,5 +1,6 @@
-"""cProfile of one warm mix+prove pass (bench.mix_prove) to see where host time goes.  GPU box only."""
-import cProfile, os, pstats, sys
+"""cProfile of one warm pass of a mix leg (bench.mix_prove / mix_ec / mix_ccpos) to see where host time goes.
+usage: host_profile.py [prove|ec|ccpos] [n]      GPU box only."""
+import cProfile, gc, os, pstats, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -8,16 +9,24 @@ import bench
 
 vmn = entry.load_package()
 ctx = vmn.Context(0)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import load_golden
-g, _ = load_golden(2048)
-grp = vmn.ModPGroup(ctx, g["p"], g["q"], g["g"])
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+leg = sys.argv[1] if len(sys.argv) > 1 else "prove"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else (1_000_000 if leg == "prove" else 400_000)
 sync = ctx.synchronize
-bench.mix_prove(entry, vmn, ctx, grp, n, 7, sync)          # warm-up (tables, pool)
+if leg == "prove":
+    p, q, g = bench.load_sub(entry, "stdgroups").modp_group(2048)
+    grp = vmn.ModPGroup(ctx, p, q, g)
+    run = lambda seed: bench.mix_prove(entry, vmn, ctx, grp, n, seed, sync)
+elif leg == "ec":
+    run = lambda seed: bench.mix_ec(entry, vmn, ctx, n, seed, sync)
+else:
+    run = lambda seed: bench.mix_ccpos(entry, vmn, ctx, n, seed, sync)
+run(7)          # warm-up (tables, pool)
+gc.collect()
+gc.disable()
 pr = cProfile.Profile()
 pr.enable()
-res = bench.mix_prove(entry, vmn, ctx, grp, n, 8, sync)
+res = run(8)
 pr.disable()
-print({k: res[k] for k in ("reencrypt_ms", "prove_ms", "verify_ms", "total_ms")})
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+print({k: (round(v, 1) if isinstance(v, float) else v) for k, v in res.items() if k.endswith("_ms") or k.startswith("ciphertexts")})
+print(res["kernel_ms_by_family"])
+pstats.Stats(pr).sort_stats("tottime").print_stats(18)

@@ -643,19 +643,22 @@ __global__ void __launch_bounds__(BLOCK) k_ec_scan_apply(u32* __restrict__ out, 
     }
 }
 
-// Horner over the window results of a multi-exponentiation: out = sum_w 2^(c w) W[w], one lane
+// Horner over the window results of a multi-exponentiation: out[a] = sum_w 2^(c w) W[a][w]; one lane per array
+// (the chain of c * nwin doublings is sequential, so the k arrays of a multi-array call share its latency)
 template <int S>
-__global__ void k_ec_horner(u32* __restrict__ out, const u32* __restrict__ wres, int nwin, int c, ECDev E) {
+__global__ void k_ec_horner(u32* __restrict__ out, const u32* __restrict__ wres, int nwin, int c, int k, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= k) return;
+    const u32* wa = wres + (size_t)a * nwin * ROW;
     Pt<S> A, B;
     pt_set_inf<S>(A, E);
     for (int w = nwin - 1; w >= 0; --w) {
         for (int s = 0; s < c; ++s) pt_dbl<S>(A, A, E);
-        pt_load<S>(B, wres + (size_t)w * ROW);
+        pt_load<S>(B, wa + (size_t)w * ROW);
         pt_add<S>(A, A, B, E);
     }
-    pt_store<S>(out, A);
+    pt_store<S>(out + (size_t)a * ROW, A);
 }
 
 }  // namespace vmn

@@ -13,6 +13,7 @@
 #include "modp_kernels.h"
 #include "vmnhip_internal.h"
 #include "sha256.h"
+#include "hostnum64.h"
 
 using namespace vmn;
 using vmn::hostbig::Big;
@@ -360,6 +361,8 @@ static void modulus_destroy(vmn_modulus& m) {
     if (m.d_rr) (void)hipFree(m.d_rr);
     if (m.d_one) (void)hipFree(m.d_one);
     delete m.hm;
+    delete m.hm64;
+    m.hm64 = nullptr;
     m = vmn_modulus();
 }
 
@@ -397,6 +400,11 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
     VMN_TRY(upload_words(ctx, &m.d_one, words_to_row_host(r, S, LPE)));
     VMN_TRY(upload_words(ctx, &m.d_rr, words_to_row_host(rr, S, LPE)));
     m.hm = new hostbig::Mont(m.n_words);
+    {
+        std::vector<uint8_t> nbe((size_t)NW * 4);
+        hostbig::to_be(m.n_words, nbe.data(), nbe.size());
+        m.hm64 = new num64::Mod(num64::from_be(nbe.data(), nbe.size(), ((size_t)NW * 4 + 7) / 8));
+    }
     return VMN_OK;
 }
 
@@ -1966,14 +1974,13 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         set_error("fixed base out of range");
         return VMN_ERR_FORMAT;
     }
-    const hostbig::Mont& hm = *m.hm;
-    Big cur = hm.to_mont(base);
+    const num64::Mod& hm = *m.hm64;                      // 64-bit limbs: the chain is sequential host work per new base
+    num64::Num cur = hm.to_m(num64::from_be(base_be, g->nbytes, hm.nl));
     const size_t chain = (size_t)nwin * w;
     std::vector<uint8_t> sq_be(chain * g->nbytes);
     for (size_t j = 0; j < chain; ++j) {
-        Big std_form = hm.from_mont(cur);
-        hostbig::to_be(std_form, sq_be.data() + j * g->nbytes, g->nbytes);
-        hm.mul(cur, cur, cur);
+        num64::to_be(hm.from_m(cur), sq_be.data() + j * g->nbytes, g->nbytes);
+        hm.mmul(cur, cur, cur);
     }
     DevTmp sq(ctx);
     VMN_TRY(sq.alloc(chain * Wd * sizeof(uint32_t)));
@@ -2110,7 +2117,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     uint32_t* misc = bsum + scan_blocks;             // [0] = total, [1] = max count
     VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
     VMN_TRY(buckets.alloc(2 * nbuckets * Wd * sizeof(uint32_t)));
-    VMN_TRY(wres.alloc((size_t)nwin * Wd * sizeof(uint32_t)));
+    VMN_TRY(wres.alloc(k * (size_t)nwin * Wd * sizeof(uint32_t)));      // window results of all k arrays
     uint32_t* B = buckets.as<uint32_t>();
     uint32_t* Ssuf = B + nbuckets * Wd;
     auto scan_u32 = [&](uint32_t* out, uint32_t* out2, const uint32_t* in) -> int {
@@ -2130,7 +2137,6 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     std::vector<std::pair<uint32_t, uint32_t>> level_cache;      // (total items, max per bucket) per level, from the first array
     for (size_t arr = 0; arr < k; ++arr) {
     const uint32_t* x = xs[arr];
-    uint8_t* out_one = out_be + arr * ebytes_out;
     const uint32_t* cnt_in = counts;
     const uint32_t* off_in = off0;
     uint32_t* cnt_out = cntA;
@@ -2207,34 +2213,35 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     VMN_TRY(scan_affine(ctx, m, B, nullptr, (size_t)nwin * nb, nb, 1, Ssuf));
     VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for((size_t)nwin * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
                          nb, (size_t)nwin, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
-    VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, nwin, true, wres.as<uint32_t>()));
-    if (m.ec) {                                        // Horner over the windows on one lane, then export
-        DevTmp res(ctx);
-        VMN_TRY(res.alloc(Wd * sizeof(uint32_t)));
-        rc = VMN_ERR_ARG;
-#define X(S_, NW_)                                                                                                \
-    if (m.ec->S == S_) {                                                                                          \
-        hipLaunchKernelGGL(k_ec_horner<S_>, dim3(1), dim3(64), 0, ctx->stream, res.as<uint32_t>(),                \
-                           (const uint32_t*)wres.as<uint32_t>(), nwin, c, ecdev(m.ec));                           \
-        rc = hipGetLastError() == hipSuccess ? VMN_OK : VMN_ERR_DEVICE;                                           \
+    VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, nwin, true, wres.as<uint32_t>() + arr * (size_t)nwin * Wd));
     }
+    // Horner over the windows, once for all k arrays: the chain of c * nwin doublings / squarings is sequential
+    // (one lane per array on the GPU for curves; on the host for modular groups), so it is done for the k arrays
+    // together and the k results leave in one copy.
+    if (m.ec) {
+        DevTmp res(ctx);
+        VMN_TRY(res.alloc(k * Wd * sizeof(uint32_t)));
+        int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                        \
+    if (m.ec->S == S_)                                                                                                    \
+        rc = launch_light(ctx, "expprod_agg", k_ec_horner<S_>, grid_for(k), res.as<uint32_t>(), (const uint32_t*)wres.as<uint32_t>(), \
+                          nwin, c, (int)k, ecdev(m.ec));
         VMN_FOR_CURVES(X)
 #undef X
         VMN_TRY(rc);
-        VMN_TRY(export_be(ctx, m, g->nbytes, res.as<uint32_t>(), 1, out_one));
-        continue;
+        return export_be(ctx, m, g->nbytes, res.as<uint32_t>(), k, out_be);
     }
-    const hostbig::Mont& hm = *m.hm;
-    // Horner over the windows on the host: nwin elements, c squarings each (O(ebits) modmuls)
-    std::vector<uint8_t> wbe((size_t)nwin * g->nbytes);
-    VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), nwin, wbe.data()));
-    Big acc = hm.one;
-    for (int w = nwin - 1; w >= 0; --w) {
-        for (int s = 0; s < c; ++s) hm.mul(acc, acc, acc);
-        Big ww = hm.to_mont(hostbig::from_be(wbe.data() + (size_t)w * g->nbytes, g->nbytes, m.NW));
-        hm.mul(acc, acc, ww);
-    }
-    hostbig::to_be(hm.from_mont(acc), out_one, g->nbytes);
+    std::vector<uint8_t> wbe(k * (size_t)nwin * g->nbytes);
+    VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, wbe.data()));
+    const num64::Mod& hm = *m.hm64;
+    for (size_t arr = 0; arr < k; ++arr) {
+        num64::Num acc = hm.one_m;
+        for (int w = nwin - 1; w >= 0; --w) {
+            for (int s2 = 0; s2 < c; ++s2) hm.mmul(acc, acc, acc);
+            num64::Num ww = hm.to_m(num64::from_be(wbe.data() + (arr * (size_t)nwin + w) * g->nbytes, g->nbytes, hm.nl));
+            hm.mmul(acc, acc, ww);
+        }
+        num64::to_be(hm.from_m(acc), out_be + arr * ebytes_out, g->nbytes);
     }
     return VMN_OK;
 }

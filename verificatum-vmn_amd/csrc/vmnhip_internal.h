@@ -12,6 +12,7 @@
 
 #include "../../include/vmnhip.h"
 #include "hostbig.h"
+#include "hostnum64.h"
 
 namespace vmn {
 
@@ -96,6 +97,7 @@ struct vmn_modulus {
     uint32_t* d_one = nullptr; // R mod N as a row == Montgomery form of 1
     vmn::hostbig::Big n_words; // NW words
     vmn::hostbig::Mont* hm = nullptr;     // host Montgomery context (32-bit words, R = 2^(32 NW))
+    vmn::num64::Mod* hm64 = nullptr;      // the same on 64-bit limbs (the sequential tails: Horner of a multi-exponentiation)
 };
 
 struct vmn_group {
