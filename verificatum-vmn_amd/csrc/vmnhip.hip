@@ -2059,12 +2059,20 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
 }
 
 // ---- K3 multi-exponentiation -----------------------------------------------------------------------
+// Window of the multi-exponentiation: per window, n bucket insertions plus the aggregation of 2^c buckets (suffix
+// scan + reduction).  The weight of a bucket against an insertion was swept on the GPU (3, 6, 10, 16 at N = 10^6 /
+// 4 x 10^5, 2048 / 3072 bits / P-256): flat between 3 and 10 (fewer buckets = more windows to fill), worse at 16.
+static double bucket_agg_weight() {
+    const char* env = getenv("VMN_BUCKET_AGG_WEIGHT");           // tuning knob
+    return env && *env ? atof(env) : 3.0;
+}
 static int pick_bucket_bits(size_t n, int ebits) {
     int best = 1;
     double best_cost = 1e300;
+    const double wagg = bucket_agg_weight();
     for (int c = 1; c <= 16; ++c) {
         int nwin = (ebits + c - 1) / c;
-        double cost = (double)nwin * ((double)n + 3.0 * (double)((size_t)1 << c));
+        double cost = (double)nwin * ((double)n + wagg * (double)((size_t)1 << c));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
