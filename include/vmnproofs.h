@@ -13,6 +13,8 @@
  *                 verify :519-584, plain and "raised" form)
  *   vmn_shuffle_reencrypt        mixnet/ShufflerElGamalSession.java:400-409, 273-278
  *   vmn_permutation_commitment   mixnet/PermutationCommitment.java:189-215
+ *   vmn_decryption_factors, vmn_combine_decryption_factors, vmn_decproof_*
+ *                                elgamal/DistrElGamalSession.java:365-385, elgamal/DistrElGamalSessionBasic.java
  *
  * Conventions
  *   * A ciphertext array of width w is 2w component arrays [u_1..u_w, v_1..v_w] (struct of arrays, the way
@@ -138,6 +140,40 @@ int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu);
 /* verify :519-584; raisedh / rho_be = NULL for the plain form */
 int vmn_ccpos_verify(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be,
                      size_t rho_bytes, int* verdict);
+
+/* ---- verifiable threshold decryption ------------------------------------------------------
+ * elgamal/DistrElGamalSession.java:365-385 (decryption factors f_j = u^(-x_j / c)), :536-538 (plaintexts);
+ * elgamal/DistrElGamalSessionBasic.java: prodFactor :318-344, modifiedLagrangeCoefficients :358-452,
+ * combineDecryptionFactors :465-503, setBatchVector :513-518, batchInput :524-526, commit :534-540, reply :595-598,
+ * combine :642-678, batchCombined :683-685, verifyCombined :693-700, batch :707-709, verify :718-727.
+ * Parties are numbered 1..k; arrays of per-party values have k + 1 entries with entry 0 unused. */
+int vmn_prod_factor(vmn_group* grp, int k, uint8_t* c_be);                                   /* c mod q, exp_bytes */
+/* threshold coefficients of smallest absolute value for the first `threshold` correct parties: |lambda_t| as
+ * exp_bytes rows and a sign flag each (1 = negative).  VMN_ERR_ARG when fewer than `threshold` parties are correct. */
+int vmn_lagrange_coefficients(vmn_group* grp, const uint8_t* correct, int k, int threshold, uint8_t* abs_be, int* negative);
+int vmn_decryption_factors(vmn_group* grp, const vmn_garray* u, const uint8_t* secret_be, int k, vmn_garray** f_out);
+/* out[i] = prod_t f_{j_t}[i]^(lambda_t): negative coefficients go through one batch inversion */
+int vmn_combine_decryption_factors(vmn_group* grp, const vmn_garray* const* f, const uint8_t* correct, int k, int threshold,
+                                   vmn_garray** out);
+/* plaintexts = v.mul(combinedFactors) is vmn_garray_mul. */
+
+typedef struct vmn_decproof vmn_decproof;          /* DistrElGamalSessionBasic of party j (prover and verifier of all l) */
+int vmn_decproof_create(vmn_group* grp, int j, int k, int threshold, int ebitlen, const vmn_random_source* rs, vmn_decproof** out);
+void vmn_decproof_free(vmn_decproof* p);
+/* u: first components; y_be: k + 1 public key shares g^(x_l) (entry 0 unused); f: k + 1 factor arrays (NULL = absent) */
+int vmn_decproof_set_instance(vmn_decproof* p, const vmn_garray* u, const uint8_t* y_be, const vmn_garray* const* f);
+int vmn_decproof_set_batch_vector(vmn_decproof* p, const uint8_t* e_be);
+int vmn_decproof_set_batch_vector_seed(vmn_decproof* p, const uint8_t* seed, size_t seedlen);
+int vmn_decproof_batch_input(vmn_decproof* p);                                               /* A = u.expProd(e) */
+int vmn_decproof_commit(vmn_decproof* p, const uint8_t* x_be, uint8_t* yp_out, uint8_t* Bp_out);   /* :534-540 */
+int vmn_decproof_reply(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, uint8_t* kx_out);      /* :595-598 */
+int vmn_decproof_set_commitment(vmn_decproof* p, int l, const uint8_t* yp_be, const uint8_t* Bp_be);
+int vmn_decproof_set_reply(vmn_decproof* p, int l, const uint8_t* kx_be);
+int vmn_decproof_batch(vmn_decproof* p, int l);                                              /* B_l = f_l.expProd(e) */
+int vmn_decproof_verify(vmn_decproof* p, int l, const uint8_t* v_be, size_t vbytes, int* verdict);           /* :718-727 */
+int vmn_decproof_combine(vmn_decproof* p, const uint8_t* correct, const uint8_t* combinedy_be, const vmn_garray* combinedf);
+int vmn_decproof_batch_combined(vmn_decproof* p);                                            /* :683-685 */
+int vmn_decproof_verify_combined(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, int* verdict);         /* :693-700 */
 
 /* ---- shuffler lines ----------------------------------------------------------------------------------------- */
 /* w' = permute(w * pk^s, pi^-1): ShufflerElGamalSession.java:400-409 (widePublicKey.exp(reencExponents)), :273-278

@@ -219,17 +219,20 @@ def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, vmn, gpu_ct
     assert not cv.verify(bad)
 
 
-def test_threshold_decryption_over_p256(vmn, gpu_ctx, entry):
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_threshold_decryption_over_p256(impl, vmn, gpu_ctx, entry):
     """Row A6 over the curve group: factors, Lagrange combination (negative integers = point negation), plaintext
     recovery and the batched proofs."""
     import importlib.util, os, sys
     from tape import Tape
-    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.elgamal", os.path.join(entry.PKG_DIR, "elgamal.py"))
+    modname = "elgamal" if impl == "python" else "native"
+    spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{modname}", os.path.join(entry.PKG_DIR, f"{modname}.py"))
     eg = importlib.util.module_from_spec(spec)
     sys.modules[spec.name] = eg
     spec.loader.exec_module(eg)
     c = Curve("P-256")
     G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    kw = {} if impl == "python" else {"group": G}          # the C++ helpers take the group instead of a bare q
     q, g = c.n, c.g
     n, k, thr = 50, 5, 3
     t = Tape(b"ecdec", q)
@@ -245,10 +248,10 @@ def test_threshold_decryption_over_p256(vmn, gpu_ctx, entry):
     correct = [False, True, False, True, True, True]
     U, V = G.toElementArray(u), G.toElementArray(v)
     F = [None] + [eg.decryptionFactors(U, xs[j], q, k) for j in range(1, k + 1)]
-    inv_c = pow(eg.prodFactor(q, k), -1, q)
+    inv_c = pow(eg.prodFactor(q, k, **kw), -1, q)
     for j in range(1, k + 1):
         assert F[j].toInts() == [c.mul((-xs[j]) * inv_c % q, P) for P in u]
-    assert any(ci < 0 for ci in eg.modifiedLagrangeCoefficients(q, correct, k, thr))
+    assert any(ci < 0 for ci in eg.modifiedLagrangeCoefficients(q, correct, k, thr, **kw))
     comb = eg.combineDecryptionFactors(F, correct, k, thr, q)
     assert eg.plaintexts(V, comb).toInts() == msgs
     e = t.int_array(n, 100)

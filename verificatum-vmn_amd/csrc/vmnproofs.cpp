@@ -952,6 +952,210 @@ struct vmn_ccpos : ProofBase {
     }
 };
 
+
+// ================================================================================================================
+// Verifiable threshold decryption: DistrElGamalSession / DistrElGamalSessionBasic
+// ================================================================================================================
+namespace vmnp {
+
+Num small(const HostGroup& G, uint64_t v) {
+    Num r(G.ql, 0);
+    r[0] = v;
+    return r;
+}
+// c = (prod over primes p <= k of the largest power of p not exceeding k)^2 mod q   (:294-344)
+Num prod_factor(const HostGroup& G, int k) {
+    static const int primes[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97};
+    Num res = G.Zq.reduce((const uint8_t*)"\x01", 1);
+    for (int pr : primes) {
+        if (pr > k) break;
+        uint64_t a = 1, b = 1;
+        while (b <= (uint64_t)k) {
+            a = b;
+            b *= (uint64_t)pr;
+        }
+        uint8_t be[8];
+        for (int i = 0; i < 8; ++i) be[i] = (uint8_t)(a >> (8 * (7 - i)));
+        res = G.Zq.mul(res, G.Zq.reduce(be, 8));
+    }
+    return G.Zq.mul(res, res);
+}
+// modified Lagrange coefficients of smallest absolute value (:358-452)
+int lagrange(const HostGroup& G, const uint8_t* correct, int k, int threshold, std::vector<Num>& abs, std::vector<int>& negative,
+             std::vector<int>* parties = nullptr) {
+    const Num pf = prod_factor(G, k);
+    abs.clear();
+    negative.clear();
+    auto num = [&](int v) {                         // small signed integer mod q
+        uint8_t be[8];
+        uint64_t a = (uint64_t)(v < 0 ? -v : v);
+        for (int i = 0; i < 8; ++i) be[i] = (uint8_t)(a >> (8 * (7 - i)));
+        Num r = G.Zq.reduce(be, 8);
+        return v < 0 ? G.Zq.neg(r) : r;
+    };
+    for (int i = 1; i <= k && (int)abs.size() < threshold; ++i) {
+        if (!correct[i]) continue;
+        Num res = pf;
+        int t = 0;
+        for (int l = 1; l <= k && t < threshold; ++l) {
+            if (!correct[l]) continue;
+            if (l != i) res = G.Zq.mul(G.Zq.mul(res, num(l)), G.Zq.inv(num(l - i)));
+            ++t;
+        }
+        Num alt = G.Zq.neg(res);                    // q - res = |res - q|
+        const bool neg = !vmn::num64::is_zero(res) && vmn::num64::cmp(alt, res) < 0;
+        abs.push_back(neg ? alt : res);
+        negative.push_back(neg ? 1 : 0);
+        if (parties) parties->push_back(i);
+    }
+    if ((int)abs.size() < threshold) return fail(VMN_ERR_ARG, "attempting to combine too few decryption factors");
+    return VMN_OK;
+}
+
+}  // namespace vmnp
+
+struct vmn_decproof {
+    HostGroup G;
+    int j = 0, k = 0, threshold = 0, ebitlen = 0, e_bits = 0;
+    bool has_rs = false;
+    vmn_random_source rs{};
+    Num inverseFactor;
+    const vmn_garray* u = nullptr;
+    std::vector<Bytes> y;
+    std::vector<const vmn_garray*> f;
+    RA e;
+    Bytes A;
+    Num x, r;
+    std::vector<Bytes> yp, Bp, B;
+    std::vector<Num> k_x;
+    std::vector<char> have_kx;
+    // combined
+    Bytes combinedyp, combinedBp, combinedy, combinedB;
+    Num combinedk_x;
+    const vmn_garray* combinedf = nullptr;
+
+    int init(vmn_group* grp, int j_, int k_, int threshold_, int ebitlen_, const vmn_random_source* r_) {
+        TRY(G.init(grp));
+        j = j_;
+        k = k_;
+        threshold = threshold_;
+        ebitlen = ebitlen_;
+        e_bits = std::min(ebitlen_, G.qbits);
+        if (r_) {
+            if (!r_->ring_elements) return fail(VMN_ERR_ARG, "random source lacks a callback");
+            rs = *r_;
+            has_rs = true;
+        }
+        inverseFactor = G.Zq.inv(prod_factor(G, k));
+        y.assign(k + 1, Bytes());
+        f.assign(k + 1, nullptr);
+        yp.assign(k + 1, Bytes());
+        Bp.assign(k + 1, Bytes());
+        B.assign(k + 1, Bytes());
+        k_x.assign(k + 1, Num());
+        have_kx.assign(k + 1, 0);
+        return VMN_OK;
+    }
+    int party(int l) const { return l >= 1 && l <= k ? VMN_OK : fail(VMN_ERR_ARG, "party index %d outside 1..%d", l, k); }
+    int set_instance(const vmn_garray* u_, const uint8_t* y_be, const vmn_garray* const* f_) {
+        REQUIRE(u_ && y_be && f_, "null argument");
+        u = u_;
+        for (int l = 1; l <= k; ++l) {
+            y[l].assign(y_be + (size_t)l * G.eb, y_be + (size_t)(l + 1) * G.eb);
+            f[l] = f_[l];
+            if (f[l] && vmn_garray_size(f[l]) != vmn_garray_size(u)) return fail(VMN_ERR_ARG, "decryption factors of party %d differ in size from u", l);
+        }
+        return VMN_OK;
+    }
+    int batch_input() {
+        REQUIRE(u && e.p, "batchInput needs the instance and the batching vector");
+        A.resize(G.eb);
+        return vmn_garray_expprod(u, e, e_bits, A.data());                       // :524-526
+    }
+    int commit(const uint8_t* x_be, uint8_t* yp_out, uint8_t* Bp_out) {
+        REQUIRE(x_be && yp_out && Bp_out && has_rs && !A.empty(), "commit needs a random source and batchInput()");
+        x = G.ring_from(x_be);
+        const uint8_t* rows = nullptr;
+        if (rs.ring_elements(rs.user, 1, &rows) != 0 || !rows) return fail(VMN_ERR_ARG, "random source failed");
+        r = G.ring_from(rows);
+        TRY(G.el_exp(G.g, r, yp[j]));                                            // y' = g^r
+        TRY(G.el_exp(A, r, Bp[j]));                                              // B' = A^r
+        memcpy(yp_out, yp[j].data(), G.eb);
+        memcpy(Bp_out, Bp[j].data(), G.eb);
+        return VMN_OK;
+    }
+    int reply(const uint8_t* v_be, size_t vbytes, uint8_t* kx_out) {
+        REQUIRE(v_be && vbytes && kx_out && !x.empty() && !r.empty(), "reply needs commit()");
+        Num v = G.reduce(v_be, vbytes);
+        k_x[j] = G.Zq.add(G.Zq.mul(G.Zq.mul(G.Zq.neg(x), inverseFactor), v), r);  // -x c^-1 v + r   :595-598
+        have_kx[j] = 1;
+        Bytes out = G.ring_bytes(k_x[j]);
+        memcpy(kx_out, out.data(), G.xb);
+        return VMN_OK;
+    }
+    int verify(int l, const uint8_t* v_be, size_t vbytes, int* verdict) {
+        TRY(party(l));
+        REQUIRE(verdict && v_be && vbytes && !A.empty() && !B[l].empty() && !yp[l].empty() && have_kx[l], "verify needs batch(l), the commitment and the reply of l");
+        Num v = G.reduce(v_be, vbytes);
+        Bytes yinv, t, lhs, rhs;
+        TRY(G.el_inv(y[l], yinv));
+        TRY(G.el_exp(yinv, G.Zq.mul(inverseFactor, v), t));
+        TRY(G.el_mul(t, yp[l], lhs));
+        TRY(G.el_exp(G.g, k_x[l], rhs));
+        const int ok1 = lhs == rhs;
+        TRY(G.el_exp(B[l], v, t));
+        TRY(G.el_mul(t, Bp[l], lhs));
+        TRY(G.el_exp(A, k_x[l], rhs));
+        *verdict = ok1 && lhs == rhs;
+        return VMN_OK;
+    }
+    int combine(const uint8_t* correct, const uint8_t* combinedy_be, const vmn_garray* combinedf_) {
+        REQUIRE(correct && combinedy_be && combinedf_, "null argument");
+        std::vector<Num> abs;
+        std::vector<int> neg, parties;
+        TRY(lagrange(G, correct, k, threshold, abs, neg, &parties));
+        combinedyp = G.one();
+        combinedBp = G.one();
+        combinedk_x = Num(G.ql, 0);
+        for (size_t t = 0; t < parties.size(); ++t) {
+            const int l = parties[t];
+            REQUIRE(!yp[l].empty() && have_kx[l], "combine needs the commitment and the reply of every combined party");
+            Num ex = neg[t] ? G.Zq.neg(abs[t]) : abs[t];
+            Bytes a, b2;
+            TRY(G.el_exp(yp[l], ex, a));
+            TRY(G.el_mul(combinedyp, a, b2));
+            combinedyp = b2;
+            TRY(G.el_exp(Bp[l], ex, a));
+            TRY(G.el_mul(combinedBp, a, b2));
+            combinedBp = b2;
+            combinedk_x = G.Zq.add(combinedk_x, G.Zq.mul(k_x[l], ex));
+        }
+        combinedy.assign(combinedy_be, combinedy_be + G.eb);
+        combinedf = combinedf_;
+        return VMN_OK;
+    }
+    int batch_combined() {
+        REQUIRE(combinedf && e.p, "batchCombined needs combine() and the batching vector");
+        combinedB.resize(G.eb);
+        return vmn_garray_expprod(combinedf, e, e_bits, combinedB.data());
+    }
+    int verify_combined(const uint8_t* v_be, size_t vbytes, int* verdict) {
+        REQUIRE(verdict && v_be && vbytes && !combinedB.empty() && !A.empty(), "verifyCombined needs batchCombined()");
+        Num v = G.reduce(v_be, vbytes);
+        Bytes yinv, t, lhs, rhs;
+        TRY(G.el_inv(combinedy, yinv));
+        TRY(G.el_exp(yinv, v, t));
+        TRY(G.el_mul(t, combinedyp, lhs));
+        TRY(G.el_exp(G.g, combinedk_x, rhs));
+        const int ok1 = lhs == rhs;
+        TRY(G.el_exp(combinedB, v, t));
+        TRY(G.el_mul(t, combinedBp, lhs));
+        TRY(G.el_exp(A, combinedk_x, rhs));
+        *verdict = ok1 && lhs == rhs;
+        return VMN_OK;
+    }
+};
+
 // ================================================================================================================
 // C entry points
 // ================================================================================================================
@@ -1320,6 +1524,159 @@ int vmn_ccpos_verify(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raise
                      int* verdict) {
     NONNULL(p);
     return p->verify(reply, raisedh, rho_be, rho_bytes, verdict);
+}
+
+// ---- threshold decryption --------------------------------------------------------------------------------------
+int vmn_prod_factor(vmn_group* grp, int k, uint8_t* c_be) {
+    if (!grp || !c_be || k < 1) return fail(VMN_ERR_ARG, "vmn_prod_factor: bad argument");
+    HostGroup G;
+    TRY(G.init(grp));
+    Bytes b = G.ring_bytes(prod_factor(G, k));
+    memcpy(c_be, b.data(), G.xb);
+    return VMN_OK;
+}
+int vmn_lagrange_coefficients(vmn_group* grp, const uint8_t* correct, int k, int threshold, uint8_t* abs_be, int* negative) {
+    if (!grp || !correct || !abs_be || !negative || k < 1 || threshold < 1) return fail(VMN_ERR_ARG, "vmn_lagrange_coefficients: bad argument");
+    HostGroup G;
+    TRY(G.init(grp));
+    std::vector<Num> abs;
+    std::vector<int> neg;
+    TRY(lagrange(G, correct, k, threshold, abs, neg));
+    for (size_t t = 0; t < abs.size(); ++t) {
+        Bytes b = G.ring_bytes(abs[t]);
+        memcpy(abs_be + t * G.xb, b.data(), G.xb);
+        negative[t] = neg[t];
+    }
+    return VMN_OK;
+}
+int vmn_decryption_factors(vmn_group* grp, const vmn_garray* u, const uint8_t* secret_be, int k, vmn_garray** f_out) {
+    if (!grp || !u || !secret_be || !f_out || k < 1) return fail(VMN_ERR_ARG, "vmn_decryption_factors: bad argument");
+    HostGroup G;
+    TRY(G.init(grp));
+    // firstComponents.exp(secretKey.neg().mul(inverseFactor))   DistrElGamalSession.java:384-385
+    Num ex = G.Zq.mul(G.Zq.neg(G.ring_from(secret_be)), G.Zq.inv(prod_factor(G, k)));
+    Bytes eb = G.ring_bytes(ex);
+    return vmn_garray_exp_scalar(u, eb.data(), eb.size(), f_out);
+}
+int vmn_combine_decryption_factors(vmn_group* grp, const vmn_garray* const* f, const uint8_t* correct, int k, int threshold,
+                                   vmn_garray** out) {
+    if (!grp || !f || !correct || !out) return fail(VMN_ERR_ARG, "vmn_combine_decryption_factors: null argument");
+    HostGroup G;
+    TRY(G.init(grp));
+    std::vector<Num> abs;
+    std::vector<int> neg, parties;
+    TRY(lagrange(G, correct, k, threshold, abs, neg, &parties));
+    GA pos, negp;                                   // products of the positive / negative parts (:465-503)
+    for (size_t t = 0; t < parties.size(); ++t) {
+        if (vmn::num64::is_zero(abs[t])) continue;
+        const vmn_garray* base = f[parties[t]];
+        if (!base) return fail(VMN_ERR_ARG, "vmn_combine_decryption_factors: factors of party %d are missing", parties[t]);
+        Bytes eb = G.ring_bytes(abs[t]);
+        GA tpow;
+        TRY(vmn_garray_exp_scalar(base, eb.data(), eb.size(), tpow.out()));
+        GA& acc = neg[t] ? negp : pos;
+        if (!acc.p) {
+            acc.p = tpow.release();
+        } else {
+            GA prod;
+            TRY(vmn_garray_mul(acc, tpow, prod.out()));
+            acc.reset();
+            acc.p = prod.release();
+        }
+    }
+    if (negp.p) {
+        GA ninv;
+        TRY(vmn_garray_inv(negp, ninv.out()));
+        if (!pos.p) {
+            *out = ninv.release();
+            return VMN_OK;
+        }
+        return vmn_garray_mul(pos, ninv, out);
+    }
+    if (!pos.p) return fail(VMN_ERR_ARG, "vmn_combine_decryption_factors: all coefficients are zero");
+    *out = pos.release();
+    return VMN_OK;
+}
+
+int vmn_decproof_create(vmn_group* grp, int j, int k, int threshold, int ebitlen, const vmn_random_source* rs, vmn_decproof** out) {
+    if (!grp || !out || k < 1 || j < 1 || j > k || threshold < 1 || threshold > k || ebitlen <= 0)
+        return fail(VMN_ERR_ARG, "vmn_decproof_create: bad argument");
+    std::unique_ptr<vmn_decproof> p(new vmn_decproof());
+    TRY(p->init(grp, j, k, threshold, ebitlen, rs));
+    *out = p.release();
+    return VMN_OK;
+}
+void vmn_decproof_free(vmn_decproof* p) { delete p; }
+int vmn_decproof_set_instance(vmn_decproof* p, const vmn_garray* u, const uint8_t* y_be, const vmn_garray* const* f) {
+    NONNULL(p);
+    return p->set_instance(u, y_be, f);
+}
+int vmn_decproof_set_batch_vector(vmn_decproof* p, const uint8_t* e_be) {
+    NONNULL(p);
+    if (!p->u || !e_be) return fail(VMN_ERR_ARG, "vmn_decproof_set_batch_vector: instance not set");
+    int ok = 1;
+    TRY(vmn_rarray_from_be(p->G.grp, e_be, vmn_garray_size(p->u), p->e.out(), &ok));
+    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "batching vector entry >= q");
+}
+int vmn_decproof_set_batch_vector_seed(vmn_decproof* p, const uint8_t* seed, size_t seedlen) {
+    NONNULL(p);
+    if (!p->u) return fail(VMN_ERR_ARG, "vmn_decproof_set_batch_vector_seed: instance not set");
+    return vmn_rarray_from_prg(p->G.grp, seed, seedlen, vmn_garray_size(p->u), p->ebitlen, p->e.out());
+}
+int vmn_decproof_batch_input(vmn_decproof* p) {
+    NONNULL(p);
+    return p->batch_input();
+}
+int vmn_decproof_commit(vmn_decproof* p, const uint8_t* x_be, uint8_t* yp_out, uint8_t* Bp_out) {
+    NONNULL(p);
+    return p->commit(x_be, yp_out, Bp_out);
+}
+int vmn_decproof_reply(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, uint8_t* kx_out) {
+    NONNULL(p);
+    return p->reply(v_be, vbytes, kx_out);
+}
+int vmn_decproof_set_commitment(vmn_decproof* p, int l, const uint8_t* yp_be, const uint8_t* Bp_be) {
+    NONNULL(p);
+    TRY(p->party(l));
+    if (!yp_be || !Bp_be) return fail(VMN_ERR_ARG, "vmn_decproof_set_commitment: null argument");
+    Bytes a(yp_be, yp_be + p->G.eb), b(Bp_be, Bp_be + p->G.eb);
+    int ok = 1;
+    TRY(p->G.check_elements({&a, &b}, &ok));
+    if (!ok) return fail(VMN_ERR_FORMAT, "commitment holds a value that is not a group element");
+    p->yp[l] = a;
+    p->Bp[l] = b;
+    return VMN_OK;
+}
+int vmn_decproof_set_reply(vmn_decproof* p, int l, const uint8_t* kx_be) {
+    NONNULL(p);
+    TRY(p->party(l));
+    if (!kx_be) return fail(VMN_ERR_ARG, "vmn_decproof_set_reply: null argument");
+    p->k_x[l] = p->G.reduce(kx_be, p->G.xb);
+    p->have_kx[l] = 1;
+    return VMN_OK;
+}
+int vmn_decproof_batch(vmn_decproof* p, int l) {
+    NONNULL(p);
+    TRY(p->party(l));
+    if (!p->f[l] || !p->e.p) return fail(VMN_ERR_ARG, "vmn_decproof_batch: factors of party %d or the batching vector are missing", l);
+    p->B[l].resize(p->G.eb);
+    return vmn_garray_expprod(p->f[l], p->e, p->e_bits, p->B[l].data());              // :707-709
+}
+int vmn_decproof_verify(vmn_decproof* p, int l, const uint8_t* v_be, size_t vbytes, int* verdict) {
+    NONNULL(p);
+    return p->verify(l, v_be, vbytes, verdict);
+}
+int vmn_decproof_combine(vmn_decproof* p, const uint8_t* correct, const uint8_t* combinedy_be, const vmn_garray* combinedf) {
+    NONNULL(p);
+    return p->combine(correct, combinedy_be, combinedf);
+}
+int vmn_decproof_batch_combined(vmn_decproof* p) {
+    NONNULL(p);
+    return p->batch_combined();
+}
+int vmn_decproof_verify_combined(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, int* verdict) {
+    NONNULL(p);
+    return p->verify_combined(v_be, vbytes, verdict);
 }
 
 }  // extern "C"

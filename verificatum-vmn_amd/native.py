@@ -402,3 +402,131 @@ def permutation_commitment_native(group, g, h, r, pi):
     ptr, keep = _u32_array(pi)
     _check(plib().vmn_permutation_commitment(group._h, group.enc_el(g), h._h, r._h, ptr, C.byref(out)))
     return PGroupElementArray(group, out)
+
+
+# ---- verifiable threshold decryption (the interface of elgamal.py over the C++ drivers) -------------------------------
+def _flags(correct):
+    return bytes(1 if c else 0 for c in correct)
+
+
+def prodFactor(q: int, k: int, group=None) -> int:
+    """``vmn_prod_factor`` (needs the group whose order is q)."""
+    out = C.create_string_buffer(group.nbytes)
+    _check(plib().vmn_prod_factor(group._h, C.c_int(k), out))
+    return int.from_bytes(out.raw, "big")
+
+
+def modifiedLagrangeCoefficients(q: int, correct, k: int, threshold: int, group=None):
+    """``vmn_lagrange_coefficients``: signed integers of smallest absolute value."""
+    absb = C.create_string_buffer(threshold * group.nbytes)
+    neg = (C.c_int * threshold)()
+    _check(plib().vmn_lagrange_coefficients(group._h, _flags(correct), C.c_int(k), C.c_int(threshold), absb, neg))
+    nb = group.nbytes
+    return [(-1 if neg[t] else 1) * int.from_bytes(absb.raw[t * nb:(t + 1) * nb], "big") for t in range(threshold)]
+
+
+def decryptionFactors(u, secretKey: int, q: int, k: int):
+    out = C.c_void_p()
+    _check(plib().vmn_decryption_factors(u.group._h, u._h, int_to_be(secretKey % q, u.group.nbytes), C.c_int(k), C.byref(out)))
+    return PGroupElementArray(u.group, out)
+
+
+def _opt_ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[(a._h.value if a is not None else None) for a in arrs])
+
+
+def combineDecryptionFactors(decryptionFactors_, correct, k: int, threshold: int, q: int):
+    group = next(a for a in decryptionFactors_ if a is not None).group
+    out = C.c_void_p()
+    _check(plib().vmn_combine_decryption_factors(group._h, _opt_ptr_array(decryptionFactors_), _flags(correct), C.c_int(k),
+                                                 C.c_int(threshold), C.byref(out)))
+    return PGroupElementArray(group, out)
+
+
+def plaintexts(v, combinedFactors):
+    return v.mul(combinedFactors)
+
+
+class DistrElGamalSessionBasic:
+    """``vmn_decproof_*`` — ref: elgamal/DistrElGamalSessionBasic.java (one instance per party j)."""
+
+    def __init__(self, group, j: int, k: int, threshold: int, ebitlen: int, rand=None):
+        self.G, self.j, self.k, self.q = group, j, k, group.q
+        self._rs = RandomSource(group, rand) if rand is not None else None
+        self._h = C.c_void_p()
+        _check(plib().vmn_decproof_create(group._h, C.c_int(j), C.c_int(k), C.c_int(threshold), C.c_int(ebitlen),
+                                          C.byref(self._rs.struct) if self._rs else None, C.byref(self._h)))
+        self.k_x = {}
+        self._keep = []
+
+    def free(self):
+        if self._h and self.G.alive:
+            plib().vmn_decproof_free(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _check(getattr(plib(), "vmn_decproof_" + name)(self._h, *args))
+
+    def setInstance(self, u, y, f):
+        G = self.G
+        ybuf = b"".join(G.enc_el(el) if el is not None else bytes(G.elem_bytes) for el in y)
+        self._keep = [u, f]
+        self._call("set_instance", u._h, ybuf, _opt_ptr_array(f))
+
+    def setBatchVector(self, e_ints):
+        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
+        self._call("set_batch_vector", blk[0])
+
+    def setBatchVectorSeed(self, seed: bytes):
+        self._call("set_batch_vector_seed", bytes(seed), C.c_size_t(len(seed)))
+
+    def batchInput(self):
+        self._call("batch_input")
+
+    def commit(self, x: int):
+        G = self.G
+        yp, Bp = C.create_string_buffer(G.elem_bytes), C.create_string_buffer(G.elem_bytes)
+        self._call("commit", int_to_be(x % self.q, G.nbytes), yp, Bp)
+        return G.dec_el(yp.raw), G.dec_el(Bp.raw)
+
+    def reply(self, v: int) -> int:
+        b = _be(v)
+        out = C.create_string_buffer(self.G.nbytes)
+        self._call("reply", b, C.c_size_t(len(b)), out)
+        self.k_x[self.j] = int.from_bytes(out.raw, "big")
+        return self.k_x[self.j]
+
+    def setCommitment(self, l: int, yp, Bp):
+        self._call("set_commitment", C.c_int(l), self.G.enc_el(yp), self.G.enc_el(Bp))
+
+    def setReply(self, l: int, k_x: int):
+        self.k_x[l] = k_x % self.q
+        self._call("set_reply", C.c_int(l), int_to_be(k_x % self.q, self.G.nbytes))
+
+    def batch(self, l: int):
+        self._call("batch", C.c_int(l))
+
+    def verify(self, l: int, v: int) -> bool:
+        b = _be(v)
+        verdict = C.c_int(0)
+        self._call("verify", C.c_int(l), b, C.c_size_t(len(b)), C.byref(verdict))
+        return bool(verdict.value)
+
+    def combine(self, correct, combinedy, combinedf):
+        self._keep.append(combinedf)
+        self._call("combine", _flags(correct), self.G.enc_el(combinedy), combinedf._h)
+
+    def batchCombined(self):
+        self._call("batch_combined")
+
+    def verifyCombined(self, v: int) -> bool:
+        b = _be(v)
+        verdict = C.c_int(0)
+        self._call("verify_combined", b, C.c_size_t(len(b)), C.byref(verdict))
+        return bool(verdict.value)
