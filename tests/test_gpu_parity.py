@@ -205,7 +205,7 @@ def test_helper_thread_runs_concurrently_with_main_thread(groups):
     import threading
     G, grp, _ = groups[2048]
     p, q = grp["p"], grp["q"]
-    n = 3000
+    n = 700
     xs, es = _inputs(b"thr", n, p, q)
     ys, _ = _inputs(b"thr2", n, p, q)
     perm = sorted(range(n), key=lambda i: (xs[i], i))

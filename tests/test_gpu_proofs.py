@@ -58,7 +58,7 @@ def same_msg(a, b):
 
 
 @pytest.mark.parametrize("bits,n,width,nbits", [(512, 70, 1, (100, 100, 50)), (512, 33, 2, (100, 100, 50)),
-                                                (2048, 300, 1, (256, 256, 100)), (4096, 24, 1, (256, 256, 100))])
+                                                (2048, 130, 1, (256, 256, 100)), (4096, 12, 1, (256, 256, 100))])
 def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods, hv):
     NV, NE, NR = nbits
     p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"pos%d" % bits)
