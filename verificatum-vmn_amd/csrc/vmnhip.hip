@@ -1856,14 +1856,24 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
 }
 
 // ---- K2 fixed base ---------------------------------------------------------------------------------
-static int pick_fixed_window(size_t n, int ebits, size_t row_bytes) {
+// Window of a fixed-base table: ceil(ebits / w) products per exponentiation against 2^w * ceil(ebits / w) products
+// to build the table, the build shared by `reuse` calls.  A base seen for the first time (the per-proof h_0) gets
+// the window that is best for one call (w = 16 at N = 10^6: 2.5 GB); a base that keeps coming back (g, the public
+// key) is rebuilt with the window that is best over its uses (w = 19: 17 GB at 2048 bits -- 288 GB of HBM are
+// there to be used), capped per table.
+static int pick_fixed_window(size_t n, int ebits, size_t row_bytes, int reuse = 1) {
+    if (const char* env = getenv("VMN_FIXED_WINDOW")) {          // measurement knob: force the window
+        int w = atoi(env);
+        if (w >= 2 && w <= 22) return w;
+    }
     int best = 4;
     double best_cost = 1e300;
-    for (int w = 2; w <= 18; ++w) {
+    const double cap = reuse > 1 ? 20e9 : 6e9;
+    for (int w = 2; w <= 20; ++w) {
         int nwin = (ebits + w - 1) / w;
         double table_bytes = (double)nwin * (double)((size_t)1 << w) * (double)row_bytes;
-        if (table_bytes > 6e9) break;
-        double cost = (double)nwin * ((double)((size_t)1 << w) + (double)n);
+        if (table_bytes > cap) break;
+        double cost = (double)nwin * ((double)((size_t)1 << w) / (double)reuse + (double)n);
         if (cost < best_cost) {
             best_cost = cost;
             best = w;
@@ -1877,7 +1887,7 @@ static int pick_fixed_window(size_t n, int ebits, size_t row_bytes) {
 static size_t fixed_cache_limit() {
     const char* env = getenv("VMN_FIXED_CACHE_BYTES");       // operational override (and the eviction test)
     if (env && *env) return (size_t)strtoull(env, nullptr, 10);
-    return (size_t)32 << 30;
+    return (size_t)64 << 30;
 }
 
 static void fixed_drop(vmn_group* g, std::map<std::string, vmn_group::FixedTable>::iterator it) {
@@ -1913,13 +1923,23 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     const size_t Wd = elem_words(m);
     std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
     int w = pick_fixed_window(n, ebits, Wd * sizeof(uint32_t));
+    int carry_uses = 1;
     auto it = g->fixed.find(key);
     if (it != g->fixed.end()) {
         vmn_group::FixedTable& ft = it->second;
-        if (ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
+        ft.uses += 1;
+        // a base that keeps coming back earns a larger window (amortised over the uses so far, at most 16)
+        // (from the sixth call on: the per-proof base h_0 is used twice and never again)
+        const int w_many = ft.uses >= 6 ? pick_fixed_window(n, ebits, Wd * sizeof(uint32_t), ft.uses < 16 ? ft.uses : 16) : w;
+        const bool grow = w_many >= ft.wbits + 2;
+        if (!grow && ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
             ft.last_use = ++g->fixed_clock;
             *out = &ft;
             return VMN_OK;
+        }
+        if (grow) {
+            w = w_many;
+            carry_uses = ft.uses;
         }
         fixed_drop(g, it);
     }
@@ -1963,6 +1983,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
             return rc;
         }
         ft.last_use = ++g->fixed_clock;
+        ft.uses = carry_uses;
         g->fixed_bytes += ft.bytes;
         auto ins = g->fixed.emplace(key, ft);
         *out = &ins.first->second;
@@ -2006,6 +2027,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         return rc;
     }
     ft.last_use = ++g->fixed_clock;
+    ft.uses = carry_uses;
     g->fixed_bytes += ft.bytes;
     auto ins = g->fixed.emplace(key, ft);
     *out = &ins.first->second;

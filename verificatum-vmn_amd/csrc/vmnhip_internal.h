@@ -114,9 +114,10 @@ struct vmn_group {
         int nwin = 0;
         size_t bytes = 0;
         uint64_t last_use = 0;
+        int uses = 0;              // calls served (a base that keeps coming back earns a larger window)
     };
     std::map<std::string, FixedTable> fixed;
-    // least-recently-used tables are dropped beyond fixed_cache_limit() bytes (32 GB, env VMN_FIXED_CACHE_BYTES) (every proof brings a new base h_0)
+    // least-recently-used tables are dropped beyond fixed_cache_limit() bytes (64 GB, env VMN_FIXED_CACHE_BYTES) (every proof brings a new base h_0)
     size_t fixed_bytes = 0;
     uint64_t fixed_clock = 0;
 };
