@@ -211,3 +211,54 @@ def test_ccpos_transcript_matches_oracle(raised, vmn, gpu_ctx, mods, hv):
         bad = dict(rep)
         bad["k_B"] = [(x + 1) % q for x in rep["k_B"]]
         assert not ver.verify(bad)
+
+
+def test_proof_level_abi_reports_misuse_and_malformed_messages(vmn, gpu_ctx, mods):
+    """Error conventions of SURVEY.md §8b at the proof level: misuse comes back as a status (VmnError), a commitment
+    holding a value that is not a group element as a format error the caller can catch (PoSBasicTW.java:794-815),
+    a wrong reply as verdict False -- never a crash."""
+    nat = mods["native"]
+    NV, NE, NR, n = 100, 100, 50, 16
+    p, q, g, h, pkey, w, t = make_instance(512, n, 1, b"misuse")
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H, W = G.toElementArray(h), [G.toElementArray(c) for c in w]
+    pi, s, e, v = t.permutation(n), [t.ring_array(n)], t.int_array(n, NE), t.int_array(1, NV)[0]
+    S = [G.ringArray(s[0])]
+    pr = nat.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"m", q))
+    with pytest.raises(vmn.VmnError):
+        pr.commit()                                            # before precompute / instance / batching vector
+    with pytest.raises(vmn.VmnError):
+        pr.precompute(g, H, [0] * n)                           # not a permutation
+    pr.precompute(g, H, pi)
+    WP = nat.reencrypt_native(G, pkey, W, S, pi)
+    short = G.toElementArray(w[0][:-1])
+    with pytest.raises(vmn.VmnError):
+        pr.setInstance(pkey, [short, W[1]], WP, S)             # component of the wrong size
+    with pytest.raises(vmn.VmnError):
+        nat.PoSBasicTW(G, NV, NE, NR).commit()                 # a verifier object has no random source
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    ver = nat.PoSBasicTW(G, NV, NE, NR)
+    ver.precompute(g, H)
+    ver.setPermutationCommitment(pr.u)
+    ver.setInstance(pkey, W, WP)
+    ver.setBatchVector(e)
+    with pytest.raises(vmn.VmnError):
+        ver.verify(rep)                                        # before computeAF / setCommitment / setChallenge
+    ver.computeAF()
+    bad = dict(com)
+    bad["Cp"] = p                                              # not a group element (>= p)
+    with pytest.raises(vmn.VmnError) as ei:
+        ver.setCommitment(bad)
+    assert ei.value.status == -4                               # VMN_ERR_FORMAT: the caller substitutes trivial values
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep)
+    wrong = dict(rep)
+    wrong["k_A"] = (rep["k_A"] + 1) % q
+    assert not ver.verify(wrong) and ver.verdicts == (False, True, True, True, True)
+    truncated = dict(rep)
+    truncated["k_F"] = []                                      # wrong shape: status, not a crash
+    with pytest.raises(vmn.VmnError):
+        ver.verify(truncated)
