@@ -68,6 +68,10 @@ void* vmn_ctx_get_stream(vmn_ctx* ctx);
 int vmn_ctx_synchronize(vmn_ctx* ctx);
 /* Number of compute units of the context's device (used by the benchmark to state the roofline). */
 int vmn_ctx_num_cus(vmn_ctx* ctx);
+/* Memory accounting (operations / leak hunting): bytes and blocks of freed arrays cached for reuse, bytes of live
+ * allocations handed out and not yet freed (arrays + temporaries), and a group's cached fixed-base tables. */
+int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes);
+size_t vmn_group_table_bytes(const vmn_group* grp);
 
 /* ---- groups -------------------------------------------------------------------------------
  * ModPGroup(p, q, g): ref: P/elgamal/ProtocolElGamal.java:738-800 (group shapes), the marshalled

@@ -252,3 +252,27 @@ def test_fixed_base_table_cache_is_bounded(vmn, gpu_ctx, monkeypatch):
     for rnd in range(2):
         for b in bases + [bases[0]]:
             assert G.exp(b, E).toInts() == pyref.exp_fixed(b, es, p), rnd
+
+
+def test_array_pool_levels_off_and_nothing_stays_live(vmn, groups):
+    """Temporaries whose size depends on the data (the level buffers of a multi-exponentiation) land in size classes,
+    so repeated calls on different data reuse the cached blocks instead of adding new ones; when every array of a
+    context has been freed, no allocation is live (tools/soak.py found the growth this guards against)."""
+    G, grp, _ = groups[1024]
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    ctx = G.ctx
+    n = 20000
+    base = ctx.memory_stats()["live_bytes"]
+    blocks = []
+    for it in range(14):
+        es = pyref.stream_ints(b"pool%d" % it, n, q)
+        E = G.ringArray(es)
+        X = G.exp(g, E)
+        _ = X.expProd(E)
+        X.free()
+        E.free()
+        st = ctx.memory_stats()
+        assert st["live_bytes"] == base
+        blocks.append(st["pool_blocks"])
+    # a data-dependent size may straddle a class boundary now and then; without classes every call adds a block
+    assert blocks[-1] <= blocks[2] + 3, blocks

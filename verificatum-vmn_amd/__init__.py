@@ -78,7 +78,7 @@ def lib() -> C.CDLL:
         _lib.vmn_last_error.restype = C.c_char_p
         _lib.vmn_version.restype = C.c_char_p
         _lib.vmn_ctx_get_stream.restype = C.c_void_p
-        for name in ("vmn_group_elem_bytes", "vmn_group_exp_bytes", "vmn_garray_size", "vmn_rarray_size",
+        for name in ("vmn_group_elem_bytes", "vmn_group_exp_bytes", "vmn_garray_size", "vmn_rarray_size", "vmn_group_table_bytes",
                      "vmn_garray_bytetree_size", "vmn_rarray_bytetree_size"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
@@ -133,6 +133,12 @@ class Context:
     @property
     def num_cus(self) -> int:
         return lib().vmn_ctx_num_cus(self._h)
+
+    def memory_stats(self) -> dict:
+        """Bytes / blocks of freed arrays cached for reuse and bytes of live allocations (arrays + temporaries)."""
+        pb, nb, lb = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(lib().vmn_ctx_memory_stats(self._h, C.byref(pb), C.byref(nb), C.byref(lb)))
+        return {"pool_bytes": pb.value, "pool_blocks": nb.value, "live_bytes": lb.value}
 
     def timing_enable(self, on: bool = True) -> None:
         _check(lib().vmn_ctx_timing_enable(self._h, C.c_int(1 if on else 0)))

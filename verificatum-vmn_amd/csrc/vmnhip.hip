@@ -150,7 +150,16 @@ static void pool_release_all(vmn_ctx* ctx) {
     ctx->pool.clear();
     ctx->pool_bytes = 0;
 }
-static size_t pool_round(size_t bytes) { return bytes < 256 ? 256 : (bytes + 255) & ~(size_t)255; }
+// Size classes of the pool: multiples of 256 B below 1 MB; above, eight classes per power of two (<= 12.5 % slack).
+// Temporaries whose size depends on the data (the level buffers of a multi-exponentiation) would otherwise add a
+// new exact size -- and a block that is never reused -- with every call (found by tools/soak.py).
+static size_t pool_round(size_t bytes) {
+    if (bytes < 256) return 256;
+    if (bytes < ((size_t)1 << 20)) return (bytes + 255) & ~(size_t)255;
+    int top = 63 - __builtin_clzll((unsigned long long)bytes);
+    size_t gran = (size_t)1 << (top - 3);
+    return (bytes + gran - 1) & ~(gran - 1);
+}
 static int pool_alloc(vmn_ctx* ctx, size_t bytes, void** out) {
     bytes = pool_round(bytes);
     auto it = ctx->pool.find(bytes);
@@ -158,6 +167,7 @@ static int pool_alloc(vmn_ctx* ctx, size_t bytes, void** out) {
         *out = it->second.back();
         it->second.pop_back();
         ctx->pool_bytes -= bytes;
+        ctx->live_bytes += bytes;
         return VMN_OK;
     }
     hipError_t e = hipMalloc(out, bytes);
@@ -170,11 +180,13 @@ static int pool_alloc(vmn_ctx* ctx, size_t bytes, void** out) {
         set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? VMN_ERR_NOMEM : VMN_ERR_DEVICE;
     }
+    ctx->live_bytes += bytes;
     return VMN_OK;
 }
 static void pool_free(vmn_ctx* ctx, void* p, size_t bytes) {
     if (!p) return;
     bytes = pool_round(bytes);
+    ctx->live_bytes -= bytes;
     if (ctx->pool_bytes + bytes > POOL_LIMIT) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
@@ -273,6 +285,16 @@ extern "C" int vmn_ctx_synchronize(vmn_ctx* ctx) {
     return VMN_OK;
 }
 extern "C" int vmn_ctx_num_cus(vmn_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+extern "C" int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes) {
+    ARG_CHECK(ctx, "null ctx");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
+    size_t blocks = 0;
+    for (auto& kv : ctx->pool) blocks += kv.second.size();
+    if (pool_bytes) *pool_bytes = ctx->pool_bytes;
+    if (pool_blocks) *pool_blocks = blocks;
+    if (live_bytes) *live_bytes = ctx->live_bytes;
+    return VMN_OK;
+}
 
 static int timing_collect(vmn_ctx* ctx) {
     if (ctx->recs.empty()) return VMN_OK;
@@ -454,6 +476,7 @@ extern "C" void vmn_group_destroy(vmn_group* grp) {
 extern "C" size_t vmn_group_elem_bytes(const vmn_group* grp) { return grp ? (grp->curve ? 2 * grp->nbytes : grp->nbytes) : 0; }
 extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->nbytes : 0; }
 extern "C" int vmn_group_kind(const vmn_group* grp) { return grp && grp->curve ? 1 : 0; }
+extern "C" size_t vmn_group_table_bytes(const vmn_group* grp) { return grp ? grp->fixed_bytes : 0; }
 extern "C" int vmn_group_get_order(const vmn_group* grp, uint8_t* q_be) {
     ARG_CHECK(grp && q_be, "null argument");
     hostbig::to_be(grp->Q.n_words, q_be, grp->nbytes);

@@ -61,6 +61,7 @@ struct vmn_ctx {
     // (all work of a context is on one stream, so reuse is ordered after the previous user)
     std::map<size_t, std::vector<void*>> pool;
     size_t pool_bytes = 0;
+    size_t live_bytes = 0;                // handed out by pool_alloc and not yet returned
     std::unordered_set<const void*> lds_attr_set;
     bool timing = false;
     std::vector<vmn::TimingRec> recs;
