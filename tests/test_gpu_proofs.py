@@ -262,3 +262,54 @@ def test_proof_level_abi_reports_misuse_and_malformed_messages(vmn, gpu_ctx, mod
     truncated["k_F"] = []                                      # wrong shape: status, not a crash
     with pytest.raises(vmn.VmnError):
         ver.verify(truncated)
+
+
+def test_two_party_threads_with_their_own_contexts(vmn, mods):
+    """vdemo runs k parties as threads of one JVM (demo/Demo.java:282-291): two threads, each with its own context and
+    group, prove and verify concurrently through the C++ drivers; both transcripts equal the oracle's."""
+    import threading
+    nat = mods["native"]
+    NV, NE, NR, n = 100, 100, 50, 400
+    p, q, g, h, _, _, t = make_instance(512, n, 1, b"threads")
+    pi, r, e, v = t.permutation(n), t.ring_array(n), t.int_array(n, NE), t.int_array(1, NV)[0]
+    u = P.permutation_commitment(g, h, r, pi, p)
+    want = {}
+    for party in (1, 2):
+        o = P.PoSC(p, q, NV, NE, NR, rand=Tape(b"party%d" % party, q))
+        o.setInstance(g, h, u, r, pi)
+        o.setBatchVector(e)
+        want[party] = (o.commit(), o.reply(v))
+    got, errors = {}, []
+
+    def party_thread(party):
+        try:
+            ctx = vmn.Context(0)
+            G = vmn.ModPGroup(ctx, p, q, g)
+            H, U, R = G.toElementArray(h), G.toElementArray(u), G.ringArray(r)
+            for rep_no in range(3):
+                pr = nat.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"party%d" % party, q))
+                pr.setInstance(g, H, U, R, pi)
+                pr.setBatchVector(e)
+                com, rep = pr.commit(), pr.reply(v)
+                ver = nat.PoSCBasicTW(G, NV, NE, NR)
+                ver.setInstance(g, H, U)
+                ver.setBatchVector(e)
+                ver.setCommitment(com)
+                ver.setChallenge(v)
+                ok = ver.verify(rep)
+                got[(party, rep_no)] = ({k: ints_of(x) for k, x in com.items()}, {k: ints_of(x) for k, x in rep.items()}, ok)
+                ver.free()
+                pr.free()
+        except Exception as exc:      # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=party_thread, args=(party,)) for party in (1, 2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for party in (1, 2):
+        for rep_no in range(3):
+            com, rep, ok = got[(party, rep_no)]
+            assert ok and (com, rep) == want[party]
