@@ -276,3 +276,25 @@ def test_array_pool_levels_off_and_nothing_stays_live(vmn, groups):
         blocks.append(st["pool_blocks"])
     # a data-dependent size may straddle a class boundary now and then; without classes every call adds a block
     assert blocks[-1] <= blocks[2] + 3, blocks
+
+
+@pytest.mark.parametrize("bits", [2048, 3072, 4096])
+def test_worst_case_column_magnitudes(bits, vmn, gpu_ctx):
+    """Lazy 64-bit columns must not overflow for the largest limbs: an all-ones odd modulus N = 2^bits - 1 (Montgomery
+    arithmetic needs no primality), operands N - 1, N - 2 and all-ones patterns, products and powers against Python.
+    4096 bits exercises the mid-product column relief of the four-lane geometry."""
+    N = (1 << bits) - 1
+    G = vmn.ModPGroup(gpu_ctx, N, N, 3, nbytes=bits // 8)
+    vals = [N - 1, N - 2, (1 << (bits - 1)) - 1, N >> 1, (N // 3) | 1, 1, 2, N - (1 << 28)] + \
+           [v | 1 for v in pyref.stream_ints(b"worst%d" % bits, 24, N)]
+    X = G.toElementArray(vals)
+    Y = G.toElementArray(list(reversed(vals)))
+    assert X.mul(Y).toInts() == [a * b % N for a, b in zip(vals, reversed(vals))]
+    assert X.mul(X).toInts() == [a * a % N for a in vals]
+    es = [N - 1, N - 2, (1 << bits) - (1 << 64) - 1, 1, 0, 2, 3, (1 << (bits - 1)) + 1] + pyref.stream_ints(b"worst-e%d" % bits, 24, N)
+    assert X.exp(G.ringArray(es)).toInts() == [pow(a, e, N) for a, e in zip(vals, es)]
+    assert G.exp(N - 1, G.ringArray(es)).toInts() == [pow(N - 1, e, N) for e in es]
+    E = G.ringArray(es)
+    F = G.ringArray(list(reversed(es)))
+    assert E.mul(F).toInts() == [a * b % N for a, b in zip(es, reversed(es))]
+    assert X.prod() == pyref.prod(vals, N)
