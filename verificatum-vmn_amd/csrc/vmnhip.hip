@@ -1475,6 +1475,19 @@ extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, cons
 // ---- K8 scans --------------------------------------------------------------------------------------
 // out[i] = out[i-1]*e[i] + b[i]  (b == nullptr: out[i] = out[i-1]*e[i], starting from one), per segment.
 // Chunked three-phase scan; the totals of one level are the inputs of the next (same recurrence).
+// Chunk length of the three-phase scans: a lane walks `chunk` elements sequentially, so short chunks give more
+// lanes (latency hiding) and long chunks fewer levels (work: 2n(1 + 1/chunk + ...)).  `lanes_wanted` is what fills
+// the chip for the kernel family; the chunk shrinks (down to 4) until the top level has that many lanes.
+static size_t scan_chunk(size_t n, size_t lanes_wanted) {
+    if (const char* env = getenv("VMN_SCAN_CHUNK")) {            // measurement knob
+        int c = atoi(env);
+        if (c >= 2 && c <= 64) return (size_t)c;
+    }
+    size_t c = 16;
+    while (c > 4 && n / c < lanes_wanted) c >>= 1;
+    return c;
+}
+
 static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, const uint32_t* b, size_t n, size_t seglen,
                        int rev, uint32_t* out) {
     if (n == 0) return VMN_OK;
@@ -1482,7 +1495,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     if (seglen == 0 || seglen > n) seglen = n;
     if (m.ec) {                                        // running sums of curve points (b must be null)
         if (b) return VMN_ERR_ARG;
-        size_t Cc = 16;
+        size_t Cc = scan_chunk(n, (size_t)ctx->num_cus * 4 * 64 * 4);          // light kernels: 4 waves per SIMD
         if (seglen != n) {
             while (Cc > 1 && seglen % Cc) Cc >>= 1;
         }
@@ -1519,7 +1532,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
         return rc;
     }
     // chunk length: divides seglen when there are several segments
-    size_t C = 16;
+    size_t C = scan_chunk(n, (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE));   // one tile per resident workgroup
     if (seglen != n) {
         while (C > 1 && seglen % C) C >>= 1;
     }
