@@ -136,6 +136,13 @@ int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, size_t ebyte
 /* K2  g.exp(E): out[i] = base^E[i] for one fixed base.  ref: P/mixnet/ShufflerElGamalSession.java:407,
  * 658; P/hvzk/PoSBasicTW.java:447, 606, 608, 644, 646, 1030; P/mixnet/PermutationCommitment.java:200. */
 int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out);
+/* Session setup: build the fixed-base table of a long-lived base (the generator, the public key) for arrays of about
+ * n_hint exponents and about uses_hint calls.  The window is the one that is best over those uses (w = 19 = a 17 GB
+ * table at 2048 bits, N = 10^6, instead of w = 16 = 2.5 GB for a base seen once: 108 instead of 128 products per
+ * exponentiation); allocating it takes ~0.6 s, which is why it belongs to setup.  VCR precomputes fixed-base tables
+ * the same way when it is handed a generator it will exponentiate many times.  Bases that are never announced get
+ * the one-call window on first use. */
+int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be, size_t n_hint, int uses_hint);
 /* K3  X.expProd(E) = prod_i X[i]^E[i] -> one element (big-endian, elem_bytes).
  * ref: P/hvzk/PoSBasicTW.java:408, 409, 481, 690, 1021, 1063; P/hvzk/CCPoSBasicW.java:380, 391, 497-503. */
 int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int ebits, uint8_t* out_be);

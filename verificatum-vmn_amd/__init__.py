@@ -288,6 +288,11 @@ class ModPGroup:
         _check(lib().vmn_group_exp_fixed(self._h, self.enc_el(base), exponents._h, C.byref(h)))
         return PGroupElementArray(self, h)
 
+    def precomputeFixed(self, base, n_hint: int, uses_hint: int = 16) -> None:
+        """Session setup: build the fixed-base table of a long-lived base (generator, public key) sized for about
+        ``uses_hint`` calls on arrays of about ``n_hint`` exponents (``vmn_group_precompute_fixed``)."""
+        _check(lib().vmn_group_precompute_fixed(self._h, self.enc_el(base), C.c_size_t(n_hint), C.c_int(uses_hint)))
+
     def mulPartials(self, partials):
         out = C.create_string_buffer(self.elem_bytes)
         _check(lib().vmn_group_mul_partials(self._h, self.enc_els(partials), C.c_size_t(len(partials)), out))

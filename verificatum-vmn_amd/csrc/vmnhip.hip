@@ -1953,20 +1953,22 @@ static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
 }
 
 // Table for (base, window) cached in the group; built on the GPU from the host squaring chain.
-static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out) {
+static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out, int reuse_hint = 1) {
     vmn_ctx* ctx = g->ctx;
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
-    int w = pick_fixed_window(n, ebits, Wd * sizeof(uint32_t));
+    int w = pick_fixed_window(n, ebits, Wd * sizeof(uint32_t), reuse_hint);
     int carry_uses = 1;
     auto it = g->fixed.find(key);
     if (it != g->fixed.end()) {
         vmn_group::FixedTable& ft = it->second;
         ft.uses += 1;
         // a base that keeps coming back earns a larger window (amortised over the uses so far, at most 16)
-        // (from the sixth call on: the per-proof base h_0 is used twice and never again)
-        const int w_many = ft.uses >= 6 ? pick_fixed_window(n, ebits, Wd * sizeof(uint32_t), ft.uses < 16 ? ft.uses : 16) : w;
+        // (only after many calls: allocating and mapping a 17 GB table takes ~0.6 s, so growing on its own pays off
+        // for long-lived services only; a session that knows its long-lived bases says so at setup,
+        // vmn_group_precompute_fixed)
+        const int w_many = ft.uses >= 64 ? pick_fixed_window(n, ebits, Wd * sizeof(uint32_t), 16) : w;
         const bool grow = w_many >= ft.wbits + 2;
         if (!grow && ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
             ft.last_use = ++g->fixed_clock;
@@ -2068,6 +2070,13 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     auto ins = g->fixed.emplace(key, ft);
     *out = &ins.first->second;
     return VMN_OK;
+}
+
+extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be, size_t n_hint, int uses_hint) {
+    ARG_CHECK(grp && base_be && n_hint > 0, "bad argument");
+    VMN_ENTER(grp->ctx);
+    vmn_group::FixedTable* ft = nullptr;
+    return fixed_table(grp, base_be, grp->Q.nbits, n_hint, &ft, uses_hint < 1 ? 1 : (uses_hint > 16 ? 16 : uses_hint));
 }
 
 extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out) {
