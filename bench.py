@@ -392,9 +392,11 @@ def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dis
     n = min(n_per_gpu * comm.world, 4_194_304)
     p, q, g = grp.p, grp.q, grp.g
     pub = mx.BulkRandomSource(seed, q, grp.nbytes)             # same seed on every rank: replicated public instance
-    H = grp.exp(g, grp.ringArray(pub.ring_array(n)))
     y = pow(g, pub.ring_element(), p)
     pkey = [g, y]
+    for base in pkey:                      # session setup (tables sized for this rank's shard)
+        grp.precomputeFixed(base, max(1, n // comm.world), 16)
+    H = grp.exp(g, grp.ringArray(pub.ring_array(n)))
     T = grp.ringArray(pub.ring_array(n))
     M = grp.exp(g, grp.ringArray(pub.ring_array(n)))
     YT = grp.exp(y, T)
