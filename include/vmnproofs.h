@@ -175,6 +175,14 @@ int vmn_decproof_combine(vmn_decproof* p, const uint8_t* correct, const uint8_t*
 int vmn_decproof_batch_combined(vmn_decproof* p);                                            /* :683-685 */
 int vmn_decproof_verify_combined(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, int* verdict);         /* :693-700 */
 
+/* ---- single group elements on the host (what the drivers above use for A', C', ... ; exposed for callers that hold
+ * such elements themselves, e.g. the sharded multi-GPU proof driver): big-endian elem_bytes in and out; the exponent
+ * is a non-negative big-endian integer of any length.  ModPGroup: 64-bit Montgomery arithmetic; curves: Jacobian
+ * arithmetic (csrc/hostnum64.h, csrc/hostcurve.h).  No GPU work. */
+int vmn_element_exp(vmn_group* grp, const uint8_t* base_be, const uint8_t* e_be, size_t ebytes, uint8_t* out_be);
+int vmn_element_mul(vmn_group* grp, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be);
+int vmn_element_inv(vmn_group* grp, const uint8_t* a_be, uint8_t* out_be);
+
 /* ---- shuffler lines ----------------------------------------------------------------------------------------- */
 /* w' = permute(w * pk^s, pi^-1): ShufflerElGamalSession.java:400-409 (widePublicKey.exp(reencExponents)), :273-278
  * (input.mul(reencFactors), permute(inverse), reencFactors.free()).  wp_out receives 2w new arrays. */

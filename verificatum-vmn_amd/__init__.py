@@ -66,6 +66,7 @@ class VmnError(RuntimeError):
 
 
 _lib: Optional[C.CDLL] = None
+_plib_scalar = None        # libvmnproofs.so for the host arithmetic on single elements (False: not built)
 
 
 def lib() -> C.CDLL:
@@ -212,13 +213,45 @@ class ModPGroup:
     def dec_els(self, buf: bytes) -> list:
         return be_to_ints(buf, self.nbytes)
 
+    # Single elements: through the host arithmetic of libvmnproofs.so (vmn_element_*: 64-bit Montgomery / Jacobian
+    # curve code, several times faster than Python integers / the affine Python curve code for the ~20
+    # exponentiations of a proof) when that library is there, else plain Python.
+    def _scalar_lib(self):
+        global _plib_scalar
+        if _plib_scalar is None:
+            path = os.path.join(_HERE, "libvmnproofs.so")
+            _plib_scalar = C.CDLL(path) if os.path.exists(path) else False
+        return _plib_scalar
+
+    def _k_native(self, fn: str, *args):
+        """(True, element) through libvmnproofs.so, or (False, None) when that library is not built."""
+        pl = self._scalar_lib()
+        if not pl or not self.alive:
+            return False, None
+        out = C.create_string_buffer(self.elem_bytes)
+        _check(getattr(pl, fn)(self._h, *args, out))
+        return True, self.dec_el(out.raw)
+
     def k_mul(self, a, b):
-        return a * b % self.p
+        ok, r = self._k_native("vmn_element_mul", self.enc_el(a), self.enc_el(b))
+        return r if ok else self._py_mul(a, b)
 
     def k_exp(self, a, e: int):
-        return pow(a, e % self.q, self.p)
+        eb = int(e % self.q).to_bytes(self.nbytes, "big")
+        ok, r = self._k_native("vmn_element_exp", self.enc_el(a), eb, C.c_size_t(len(eb)))
+        return r if ok else self._py_exp(a, e)
 
     def k_inv(self, a):
+        ok, r = self._k_native("vmn_element_inv", self.enc_el(a))
+        return r if ok else self._py_inv(a)
+
+    def _py_mul(self, a, b):
+        return a * b % self.p
+
+    def _py_exp(self, a, e: int):
+        return pow(a, e % self.q, self.p)
+
+    def _py_inv(self, a):
         return pow(a, -1, self.p)
 
     # -- constructors mirroring pGroup.toElementArray / pRing.toElementArray --------------------
@@ -341,13 +374,13 @@ class ECqPGroup(ModPGroup):
         w = 2 * self.nbytes
         return [self.dec_el(buf[i:i + w]) for i in range(0, len(buf), w)]
 
-    def k_mul(self, a, b):
+    def _py_mul(self, a, b):
         return self._ec.add(a, b, self.p)
 
-    def k_exp(self, a, e: int):
+    def _py_exp(self, a, e: int):
         return self._ec.mul(e, a, self.p, self.q)
 
-    def k_inv(self, a):
+    def _py_inv(self, a):
         return self._ec.neg(a, self.p)
 
     def toElementArray(self, values, checked: bool = True) -> "PGroupElementArray":

@@ -1679,4 +1679,57 @@ int vmn_decproof_verify_combined(vmn_decproof* p, const uint8_t* v_be, size_t vb
     return p->verify_combined(v_be, vbytes, verdict);
 }
 
+// ---- single elements ------------------------------------------------------------------------------------------------
+namespace vmnp {
+// one HostGroup per thread, rebuilt when the handle or the group behind it changes (a freed handle's address may be
+// handed out again for another group: the cached modulus, order and kind are compared on every call)
+const HostGroup* host_group(vmn_group* grp) {
+    thread_local vmn_group* cached = nullptr;
+    thread_local std::unique_ptr<HostGroup> hg;
+    thread_local Bytes id;
+    const size_t xb = vmn_group_exp_bytes(grp);
+    Bytes now(2 * xb + 1);
+    if (vmn_group_get_modulus(grp, now.data()) != VMN_OK || vmn_group_get_order(grp, now.data() + xb) != VMN_OK) return nullptr;
+    now[2 * xb] = (uint8_t)vmn_group_kind(grp);
+    if (cached != grp || !hg || id != now) {
+        hg.reset(new HostGroup());
+        if (hg->init(grp) != VMN_OK) {
+            hg.reset();
+            cached = nullptr;
+            return nullptr;
+        }
+        cached = grp;
+        id = now;
+    }
+    return hg.get();
+}
+}  // namespace vmnp
+int vmn_element_exp(vmn_group* grp, const uint8_t* base_be, const uint8_t* e_be, size_t ebytes, uint8_t* out_be) {
+    if (!grp || !base_be || !e_be || !ebytes || !out_be) return fail(VMN_ERR_ARG, "vmn_element_exp: null argument");
+    const HostGroup* G = host_group(grp);
+    if (!G) return VMN_ERR_ARG;
+    Bytes out;
+    TRY(G->el_exp(Bytes(base_be, base_be + G->eb), e_be, ebytes, out));
+    memcpy(out_be, out.data(), G->eb);
+    return VMN_OK;
+}
+int vmn_element_mul(vmn_group* grp, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be) {
+    if (!grp || !a_be || !b_be || !out_be) return fail(VMN_ERR_ARG, "vmn_element_mul: null argument");
+    const HostGroup* G = host_group(grp);
+    if (!G) return VMN_ERR_ARG;
+    Bytes out;
+    TRY(G->el_mul(Bytes(a_be, a_be + G->eb), Bytes(b_be, b_be + G->eb), out));
+    memcpy(out_be, out.data(), G->eb);
+    return VMN_OK;
+}
+int vmn_element_inv(vmn_group* grp, const uint8_t* a_be, uint8_t* out_be) {
+    if (!grp || !a_be || !out_be) return fail(VMN_ERR_ARG, "vmn_element_inv: null argument");
+    const HostGroup* G = host_group(grp);
+    if (!G) return VMN_ERR_ARG;
+    Bytes out;
+    TRY(G->el_inv(Bytes(a_be, a_be + G->eb), out));
+    memcpy(out_be, out.data(), G->eb);
+    return VMN_OK;
+}
+
 }  // extern "C"
