@@ -153,7 +153,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
         EB = NE + NV + NR
         rnd = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, s
                                   ("ring_array", n), ("ring_element",), ("int_array", n, EB),   # r, alpha, epsilon
-                                  ("int_array", n, NE),                                         # e (batching vector)
+                                  ("int_array", 1, 256),                                        # seed of the batching vector
                                   ("ring_array", n), ("ring_array", n),                         # b, beta
                                   ("ring_element",), ("ring_element",), ("ring_element",),      # gamma, delta, phi
                                   ("int_array", 1, NV)])                                        # v (challenge)
@@ -172,8 +172,8 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
         # --- A1 prover
         prover.precompute(g, H, pi)
         prover.setInstance(pkey, W, WP, S)
-        e = rnd.int_array(n, NE)
-        prover.setBatchVector(e)
+        e_seed = bytes(rnd.int_array(1, 256))[-32:]        # setBatchVector(byte[] prgSeed): e is derived on the GPU
+        prover.setBatchVectorSeed(e_seed)
         com = prover.commit()
         v = int.from_bytes(rnd.int_array(1, NV), "big")
         rep = prover.reply(v)
@@ -184,7 +184,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
         ver.precompute(g, H)
         ver.setPermutationCommitment(prover.u)
         ver.setInstance(pkey, W, WP)
-        ver.setBatchVector(e)
+        ver.setBatchVectorSeed(e_seed)
         ver.computeAF()
         ver.setCommitment(com)
         ver.setChallenge(v)
@@ -240,11 +240,11 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     for a in (T, M, YT):
         a.free()
     tape = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, commitment exponents r
-                               ("int_array", n, NE),                                         # PoSC batching vector
+                               ("int_array", 1, 256),                                        # seed of the PoSC batching vector
                                ("ring_array", n), ("ring_element",), ("int_array", n, EB), ("ring_array", n),   # b, alpha, eps, beta
                                ("ring_element",), ("ring_element",), ("int_array", 1, NV),                        # gamma, delta, v
                                ("ring_array", n),                                            # s
-                               ("int_array", n, NE), ("ring_element",), ("int_array", n, EB), ("ring_element",), # e, alpha, eps, beta
+                               ("int_array", 1, 256), ("ring_element",), ("int_array", n, EB), ("ring_element",), # e seed, alpha, eps, beta
                                ("int_array", 1, NV)])
     ctx.timing_reset()
     ctx.timing_enable(True)
@@ -255,16 +255,16 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     pi = tape.permutation(n)
     r_bytes = tape.ring_array(n)
     U, R = do_permutation_commitment(hv, mx, grp, g, H, r_bytes, pi)
-    e1 = tape.int_array(n, NE)
+    e1 = bytes(tape.int_array(1, 256))[-32:]
     pr = hv.PoSCBasicTW(grp, NV, NE, NR, rand=tape)
     pr.setInstance(g, H, U, R, pi)
-    pr.setBatchVector(e1)
+    pr.setBatchVectorSeed(e1)
     com = pr.commit()
     v1 = int.from_bytes(tape.int_array(1, NV), "big")
     rep = pr.reply(v1)
     ver = hv.PoSCBasicTW(grp, NV, NE, NR)
     ver.setInstance(g, H, U)
-    ver.setBatchVector(e1)
+    ver.setBatchVectorSeed(e1)
     ver.setCommitment(com)
     ver.setChallenge(v1)
     ok_posc = ver.verify(rep)
@@ -275,10 +275,10 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     WP = do_reencrypt(hv, mx, grp, pkey, W, S, pi)
     sync()
     t2 = time.perf_counter()
-    e2 = tape.int_array(n, NE)
+    e2 = bytes(tape.int_array(1, 256))[-32:]
     cp = hv.CCPoSBasicW(grp, NV, NE, NR, rand=tape)
     cp.setInstance(g, H, U, pkey, W, WP, R, pi, S)
-    cp.setBatchVector(e2)
+    cp.setBatchVectorSeed(e2)
     com2 = cp.commit()
     v2 = int.from_bytes(tape.int_array(1, NV), "big")
     rep2 = cp.reply(v2)
@@ -286,7 +286,7 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     t3 = time.perf_counter()
     cv = hv.CCPoSBasicW(grp, NV, NE, NR)
     cv.setInstance(g, H, U, pkey, W, WP)
-    cv.setBatchVector(e2)
+    cv.setBatchVectorSeed(e2)
     cv.setCommitment(com2)
     cv.setChallenge(v2)
     cv.computeAB()
@@ -336,7 +336,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
     for t in Ts:
         t.free()
     plan = [("permutation", n), ("ring_array", n)] + [("ring_array", n)] * width + \
-           [("int_array", n, NE), ("ring_element",), ("int_array", n, EB)] + [("ring_element",)] * width + [("int_array", 1, NV)]
+           [("int_array", 1, 256), ("ring_element",), ("int_array", n, EB)] + [("ring_element",)] * width + [("int_array", 1, NV)]
     tape = ReplaySource(bulk, plan)
     ctx.timing_reset()
     ctx.timing_enable(True)
@@ -351,10 +351,10 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
     WP = do_reencrypt(hv, mx, grp, pkey, W, S, pi)
     sync()
     t2 = time.perf_counter()
-    e = tape.int_array(n, NE)
+    e = bytes(tape.int_array(1, 256))[-32:]            # seed of the batching vector
     cp = hv.CCPoSBasicW(grp, NV, NE, NR, rand=tape)
     cp.setInstance(g, H, U, pkey, W, WP, R, pi, S)
-    cp.setBatchVector(e)
+    cp.setBatchVectorSeed(e)
     com = cp.commit()
     v = int.from_bytes(tape.int_array(1, NV), "big")
     rep = cp.reply(v)
@@ -362,7 +362,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
     t3 = time.perf_counter()
     cv = hv.CCPoSBasicW(grp, NV, NE, NR)
     cv.setInstance(g, H, U, pkey, W, WP)
-    cv.setBatchVector(e)
+    cv.setBatchVectorSeed(e)
     cv.setCommitment(com)
     cv.setChallenge(v)
     cv.computeAB()
