@@ -121,8 +121,8 @@ def test_scalar_field_arrays(ecg):
     assert x.toInts() == want and d == want[-1]
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
-def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, vmn, gpu_ctx, entry):
+@pytest.mark.parametrize("impl,curve_name", [("python", "P-256"), ("native", "P-256"), ("native", "P-384")])
+def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, curve_name, vmn, gpu_ctx, entry):
     """PoS and CCPoS with ECqPGroup P-256 (the reference's default group): the GPU provers' messages equal the
     group-generic Python restatement on the same tape; verifiers accept; a tampered reply is rejected."""
     import importlib.util, os, sys
@@ -136,9 +136,9 @@ def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, vmn, gpu_ct
         spec.loader.exec_module(m)
         mods[name] = m
     hv, mx = mods["hvzk" if impl == "python" else "native"], mods["mixnet"]      # Python mirror or the C++ drivers
-    c = Curve("P-256")
+    c = Curve(curve_name)
     K = P.ECAdapter(c)
-    G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    G = vmn.ECqPGroup(gpu_ctx, curve_name)
     NV, NE, NR = 128, 128, 64
     n, width = 40, 1
     t = Tape(b"ecgpu", c.n)
