@@ -40,6 +40,11 @@ struct ECfg {
     static constexpr int FW = stride_for_limbs(S);
     static constexpr int ROW = 3 * FW;             // words per point row
     static constexpr int FLAG = ROW - 1;           // infinity flag word
+    // waves per SIMD the point kernels are compiled for (VGPR budget 512 / MINW): measured, see DESIGN.md §5
+#ifndef VMN_EC_MINW
+#define VMN_EC_MINW 2
+#endif
+    static constexpr int MINW = S <= 10 ? VMN_EC_MINW : 1;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_export(uint8_t* __restrict__ be, s
 
 // K4: out[i] = x[i] + y[i]   (ystride = 0: one shared point)
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_add(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ y,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_add(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ y,
                                                   size_t ystride, size_t n, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -468,7 +473,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_equal(const u32* __restrict__ x, c
 
 // K1a / K1b: out[i] = e[i] * x[i]  (fixed window, per-lane table of multiples in scratch)
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_mulvar(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_mulvar(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e,
                                                      int ewords, size_t estride, int ebits, int wbits, size_t n, ECDev E,
                                                      u32* __restrict__ tab) {
     constexpr int ROW = ECfg<S>::ROW;
@@ -522,7 +527,7 @@ __global__ void k_ec_chain(u32* __restrict__ sq, const u32* __restrict__ base, i
 
 // K2 table level l: T[k][2^l + r] = T[k][r] + T[k][2^l]
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_fixed_level(u32* __restrict__ T, int w, int nwin, int l, ECDev E) {
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_fixed_level(u32* __restrict__ T, int w, int nwin, int l, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t per = ((size_t)1 << l) - 1;
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -538,7 +543,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_fixed_level(u32* __restrict__ T, i
 
 // K2: out[i] = sum_k T[k][digit_k(e[i])]
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin,
                                                         const u32* __restrict__ e, int ewords, size_t n, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -558,7 +563,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_fixed_exp(u32* __restrict__ out, c
 
 // K3 product-tree level (see k_bucket_level)
 template <int S, bool FIRST>
-__global__ void __launch_bounds__(BLOCK) k_ec_bucket_level(u32* __restrict__ out, const u32* __restrict__ in,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* __restrict__ out, const u32* __restrict__ in,
                                                            const u32* __restrict__ sorted, const u32* __restrict__ off_in,
                                                            const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
                                                            size_t nbuckets, size_t total_out, u32 F, ECDev E) {
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_bucket_level(u32* __restrict__ out
 
 // K5: strided sum (see k_reduce_strided)
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_reduce(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t Lout,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_reduce(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t Lout,
                                                      size_t nseg, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -606,7 +611,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_reduce(u32* __restrict__ out, cons
 
 // running sums (the "prods" scan of the modular kernels with + as the operation)
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_scan_totals(u32* __restrict__ tot, const u32* __restrict__ e, size_t n, size_t Cc,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_scan_totals(u32* __restrict__ tot, const u32* __restrict__ e, size_t n, size_t Cc,
                                                           size_t seglen, int rev, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t nchunks = (n + Cc - 1) / Cc;
@@ -623,7 +628,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_scan_totals(u32* __restrict__ tot,
     pt_store<S>(tot + c * ROW, A);
 }
 template <int S>
-__global__ void __launch_bounds__(BLOCK) k_ec_scan_apply(u32* __restrict__ out, const u32* __restrict__ e,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_scan_apply(u32* __restrict__ out, const u32* __restrict__ e,
                                                          const u32* __restrict__ incoming, size_t n, size_t Cc, size_t seglen,
                                                          int rev, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
