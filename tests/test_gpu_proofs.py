@@ -252,6 +252,11 @@ def test_proof_level_abi_reports_misuse_and_malformed_messages(vmn, gpu_ctx, mod
     with pytest.raises(vmn.VmnError) as ei:
         ver.setCommitment(bad)
     assert ei.value.status == -4                               # VMN_ERR_FORMAT: the caller substitutes trivial values
+    bad = dict(com)
+    bad["Dp"] = p - 1                                          # in range but outside the subgroup of order q
+    with pytest.raises(vmn.VmnError) as ei:
+        ver.setCommitment(bad)
+    assert ei.value.status == -4
     ver.setCommitment(com)
     ver.setChallenge(v)
     assert ver.verify(rep)

@@ -187,7 +187,19 @@ struct HostGroup {
         for (const Bytes* e : els) flat.insert(flat.end(), e->begin(), e->end());
         GA x;
         *ok = 1;
-        return vmn_garray_from_be(grp, flat.data(), els.size(), x.out(), ok);
+        TRY(vmn_garray_from_be(grp, flat.data(), els.size(), x.out(), ok));
+        if (!*ok || ec) return VMN_OK;                 // curves: on the curve = in the group (cofactor 1)
+        // ModPGroup: in range is not yet in the subgroup of order q: x^q = 1 on the host (a handful of elements)
+        Bytes qb = vmn::num64::to_bytes(Zq.n, xb);
+        Num one(ql, 0);
+        one[0] = 1;
+        for (const Bytes* e : els) {
+            if (vmn::num64::cmp(Zp.pow(vmn::num64::from_be(e->data(), eb, ql), qb.data(), qb.size()), one) != 0) {
+                *ok = 0;
+                break;
+            }
+        }
+        return VMN_OK;
     }
     int el_div(const Bytes& a, const Bytes& b, Bytes& out) const {
         Bytes bi;
