@@ -298,3 +298,27 @@ def test_worst_case_column_magnitudes(bits, vmn, gpu_ctx):
     F = G.ringArray(list(reversed(es)))
     assert E.mul(F).toInts() == [a * b % N for a, b in zip(es, reversed(es))]
     assert X.prod() == pyref.prod(vals, N)
+
+
+@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072])
+def test_subgroup_membership_by_jacobi_symbol(bits, groups):
+    """K10: x is in the order-q subgroup of a safe-prime group iff (x / p) = 1.  The Jacobi kernel (one element per
+    lane; 3072 bits falls back to x^q = 1) against Python on residues, non-residues and special values, one element
+    at a time and inside large arrays."""
+    G, grp, _ = groups[bits]
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    rnd = pyref.stream_ints(b"jacobi%d" % bits, 40, p)
+    vals = [1, 4, p - 1, p - 4, 2, p - 2, 3, (p - 1) // 2, (p + 1) // 2, 1 << 28, (1 << 56) + 1, (1 << (bits - 2)), 9] + [1 + v % (p - 1) for v in rnd]
+    seen = set()
+    for x in vals:
+        want = pow(x, q, p) == 1
+        seen.add(want)
+        assert G.toElementArray([x]).isMember() is want, hex(x)
+    assert seen == {True, False}
+    members = [pow(v, 2, p) for v in pyref.stream_ints(b"jac-members%d" % bits, 3000, p) if v % p]
+    assert G.toElementArray(members).isMember()
+    nonres = next(x for x in range(2, 50) if pow(x, q, p) != 1)
+    for pos in (0, 1234, len(members) - 1):
+        tampered = list(members)
+        tampered[pos] = tampered[pos] * nonres % p
+        assert not G.toElementArray(tampered).isMember(), pos

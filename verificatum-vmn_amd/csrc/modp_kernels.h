@@ -1024,4 +1024,96 @@ __global__ void __launch_bounds__(BLOCK) k_set_segment_heads(uint4* __restrict__
     a[s * seglen * cpr + ch] = one_row[ch];
 }
 
+// ---------------------------------------------------------------------------------------------
+// K10: membership in the order-q subgroup of a safe-prime group (p = 2q + 1): x is a member iff it is a quadratic
+// residue iff the Jacobi symbol (x / p) = 1.  Binary Jacobi algorithm on 28-bit limbs, one element per lane (LPE = 1
+// geometries), no multiplications: ~12 limb passes per step, at most 2 * bits(p) steps -- about a tenth of the
+// instructions of the x^q = 1 test.  The rows are in Montgomery form x R mod p; (R / p) = 1 because R is an even
+// power of two, so the symbol of the row is the symbol of x.  flags[0] |= 1 when some element is not a member
+// (zero included).  ref: the membership test VCR makes when an array is read (pGroup.toElementArray), e.g.
+// P/hvzk/PoSBasicTW.java:787-792.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_jacobi_member(const u32* __restrict__ x, size_t n, const u32* __restrict__ nmod, u32* __restrict__ flags) {
+    static_assert(C::LPE == 1, "one element per lane");
+    constexpr int S = C::S;
+    size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool live = el < n;
+    size_t ec = live ? el : n - 1;
+    u32 a[S], m[S];
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(x + ec * C::W);
+#pragma unroll
+        for (int k = 0; k < C::LW / 4; ++k) {
+            uint4 v = q[k];
+            if (4 * k + 0 < S) a[4 * k + 0] = v.x;
+            if (4 * k + 1 < S) a[4 * k + 1] = v.y;
+            if (4 * k + 2 < S) a[4 * k + 2] = v.z;
+            if (4 * k + 3 < S) a[4 * k + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) m[j] = nmod[j];
+    u32 t = 0;                                   // parity of the sign flips: symbol = (-1)^t
+    u32 nz = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) nz |= a[j];
+    bool zero_in = nz == 0;
+    // invariant: m odd, 0 <= a < m at loop entry (a < p on input)
+    while (nz != 0) {
+        // strip the factors of two of a: (2 / m) = -1 iff m = 3, 5 mod 8
+        u32 low = a[0];
+        if (low == 0) {                          // a whole zero limb: shift by one limb (28 bits: even count, no flip)
+#pragma unroll
+            for (int j = 0; j + 1 < S; ++j) a[j] = a[j + 1];
+            a[S - 1] = 0;
+            continue;
+        }
+        int k = __builtin_ctz(low);
+        if (k) {
+            u32 m8 = m[0] & 7u;
+            if ((k & 1) && (m8 == 3u || m8 == 5u)) t ^= 1u;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                u32 hi = j + 1 < S ? a[j + 1] : 0u;
+                a[j] = ((a[j] >> k) | (hi << (LIMB_BITS - k))) & LIMB_MASK;
+            }
+        }
+        // a odd now.  d = a - m
+        u32 d[S];
+        int32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            int32_t v = (int32_t)a[j] - (int32_t)m[j] + borrow;
+            d[j] = (u32)v & LIMB_MASK;
+            borrow = v >> LIMB_BITS;
+        }
+        if (borrow == 0) {                       // a >= m: a := a - m (even; symbol unchanged: a = a mod m step)
+#pragma unroll
+            for (int j = 0; j < S; ++j) a[j] = d[j];
+        } else {                                 // a < m: swap by reciprocity, then a := m - a_old = -(d)
+            if ((a[0] & 3u) == 3u && (m[0] & 3u) == 3u) t ^= 1u;
+            int32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {        // negate d (two's complement over the limbs), m := a_old
+                int32_t v = c - (int32_t)d[j];
+                u32 nd = (u32)v & LIMB_MASK;
+                c = v >> LIMB_BITS;
+                m[j] = a[j];
+                a[j] = nd;
+            }
+        }
+        nz = 0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) nz |= a[j];
+    }
+    // a = 0: the symbol is (-1)^t when m = 1 (coprime), 0 otherwise
+    u32 rest = m[0] ^ 1u;
+#pragma unroll
+    for (int j = 1; j < S; ++j) rest |= m[j];
+    bool member = !zero_in && rest == 0 && t == 0;
+    if (live && !member) atomicOr(flags, 1u);
+}
+
 }  // namespace vmn

@@ -2379,9 +2379,31 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     *all_members = 1;
     if (x->n == 0) return VMN_OK;
     if (g->P.ec) return VMN_OK;      // prime-order curve: every point that passed the import's curve check is a member
-    // x^q == 1 for every element: shared-exponent modpow, then compare with a broadcast of one
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
+    // safe-prime group held one element per lane: the Jacobi symbol decides (a tenth of the work of x^q = 1)
+    if (m.LPE == 1 && !getenv("VMN_MEMBER_BY_POWER")) {
+        Big twoq = g->Q.n_words;
+        hostbig::dbl_mod(twoq, m.n_words);
+        Big pm1 = m.n_words;
+        pm1[0] -= 1;
+        if (hostbig::cmp(twoq, pm1) == 0) {
+            VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+            int rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                                   \
+    if constexpr (LPE_ == 1) {                                                                                             \
+        if (m.S == S_) rc = launch_light(ctx, "member", k_jacobi_member<Cfg<S_, 1>>, grid_for(x->n), (const uint32_t*)x->d, x->n, (const uint32_t*)m.d_n, ctx->flags); \
+    }
+            VMN_FOR_SIZES(X)
+#undef X
+            VMN_TRY(rc);
+            uint32_t fl = 0;
+            VMN_TRY(d2h(ctx, &fl, ctx->flags, sizeof(fl)));
+            *all_members = fl ? 0 : 1;
+            return VMN_OK;
+        }
+    }
+    // x^q == 1 for every element: shared-exponent modpow, then compare with a broadcast of one
     DevTmp ew(ctx), pw(ctx);
     VMN_TRY(ew.alloc(m.NW * sizeof(uint32_t)));
     VMN_TRY(h2d(ctx, ew.p, g->Q.n_words.data(), m.NW * sizeof(uint32_t)));
