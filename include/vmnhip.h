@@ -176,7 +176,7 @@ int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to, vmn_garra
 int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host, vmn_garray** out);
 int vmn_garray_get(const vmn_garray* x, size_t i, uint8_t* out_be);
 /* Subgroup membership of every element; *all_members = 1/0.  Part of K10 (the check pGroup.toElementArray makes
- * when an array is read).  Safe-prime groups up to 2048 bits: Jacobi symbol (x / p) = 1 by the binary algorithm,
+ * when an array is read).  Safe-prime groups up to 3072 bits: Jacobi symbol (x / p) = 1 by the binary algorithm,
  * one element per lane (10^6 elements in 46 ms); otherwise x^q = 1 (749 ms); curves: the import's on-curve check
  * already is the membership test (cofactor 1). */
 int vmn_garray_is_member(const vmn_garray* x, int* all_members);

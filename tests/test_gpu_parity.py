@@ -303,7 +303,7 @@ def test_worst_case_column_magnitudes(bits, vmn, gpu_ctx):
 @pytest.mark.parametrize("bits", [512, 1024, 2048, 3072])
 def test_subgroup_membership_by_jacobi_symbol(bits, groups):
     """K10: x is in the order-q subgroup of a safe-prime group iff (x / p) = 1.  The Jacobi kernel (one element per
-    lane; 3072 bits falls back to x^q = 1) against Python on residues, non-residues and special values, one element
+    lane, also at 3072 bits where the arithmetic kernels use two) against Python on residues, non-residues and special values, one element
     at a time and inside large arrays."""
     G, grp, _ = groups[bits]
     p, q, g = grp["p"], grp["q"], grp["g"]

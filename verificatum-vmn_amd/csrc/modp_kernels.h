@@ -1026,35 +1026,37 @@ __global__ void __launch_bounds__(BLOCK) k_set_segment_heads(uint4* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // K10: membership in the order-q subgroup of a safe-prime group (p = 2q + 1): x is a member iff it is a quadratic
-// residue iff the Jacobi symbol (x / p) = 1.  Binary Jacobi algorithm on 28-bit limbs, one element per lane (LPE = 1
-// geometries), no multiplications: ~12 limb passes per step, at most 2 * bits(p) steps -- about a tenth of the
-// instructions of the x^q = 1 test.  The rows are in Montgomery form x R mod p; (R / p) = 1 because R is an even
+// residue iff the Jacobi symbol (x / p) = 1.  Binary Jacobi algorithm on 28-bit limbs, one element per lane (moduli
+// up to 3072 bits), no multiplications: a few limb passes per step, at most 2 * bits(p) steps -- about a tenth of
+// the instructions of the x^q = 1 test.  The rows are in Montgomery form x R mod p; (R / p) = 1 because R is an even
 // power of two, so the symbol of the row is the symbol of x.  flags[0] |= 1 when some element is not a member
 // (zero included).  ref: the membership test VCR makes when an array is read (pGroup.toElementArray), e.g.
 // P/hvzk/PoSBasicTW.java:787-792.
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(BLOCK, C::MINW)
+__global__ void __launch_bounds__(BLOCK, 2)
 k_jacobi_member(const u32* __restrict__ x, size_t n, const u32* __restrict__ nmod, u32* __restrict__ flags) {
-    static_assert(C::LPE == 1, "one element per lane");
-    constexpr int S = C::S;
+    // ONE lane holds the whole element here, also when the arithmetic kernels split it over two lanes (the row is
+    // then two shares of L limbs, LW words apart): a and m in registers (2 S <= 220 VGPRs), updated in place.
+    static_assert(C::LPE <= 2, "the element must fit one lane");
+    constexpr int S = C::S, L = C::L, LW = C::LW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     bool live = el < n;
     size_t ec = live ? el : n - 1;
     u32 a[S], m[S];
-    {
-        const uint4* q = reinterpret_cast<const uint4*>(x + ec * C::W);
 #pragma unroll
-        for (int k = 0; k < C::LW / 4; ++k) {
-            uint4 v = q[k];
-            if (4 * k + 0 < S) a[4 * k + 0] = v.x;
-            if (4 * k + 1 < S) a[4 * k + 1] = v.y;
-            if (4 * k + 2 < S) a[4 * k + 2] = v.z;
-            if (4 * k + 3 < S) a[4 * k + 3] = v.w;
+    for (int h = 0; h < C::LPE; ++h) {
+        const uint4* q = reinterpret_cast<const uint4*>(x + ec * C::W + h * LW);
+        const uint4* qm = reinterpret_cast<const uint4*>(nmod + h * LW);
+#pragma unroll
+        for (int k = 0; k < LW / 4; ++k) {
+            uint4 v = q[k], w = qm[k];
+            if (4 * k + 0 < L) { a[h * L + 4 * k + 0] = v.x; m[h * L + 4 * k + 0] = w.x; }
+            if (4 * k + 1 < L) { a[h * L + 4 * k + 1] = v.y; m[h * L + 4 * k + 1] = w.y; }
+            if (4 * k + 2 < L) { a[h * L + 4 * k + 2] = v.z; m[h * L + 4 * k + 2] = w.z; }
+            if (4 * k + 3 < L) { a[h * L + 4 * k + 3] = v.w; m[h * L + 4 * k + 3] = w.w; }
         }
     }
-#pragma unroll
-    for (int j = 0; j < S; ++j) m[j] = nmod[j];
     u32 t = 0;                                   // parity of the sign flips: symbol = (-1)^t
     u32 nz = 0;
 #pragma unroll
@@ -1080,28 +1082,28 @@ k_jacobi_member(const u32* __restrict__ x, size_t n, const u32* __restrict__ nmo
                 a[j] = ((a[j] >> k) | (hi << (LIMB_BITS - k))) & LIMB_MASK;
             }
         }
-        // a odd now.  d = a - m
-        u32 d[S];
+        // a odd now: compare (borrow of a - m), then subtract in place in the right direction
         int32_t borrow = 0;
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-            int32_t v = (int32_t)a[j] - (int32_t)m[j] + borrow;
-            d[j] = (u32)v & LIMB_MASK;
-            borrow = v >> LIMB_BITS;
-        }
-        if (borrow == 0) {                       // a >= m: a := a - m (even; symbol unchanged: a = a mod m step)
+        for (int j = 0; j < S; ++j) borrow = ((int32_t)a[j] - (int32_t)m[j] + borrow) >> LIMB_BITS;
+        if (borrow == 0) {                       // a >= m: a := a - m (even; the symbol is unchanged)
+            int32_t c = 0;
 #pragma unroll
-            for (int j = 0; j < S; ++j) a[j] = d[j];
-        } else {                                 // a < m: swap by reciprocity, then a := m - a_old = -(d)
+            for (int j = 0; j < S; ++j) {
+                int32_t v = (int32_t)a[j] - (int32_t)m[j] + c;
+                a[j] = (u32)v & LIMB_MASK;
+                c = v >> LIMB_BITS;
+            }
+        } else {                                 // a < m: swap by reciprocity, (a, m) := (m - a, a)
             if ((a[0] & 3u) == 3u && (m[0] & 3u) == 3u) t ^= 1u;
             int32_t c = 0;
 #pragma unroll
-            for (int j = 0; j < S; ++j) {        // negate d (two's complement over the limbs), m := a_old
-                int32_t v = c - (int32_t)d[j];
-                u32 nd = (u32)v & LIMB_MASK;
+            for (int j = 0; j < S; ++j) {
+                u32 old = a[j];
+                int32_t v = (int32_t)m[j] - (int32_t)old + c;
+                a[j] = (u32)v & LIMB_MASK;
                 c = v >> LIMB_BITS;
-                m[j] = a[j];
-                a[j] = nd;
+                m[j] = old;
             }
         }
         nz = 0;

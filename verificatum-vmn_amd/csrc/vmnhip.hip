@@ -2382,7 +2382,7 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     // safe-prime group held one element per lane: the Jacobi symbol decides (a tenth of the work of x^q = 1)
-    if (m.LPE == 1 && !getenv("VMN_MEMBER_BY_POWER")) {
+    if (m.LPE <= 2 && !getenv("VMN_MEMBER_BY_POWER")) {
         Big twoq = g->Q.n_words;
         hostbig::dbl_mod(twoq, m.n_words);
         Big pm1 = m.n_words;
@@ -2391,8 +2391,8 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
             VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
             int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                   \
-    if constexpr (LPE_ == 1) {                                                                                             \
-        if (m.S == S_) rc = launch_light(ctx, "member", k_jacobi_member<Cfg<S_, 1>>, grid_for(x->n), (const uint32_t*)x->d, x->n, (const uint32_t*)m.d_n, ctx->flags); \
+    if constexpr (LPE_ <= 2) {                                                                                             \
+        if (m.S == S_) rc = launch_light(ctx, "member", k_jacobi_member<Cfg<S_, LPE_>>, grid_for(x->n), (const uint32_t*)x->d, x->n, (const uint32_t*)m.d_n, ctx->flags); \
     }
             VMN_FOR_SIZES(X)
 #undef X
