@@ -75,8 +75,9 @@ int vmn_msg_push_ring(vmn_msg* m, const uint8_t* be, size_t count, size_t width)
 size_t vmn_msg_bytetree_size(const vmn_msg* m);
 int vmn_msg_to_bytetree(const vmn_msg* m, uint8_t* out);
 /* `layout` lists the expected item kinds (VMN_ITEM_*), `counts[i]` the element count of items of kind 3 / 4 and
- * the array size of kinds 1 / 2.  *format_ok = 0 (and no message) on malformed input: the caller substitutes
- * trivial values as the reference does (PoSBasicTW.java:794-815). */
+ * the array size of kinds 1 / 2.  *format_ok = 0 (and no message) on malformed input -- framing, a value out of
+ * range, an array element outside the subgroup (vmn_garray_is_member: the check pGroup.toElementArray makes): the
+ * caller substitutes trivial values as the reference does (PoSBasicTW.java:794-815). */
 int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const int* layout, const size_t* counts,
                           size_t items, vmn_msg** out, int* format_ok);
 

@@ -151,5 +151,8 @@ def test_proof_messages_cross_the_wire_as_byte_trees(width, vmn, gpu_ctx, eio, e
     assert nat.Message.fromByteTree(G, com_bt, nat.PoSBasicTW._com_kinds, [n + 1, 1, n, 1, 1, 2 * width]) is None
     assert nat.Message.fromByteTree(G, rep_bt, nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width]) is None
     bad = bytearray(com_bt)
+    bad[5 + 5 + 5:5 + 5 + 5 + nb] = eio.int_leaf(p - 1, nb)     # B_0 := p - 1: in range, outside the subgroup
+    assert nat.Message.fromByteTree(G, bytes(bad), nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width]) is None
+    bad = bytearray(com_bt)
     bad[5 + 5 + 5:5 + 5 + 5 + nb] = eio.int_leaf(p, nb)         # B_0 := p
     assert nat.Message.fromByteTree(G, bytes(bad), nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2 * width]) is None

@@ -1331,6 +1331,11 @@ int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const i
                 vmn_garray* a = nullptr;
                 TRY(vmn_garray_from_bytetree(grp, rd.p, need, counts[i], &a, &ok, &in_range));
                 if (a) vmn_msg_push_garray(m.get(), a);
+                if (a && ok && in_range) {                 // pGroup.toElementArray also checks subgroup membership
+                    int member = 1;
+                    TRY(vmn_garray_is_member(a, &member));
+                    if (!member) in_range = 0;
+                }
             } else {
                 vmn_rarray* a = nullptr;
                 TRY(vmn_rarray_from_bytetree(grp, rd.p, need, counts[i], &a, &ok, &in_range));
