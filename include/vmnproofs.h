@@ -176,6 +176,28 @@ int vmn_decproof_combine(vmn_decproof* p, const uint8_t* correct, const uint8_t*
 int vmn_decproof_batch_combined(vmn_decproof* p);                                            /* :683-685 */
 int vmn_decproof_verify_combined(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, int* verdict);         /* :693-700 */
 
+/* ---- interactive derivation of independent generators -----------------------------------
+ * distr/IndependentGeneratorsBasicI.java: setInstance :166-175, setBatchVector :186-193, commit :201-208,
+ * setCommitment :219-227, setChallenge :235-238, reply :245-248, setReply :259-267, verify() :275-289 (combined),
+ * verify(l) :297-299.  Party j proves knowledge of the exponents s of its generator parts h_j = g^s:
+ * a = <s, e>, A'_j = g^r, k_a = a v + r;  h_l.expProd(e)^v A'_l = g^(k_a,l).  Parties 1..threshold; arrays of
+ * per-party values have threshold + 1 entries, entry 0 unused. */
+typedef struct vmn_igen vmn_igen;
+int vmn_igen_create(vmn_group* grp, int j, int threshold, int ebitlen, const vmn_random_source* rs, vmn_igen** out);
+void vmn_igen_free(vmn_igen* p);
+/* h: threshold + 1 arrays of generator parts (NULL = absent); s: this party's exponents (NULL for a pure verifier);
+ * combinedh: the product of the parts */
+int vmn_igen_set_instance(vmn_igen* p, const uint8_t* g_be, const vmn_garray* const* h, const vmn_rarray* s, const vmn_garray* combinedh);
+int vmn_igen_set_batch_vector(vmn_igen* p, const uint8_t* e_be);
+int vmn_igen_set_batch_vector_seed(vmn_igen* p, const uint8_t* seed, size_t seedlen);
+int vmn_igen_commit(vmn_igen* p, uint8_t* Ap_out);
+int vmn_igen_set_commitment(vmn_igen* p, int l, const uint8_t* Ap_be);     /* not a group element: the unit is taken (:223-226) */
+int vmn_igen_set_challenge(vmn_igen* p, const uint8_t* v_be, size_t vbytes);
+int vmn_igen_reply(vmn_igen* p, uint8_t* ka_out);
+int vmn_igen_set_reply(vmn_igen* p, int l, const uint8_t* ka_be);          /* out of range: zero is taken (:263-266) */
+int vmn_igen_verify_combined(vmn_igen* p, int* verdict);
+int vmn_igen_verify(vmn_igen* p, int l, int* verdict);
+
 /* ---- single group elements on the host (what the drivers above use for A', C', ... ; exposed for callers that hold
  * such elements themselves, e.g. the sharded multi-GPU proof driver): big-endian elem_bytes in and out; the exponent
  * is a non-negative big-endian integer of any length.  ModPGroup: 64-bit Montgomery arithmetic; curves: Jacobian

@@ -562,3 +562,40 @@ class GCCPoS:
         width = len(self.pkey) // 2
         return all(K.mul(K.exp(Bc, v), Bpc) == K.mul(K.exp(pk, -k_B[c % width]), t)
                    for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, prods)))
+
+
+class IndependentGeneratorsI:
+    """IndependentGeneratorsBasicI over Python integers (distr/IndependentGeneratorsBasicI.java:166-299): party j
+    proves knowledge of the exponents s of its generator parts h_j = g^s.  Parties 1..threshold."""
+
+    def __init__(self, p, q, j, threshold, rand=None):
+        self.p, self.q, self.j, self.threshold, self.rand = p, q, j, threshold, rand
+        self.Ap, self.k_a = {}, {}
+
+    def setInstance(self, g, h, s, combinedh):
+        self.g, self.h, self.s, self.combinedh = g, h, s, combinedh
+
+    def setBatchVector(self, e):
+        self.e = list(e)
+
+    def commit(self):
+        self.a = pyref.inner_product(self.s, self.e, self.q)
+        self.r = self.rand.ring_element()
+        self.Ap[self.j] = pow(self.g, self.r, self.p)
+        return self.Ap[self.j]
+
+    def reply(self, v):
+        self.k_a[self.j] = (self.a * v + self.r) % self.q
+        return self.k_a[self.j]
+
+    def verify(self, l, v):
+        lhs = pow(pyref.exp_prod(self.h[l], self.e, self.p), v % self.q, self.p) * self.Ap[l] % self.p
+        return lhs == pow(self.g, self.k_a[l], self.p)
+
+    def verify_combined(self, v):
+        k, A = 0, 1
+        for l in range(1, self.threshold + 1):
+            k = (k + self.k_a[l]) % self.q
+            A = A * self.Ap[l] % self.p
+        lhs = pow(pyref.exp_prod(self.combinedh, self.e, self.p), v % self.q, self.p) * A % self.p
+        return lhs == pow(self.g, k, self.p)

@@ -318,3 +318,51 @@ def test_two_party_threads_with_their_own_contexts(vmn, mods):
         for rep_no in range(3):
             com, rep, ok = got[(party, rep_no)]
             assert ok and (com, rep) == want[party]
+
+
+def test_interactive_independent_generators(vmn, gpu_ctx, mods, hv):
+    """SURVEY.md §8a row A7 (distr/IndependentGeneratorsBasicI.java): every party proves knowledge of the exponents
+    of its generator parts; the per-party and the combined checks accept, a wrong reply is rejected; commitments and
+    replies equal the oracle's."""
+    from oracle import pyref_prg
+    NE, NV, n, thr = 100, 100, 60, 3
+    grp, _ = load_golden(512)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    t = Tape(b"igen", q)
+    s = [None] + [t.ring_array(n) for _ in range(thr)]
+    h = [None] + [pyref.exp_fixed(g, s[l], p) for l in range(1, thr + 1)]
+    combined = h[1]
+    for l in range(2, thr + 1):
+        combined = pyref.mul(combined, h[l], p)
+    seed = pyref_prg.random_oracle(b"igen-seed", 256)
+    e = pyref_prg.random_integers(seed, n, NE)
+    v = t.int_array(1, NV)[0]
+    H = [None] + [G.toElementArray(h[l]) for l in range(1, thr + 1)]
+    CH = G.toElementArray(combined)
+    ver = hv.IndependentGeneratorsBasicI(G, 1, thr, NE)
+    ver.setInstance(g, H, None, CH)
+    ver.setBatchVectorSeed(seed)
+    ver.setChallenge(v)
+    over = P.IndependentGeneratorsI(p, q, 1, thr)
+    over.setInstance(g, h, None, combined)
+    over.setBatchVector(e)
+    for j in range(1, thr + 1):
+        o = P.IndependentGeneratorsI(p, q, j, thr, rand=Tape(b"igen-party%d" % j, q))
+        o.setInstance(g, h, s[j], combined)
+        o.setBatchVector(e)
+        Ap_o, ka_o = o.commit(), o.reply(v)
+        pr = hv.IndependentGeneratorsBasicI(G, j, thr, NE, rand=Tape(b"igen-party%d" % j, q))
+        pr.setInstance(g, H, G.ringArray(s[j]), CH)
+        pr.setBatchVectorSeed(seed)
+        Ap = pr.commit()
+        pr.setChallenge(v)
+        ka = pr.reply()
+        assert (Ap, ka) == (Ap_o, ka_o)
+        ver.setCommitment(j, Ap)
+        ver.setReply(j, ka)
+        over.Ap[j], over.k_a[j] = Ap, ka
+    assert all(ver.verify(l) for l in range(1, thr + 1)) and ver.verify()
+    assert all(over.verify(l, v) for l in range(1, thr + 1)) and over.verify_combined(v)
+    ver.setReply(2, (over.k_a[2] + 1) % q)
+    assert not ver.verify(2) and not ver.verify() and ver.verify(1)

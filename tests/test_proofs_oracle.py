@@ -176,3 +176,29 @@ def test_proofs_over_an_elliptic_curve_accept_and_reject(name):
     bad = dict(rep)
     bad["k_D"] = (rep["k_D"] + 1) % c.n
     assert not ver.verify(bad, v) and ver.verdicts == (True, True, True, False, True)
+
+
+def test_interactive_independent_generators_oracle():
+    """Row A7 restated (distr/IndependentGeneratorsBasicI.java): honest parties accept one by one and combined; a
+    wrong reply of one party fails its own check and the combined one."""
+    p = pyref.find_safe_prime(512, b"vmn-test-group-512")
+    q, g = (p - 1) // 2, 4
+    n, thr = 25, 3
+    t = Tape(b"igen-oracle", q)
+    s = [None] + [t.ring_array(n) for _ in range(thr)]
+    h = [None] + [pyref.exp_fixed(g, s[l], p) for l in range(1, thr + 1)]
+    combined = h[1]
+    for l in range(2, thr + 1):
+        combined = pyref.mul(combined, h[l], p)
+    e, v = t.int_array(n, 100), t.int_array(1, 100)[0]
+    ver = P.IndependentGeneratorsI(p, q, 1, thr)
+    ver.setInstance(g, h, None, combined)
+    ver.setBatchVector(e)
+    for j in range(1, thr + 1):
+        o = P.IndependentGeneratorsI(p, q, j, thr, rand=Tape(b"p%d" % j, q))
+        o.setInstance(g, h, s[j], combined)
+        o.setBatchVector(e)
+        ver.Ap[j], ver.k_a[j] = o.commit(), o.reply(v)
+    assert all(ver.verify(l, v) for l in range(1, thr + 1)) and ver.verify_combined(v)
+    ver.k_a[3] = (ver.k_a[3] + 1) % q
+    assert not ver.verify(3, v) and not ver.verify_combined(v) and ver.verify(1, v)

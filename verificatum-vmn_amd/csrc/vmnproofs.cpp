@@ -1168,6 +1168,68 @@ struct vmn_decproof {
     }
 };
 
+
+// ================================================================================================================
+// IndependentGeneratorsBasicI (interactive derivation of independent generators)
+// ================================================================================================================
+struct vmn_igen {
+    HostGroup G;
+    int j = 0, threshold = 0, ebitlen = 0, e_bits = 0;
+    bool has_rs = false;
+    vmn_random_source rs{};
+    Bytes g;
+    std::vector<const vmn_garray*> h;
+    const vmn_rarray* s = nullptr;
+    const vmn_garray* combinedh = nullptr;
+    size_t N = 0;
+    RA e;
+    Num a, r, v;
+    Bytes v_be;
+    std::vector<Bytes> Ap;
+    std::vector<Num> k_a;
+    std::vector<char> have;
+
+    int init(vmn_group* grp, int j_, int threshold_, int ebitlen_, const vmn_random_source* r_) {
+        TRY(G.init(grp));
+        j = j_;
+        threshold = threshold_;
+        ebitlen = ebitlen_;
+        e_bits = std::min(ebitlen_, G.qbits);
+        if (r_) {
+            if (!r_->ring_elements) return fail(VMN_ERR_ARG, "random source lacks a callback");
+            rs = *r_;
+            has_rs = true;
+        }
+        h.assign(threshold + 1, nullptr);
+        Ap.assign(threshold + 1, Bytes());
+        k_a.assign(threshold + 1, Num());
+        have.assign(threshold + 1, 0);
+        return VMN_OK;
+    }
+    int party(int l) const { return l >= 1 && l <= threshold ? VMN_OK : fail(VMN_ERR_ARG, "party index %d outside 1..%d", l, threshold); }
+    int commit(uint8_t* out) {
+        REQUIRE(out && s && e.p && has_rs, "commit needs the exponents s, the batching vector and a random source");
+        Bytes ab(G.xb);
+        TRY(vmn_rarray_inner_product(s, e, ab.data()));                            // a = <s, e>   :202
+        a = G.ring_from(ab.data());
+        const uint8_t* rows = nullptr;
+        if (rs.ring_elements(rs.user, 1, &rows) != 0 || !rows) return fail(VMN_ERR_ARG, "random source failed");
+        r = G.ring_from(rows);
+        TRY(G.el_exp(g, r, Ap[j]));                                                // A' = g^r     :205
+        memcpy(out, Ap[j].data(), G.eb);
+        return VMN_OK;
+    }
+    int check(const vmn_garray* harr, const Bytes& Apl, const Num& kal, int* verdict) {
+        Bytes A(G.eb), t, lhs, rhs;
+        TRY(vmn_garray_expprod(harr, e, e_bits, A.data()));
+        TRY(G.el_exp(A, v, t));
+        TRY(G.el_mul(t, Apl, lhs));
+        TRY(G.el_exp(g, kal, rhs));
+        *verdict = lhs == rhs;
+        return VMN_OK;
+    }
+};
+
 // ================================================================================================================
 // C entry points
 // ================================================================================================================
@@ -1694,6 +1756,102 @@ int vmn_decproof_batch_combined(vmn_decproof* p) {
 int vmn_decproof_verify_combined(vmn_decproof* p, const uint8_t* v_be, size_t vbytes, int* verdict) {
     NONNULL(p);
     return p->verify_combined(v_be, vbytes, verdict);
+}
+
+// ---- independent generators, interactive --------------------------------------------------------------------------
+int vmn_igen_create(vmn_group* grp, int j, int threshold, int ebitlen, const vmn_random_source* rs, vmn_igen** out) {
+    if (!grp || !out || threshold < 1 || j < 1 || j > threshold || ebitlen <= 0) return fail(VMN_ERR_ARG, "vmn_igen_create: bad argument");
+    std::unique_ptr<vmn_igen> p(new vmn_igen());
+    TRY(p->init(grp, j, threshold, ebitlen, rs));
+    *out = p.release();
+    return VMN_OK;
+}
+void vmn_igen_free(vmn_igen* p) { delete p; }
+int vmn_igen_set_instance(vmn_igen* p, const uint8_t* g_be, const vmn_garray* const* h, const vmn_rarray* s, const vmn_garray* combinedh) {
+    NONNULL(p);
+    if (!g_be || !h || !combinedh) return fail(VMN_ERR_ARG, "vmn_igen_set_instance: null argument");
+    p->N = vmn_garray_size(combinedh);
+    for (int l = 1; l <= p->threshold; ++l) {
+        p->h[l] = h[l];
+        if (h[l] && vmn_garray_size(h[l]) != p->N) return fail(VMN_ERR_ARG, "vmn_igen_set_instance: parts of party %d differ in size", l);
+    }
+    if (s && vmn_rarray_size(s) != p->N) return fail(VMN_ERR_ARG, "vmn_igen_set_instance: exponents differ in size");
+    p->g.assign(g_be, g_be + p->G.eb);
+    p->s = s;
+    p->combinedh = combinedh;
+    return VMN_OK;
+}
+int vmn_igen_set_batch_vector(vmn_igen* p, const uint8_t* e_be) {
+    NONNULL(p);
+    if (!p->combinedh || !e_be) return fail(VMN_ERR_ARG, "vmn_igen_set_batch_vector: instance not set");
+    int ok = 1;
+    TRY(vmn_rarray_from_be(p->G.grp, e_be, p->N, p->e.out(), &ok));
+    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "batching vector entry >= q");
+}
+int vmn_igen_set_batch_vector_seed(vmn_igen* p, const uint8_t* seed, size_t seedlen) {
+    NONNULL(p);
+    if (!p->combinedh) return fail(VMN_ERR_ARG, "vmn_igen_set_batch_vector_seed: instance not set");
+    return vmn_rarray_from_prg(p->G.grp, seed, seedlen, p->N, p->ebitlen, p->e.out());          // :186-193
+}
+int vmn_igen_commit(vmn_igen* p, uint8_t* Ap_out) {
+    NONNULL(p);
+    return p->commit(Ap_out);
+}
+int vmn_igen_set_commitment(vmn_igen* p, int l, const uint8_t* Ap_be) {
+    NONNULL(p);
+    TRY(p->party(l));
+    if (!Ap_be) return fail(VMN_ERR_ARG, "vmn_igen_set_commitment: null argument");
+    Bytes a(Ap_be, Ap_be + p->G.eb);
+    int ok = 1;
+    TRY(p->G.check_elements({&a}, &ok));
+    p->Ap[l] = ok ? a : p->G.one();                                               // :223-226
+    return VMN_OK;
+}
+int vmn_igen_set_challenge(vmn_igen* p, const uint8_t* v_be, size_t vbytes) {
+    NONNULL(p);
+    if (!v_be || !vbytes) return fail(VMN_ERR_ARG, "vmn_igen_set_challenge: null argument");
+    p->v = p->G.reduce(v_be, vbytes);
+    return VMN_OK;
+}
+int vmn_igen_reply(vmn_igen* p, uint8_t* ka_out) {
+    NONNULL(p);
+    if (!ka_out || p->a.empty() || p->r.empty() || p->v.empty()) return fail(VMN_ERR_ARG, "vmn_igen_reply: needs commit() and the challenge");
+    p->k_a[p->j] = p->G.mul_add(p->a, p->v, p->r);                                // k_a = a v + r   :246
+    p->have[p->j] = 1;
+    Bytes b = p->G.ring_bytes(p->k_a[p->j]);
+    memcpy(ka_out, b.data(), p->G.xb);
+    return VMN_OK;
+}
+int vmn_igen_set_reply(vmn_igen* p, int l, const uint8_t* ka_be) {
+    NONNULL(p);
+    TRY(p->party(l));
+    if (!ka_be) return fail(VMN_ERR_ARG, "vmn_igen_set_reply: null argument");
+    Num k = p->G.ring_from(ka_be);
+    if (vmn::num64::cmp(k, p->G.Zq.n) >= 0) k = Num(p->G.ql, 0);                  // :263-266
+    p->k_a[l] = k;
+    p->have[l] = 1;
+    return VMN_OK;
+}
+int vmn_igen_verify_combined(vmn_igen* p, int* verdict) {
+    NONNULL(p);
+    if (!verdict || !p->combinedh || !p->e.p || p->v.empty()) return fail(VMN_ERR_ARG, "vmn_igen_verify_combined: instance, batching vector or challenge missing");
+    Num ksum(p->G.ql, 0);
+    Bytes Aprod = p->G.one();
+    for (int l = 1; l <= p->threshold; ++l) {
+        if (p->Ap[l].empty() || !p->have[l]) return fail(VMN_ERR_ARG, "vmn_igen_verify_combined: commitment or reply of party %d missing", l);
+        ksum = p->G.Zq.add(ksum, p->k_a[l]);
+        Bytes t;
+        TRY(p->G.el_mul(Aprod, p->Ap[l], t));
+        Aprod = t;
+    }
+    return p->check(p->combinedh, Aprod, ksum, verdict);                          // :275-289
+}
+int vmn_igen_verify(vmn_igen* p, int l, int* verdict) {
+    NONNULL(p);
+    TRY(p->party(l));
+    if (!verdict || !p->h[l] || !p->e.p || p->v.empty() || p->Ap[l].empty() || !p->have[l])
+        return fail(VMN_ERR_ARG, "vmn_igen_verify: parts, batching vector, challenge, commitment or reply of party %d missing", l);
+    return p->check(p->h[l], p->Ap[l], p->k_a[l], verdict);                       // :297-299
 }
 
 // ---- single elements ------------------------------------------------------------------------------------------------

@@ -400,3 +400,55 @@ class CCPoSBasicW(_Base):
             rhs = KG.k_mul(KG.k_mul(self._gexp(pk, -k_B[c % width]), t), g_term)
             ok = ok and lhs == rhs
         return ok
+
+
+class IndependentGeneratorsBasicI:
+    """ref: protocol/distr/IndependentGeneratorsBasicI.java (interactive derivation of independent generators,
+    SURVEY.md §8a row A7): setInstance :166-175, setBatchVector :186-193, commit :201-208, reply :245-248,
+    verify() :275-289, verify(l) :297-299.  Parties are numbered 1..threshold."""
+
+    def __init__(self, group, j: int, threshold: int, ebitlen: int, rand=None):
+        self.G, self.j, self.threshold, self.ebitlen, self.rand = group, j, threshold, ebitlen, rand
+        self.q = group.q
+        self.e_bits = min(ebitlen, self.q.bit_length())
+        self.Ap, self.k_a = {}, {}
+
+    def setInstance(self, g, h, s, combinedh):
+        self.g, self.h, self.s, self.combinedh = g, h, s, combinedh
+
+    def setBatchVector(self, e_ints):
+        self.e = self.G.ringArray(e_ints if _is_bytes(e_ints) else list(e_ints))
+
+    def setBatchVectorSeed(self, seed: bytes):
+        self.e = self.G.ringArrayFromPRG(seed, self.combinedh.size(), self.ebitlen)
+
+    def commit(self):
+        self.a = self.s.innerProduct(self.e)                  # :202
+        self.r = self.rand.ring_element()
+        self.Ap[self.j] = self.G.k_exp(self.g, self.r)        # :205
+        return self.Ap[self.j]
+
+    def setCommitment(self, l: int, Ap):
+        self.Ap[l] = Ap
+
+    def setChallenge(self, v: int):
+        self.v = int(v) % self.q
+
+    def reply(self) -> int:
+        self.k_a[self.j] = (self.a * self.v + self.r) % self.q    # :246
+        return self.k_a[self.j]
+
+    def setReply(self, l: int, k_a: int):
+        self.k_a[l] = k_a if 0 <= k_a < self.q else 0
+
+    def verify(self, l: Optional[int] = None) -> bool:
+        G = self.G
+        if l is not None:                                         # :297-299
+            A = self.h[l].expProd(self.e, self.e_bits)
+            return G.k_mul(G.k_exp(A, self.v), self.Ap[l]) == G.k_exp(self.g, self.k_a[l])
+        k, Ap = 0, G.ONE                                          # :275-289
+        for p in range(1, self.threshold + 1):
+            k = (k + self.k_a[p]) % self.q
+            Ap = G.k_mul(Ap, self.Ap[p])
+        A = self.combinedh.expProd(self.e, self.e_bits)
+        return G.k_mul(G.k_exp(A, self.v), Ap) == G.k_exp(self.g, k)

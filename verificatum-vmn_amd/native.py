@@ -530,3 +530,68 @@ class DistrElGamalSessionBasic:
         verdict = C.c_int(0)
         self._call("verify_combined", b, C.c_size_t(len(b)), C.byref(verdict))
         return bool(verdict.value)
+
+
+class IndependentGeneratorsBasicI:
+    """``vmn_igen_*`` — ref: distr/IndependentGeneratorsBasicI.java (the interface of hvzk.IndependentGeneratorsBasicI)."""
+
+    def __init__(self, group, j: int, threshold: int, ebitlen: int, rand=None):
+        self.G, self.j, self.threshold, self.q = group, j, threshold, group.q
+        self._rs = RandomSource(group, rand) if rand is not None else None
+        self._h = C.c_void_p()
+        _check(plib().vmn_igen_create(group._h, C.c_int(j), C.c_int(threshold), C.c_int(ebitlen),
+                                      C.byref(self._rs.struct) if self._rs else None, C.byref(self._h)))
+        self._keep = []
+
+    def free(self):
+        if self._h and self.G.alive:
+            plib().vmn_igen_free(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _check(getattr(plib(), "vmn_igen_" + name)(self._h, *args))
+
+    def setInstance(self, g, h, s, combinedh):
+        self._keep = [h, s, combinedh]
+        self._call("set_instance", self.G.enc_el(g), _opt_ptr_array(h), s._h if s is not None else None, combinedh._h)
+
+    def setBatchVector(self, e_ints):
+        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
+        self._call("set_batch_vector", blk[0])
+
+    def setBatchVectorSeed(self, seed: bytes):
+        self._call("set_batch_vector_seed", bytes(seed), C.c_size_t(len(seed)))
+
+    def commit(self):
+        out = C.create_string_buffer(self.G.elem_bytes)
+        self._call("commit", out)
+        return self.G.dec_el(out.raw)
+
+    def setCommitment(self, l: int, Ap):
+        self._call("set_commitment", C.c_int(l), self.G.enc_el(Ap))
+
+    def setChallenge(self, v: int):
+        b = _be(v)
+        self._call("set_challenge", b, C.c_size_t(len(b)))
+
+    def reply(self) -> int:
+        out = C.create_string_buffer(self.G.nbytes)
+        self._call("reply", out)
+        return int.from_bytes(out.raw, "big")
+
+    def setReply(self, l: int, k_a: int):
+        self._call("set_reply", C.c_int(l), int_to_be(k_a % (1 << (8 * self.G.nbytes)), self.G.nbytes))
+
+    def verify(self, l: Optional[int] = None) -> bool:
+        verdict = C.c_int(0)
+        if l is None:
+            self._call("verify_combined", C.byref(verdict))
+        else:
+            self._call("verify", C.c_int(l), C.byref(verdict))
+        return bool(verdict.value)
