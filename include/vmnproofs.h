@@ -15,6 +15,8 @@
  *   vmn_permutation_commitment   mixnet/PermutationCommitment.java:189-215
  *   vmn_decryption_factors, vmn_combine_decryption_factors, vmn_decproof_*
  *                                elgamal/DistrElGamalSession.java:365-385, elgamal/DistrElGamalSessionBasic.java
+ *   vmn_igen_*                   distr/IndependentGeneratorsBasicI.java (interactive independent generators)
+ *   vmn_element_*                single group elements on the host (what VCR keeps in PGroupElement objects)
  *
  * Conventions
  *   * A ciphertext array of width w is 2w component arrays [u_1..u_w, v_1..v_w] (struct of arrays, the way
