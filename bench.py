@@ -99,6 +99,27 @@ class ReplaySource:
         return self._next("int_array")
 
 
+def fiat_shamir_seed(grp, arrays, prefix: bytes = b"bench"):
+    """The hashing the reference does on the host around a proof (reported as its own line, never part
+    of ciphertexts/s): seed = RO(prefix || bytetree(g, h, u, pk, w, w')) as in PoSTW.java:118-130 -- the byte trees of
+    the N-sized arrays are framed on the GPU, downloaded into one page-locked buffer and fed to SHA-256 (hashlib).
+    Returns (seed, milliseconds, bytes hashed)."""
+    import hashlib
+    import torch
+    size = max(a.byteTreeSize() for a in arrays)
+    buf = torch.empty(size, dtype=torch.uint8).pin_memory()
+    view = memoryview(buf.numpy())
+    t0 = time.perf_counter()
+    hsh = hashlib.sha256((256).to_bytes(4, "big") + prefix)          # RandomOracle: H(uint32(nout) || data)
+    total = 0
+    for a in arrays:
+        nbytes = a.toByteTreeInto(buf)
+        hsh.update(view[:nbytes])
+        total += nbytes
+    seed = hsh.digest()
+    return seed, (time.perf_counter() - t0) * 1e3, total
+
+
 def proof_drivers(entry, drivers: str):
     """The proof drivers of a leg: "native" = the C++ drivers behind include/vmnproofs.h (what an integration binds),
     "python" = the Python mirror of the same classes (hvzk.py / mixnet.py)."""
@@ -211,6 +232,12 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
                 a.free()
     best["ciphertexts_per_s"] = n / (best["total_ms"] / 1e3)
     best["n"] = n
+    # the Fiat-Shamir hashing of the public arrays (host, SHA-256), its own line
+    Hh = grp.exp(g, grp.ringArray(bulk.ring_array(n)))
+    _, fs_ms, fs_bytes = fiat_shamir_seed(grp, [H, Hh] + W + W)      # stands for h, u, w, w' (six N-sized arrays)
+    Hh.free()
+    best["fiat_shamir_host_ms"] = fs_ms
+    best["fiat_shamir_bytes"] = fs_bytes
     # canonical cost, SURVEY.md §8d: ~3280 M(64) = 2.7e7 MAC per ciphertext (PoS path, n = 2048, width 1)
     best["algorithmic_TMACs"] = 3280 * 8256 * n / (best["total_ms"] / 1e3) / 1e12
     return best

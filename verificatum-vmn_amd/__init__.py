@@ -443,6 +443,19 @@ class PGroupElementArray(_ArrayBase):
         _check(lib().vmn_garray_to_bytetree(self._h, out))
         return out.raw[:size]
 
+    def byteTreeSize(self) -> int:
+        return lib().vmn_garray_bytetree_size(self._h)
+
+    def toByteTreeInto(self, host_buffer) -> int:
+        """The byte tree written into a caller-owned host buffer (a pinned ``torch`` uint8 tensor or a uint8 array of
+        at least ``byteTreeSize()`` bytes): no intermediate copies, the download runs at PCIe speed."""
+        blk = host_block(host_buffer)
+        size = self.byteTreeSize()
+        if blk is None or blk[1] < size:
+            raise ValueError("host buffer too small for the byte tree")
+        _check(lib().vmn_garray_to_bytetree(self._h, blk[0]))
+        return size
+
     def _new(self, h) -> "PGroupElementArray":
         return PGroupElementArray(self.group, h)
 
