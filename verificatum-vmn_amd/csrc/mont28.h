@@ -70,7 +70,7 @@ __device__ __forceinline__ void mont_mul_columns(u64 (&T)[S], const u32 (&a)[S],
     u32 bi = b_lds[0];
     u32 bn = b_lds[bstride];
     mont_row_asm_first<S>(T, a, bi, n, n0inv);
-#pragma unroll 1
+#pragma unroll 2
     for (int i = 2; i <= S; ++i) {
         bi = bn;
         bn = b_lds[(i < S ? i : 0) * bstride];          // prefetch the next limb under this row
@@ -86,7 +86,7 @@ template <int S, int J0>
 __device__ __forceinline__ void mont_sqr_blocks(u64 (&T)[S], const u32 (&a)[S], const u32* a_lds, int bstride,
                                                 const u32 (&n)[S], u32 n0inv, u32& bn) {
     constexpr int END = J0 + SQR_BLK < S ? J0 + SQR_BLK : S;
-#pragma unroll 1
+#pragma unroll 2
     for (int i = (J0 == 0 ? 1 : J0); i < END; ++i) {
         u32 bi = bn;
         bn = a_lds[(i + 1 < S ? i + 1 : 0) * bstride];            // prefetch the next row's limb under this row
@@ -140,7 +140,7 @@ __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&
     u32 bi = b_lds[0];
     u32 bn = b_lds[bstride];
     mont_lanes_row_asm_first<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
-#pragma unroll 1
+#pragma unroll 2
     for (int i = 2; i <= HALF; ++i) {
         bi = bn;
         bn = b_lds[(i < S ? i : 0) * bstride];
@@ -148,7 +148,7 @@ __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&
     }
     if constexpr (HALF < S) {
         relieve_columns<L, LPE>(T, lowmask, nottopmask);
-#pragma unroll 1
+#pragma unroll 2
         for (int i = HALF + 1; i <= S; ++i) {
             bi = bn;
             bn = b_lds[(i < S ? i : 0) * bstride];
