@@ -617,11 +617,11 @@ def main() -> None:
     # written once and read once per window (they stay in L2/MALL mostly); SURVEY.md §8d: 768 B/element
     alg_bytes = 768 * n
     # HBM traffic from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, summarised in
-    # profiles/r01_pmc_modpow_v3.json by tools/profile_pmc.sh); per element, scaled to this launch.
+    # profiles/r01_pmc_modpow_v11.json by tools/profile_pmc.sh); per element, scaled to this launch.
     traffic = None
     valu_busy = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_modpow_v3.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_modpow_v11.json")) as f:
             pmc = json.load(f)
         traffic = pmc["hbm_bytes_per_element"] * n
         valu_busy = pmc["valu_busy_frac"]
@@ -647,7 +647,7 @@ def main() -> None:
         "roofline": {"bound": "valu-int", "kernel": "k_modpow<74>", "achieved": achieved, "peak": PEAK_TMACS,
                      "unit": "TMAC/s (32x32->64-bit multiply-accumulate)", "frac": achieved / PEAK_TMACS,
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
-                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_modpow_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per element x n)",
+                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_modpow_v11.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per element x n)",
                      "valu_busy_pmc": valu_busy,
                      "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                              "achieved_GBs": alg_bytes / avg_kernel_s / 1e9, "peak_GBs": HBM_PEAK_GBS}},

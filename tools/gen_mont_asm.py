@@ -25,6 +25,7 @@ import sys
 
 P0REG = 2   # column 0 is pinned to v[2:3]: inline asm cannot name the low half of a 64-bit operand
 SQR_BLK = 8  # rows per block of the squaring schedule
+LEAD = int(__import__("os").environ.get("VMN_ROW_LEAD", "3"))   # products issued ahead of the reduction (see _row)
 
 
 def _row(S: int, first: bool, j0: int = 0, blk: int = 0):
@@ -64,20 +65,32 @@ def _row(S: int, first: bool, j0: int = 0, blk: int = 0):
         else:
             L.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {mult}, {P(j)}")
 
+    # head: the chain  P[0] -> m -> c -> P[0]  is five dependent instructions; LEAD independent products of the
+    # same row are spread between its links so that a wave has something to issue while a link is in flight
+    # (LEAD = 3 was the first schedule; see DESIGN.md for the measurement)
     ab(0)
-    ab(1)
+    k = 1
+    def lead(cnt):
+        nonlocal k
+        for _ in range(cnt):
+            ab(k)
+            k += 1
+    per = max(1, (LEAD - 1) // 4)
+    lead(per)
     L.append(f"v_mul_lo_u32 {M}, v{P0REG}, {NI}")   # low dword of column 0 (operand 0 is pinned to v[P0REG:P0REG+1])
-    ab(2)
+    lead(per)
     L.append(f"v_and_b32 {M}, {MASK}, {M}")
-    ab(3)
+    lead(per)
     L.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
+    ab(1)                                            # column 1 must have its product before it moves to column 0
     L.append(f"v_mad_u64_u32 {P(0)}, vcc, {M}, {N(1)}, {P(1)}")
     L.append(f"v_lshrrev_b64 {C}, 28, {C}")
-    ab(4)
+    lead(per)
     L.append(f"v_lshl_add_u64 {P(0)}, {P(0)}, 0, {C}")
-    # steady state: a*b for column j+3 is issued three slots before m*N consumes column j
+    # steady state: a*b for column j+LEAD is issued LEAD slots before m*N consumes column j
     for j in range(2, S):
-        ab(j + 3)
+        ab(j + LEAD)
+        ab(j)                                        # (no-op when already emitted)
         L.append(f"v_mad_u64_u32 {P(j - 1)}, vcc, {M}, {N(j)}, {P(j)}")
     return L
 
