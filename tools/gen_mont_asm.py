@@ -25,6 +25,7 @@ import sys
 
 P0REG = 2   # column 0 is pinned to v[2:3]: inline asm cannot name the low half of a 64-bit operand
 SQR_BLK = 8  # rows per block of the squaring schedule
+FILL_FROM_BLOCK = int(__import__("os").environ.get("VMN_ROW_FILL", "0"))
 LEAD = int(__import__("os").environ.get("VMN_ROW_LEAD", "3"))   # products issued ahead of the reduction (see _row)
 
 
@@ -73,7 +74,9 @@ def _row(S: int, first: bool, j0: int = 0, blk: int = 0):
     def lead(cnt):
         nonlocal k
         for _ in range(cnt):
-            ab(k)
+            if sqr and FILL_FROM_BLOCK and k < j0:
+                k = j0                               # squaring rows: columns before the block get no product; fill
+            ab(k)                                    # the chain's gaps with the block's own products instead
             k += 1
     per = max(1, (LEAD - 1) // 4)
     lead(per)
