@@ -620,11 +620,14 @@ def main() -> None:
     # profiles/r01_pmc_modpow_v11.json by tools/profile_pmc.sh); per element, scaled to this launch.
     traffic = None
     valu_busy = None
+    pmc_instr = None
+    n_launch = n
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_modpow_v11.json")) as f:
             pmc = json.load(f)
         traffic = pmc["hbm_bytes_per_element"] * n
         valu_busy = pmc["valu_busy_frac"]
+        pmc_instr = pmc["valu_instr_per_element_lane"]
     except Exception:
         pass
 
@@ -649,6 +652,10 @@ def main() -> None:
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                      "traffic": traffic, "traffic_source": "profiles/r01_pmc_modpow_v11.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per element x n)",
                      "valu_busy_pmc": valu_busy,
+                     # what the hardware sustains for v_mad_u64_u32 at this kernel's two waves per SIMD
+                     # (profiles/valu_rate_r01.txt), and the kernel's issue rate from the PMC instruction count
+                     "peak_measured": 33.1,
+                     "issued_Tlaneinstr_per_s": (pmc_instr * n_launch / avg_kernel_s / 1e12) if pmc_instr else None,
                      "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                              "achieved_GBs": alg_bytes / avg_kernel_s / 1e9, "peak_GBs": HBM_PEAK_GBS}},
     }
