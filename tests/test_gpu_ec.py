@@ -275,3 +275,30 @@ def test_threshold_decryption_over_p256(impl, vmn, gpu_ctx, entry):
     assert ver.verifyCombined(chal)
     ver.setReply(3, (ver.k_x[3] + 1) % q)
     assert not ver.verify(3, chal)
+
+
+def test_properties_at_full_baseline_size_p256(vmn, gpu_ctx):
+    """BASELINE.json configs[4] size (10^6 points of P-256): the affine Python reference would need hours, so the
+    result is pinned through size-independent properties plus spot checks against the reference."""
+    import numpy as np
+    c = Curve("P-256")
+    G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    n = 1_000_000
+    rng = np.random.Generator(np.random.PCG64(2024))
+
+    def block(clear_top_bits):
+        a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        a[:, 0] &= 0xFF >> clear_top_bits
+        return a
+    eb, fb = block(2), block(2)                        # exponents < 2^254: e + f < n, no wrap
+    E, F = G.ringArray(eb.tobytes()), G.ringArray(fb.tobytes())
+    X = G.exp(c.g, G.ringArray(block(1).tobytes()))    # random points (fixed-base path)
+    XE, XF = X.exp(E), X.exp(F)
+    assert XE.mul(XF).equals(X.exp(E.add(F)))          # e P + f P = (e + f) P, point-wise over 10^6 points
+    Gs = G.toElementArray(G.enc_el(c.g) * n)
+    assert G.exp(c.g, E).equals(Gs.exp(E))             # fixed-base table path = variable-base path
+    assert X.expProd(E) == XE.prod()                   # Pippenger = sum of the individual multiples
+    assert X.mul(X.inv()).equals(G.toElementArray(G.enc_el(None) * n))       # P + (-P) = infinity everywhere
+    for i in (0, 1, 499_999, 999_999):
+        e = int.from_bytes(eb[i].tobytes(), "big")
+        assert XE.get(i) == c.mul(e, X.get(i))
