@@ -88,6 +88,13 @@ int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_group** out);
 void vmn_group_destroy(vmn_group* grp);
 size_t vmn_group_elem_bytes(const vmn_group* grp);     /* bytes per group element on the wire */
 size_t vmn_group_exp_bytes(const vmn_group* grp);      /* bytes per exponent (ring element) on the wire */
+/* The two widths are those the group was created with until this is called (vmn_modp_group_create: nbytes for both;
+ * curves: the coordinate size).  0 selects the reference's own width, the length of Java's
+ * BigInteger.toByteArray() of the modulus resp. the order -- floor(bits / 8) + 1, e.g. 257-byte elements and 256-byte
+ * exponents for an RFC 3526 2048-bit group, 33 / 33 for P-256 -- which is what VCR writes into byte-tree leaves
+ * (the 15 492-bit group of demo/mixnet/benchmarks/bench_config:43 has 1 937-byte leaves).  A JNI
+ * binding calls this with (0, 0) right after creating the group.  Must precede any other use of the group. */
+int vmn_group_set_wire_bytes(vmn_group* grp, size_t elem_bytes, size_t exp_bytes);
 /* PGroup accessors used by host-side protocol code: getElementOrder() (P/hvzk/PoSBasicTW.java:470 uses its
  * bit length), getg() (P/mixnet/PermutationCommitment.java:200), and the modulus / field prime.
  * kind: 0 = ModPGroup, 1 = ECqPGroup.  order / modulus: exp_bytes big-endian bytes; generator: elem_bytes. */
@@ -207,6 +214,11 @@ int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray*
 int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal);
 int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be);
 int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out);
+/* Largest bit length among the entries (0 for an empty or all-zero array).  A verifier must use EVERY bit of an
+ * exponent array it received (pField.toElementArray parses full field elements, ref: P/hvzk/PoSBasicTW.java:985-989, and
+ * h.expProd(k_E) :1021, B_shift.exp(k_E) :1032 use them whole); this tells it how many there are, so that honest
+ * replies (n_e + n_v + n_r + 1 bits) keep their short exponentiations and anything longer is still computed exactly. */
+int vmn_rarray_max_bits(const vmn_rarray* x, int* bits);
 
 /* ---- pseudo-random derivations ---------------------------------------------
  * VCR's PRGHeuristic and RandomOracle over SHA-256, restated from their published definition (the classes are not

@@ -217,6 +217,22 @@ int vmn_shuffle_reencrypt(vmn_group* grp, const uint8_t* pkey_be, size_t width, 
 int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h, const vmn_rarray* r,
                                const uint32_t* pi, vmn_garray** u_out);
 
+/* PermutationCommitment.shrink (mixnet/PermutationCommitment.java:390-471), the prover's side: the commitment was
+ * precomputed for n_max ciphertexts (`vmn -precomp`, ShufflerElGamalSession.java:645-661) and only n <= n_max arrive
+ * (:673-712: generators, raised generators, re-encryption exponents and factors are cut with copyOfRange(0, n) =
+ * vmn_*_copy_range; the commitments with extract(keepList) = vmn_garray_extract).  keep_out[i] = 1 for the n positions
+ * of u that commit to the first n generators (:398-405), pi_out = the permutation of [0, n) those positions carry
+ * (Permutation.shrink).  pi is the table vmn_permutation_commitment was given (u[i] = (h g^r)[pi[i]]), so
+ * keep_out[i] = (pi[i] < n).  Host work only.  The reference's keepList[permutation.map(i)] = true, i < n, is the same
+ * list when pi is the table of its permutation's inverse -- which also settles App. B's open question: the positions
+ * kept must be those of the first n generators (exponents and generators are cut to [0, n)), so VCR's
+ * X.permute(pi) puts X[i] at position pi.map(i), and a JNI binding hands this library the inverse table. */
+int vmn_permutation_shrink(const uint32_t* pi, size_t n_max, size_t n, uint8_t* keep_out, uint32_t* pi_out);
+/* The verifiers' side (:424-447): a keep list read from another party is accepted only if it has n_max flags of which
+ * exactly n are set; otherwise the trivial list (first n set) takes its place.  keep is rewritten in place; *replaced
+ * (may be NULL) tells whether that happened.  keep_len = number of flags actually received. */
+int vmn_keep_list_sanitize(uint8_t* keep, size_t keep_len, size_t n_max, size_t n, int* replaced);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,29 @@ def permutation_commitment(g: int, generators: Sequence[int], exponents: Sequenc
     return pyref.permute(ident, permutation)
 
 
+def shrink_permutation(permutation: Sequence[int], n: int):
+    """PermutationCommitment.shrink, P/mixnet/PermutationCommitment.java:390-471: (keep list, compressed permutation).
+    The kept positions of the commitment are those that commit to the first n generators -- the exponents and the
+    generators are cut to [0, n) (:415, ShufflerElGamalSession.java:684-703) -- which in the gather convention of
+    pyref.permute (out[i] = X[perm[i]]) is perm[i] < n; the reference writes keepList[permutation.map(i)] = true for
+    i < n (:398-405), the same list when perm is the table of its permutation's inverse."""
+    keep = [src < n for src in permutation]
+    return keep, [src for src in permutation if src < n]
+
+
+def extract(xs: Sequence, keep: Sequence[bool]) -> list:
+    """``array.extract(boolean[])``: the elements whose flag is set, order preserved (:462-469)."""
+    return [x for x, k in zip(xs, keep) if k]
+
+
+def sanitize_keep_list(keep: Sequence[bool], n_max: int, n: int):
+    """:424-447: a received keep list is used only if it has n_max flags of which exactly n are set."""
+    keep = list(keep)
+    if len(keep) != n_max or sum(1 for k in keep if k) != n:
+        return [i < n for i in range(n_max)]
+    return keep
+
+
 class _Base:
     def __init__(self, p, q, vbitlen, ebitlen, rbitlen, rand=None):
         self.p, self.q = p, q
@@ -549,19 +572,36 @@ class GCCPoS:
     def setCommitment(self, msg):
         self.Ap, self.Bp = msg["Ap"], msg["Bp"]
 
-    def computeAB(self):
-        self.A = self.K.exp_prod(self.u, self.e)
-        self.B = self._cx(self.w, self.e)
+    def computeAB(self, raisedu=None):
+        """CCPoSBasicW.java:493-506: plain, or AB = (w * raisedu).expProd(e) -- the base-group array multiplies every
+        component of the ciphertext array."""
+        K = self.K
+        if raisedu is None:
+            self.A = K.exp_prod(self.u, self.e)
+            self.B = self._cx(self.w, self.e)
+        else:
+            self.AB = [K.exp_prod(K.mul_arrays(c, raisedu), self.e) for c in self.w]
 
-    def verify(self, reply, v):
+    def verify(self, reply, v, raisedh=None, raisedExponent=None):
+        """:519-584; with raisedExponent the single equation :571-580:
+        AB^v (B' A'^rho) = pk^(-k_B) prod (w'_i h_i^rho)^(k_E,i) g^(k_A rho)."""
         K, g, h = self.K, self.g, self.h
         k_A, k_B, k_E = reply["k_A"], reply["k_B"], reply["k_E"]
-        if K.mul(K.exp(self.A, v), self.Ap) != K.mul(K.exp(g, k_A), K.exp_prod(h, k_E)):
-            return False
-        prods = self._cx(self.wp, k_E)
         width = len(self.pkey) // 2
-        return all(K.mul(K.exp(Bc, v), Bpc) == K.mul(K.exp(pk, -k_B[c % width]), t)
-                   for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, prods)))
+        if raisedExponent is None:
+            if K.mul(K.exp(self.A, v), self.Ap) != K.mul(K.exp(g, k_A), K.exp_prod(h, k_E)):
+                return False
+            prods = self._cx(self.wp, k_E)
+            return all(K.mul(K.exp(Bc, v), Bpc) == K.mul(K.exp(pk, -k_B[c % width]), t)
+                       for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, prods)))
+        rho = raisedExponent
+        Ap_rho = K.exp(self.Ap, rho)
+        g_term = K.exp(g, k_A * rho % self.q)
+        ok = True
+        for c, (ABc, Bpc, pk, col) in enumerate(zip(self.AB, self.Bp, self.pkey, self.wp)):
+            t = K.exp_prod(K.mul_arrays(col, raisedh), k_E)
+            ok = ok and K.mul(K.exp(ABc, v), K.mul(Bpc, Ap_rho)) == K.mul(K.mul(K.exp(pk, -k_B[c % width]), t), g_term)
+        return ok
 
 
 class IndependentGeneratorsI:

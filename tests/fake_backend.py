@@ -9,6 +9,7 @@ class FakeGroup:
     def __init__(self, p, q, g, nbytes=None):
         self.p, self.q, self.g = p, q, g
         self.nbytes = nbytes or (p.bit_length() + 7) // 8
+        self.exp_bytes = self.nbytes
 
     def _ints(self, values):
         if isinstance(values, (bytes, bytearray)):
@@ -70,6 +71,9 @@ class _Arr:
     def permute(self, perm):
         return type(self)(self.group, [self.v[int(j)] for j in perm])
 
+    def extract(self, keep):
+        return type(self)(self.group, [x for x, k in zip(self.v, keep) if k])
+
     def shiftPush(self, el):
         return type(self)(self.group, pyref.shift_push(self.v, el) if self.v else [])
 
@@ -129,6 +133,9 @@ class FakeR(_Arr):
             acc = acc * t % self.group.q
         return acc
 
+    def maxBits(self):
+        return max((int(t).bit_length() for t in self.v), default=0)
+
 
 class FakeECGroup(FakeGroup):
     """The same stand-in over an elliptic curve (oracle/pyref_ec.Curve); elements are affine points or None."""
@@ -137,6 +144,7 @@ class FakeECGroup(FakeGroup):
         self.c = curve
         self.p, self.q, self.g = curve.p, curve.n, curve.g
         self.nbytes = curve.nbytes
+        self.exp_bytes = self.nbytes
 
     elem_bytes = property(lambda self: 2 * self.nbytes)
     ONE = None

@@ -168,12 +168,22 @@ class ModPGroup:
     """``com.verificatum.arithm.ModPGroup``: the order-q subgroup of Z_p^* with generator g."""
 
     def __init__(self, ctx: Context, p: int, q: int, g: int, nbytes: Optional[int] = None):
+        """``nbytes`` = one explicit width for elements and exponents on the host side; ``None`` = the reference's own
+        widths (Java ``BigInteger.toByteArray().length`` of p resp. q: 257 / 256 bytes for an RFC 3526 2048-bit
+        group), which is what VCR writes into byte-tree leaves."""
         self.ctx = ctx
         self.p, self.q, self.g = int(p), int(q), int(g)
-        self.nbytes = nbytes or (self.p.bit_length() + 7) // 8
+        nb = nbytes or (self.p.bit_length() + 7) // 8
         self._h = C.c_void_p()
-        _check(lib().vmn_modp_group_create(ctx._h, int_to_be(p, self.nbytes), int_to_be(q, self.nbytes),
-                                           int_to_be(g, self.nbytes), C.c_size_t(self.nbytes), C.byref(self._h)))
+        _check(lib().vmn_modp_group_create(ctx._h, int_to_be(p, nb), int_to_be(q, nb),
+                                           int_to_be(g, nb), C.c_size_t(nb), C.byref(self._h)))
+        if nbytes is None:
+            _check(lib().vmn_group_set_wire_bytes(self._h, C.c_size_t(0), C.c_size_t(0)))
+        self._read_widths()
+
+    def _read_widths(self) -> None:
+        self.nbytes = lib().vmn_group_elem_bytes(self._h)        # bytes of a group element
+        self.exp_bytes = lib().vmn_group_exp_bytes(self._h)      # bytes of a ring element (exponent)
 
     def close(self) -> None:
         # the garbage collector may finalise a context before the groups / arrays that were created on it
@@ -237,7 +247,7 @@ class ModPGroup:
         return r if ok else self._py_mul(a, b)
 
     def k_exp(self, a, e: int):
-        eb = int(e % self.q).to_bytes(self.nbytes, "big")
+        eb = int(e % self.q).to_bytes(self.exp_bytes, "big")
         ok, r = self._k_native("vmn_element_exp", self.enc_el(a), eb, C.c_size_t(len(eb)))
         return r if ok else self._py_exp(a, e)
 
@@ -270,8 +280,8 @@ class ModPGroup:
         return arr
 
     def ringArray(self, values, checked: bool = True) -> "PRingElementArray":
-        blk = host_block(values) or host_block(ints_to_be(values, self.nbytes))
-        n = blk[1] // self.nbytes
+        blk = host_block(values) or host_block(ints_to_be(values, self.exp_bytes))
+        n = blk[1] // self.exp_bytes
         h = C.c_void_p()
         ok = C.c_int(1)
         _check(lib().vmn_rarray_from_be(self._h, blk[0], C.c_size_t(n), C.byref(h), C.byref(ok)))
@@ -337,16 +347,22 @@ class ECqPGroup(ModPGroup):
     demo/mixnet/.conf:153).  Elements are affine points ``(x, y)`` (``None`` = infinity); on the wire
     x || y fixed width; ``mul`` is point addition, ``exp`` scalar multiplication; exponents live in Z_n."""
 
-    def __init__(self, ctx: Context, name: str = "P-256"):
+    def __init__(self, ctx: Context, name: str = "P-256", java_widths: bool = False):
         from . import ecscalar
         self._ec = ecscalar
         c = ecscalar.CURVES[name]
         self.ctx, self.name = ctx, name
         self.p, self.q, self.b = c["p"], c["n"], c["b"]
         self.g = (c["gx"], c["gy"])
-        self.nbytes = (self.p.bit_length() + 7) // 8
         self._h = C.c_void_p()
         _check(lib().vmn_ec_group_create(ctx._h, name.encode(), C.byref(self._h)))
+        if java_widths:
+            _check(lib().vmn_group_set_wire_bytes(self._h, C.c_size_t(0), C.c_size_t(0)))
+        self._read_widths()
+
+    def _read_widths(self) -> None:
+        self.nbytes = lib().vmn_group_elem_bytes(self._h) // 2   # bytes of one coordinate
+        self.exp_bytes = lib().vmn_group_exp_bytes(self._h)
 
     @property
     def elem_bytes(self) -> int:
@@ -564,12 +580,12 @@ class PRingElementArray(_ArrayBase):
         return lib().vmn_rarray_size(self._h)
 
     def toBytes(self) -> bytes:
-        out = C.create_string_buffer(max(1, self.size() * self.group.nbytes))
+        out = C.create_string_buffer(max(1, self.size() * self.group.exp_bytes))
         _check(lib().vmn_rarray_to_be(self._h, out))
-        return out.raw[: self.size() * self.group.nbytes]
+        return out.raw[: self.size() * self.group.exp_bytes]
 
     def toInts(self) -> list:
-        return be_to_ints(self.toBytes(), self.group.nbytes)
+        return be_to_ints(self.toBytes(), self.group.exp_bytes)
 
     def toByteTree(self) -> bytes:
         size = lib().vmn_rarray_bytetree_size(self._h)
@@ -599,14 +615,21 @@ class PRingElementArray(_ArrayBase):
     def mulAdd(self, v: int, other: Optional["PRingElementArray"]) -> "PRingElementArray":
         """x.mulAdd(v, y) = x*v + y ; other=None: x*v."""
         h = C.c_void_p()
-        _check(lib().vmn_rarray_mul_add(self._h, int_to_be(v, self.group.nbytes), other._h if other is not None else None,
+        _check(lib().vmn_rarray_mul_add(self._h, int_to_be(v, self.group.exp_bytes), other._h if other is not None else None,
                                         C.byref(h)))
         return self._new(h)
 
     def get(self, i: int) -> int:
-        out = C.create_string_buffer(self.group.nbytes)
+        out = C.create_string_buffer(self.group.exp_bytes)
         _check(lib().vmn_rarray_get(self._h, C.c_size_t(i), out))
         return int.from_bytes(out.raw, "big")
+
+    def maxBits(self) -> int:
+        """Largest bit length among the entries (``vmn_rarray_max_bits``): what a verifier uses for an exponent array
+        it was sent, so that every bit of it counts."""
+        out = C.c_int()
+        _check(lib().vmn_rarray_max_bits(self._h, C.byref(out)))
+        return out.value
 
     def copyOfRange(self, start: int, end: int) -> "PRingElementArray":
         h = C.c_void_p()
@@ -616,7 +639,7 @@ class PRingElementArray(_ArrayBase):
     def recLin(self, e: "PRingElementArray"):
         """``b.recLin(e)`` -> (x, d): x0 = b0, xi = x(i-1)*ei + bi, d = x(N-1)."""
         h = C.c_void_p()
-        last = C.create_string_buffer(self.group.nbytes)
+        last = C.create_string_buffer(self.group.exp_bytes)
         _check(lib().vmn_rarray_rec_lin(self._h, e._h, C.byref(h), last))
         return self._new(h), int.from_bytes(last.raw, "big")
 
@@ -626,7 +649,7 @@ class PRingElementArray(_ArrayBase):
         return self._new(h)
 
     def _scalar(self, fn: str, *others) -> int:
-        out = C.create_string_buffer(self.group.nbytes)
+        out = C.create_string_buffer(self.group.exp_bytes)
         _check(getattr(lib(), fn)(self._h, *[o._h for o in others], out))
         return int.from_bytes(out.raw, "big")
 
@@ -647,7 +670,7 @@ class PRingElementArray(_ArrayBase):
 
     def shiftPush(self, el: int) -> "PRingElementArray":
         h = C.c_void_p()
-        _check(lib().vmn_rarray_shift_push(self._h, int_to_be(el, self.group.nbytes), C.byref(h)))
+        _check(lib().vmn_rarray_shift_push(self._h, int_to_be(el, self.group.exp_bytes), C.byref(h)))
         return self._new(h)
 
     def equals(self, other) -> bool:

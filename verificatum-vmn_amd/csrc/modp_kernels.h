@@ -474,6 +474,26 @@ k_to_words(u32* __restrict__ out, const u32* __restrict__ in, size_t n, const u3
     emit_words<C, NW>(r, ln, [&](int k, u32 w) { if (live) dst[k] = w; });
 }
 
+// out[0] = max over the n integers (nw packed little-endian words each) of their bit length.  One thread per
+// integer; serves the verifier, which must use every bit of an exponent array it was sent (a reply's k_E) and
+// still wants the short path when the entries are as short as an honest prover's.
+__global__ void __launch_bounds__(BLOCK) k_words_maxbits(const u32* __restrict__ w, size_t n, int nw, u32* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    u32 bits = 0;
+    if (i < n) {
+        const u32* p = w + i * (size_t)nw;
+        for (int k = nw - 1; k >= 0; --k) {
+            u32 v = p[k];
+            if (v) {
+                bits = 32u * (u32)k + (32u - (u32)__builtin_clz(v));
+                break;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (u32)__shfl_xor((int)bits, o));
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4: out[i] = x[i] * y[i]        (ystride = 0: every x[i] times the single element y)
 // ---------------------------------------------------------------------------------------------

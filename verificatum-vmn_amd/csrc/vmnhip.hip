@@ -444,6 +444,7 @@ extern "C" int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const ui
     std::unique_ptr<vmn_group> g(new vmn_group());
     g->ctx = ctx;
     g->nbytes = nbytes;
+    g->xbytes = nbytes;
     int rc = modulus_init(ctx, g->P, p_be, nbytes, S, NW, LPE);
     if (rc == VMN_OK) rc = modulus_init(ctx, g->Q, q_be, nbytes, S, NW, LPE);
     if (rc != VMN_OK) {
@@ -474,12 +475,27 @@ extern "C" void vmn_group_destroy(vmn_group* grp) {
     delete grp;
 }
 extern "C" size_t vmn_group_elem_bytes(const vmn_group* grp) { return grp ? (grp->curve ? 2 * grp->nbytes : grp->nbytes) : 0; }
-extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->nbytes : 0; }
+extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->xbytes : 0; }
+// Java's BigInteger.toByteArray().length of a positive integer of `bits` bits: one sign bit on top
+static size_t java_width(int bits) { return (size_t)bits / 8 + 1; }
+extern "C" int vmn_group_set_wire_bytes(vmn_group* grp, size_t elem_bytes, size_t exp_bytes) {
+    ARG_CHECK(grp, "null group");
+    VMN_ENTER(grp->ctx);
+    ARG_CHECK(grp->fixed.empty(), "wire widths must be chosen before the group is used");
+    const int pbits = grp->curve ? hostbig::bit_length(grp->curve->p_words) : grp->P.nbits;
+    size_t eb = elem_bytes ? elem_bytes : java_width(pbits);
+    size_t xb = exp_bytes ? exp_bytes : java_width(grp->Q.nbits);
+    ARG_CHECK(8 * eb >= (size_t)pbits && 8 * xb >= (size_t)grp->Q.nbits, "width too small for the modulus / order");
+    ARG_CHECK(eb <= 4096 && xb <= 4096, "width too large");
+    grp->nbytes = eb;
+    grp->xbytes = xb;
+    return VMN_OK;
+}
 extern "C" int vmn_group_kind(const vmn_group* grp) { return grp && grp->curve ? 1 : 0; }
 extern "C" size_t vmn_group_table_bytes(const vmn_group* grp) { return grp ? grp->fixed_bytes : 0; }
 extern "C" int vmn_group_get_order(const vmn_group* grp, uint8_t* q_be) {
     ARG_CHECK(grp && q_be, "null argument");
-    hostbig::to_be(grp->Q.n_words, q_be, grp->nbytes);
+    hostbig::to_be(grp->Q.n_words, q_be, grp->xbytes);
     return VMN_OK;
 }
 extern "C" int vmn_group_get_modulus(const vmn_group* grp, uint8_t* p_be) {
@@ -644,6 +660,7 @@ extern "C" int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_gro
     std::unique_ptr<vmn_group> g(new vmn_group());
     g->ctx = ctx;
     g->nbytes = (size_t)cp->bits / 8;
+    g->xbytes = g->nbytes;
     vmn_curve* curve = nullptr;
     VMN_TRY(curve_create(ctx, *cp, &curve));
     g->curve = curve;
@@ -963,7 +980,7 @@ extern "C" int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, v
     VMN_ENTER(grp->ctx);
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
-    int rc = import_be(grp->ctx, grp->Q, grp->nbytes, be, n, a->d, all_in_range);
+    int rc = import_be(grp->ctx, grp->Q, grp->xbytes, be, n, a->d, all_in_range);
     if (rc != VMN_OK) {
         vmn_rarray_free(a);
         return rc;
@@ -972,7 +989,7 @@ extern "C" int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, v
     return VMN_OK;
 }
 extern "C" size_t vmn_garray_bytetree_size(const vmn_garray* a) { return a ? bytetree_size(a->n, a->grp->nbytes) : 0; }
-extern "C" size_t vmn_rarray_bytetree_size(const vmn_rarray* a) { return a ? bytetree_size(a->n, a->grp->nbytes) : 0; }
+extern "C" size_t vmn_rarray_bytetree_size(const vmn_rarray* a) { return a ? bytetree_size(a->n, a->grp->xbytes) : 0; }
 extern "C" int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
     VMN_ENTER(a->grp->ctx);
@@ -981,7 +998,7 @@ extern "C" int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out) {
 extern "C" int vmn_rarray_to_bytetree(const vmn_rarray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
     VMN_ENTER(a->grp->ctx);
-    return to_bytetree(a->grp->ctx, a->grp->Q, a->grp->nbytes, a->d, a->n, out);
+    return to_bytetree(a->grp->ctx, a->grp->Q, a->grp->xbytes, a->d, a->n, out);
 }
 extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_garray** out,
                                         int* format_ok, int* all_in_range) {
@@ -1007,11 +1024,11 @@ extern "C" int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_
     VMN_ENTER(grp->ctx);
     *out = nullptr;
     size_t n = 0;
-    VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
+    VMN_TRY(bytetree_header(bt, len, grp->xbytes, expected_n, &n, format_ok));
     if (!*format_ok) return VMN_OK;
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
-    int rc = import_be(grp->ctx, grp->Q, grp->nbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
+    int rc = import_be(grp->ctx, grp->Q, grp->xbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
     if (rc != VMN_OK || !*format_ok) {
         vmn_rarray_free(a);
         return rc;
@@ -1027,7 +1044,7 @@ extern "C" int vmn_garray_to_be(const vmn_garray* a, uint8_t* be_out) {
 extern "C" int vmn_rarray_to_be(const vmn_rarray* a, uint8_t* be_out) {
     ARG_CHECK(a && (be_out || a->n == 0), "null argument");
     VMN_ENTER(a->grp->ctx);
-    return export_be(a->grp->ctx, a->grp->Q, a->grp->nbytes, a->d, a->n, be_out);
+    return export_be(a->grp->ctx, a->grp->Q, a->grp->xbytes, a->d, a->n, be_out);
 }
 
 extern "C" int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out) {
@@ -1241,7 +1258,7 @@ extern "C" int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, 
     vmn_group* g = x->grp;
     VMN_ENTER(g->ctx);
     uint32_t* d_el = nullptr;
-    VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, el_be, &d_el));
+    VMN_TRY(import_one(g->ctx, g->Q, g->xbytes, el_be, &d_el));
     std::vector<uint32_t> idx(x->n);
     for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
     int rc = arr_gather<vmn_rarray>(x, g->Q, idx, d_el, new_rarray, vmn_rarray_free, out);
@@ -1287,7 +1304,7 @@ extern "C" int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     ARG_CHECK(i < x->n, "index out of range");
     VMN_ENTER(x->grp->ctx);
-    return export_be(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d + i * elem_words(x->grp->Q), 1, out_be);
+    return export_be(x->grp->ctx, x->grp->Q, x->grp->xbytes, x->d + i * elem_words(x->grp->Q), 1, out_be);
 }
 extern "C" int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out) {
     ARG_CHECK(x && out, "null argument");
@@ -1379,12 +1396,12 @@ extern "C" int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be) {
 extern "C" int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     VMN_ENTER(x->grp->ctx);
-    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d, x->n, true, out_be);
+    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->xbytes, x->d, x->n, true, out_be);
 }
 extern "C" int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     VMN_ENTER(x->grp->ctx);
-    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->nbytes, x->d, x->n, false, out_be);
+    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->xbytes, x->d, x->n, false, out_be);
 }
 extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* out_be) {
     ARG_CHECK(x && y && out_be, "null argument");
@@ -1394,7 +1411,7 @@ extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y
     DevTmp prod(g->ctx);
     VMN_TRY(prod.alloc(std::max<size_t>(x->n, 1) * elem_words(g->Q) * sizeof(uint32_t)));
     VMN_TRY(mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, prod.as<uint32_t>()));
-    return reduce_to_host(g->ctx, g->Q, g->nbytes, prod.as<uint32_t>(), x->n, false, out_be);
+    return reduce_to_host(g->ctx, g->Q, g->xbytes, prod.as<uint32_t>(), x->n, false, out_be);
 }
 
 // ---- K8 element-wise -------------------------------------------------------------------------------
@@ -1459,7 +1476,7 @@ extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, cons
     vmn_group* g = x->grp;
     VMN_ENTER(g->ctx);
     uint32_t* d_v = nullptr;
-    VMN_TRY(import_one(g->ctx, g->Q, g->nbytes, v_be, &d_v));
+    VMN_TRY(import_one(g->ctx, g->Q, g->xbytes, v_be, &d_v));
     vmn_rarray* r = nullptr;
     int rc = new_rarray(g, x->n, &r);
     if (rc == VMN_OK) rc = ring_elementwise(g->ctx, g->Q, x->d, y ? y->d : nullptr, d_v, y ? 2 : 3, x->n, r->d);
@@ -1580,6 +1597,24 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     return rc;
 }
 
+extern "C" int vmn_rarray_max_bits(const vmn_rarray* x, int* bits) {
+    ARG_CHECK(x && bits, "null argument");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = g->ctx;
+    VMN_ENTER(ctx);
+    *bits = 0;
+    if (x->n == 0) return VMN_OK;
+    DevTmp ew(ctx);
+    VMN_TRY(ew.alloc(x->n * (size_t)g->Q.NW * sizeof(uint32_t)));
+    VMN_TRY(to_words(ctx, g->Q, x->d, x->n, ew.as<uint32_t>()));
+    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    VMN_TRY(launch_light(ctx, "ring", k_words_maxbits, grid_for(x->n), (const uint32_t*)ew.as<uint32_t>(), x->n, g->Q.NW, ctx->flags));
+    uint32_t v = 0;
+    VMN_TRY(read_flag(ctx, &v));
+    *bits = (int)v;
+    return VMN_OK;
+}
+
 extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_rarray** out_x, uint8_t* last_be) {
     ARG_CHECK(b && e && out_x, "null argument");
     ARG_CHECK(b->grp == e->grp && b->n == e->n, "arrays differ in group or size");
@@ -1589,8 +1624,8 @@ extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_
     VMN_TRY(new_rarray(g, b->n, &r));
     int rc = scan_affine(g->ctx, g->Q, e->d, b->d, b->n, b->n, 0, r->d);
     if (rc == VMN_OK && last_be) {
-        if (b->n) rc = export_be(g->ctx, g->Q, g->nbytes, r->d + (b->n - 1) * elem_words(g->Q), 1, last_be);
-        else memset(last_be, 0, g->nbytes);
+        if (b->n) rc = export_be(g->ctx, g->Q, g->xbytes, r->d + (b->n - 1) * elem_words(g->Q), 1, last_be);
+        else memset(last_be, 0, g->xbytes);
     }
     if (rc != VMN_OK) {
         vmn_rarray_free(r);
@@ -1801,16 +1836,16 @@ extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
     uint32_t w[8];
     VMN_TRY(prg_seed_words(seed, seedlen, w));
     const size_t vb = ((size_t)bits + 7) / 8;
-    if (vb > grp->nbytes || bits > 28 * grp->Q.S) {
-        set_error("vmn_rarray_from_prg: %d-bit integers do not fit the %zu-byte exponent rows", bits, grp->nbytes);
+    if (vb > grp->xbytes || bits > 28 * grp->Q.S) {
+        set_error("vmn_rarray_from_prg: %d-bit integers do not fit the %zu-byte exponent rows", bits, grp->xbytes);
         return VMN_ERR_UNSUPPORTED;
     }
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
     DevTmp rows(ctx);
-    int rc = n ? prg_rows(ctx, w, n, vb, bits, 0, vb, grp->nbytes, rows) : VMN_OK;
+    int rc = n ? prg_rows(ctx, w, n, vb, bits, 0, vb, grp->xbytes, rows) : VMN_OK;
     // integers that may reach the order (bits >= bits of q) act as field elements: reduced
-    if (rc == VMN_OK) rc = import_dev(ctx, grp->Q, grp->nbytes, rows.as<uint8_t>(), bits >= grp->Q.nbits ? 2 : 0, n, a->d, nullptr);
+    if (rc == VMN_OK) rc = import_dev(ctx, grp->Q, grp->xbytes, rows.as<uint8_t>(), bits >= grp->Q.nbits ? 2 : 0, n, a->d, nullptr);
     if (rc != VMN_OK) {
         vmn_rarray_free(a);
         return rc;

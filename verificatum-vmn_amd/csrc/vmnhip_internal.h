@@ -104,7 +104,8 @@ struct vmn_modulus {
 struct vmn_group {
     vmn_ctx* ctx = nullptr;
     vmn_curve* curve = nullptr;   // EC group: P describes point rows (P.ec), Q the scalar field Z_n
-    size_t nbytes = 0;         // wire width of elements and exponents
+    size_t nbytes = 0;         // host / wire width of a group element (ModPGroup) or of one coordinate (curves)
+    size_t xbytes = 0;         // host / wire width of an exponent (ring element)
     vmn_modulus P;             // arithmetic mod p (group elements)
     vmn_modulus Q;             // arithmetic mod q (exponents)
     vmn::hostbig::Big g_words;

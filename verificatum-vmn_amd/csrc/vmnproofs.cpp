@@ -114,7 +114,8 @@ struct HostGroup {
     vmn_group* grp = nullptr;
     bool ec = false;
     size_t eb = 0, xb = 0;            // element / exponent bytes
-    size_t ql = 0;                    // limbs of q
+    size_t cw = 0;                    // bytes of the modulus (ModPGroup: = eb) or of one coordinate (curves: eb / 2)
+    size_t ql = 0, pl = 0;            // 64-bit limbs of q / of the modulus resp. field prime
     Mod Zq, Zp;                       // Z_q scalars; Z_p = the modulus (ModPGroup) or the coordinate field (curves)
     HostCurve curve;
     int qbits = 0;
@@ -125,16 +126,18 @@ struct HostGroup {
         ec = vmn_group_kind(grp) == 1;
         eb = vmn_group_elem_bytes(grp);
         xb = vmn_group_exp_bytes(grp);
+        cw = ec ? eb / 2 : eb;
         ql = (xb + 7) / 8;
-        Bytes qb(xb), pb(xb);
+        pl = (cw + 7) / 8;
+        Bytes qb(xb), pb(cw);
         TRY(vmn_group_get_order(grp, qb.data()));
         TRY(vmn_group_get_modulus(grp, pb.data()));
         Zq = Mod(vmn::num64::from_be(qb.data(), xb, ql));
         qbits = vmn::num64::bit_length(Zq.n);
-        Zp = Mod(vmn::num64::from_be(pb.data(), xb, ql));
+        Zp = Mod(vmn::num64::from_be(pb.data(), cw, pl));
         curve.F = &Zp;                 // (HostGroup objects are not copied after init)
-        curve.cb = xb;
-        curve.fl = ql;
+        curve.cb = cw;
+        curve.fl = pl;
         g.resize(eb);
         TRY(vmn_group_get_generator(grp, g.data()));
         return VMN_OK;
@@ -156,7 +159,7 @@ struct HostGroup {
             out = curve.exp(base, e_be, ebytes);
             return VMN_OK;
         }
-        Num b = vmn::num64::from_be(base.data(), eb, ql);
+        Num b = vmn::num64::from_be(base.data(), eb, pl);
         out = vmn::num64::to_bytes(Zp.pow(b, e_be, ebytes), eb);
         return VMN_OK;
     }
@@ -169,7 +172,7 @@ struct HostGroup {
             out = curve.add(a, b);
             return VMN_OK;
         }
-        out = vmn::num64::to_bytes(Zp.mul(vmn::num64::from_be(a.data(), eb, ql), vmn::num64::from_be(b.data(), eb, ql)), eb);
+        out = vmn::num64::to_bytes(Zp.mul(vmn::num64::from_be(a.data(), eb, pl), vmn::num64::from_be(b.data(), eb, pl)), eb);
         return VMN_OK;
     }
     int el_inv(const Bytes& a, Bytes& out) const {
@@ -177,7 +180,7 @@ struct HostGroup {
             out = curve.negate(a);
             return VMN_OK;
         }
-        out = vmn::num64::to_bytes(Zp.inv(vmn::num64::from_be(a.data(), eb, ql)), eb);
+        out = vmn::num64::to_bytes(Zp.inv(vmn::num64::from_be(a.data(), eb, pl)), eb);
         return VMN_OK;
     }
     // Single elements that arrive from outside (a commitment's A', C', ...) are validated by the GPU import:
@@ -191,10 +194,10 @@ struct HostGroup {
         if (!*ok || ec) return VMN_OK;                 // curves: on the curve = in the group (cofactor 1)
         // ModPGroup: in range is not yet in the subgroup of order q: x^q = 1 on the host (a handful of elements)
         Bytes qb = vmn::num64::to_bytes(Zq.n, xb);
-        Num one(ql, 0);
+        Num one(pl, 0);
         one[0] = 1;
         for (const Bytes* e : els) {
-            if (vmn::num64::cmp(Zp.pow(vmn::num64::from_be(e->data(), eb, ql), qb.data(), qb.size()), one) != 0) {
+            if (vmn::num64::cmp(Zp.pow(vmn::num64::from_be(e->data(), eb, pl), qb.data(), qb.size()), one) != 0) {
                 *ok = 0;
                 break;
             }
@@ -269,11 +272,37 @@ std::vector<Bytes> split(const vmn_msg::Item& it) {
     return out;
 }
 
+// An explicitly supplied batching vector must consist of ebitlen-bit integers: A / F (expProd over ebitlen bits) and
+// D (the full product of e) would otherwise be computed for different vectors.  The reference only ever derives e
+// itself (setBatchVector(byte[] prgSeed), PoSBasicTW.java:533-538), so a wider entry is a caller's mistake.
+int import_batch_vector(vmn_group* grp, const uint8_t* e_be, size_t n, int ebitlen, RA& e) {
+    if (!e_be && n) return fail(VMN_ERR_ARG, "null batching vector");
+    int ok = 1, bits = 0;
+    TRY(vmn_rarray_from_be(grp, e_be, n, e.out(), &ok));
+    if (!ok) return fail(VMN_ERR_FORMAT, "batching vector entry >= q");
+    TRY(vmn_rarray_max_bits(e, &bits));
+    if (bits > ebitlen) {
+        e.reset();
+        return fail(VMN_ERR_FORMAT, "batching vector entry of %d bits, wider than ebitlen = %d", bits, ebitlen);
+    }
+    return VMN_OK;
+}
+// Bit length to use for an exponent array that arrived in a message (a reply's k_E): every bit counts -- the reference
+// parses full field elements (pField.toElementArray, PoSBasicTW.java:985-989) and h.expProd(k_E), B_shift.exp(k_E) use
+// them whole (:1021, :1032) -- so the bound is measured, not assumed: an honest reply keeps its n_e + n_v + n_r + 1-bit
+// exponentiations, anything longer is still computed exactly, and every check of one verification sees the same bits.
+int received_bits(const vmn_rarray* a, int* bits) {
+    int b = 0;
+    TRY(vmn_rarray_max_bits(a, &b));
+    *bits = b < 1 ? 1 : b;
+    return VMN_OK;
+}
+
 // ---- what the three proofs share -----------------------------------------------------------------------------
 struct ProofBase {
     HostGroup G;
     int vbitlen, ebitlen, rbitlen;
-    int e_bits, eps_bits, kE_bits;
+    int e_bits, eps_bits;              // prover-side bounds of values this object made itself (e from the PRG, epsilon)
     bool has_rs = false;
     vmn_random_source rs{};
     size_t N = 0;
@@ -287,7 +316,6 @@ struct ProofBase {
         rbitlen = rb;
         e_bits = std::min(ebl, G.qbits);
         eps_bits = std::min(ebl + vb + rb, G.qbits);
-        kE_bits = std::min(ebl + vb + rb + 1, G.qbits);
         if (r) {
             if (!r->ring_elements || !r->integers) return fail(VMN_ERR_ARG, "random source lacks a callback");
             rs = *r;
@@ -330,12 +358,7 @@ struct ProofBase {
         if (!N) return fail(VMN_ERR_ARG, "batching vector before the instance (size unknown)");
         return vmn_rarray_from_prg(G.grp, seed, seedlen, N, ebitlen, e.out());
     }
-    int batch_vector(const uint8_t* e_be, RA& e) {
-        if (!e_be && N) return fail(VMN_ERR_ARG, "null batching vector");
-        int ok = 1;
-        TRY(vmn_rarray_from_be(G.grp, e_be, N, e.out(), &ok));
-        return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "batching vector entry >= q");
-    }
+    int batch_vector(const uint8_t* e_be, RA& e) { return import_batch_vector(G.grp, e_be, N, ebitlen, e); }
     // g^a for a ring scalar; through the cached fixed-base table when the group is a curve (one launch), on the
     // host for ModPGroup
     int gexp(const Bytes& base, const Num& e, Bytes& out) const { return G.el_exp(base, e, out); }
@@ -367,7 +390,7 @@ struct ProofBase {
     // check (B): B_i^v B'_i == g^{k_B,i} B_{i-1}^{k_E,i}, B_{-1} = h0 (PoSBasicTW.java:1023-1042).  Queues the
     // element-wise work and returns the two sides; the comparison (which blocks) is left to the caller.
     int bridging_sides(const Bytes& g, const Bytes& h0, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
-                       const vmn_rarray* k_E, GA& left, GA& right) {
+                       const vmn_rarray* k_E, int kE_bits, GA& left, GA& right) {
         GA B_exp_v, g_exp_k_B, B_shift, B_shift_exp_k_E;
         TRY(vmn_garray_exp_scalar(B, v_be.data(), v_be.size(), B_exp_v.out()));
         TRY(vmn_garray_mul(B_exp_v, Bp, left.out()));
@@ -590,10 +613,12 @@ struct vmn_pos : ProofBase {
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
         std::vector<Bytes> kE_prods;
+        int kE_bits = 0;
+        TRY(received_bits(ikE->ra, &kE_bits));
         TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));                       // :1021, :1063 — one sort of k_E
         // ... then the element-wise work of check (B) is queued ...
         GA left, right;
-        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, left, right));       // :1023-1042
+        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // :1023-1042
         // ... and the single-element checks run on the host while the GPU works
         Bytes C, D, t, lhs, rhs;
         TRY(G.el_div(uprod, hprod, C));
@@ -749,6 +774,8 @@ struct vmn_posc : ProofBase {
         TRY(vmn_garray_prod(h, hprod.data()));
         TRY(vmn_garray_get(cB, N - 1, Blast.data()));
         TRY(vmn_rarray_prod(e, eprod.data()));
+        int kE_bits = 0;
+        TRY(received_bits(ikE->ra, &kE_bits));
         TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, hk.data()));
         Bytes t, lhs, rhs, C, D;
         TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :676-682
@@ -756,7 +783,7 @@ struct vmn_posc : ProofBase {
         TRY(G.el_mul(t, hk, rhs));
         if (lhs != rhs) return VMN_OK;                                            // short-circuit :682
         GA left, right;
-        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, left, right));       // (B) :685-715
+        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // (B) :685-715
         TRY(G.el_div(uprod, hprod, C));
         TRY(G.el_exp(h0, eprod.data(), eprod.size(), t));
         TRY(G.el_div(Blast, t, D));
@@ -918,6 +945,8 @@ struct vmn_ccpos : ProofBase {
         std::vector<Num> k_B;
         for (auto& bts : split(*ikB)) k_B.push_back(G.ring_from(bts.data()));
         Bytes t, lhs, rhs;
+        int kE_bits = 0;
+        TRY(received_bits(ikE->ra, &kE_bits));
         if (!raised) {                                                            // :554-570
             std::vector<const vmn_garray*> xs{h};
             xs.insert(xs.end(), wp.begin(), wp.end());
@@ -1090,6 +1119,7 @@ struct vmn_decproof {
         const uint8_t* rows = nullptr;
         if (rs.ring_elements(rs.user, 1, &rows) != 0 || !rows) return fail(VMN_ERR_ARG, "random source failed");
         r = G.ring_from(rows);
+        if (vmn::num64::cmp(r, G.Zq.n) >= 0) return fail(VMN_ERR_FORMAT, "random source returned a value >= q");
         TRY(G.el_exp(G.g, r, yp[j]));                                            // y' = g^r
         TRY(G.el_exp(A, r, Bp[j]));                                              // B' = A^r
         memcpy(yp_out, yp[j].data(), G.eb);
@@ -1215,6 +1245,7 @@ struct vmn_igen {
         const uint8_t* rows = nullptr;
         if (rs.ring_elements(rs.user, 1, &rows) != 0 || !rows) return fail(VMN_ERR_ARG, "random source failed");
         r = G.ring_from(rows);
+        if (vmn::num64::cmp(r, G.Zq.n) >= 0) return fail(VMN_ERR_FORMAT, "random source returned a value >= q");
         TRY(G.el_exp(g, r, Ap[j]));                                                // A' = g^r     :205
         memcpy(out, Ap[j].data(), G.eb);
         return VMN_OK;
@@ -1463,6 +1494,29 @@ int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_ga
     return vmn_garray_permute(tmp2, pi, u_out);                                   // :215
 }
 
+int vmn_permutation_shrink(const uint32_t* pi, size_t n_max, size_t n, uint8_t* keep_out, uint32_t* pi_out) {
+    if (!pi || !keep_out || !pi_out || n > n_max) return fail(VMN_ERR_ARG, "vmn_permutation_shrink: bad argument");
+    if (!is_permutation(pi, n_max)) return fail(VMN_ERR_ARG, "vmn_permutation_shrink: pi is not a permutation of [0, n_max)");
+    size_t k = 0;
+    for (size_t i = 0; i < n_max; ++i) {
+        keep_out[i] = pi[i] < n ? 1 : 0;                                          // :398-405
+        if (keep_out[i]) pi_out[k++] = pi[i];                                     // permutation.shrink(noCiphertexts)
+    }
+    return VMN_OK;
+}
+int vmn_keep_list_sanitize(uint8_t* keep, size_t keep_len, size_t n_max, size_t n, int* replaced) {
+    if (!keep || n > n_max) return fail(VMN_ERR_ARG, "vmn_keep_list_sanitize: bad argument");
+    size_t count = 0;
+    bool trivial = keep_len != n_max;                                             // readBooleans(commitment.size()) failed
+    for (size_t i = 0; !trivial && i < n_max; ++i) count += keep[i] ? 1 : 0;
+    if (!trivial && count != n) trivial = true;                                   // :437-439
+    if (trivial) {
+        for (size_t i = 0; i < n_max; ++i) keep[i] = i < n ? 1 : 0;               // :442-445
+    }
+    if (replaced) *replaced = trivial ? 1 : 0;
+    return VMN_OK;
+}
+
 // ---- proof objects ---------------------------------------------------------------------------------------------
 #define CREATE(T, name)                                                                                              \
     int name(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, T** out) {          \
@@ -1693,9 +1747,7 @@ int vmn_decproof_set_instance(vmn_decproof* p, const vmn_garray* u, const uint8_
 int vmn_decproof_set_batch_vector(vmn_decproof* p, const uint8_t* e_be) {
     NONNULL(p);
     if (!p->u || !e_be) return fail(VMN_ERR_ARG, "vmn_decproof_set_batch_vector: instance not set");
-    int ok = 1;
-    TRY(vmn_rarray_from_be(p->G.grp, e_be, vmn_garray_size(p->u), p->e.out(), &ok));
-    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "batching vector entry >= q");
+    return import_batch_vector(p->G.grp, e_be, vmn_garray_size(p->u), p->ebitlen, p->e);
 }
 int vmn_decproof_set_batch_vector_seed(vmn_decproof* p, const uint8_t* seed, size_t seedlen) {
     NONNULL(p);
@@ -1784,9 +1836,7 @@ int vmn_igen_set_instance(vmn_igen* p, const uint8_t* g_be, const vmn_garray* co
 int vmn_igen_set_batch_vector(vmn_igen* p, const uint8_t* e_be) {
     NONNULL(p);
     if (!p->combinedh || !e_be) return fail(VMN_ERR_ARG, "vmn_igen_set_batch_vector: instance not set");
-    int ok = 1;
-    TRY(vmn_rarray_from_be(p->G.grp, e_be, p->N, p->e.out(), &ok));
-    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "batching vector entry >= q");
+    return import_batch_vector(p->G.grp, e_be, p->N, p->ebitlen, p->e);
 }
 int vmn_igen_set_batch_vector_seed(vmn_igen* p, const uint8_t* seed, size_t seedlen) {
     NONNULL(p);
@@ -1862,10 +1912,10 @@ const HostGroup* host_group(vmn_group* grp) {
     thread_local vmn_group* cached = nullptr;
     thread_local std::unique_ptr<HostGroup> hg;
     thread_local Bytes id;
-    const size_t xb = vmn_group_exp_bytes(grp);
-    Bytes now(2 * xb + 1);
-    if (vmn_group_get_modulus(grp, now.data()) != VMN_OK || vmn_group_get_order(grp, now.data() + xb) != VMN_OK) return nullptr;
-    now[2 * xb] = (uint8_t)vmn_group_kind(grp);
+    const size_t xb = vmn_group_exp_bytes(grp), eb = vmn_group_elem_bytes(grp);      // the modulus takes eb or eb / 2 bytes
+    Bytes now(eb + xb + 1, 0);
+    if (vmn_group_get_modulus(grp, now.data()) != VMN_OK || vmn_group_get_order(grp, now.data() + eb) != VMN_OK) return nullptr;
+    now[eb + xb] = (uint8_t)vmn_group_kind(grp);
     if (cached != grp || !hg || id != now) {
         hg.reset(new HostGroup());
         if (hg->init(grp) != VMN_OK) {

@@ -64,7 +64,12 @@ class _Base:
         qbits = self.q.bit_length()
         self.e_bits = min(ebitlen, qbits)
         self.eps_bits = min(ebitlen + vbitlen + rbitlen, qbits)
-        self.kE_bits = min(ebitlen + vbitlen + rbitlen + 1, qbits)
+
+    @staticmethod
+    def _received_bits(k_E) -> int:
+        """Bit length to use for an exponent array that came in a message: every bit of it counts (the reference parses
+        full field elements, PoSBasicTW.java:985-989), so it is measured on the GPU rather than assumed."""
+        return max(1, k_E.maxBits())
 
     # scalar helpers (single group elements on the host, as VCR's scalar classes): through the group object, so
     # the same driver serves ModPGroup (integers) and ECqPGroup (affine points)
@@ -206,13 +211,14 @@ class PoSBasicTW(_Base):
         h0 = h.get(0)
         C = self._div(self.u.prod(), h.prod())
         D = self._div(self.B.get(self.size - 1), self._gexp(h0, self.e.prod()))
-        kE_prods = self._ciph_expprod([h] + list(self.wp), k_E, self.kE_bits)         # one sort of k_E for h and w'
+        kE_bits = self._received_bits(k_E)
+        kE_prods = self._ciph_expprod([h] + list(self.wp), k_E, kE_bits)              # one sort of k_E for h and w'
         verdictA = self._expmul(self.A, v, self.Ap) == G.k_mul(self._gexp(g, k_A), kE_prods[0])
         B_exp_v = self.B.exp(v)
         leftSide = B_exp_v.mul(self.Bp)
         g_exp_k_B = G.exp(g, k_B)
         B_shift = self.B.shiftPush(h0)
-        B_shift_exp_k_E = B_shift.exp(k_E, self.kE_bits)
+        B_shift_exp_k_E = B_shift.exp(k_E, kE_bits)
         rightSide = g_exp_k_B.mul(B_shift_exp_k_E)
         verdictB = leftSide.equals(rightSide)
         for t in (B_exp_v, leftSide, g_exp_k_B, B_shift, B_shift_exp_k_E, rightSide):
@@ -299,13 +305,14 @@ class PoSCBasicTW(_Base):
         A = self.u.expProd(self.e, self.e_bits)
         C = self._div(self.u.prod(), h.prod())
         D = self._div(self.B.get(self.size - 1), self._gexp(h0, self.e.prod()))
-        if self._expmul(A, v, self.Ap) != G.k_mul(self._gexp(g, k_A), h.expProd(k_E, self.kE_bits)):
+        kE_bits = self._received_bits(k_E)
+        if self._expmul(A, v, self.Ap) != G.k_mul(self._gexp(g, k_A), h.expProd(k_E, kE_bits)):
             return False
         B_exp_v = self.B.exp(v)
         leftSide = B_exp_v.mul(self.Bp)
         g_exp_k_B = G.exp(g, k_B)
         B_shift = self.B.shiftPush(h0)
-        B_shift_exp_k_E = B_shift.exp(k_E, self.kE_bits)
+        B_shift_exp_k_E = B_shift.exp(k_E, kE_bits)
         rightSide = g_exp_k_B.mul(B_shift_exp_k_E)
         B_res = leftSide.equals(rightSide)
         for t in (B_exp_v, leftSide, g_exp_k_B, B_shift, B_shift_exp_k_E, rightSide):
@@ -379,7 +386,7 @@ class CCPoSBasicW(_Base):
         g, h, p, v = self.g, self.h, self.p, self.v
         k_A, k_B, k_E = reply["k_A"], reply["k_B"], reply["k_E"]
         if raisedExponent is None:
-            kE_prods = self._ciph_expprod([h] + list(self.wp), k_E, self.kE_bits)
+            kE_prods = self._ciph_expprod([h] + list(self.wp), k_E, self._received_bits(k_E))
             if self._expmul(self.A, v, self.Ap) != self.G.k_mul(self._gexp(g, k_A), kE_prods[0]):
                 return False
             prods = kE_prods[1:]
@@ -394,7 +401,7 @@ class CCPoSBasicW(_Base):
         width = len(self.pkey) // 2
         for c, (ABc, Bpc, pk, col) in enumerate(zip(self.AB, self.Bp, self.pkey, self.wp)):
             wp_mul_raisedh = col.mul(raisedh)
-            t = wp_mul_raisedh.expProd(k_E, self.kE_bits)
+            t = wp_mul_raisedh.expProd(k_E, self._received_bits(k_E))
             wp_mul_raisedh.free()
             lhs = self._expmul(ABc, v, KG.k_mul(Bpc, Ap_rho))
             rhs = KG.k_mul(KG.k_mul(self._gexp(pk, -k_B[c % width]), t), g_term)

@@ -76,6 +76,32 @@ class PermutationCommitment:
         self.raisedCommitment = self.commitment.exp(raisedExponent)           # :357
         return self.raisedCommitment
 
+    def shrink(self, noCiphertexts: int, keepList=None):
+        """:390-471.  Prover (``keepList is None``): the positions of the commitment that commit to the first
+        ``noCiphertexts`` generators are kept (:398-405; with this package's gather convention u[i] = X[pi[i]] that is
+        ``pi[i] < n``), exponents are cut to [0, n) (:415), the permutation is compressed (:419).  Verifier: the keep
+        list read from the prover, replaced by the trivial one unless it has exactly n flags set (:424-447).  Both:
+        ``commitment.extract(keepList)`` (:462-463), the raised commitment likewise on the verifier's side (:466-469)."""
+        n = noCiphertexts
+        if keepList is None:
+            keepList = [src < n for src in self.permutation]
+            old = self.exponents
+            self.exponents = old.copyOfRange(0, n)
+            old.free()
+            self.permutation = [src for src in self.permutation if src < n]
+        else:
+            keepList = list(keepList)
+            if len(keepList) != self.commitment.size() or sum(1 for k in keepList if k) != n:
+                keepList = [i < n for i in range(self.commitment.size())]
+        old = self.commitment
+        self.commitment = old.extract(keepList)
+        old.free()
+        if getattr(self, "raisedCommitment", None) is not None:
+            old = self.raisedCommitment
+            self.raisedCommitment = old.extract(keepList)
+            old.free()
+        return keepList
+
 
 class ShaRandomSource:
     """Deterministic random source for the benchmark and the tests (SHA-256 counter stream).  VCR's

@@ -56,7 +56,7 @@ class RandomSource:
             error = None
         st = self._state = _State()
         st.tape = tape
-        q, nbytes = group.q, group.nbytes
+        q, nbytes = group.q, group.exp_bytes
 
         def hand_over(vals, out):
             blk = host_block(vals)                     # a block of rows of the wire width (bulk sources): no copy
@@ -156,8 +156,8 @@ class Message:
                 buf = group.enc_els(part[1])
                 _check(plib().vmn_msg_push_elements(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.elem_bytes)))
             else:
-                buf = b"".join(int_to_be(x % group.q, group.nbytes) for x in part[1])
-                _check(plib().vmn_msg_push_ring(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.nbytes)))
+                buf = b"".join(int_to_be(x % group.q, group.exp_bytes) for x in part[1])
+                _check(plib().vmn_msg_push_ring(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.exp_bytes)))
         return m
 
 
@@ -245,7 +245,7 @@ class _NativeProof:
         return ([val] if scalar else list(val)) == item
 
     def setBatchVector(self, e_ints):
-        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
+        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.exp_bytes) for x in e_ints))
         self._call("set_batch_vector", blk[0])
 
     def setBatchVectorSeed(self, seed: bytes):
@@ -404,6 +404,24 @@ def permutation_commitment_native(group, g, h, r, pi):
     return PGroupElementArray(group, out)
 
 
+def permutation_shrink_native(pi, n: int):
+    """``vmn_permutation_shrink``: (keep list, compressed permutation) of PermutationCommitment.shrink."""
+    n_max = len(pi)
+    ptr, keepalive = _u32_array(pi)
+    keep = C.create_string_buffer(max(1, n_max))
+    out = (C.c_uint32 * max(1, n))()
+    _check(plib().vmn_permutation_shrink(ptr, C.c_size_t(n_max), C.c_size_t(n), keep, out))
+    return [b != 0 for b in keep.raw[:n_max]], list(out[:n])
+
+
+def keep_list_sanitize_native(keep, n_max: int, n: int):
+    """``vmn_keep_list_sanitize``: the keep list a verifier uses (the trivial one unless exactly n of n_max are set)."""
+    buf = C.create_string_buffer(bytes(1 if k else 0 for k in keep) + b"\0" * max(0, n_max - len(keep)), max(n_max, len(keep), 1))
+    replaced = C.c_int()
+    _check(plib().vmn_keep_list_sanitize(buf, C.c_size_t(len(keep)), C.c_size_t(n_max), C.c_size_t(n), C.byref(replaced)))
+    return [b != 0 for b in buf.raw[:n_max]], bool(replaced.value)
+
+
 # ---- verifiable threshold decryption (the interface of elgamal.py over the C++ drivers) -------------------------------
 def _flags(correct):
     return bytes(1 if c else 0 for c in correct)
@@ -411,23 +429,23 @@ def _flags(correct):
 
 def prodFactor(q: int, k: int, group=None) -> int:
     """``vmn_prod_factor`` (needs the group whose order is q)."""
-    out = C.create_string_buffer(group.nbytes)
+    out = C.create_string_buffer(group.exp_bytes)
     _check(plib().vmn_prod_factor(group._h, C.c_int(k), out))
     return int.from_bytes(out.raw, "big")
 
 
 def modifiedLagrangeCoefficients(q: int, correct, k: int, threshold: int, group=None):
     """``vmn_lagrange_coefficients``: signed integers of smallest absolute value."""
-    absb = C.create_string_buffer(threshold * group.nbytes)
+    absb = C.create_string_buffer(threshold * group.exp_bytes)
     neg = (C.c_int * threshold)()
     _check(plib().vmn_lagrange_coefficients(group._h, _flags(correct), C.c_int(k), C.c_int(threshold), absb, neg))
-    nb = group.nbytes
+    nb = group.exp_bytes
     return [(-1 if neg[t] else 1) * int.from_bytes(absb.raw[t * nb:(t + 1) * nb], "big") for t in range(threshold)]
 
 
 def decryptionFactors(u, secretKey: int, q: int, k: int):
     out = C.c_void_p()
-    _check(plib().vmn_decryption_factors(u.group._h, u._h, int_to_be(secretKey % q, u.group.nbytes), C.c_int(k), C.byref(out)))
+    _check(plib().vmn_decryption_factors(u.group._h, u._h, int_to_be(secretKey % q, u.group.exp_bytes), C.c_int(k), C.byref(out)))
     return PGroupElementArray(u.group, out)
 
 
@@ -480,7 +498,7 @@ class DistrElGamalSessionBasic:
         self._call("set_instance", u._h, ybuf, _opt_ptr_array(f))
 
     def setBatchVector(self, e_ints):
-        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
+        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.exp_bytes) for x in e_ints))
         self._call("set_batch_vector", blk[0])
 
     def setBatchVectorSeed(self, seed: bytes):
@@ -492,12 +510,12 @@ class DistrElGamalSessionBasic:
     def commit(self, x: int):
         G = self.G
         yp, Bp = C.create_string_buffer(G.elem_bytes), C.create_string_buffer(G.elem_bytes)
-        self._call("commit", int_to_be(x % self.q, G.nbytes), yp, Bp)
+        self._call("commit", int_to_be(x % self.q, G.exp_bytes), yp, Bp)
         return G.dec_el(yp.raw), G.dec_el(Bp.raw)
 
     def reply(self, v: int) -> int:
         b = _be(v)
-        out = C.create_string_buffer(self.G.nbytes)
+        out = C.create_string_buffer(self.G.exp_bytes)
         self._call("reply", b, C.c_size_t(len(b)), out)
         self.k_x[self.j] = int.from_bytes(out.raw, "big")
         return self.k_x[self.j]
@@ -507,7 +525,7 @@ class DistrElGamalSessionBasic:
 
     def setReply(self, l: int, k_x: int):
         self.k_x[l] = k_x % self.q
-        self._call("set_reply", C.c_int(l), int_to_be(k_x % self.q, self.G.nbytes))
+        self._call("set_reply", C.c_int(l), int_to_be(k_x % self.q, self.G.exp_bytes))
 
     def batch(self, l: int):
         self._call("batch", C.c_int(l))
@@ -562,7 +580,7 @@ class IndependentGeneratorsBasicI:
         self._call("set_instance", self.G.enc_el(g), _opt_ptr_array(h), s._h if s is not None else None, combinedh._h)
 
     def setBatchVector(self, e_ints):
-        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.nbytes) for x in e_ints))
+        blk = host_block(e_ints) or host_block(b"".join(int_to_be(x, self.G.exp_bytes) for x in e_ints))
         self._call("set_batch_vector", blk[0])
 
     def setBatchVectorSeed(self, seed: bytes):
@@ -581,12 +599,12 @@ class IndependentGeneratorsBasicI:
         self._call("set_challenge", b, C.c_size_t(len(b)))
 
     def reply(self) -> int:
-        out = C.create_string_buffer(self.G.nbytes)
+        out = C.create_string_buffer(self.G.exp_bytes)
         self._call("reply", out)
         return int.from_bytes(out.raw, "big")
 
     def setReply(self, l: int, k_a: int):
-        self._call("set_reply", C.c_int(l), int_to_be(k_a % (1 << (8 * self.G.nbytes)), self.G.nbytes))
+        self._call("set_reply", C.c_int(l), int_to_be(k_a % (1 << (8 * self.G.exp_bytes)), self.G.exp_bytes))
 
     def verify(self, l: Optional[int] = None) -> bool:
         verdict = C.c_int(0)

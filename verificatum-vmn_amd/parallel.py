@@ -108,12 +108,12 @@ class ShardedPoSBasicTW:
 
     def __init__(self, group, vbitlen: int, ebitlen: int, rbitlen: int, comm: Comm, rand=None):
         self.G, self.comm, self.rand = group, comm, rand
-        self.p, self.q, self.nb = group.p, group.q, group.nbytes
+        self.p, self.q, self.nb = group.p, group.q, max(group.nbytes, group.exp_bytes)
+        self.xb = group.exp_bytes                     # width of the tape's ring rows
         self.vbitlen, self.ebitlen, self.rbitlen = vbitlen, ebitlen, rbitlen
         qbits = self.q.bit_length()
         self.e_bits = min(ebitlen, qbits)
         self.eps_bits = min(ebitlen + vbitlen + rbitlen, qbits)
-        self.kE_bits = min(ebitlen + vbitlen + rbitlen + 1, qbits)
 
     # ---- helpers (single elements through the group object: ModPGroup integers or ECqPGroup points) --------
     def _gexp(self, base, e: int):
@@ -149,7 +149,7 @@ class ShardedPoSBasicTW:
         return acc
 
     def _ring_rows(self, arr, idx):
-        rows = _take_rows(arr, idx, self.nb)
+        rows = _take_rows(arr, idx, self.xb)
         if not isinstance(rows, (bytes, bytearray)):
             rows = [x % self.q for x in rows]        # integers longer than q (epsilon over a 256-bit curve order) act mod q
         return self.G.ringArray(rows)
@@ -308,8 +308,9 @@ class ShardedPoSBasicTW:
         n_loc = self.hi - self.lo
         # one exchange for all partial products of this phase + each shard's last B element
         b_last = self.B.get(n_loc - 1) if n_loc else self.G.ONE
-        parts = [self.u.prod(), self.h.prod(), self.h.expProd(k_E, self.kE_bits), b_last] + \
-                [c.expProd(k_E, self.kE_bits) for c in self.wp]
+        kE_bits = max(1, k_E.maxBits())            # every bit of a received exponent counts (this shard's maximum)
+        parts = [self.u.prod(), self.h.prod(), self.h.expProd(k_E, kE_bits), b_last] + \
+                [c.expProd(k_E, kE_bits) for c in self.wp]
         gathered = self._gather_elems(parts)
         mulp = lambda idx: self.G.mulPartials([pr[idx] for pr in gathered])
         u_prod, h_prod, h_kE = mulp(0), mulp(1), mulp(2)
@@ -331,7 +332,7 @@ class ShardedPoSBasicTW:
         leftSide = B_exp_v.mul(self.Bp)
         g_exp_k_B = G.exp(g, k_B)
         B_shift = self.B.shiftPush(prev)
-        B_shift_exp_k_E = B_shift.exp(k_E, self.kE_bits)
+        B_shift_exp_k_E = B_shift.exp(k_E, kE_bits)
         rightSide = g_exp_k_B.mul(B_shift_exp_k_E)
         verdictB = self.comm.all_true(leftSide.equals(rightSide))
         for t in (B_exp_v, leftSide, g_exp_k_B, B_shift, B_shift_exp_k_E, rightSide):
