@@ -184,12 +184,13 @@ def test_properties_at_full_baseline_size(groups):
         a = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
         a[:, 0] &= 0xFF >> clear_top_bits
         return a
+    assert G.exp_bytes == 256                         # Java's width of the 2047-bit q: the blocks below are exponent rows
     eb, fb = block(2), block(2)                       # exponents < 2^2046: e + f < q, no wrap
     E, F = G.ringArray(eb.tobytes()), G.ringArray(fb.tobytes())
     X = G.exp(g, G.ringArray(block(1).tobytes()))     # random subgroup elements
     XE, XF = X.exp(E), X.exp(F)
     assert XE.mul(XF).equals(X.exp(E.add(F)))         # x^e x^f = x^(e+f), element-wise over 10^6 elements
-    Gs = G.toElementArray(int(g).to_bytes(256, "big") * n)
+    Gs = G.toElementArray(int(g).to_bytes(G.nbytes, "big") * n)
     assert G.exp(g, E).equals(Gs.exp(E))              # fixed-base table path = variable-base path
     assert X.expProd(E) == XE.prod()                  # Pippenger = product of the individual powers
     for i in (0, 1, 499_999, 999_999):
