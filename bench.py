@@ -154,7 +154,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
     NV = NE = 256
     NR = 100
     p, q, g = grp.p, grp.q, grp.g
-    rnd = mx.BulkRandomSource(seed, q, grp.exp_bytes)
+    rnd = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)
     # synthetic instance (untimed): independent generators h, key y = g^x, honest ciphertexts (g^t, m*y^t)
     y = pow(g, rnd.ring_element(), p)
     pkey = [g, y]
@@ -254,7 +254,7 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     EB = NE + NV + NR
     p, q, g = load_sub(entry, "stdgroups").modp_group(bits)
     grp = vmn.ModPGroup(ctx, p, q, g, nbytes=bits // 8)
-    bulk = mx.BulkRandomSource(seed, q, grp.exp_bytes)
+    bulk = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)
     y = pow(g, bulk.ring_element(), p)
     pkey = [g, y]
     for base in pkey:                      # session setup
@@ -344,7 +344,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
     EB = NE + NV + NR
     grp = vmn.ECqPGroup(ctx, curve)
     g, q = grp.g, grp.q
-    bulk = mx.BulkRandomSource(seed, q, grp.exp_bytes)
+    bulk = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)
     y = grp.k_exp(g, bulk.ring_element())
     pkey = [g] * width + [y] * width
     for base in (g, y):                    # session setup
@@ -418,7 +418,7 @@ def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dis
     NR = 100
     n = min(n_per_gpu * comm.world, 4_194_304)
     p, q, g = grp.p, grp.q, grp.g
-    pub = mx.BulkRandomSource(seed, q, grp.exp_bytes)             # same seed on every rank: replicated public instance
+    pub = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)             # same seed on every rank: replicated public instance
     y = pow(g, pub.ring_element(), p)
     pkey = [g, y]
     for base in pkey:                      # session setup (tables sized for this rank's shard)

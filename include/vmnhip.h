@@ -66,6 +66,19 @@ void vmn_ctx_destroy(vmn_ctx* ctx);
 int vmn_ctx_set_stream(vmn_ctx* ctx, void* hip_stream);
 void* vmn_ctx_get_stream(vmn_ctx* ctx);
 int vmn_ctx_synchronize(vmn_ctx* ctx);
+/* The helper thread.  The reference runs ONE helper thread beside a party's protocol thread: it multiplies and permutes
+ * the next input while the protocol thread verifies a proof (ref: P/mixnet/ShufflerElGamalSession.java:839-859, 894-944),
+ * or writes byte trees (P/hvzk/CCPoSW.java:114-123).  A thread that calls vmn_ctx_helper_begin(ctx) becomes that helper
+ * until vmn_ctx_helper_end(ctx): its calls on arrays / groups of ctx run on a second, high-priority stream with its own
+ * pool, scratch and lock, so they neither wait for the protocol thread's calls nor queue behind its kernels (the long
+ * fixed-base launches are one workgroup per tile so that slots free up every few milliseconds).  Ordering: begin() and
+ * helper_sync() order the helper's stream behind everything the protocol thread has queued so far (call helper_sync
+ * before touching an array the protocol thread queued work on after begin); end() waits for the helper's work, so
+ * the protocol thread may use its results after joining the thread.  An array must not be freed by one thread while
+ * the other still uses it -- the reference's rule for its own arrays.  One helper per context. */
+int vmn_ctx_helper_begin(vmn_ctx* ctx);
+int vmn_ctx_helper_sync(vmn_ctx* ctx);
+int vmn_ctx_helper_end(vmn_ctx* ctx);
 /* Number of compute units of the context's device (used by the benchmark to state the roofline). */
 int vmn_ctx_num_cus(vmn_ctx* ctx);
 /* Memory accounting (operations / leak hunting): bytes and blocks of freed arrays cached for reuse, bytes of live

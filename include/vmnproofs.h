@@ -40,15 +40,30 @@ extern "C" {
 #endif
 
 /* The prover's randomness, at the granularity the reference draws it: PRing.randomElementArray / randomElement
- * (PoSBasicTW.java:446, 465, 583, 612, 667, 673, 687) and LargeIntegerArray.random (:470-475).  Each callback
- * sets *rows to n big-endian rows of vmn_group_exp_bytes() bytes, owned by the source and valid until its next
- * call; integers of `bits` bits are delivered as field elements (reduced mod q when bits exceeds the order).
- * Return 0 on success. */
+ * (PoSBasicTW.java:446, 465, 583, 612, 667, 673, 687) and LargeIntegerArray.random (:470-475).
+ *
+ * Host rows: each of the first two callbacks sets *rows to n big-endian rows of vmn_group_exp_bytes() bytes, owned by the
+ * source and valid until its next call; integers of `bits` bits are delivered as field elements (reduced mod q when bits
+ * exceeds the order).  Return 0 on success.
+ *
+ * Device arrays: when `array_seed` is not NULL, every N-sized draw (r, s, b, beta, epsilon: N > 1) asks the source for
+ * 32 fresh bytes only and expands them ON THE DEVICE (PRGHeuristic over SHA-256, csrc k_prg_rows, the generator
+ * vmn_rarray_from_prg uses): ring elements = the i-th ceil((bits(q) + rbitlen) / 8) bytes of PRG(seed), leading bits
+ * cleared, reduced mod q (statistical distance 2^-rbitlen from uniform, the meaning of the reference's rbitlen,
+ * ProtocolElGamal.java:277-306); integers of `bits` bits = the i-th ceil(bits / 8) bytes, leading bits cleared.  No N-sized
+ * host buffer, no upload.  The 32 bytes must come from the party's cryptographic RandomSource (the reference's
+ * `randomSource`, e.g. /dev/urandom behind RandomDevice, demo/mixnet/.checkbaseconf:124); VCR's own procedure inside
+ * randomElementArray is not in the reference tree, and a prover's private randomness needs no interoperability.  Single
+ * elements (alpha, gamma, ...) always come through `ring_elements`. */
 typedef struct vmn_random_source {
     void* user;
     int (*ring_elements)(void* user, size_t n, const uint8_t** rows);
     int (*integers)(void* user, size_t n, int bits, const uint8_t** rows);
+    int (*array_seed)(void* user, uint8_t seed_out[32]);          /* optional (NULL = host rows for arrays too) */
 } vmn_random_source;
+/* pRing.randomElementArray(n, randomSource, rbitlen) for a caller that needs such an array itself -- the re-encryption
+ * exponents, ShufflerElGamalSession.java:400-409 (:408-409); the commitment exponents, PermutationCommitment.java:189-199. */
+int vmn_rarray_random(vmn_group* grp, const vmn_random_source* rs, size_t n, int rbitlen, vmn_rarray** out);
 
 /* ---- messages: ordered items, each an element array, a ring array, k group elements or k ring elements ----
  *   PoS  commitment (PoSBasicTW.java:694-699):  B[N], A', B'[N], C', D', F'[2w]

@@ -309,3 +309,76 @@ def test_default_wire_widths_are_the_references(vmn, gpu_ctx, mods, entry):
                                                   el(com["Cp"]), el(com["Dp"])])
     assert rep.native.toByteTree() == eio.encode([rl(rep["k_A"]), [rl(x) for x in rep["k_B"].toInts()], rl(rep["k_C"]), rl(rep["k_D"]),
                                                   [rl(x) for x in rep["k_E"].toInts()]])
+
+
+@pytest.mark.parametrize("bits,bits3", [(512, (100, 100, 50)), (2048, (256, 256, 100)), (3072, (256, 256, 100))])
+def test_prover_randomness_expanded_on_the_device(bits, bits3, vmn, gpu_ctx, mods):
+    """The N-sized draws of a prover (r, s, b, beta, epsilon; PoSBasicTW.java:446, 473, 583, 612;
+    ShufflerElGamalSession.java:408-409) generated on the GPU from 32-byte seeds: the transcript equals the oracle's
+    run on the same seeds expanded with the Python PRG."""
+    from tape import SeedTape
+    nat = mods["native"]
+    NV, NE, NR = bits3
+    G, K, p, q, g = modp(vmn, gpu_ctx, bits)
+    n, width = 41, 2
+    h, pkey, w, t = make_instance(K, g, n, width, b"devrand%d" % bits)
+    pi = t.permutation(n)
+    e, v = t.int_array(n, NE), t.int_array(1, NV)[0]
+    s_tape_o, s_tape = SeedTape(b"s", q, NR, expanding=True), SeedTape(b"s", q, NR)
+    s = [s_tape_o.ring_array(n) for _ in range(width)]
+    S = [nat.random_ring_array_native(G, s_tape, n, NR) for _ in range(width)]
+    assert [x.toInts() for x in S] == s and all(0 <= x < q for col in s for x in col)
+    o = P.GPoS(K, NV, NE, NR, rand=SeedTape(b"prover", q, NR, expanding=True))
+    o.precompute(g, h, pi)
+    wp_o = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    o.setInstance(pkey, w, wp_o, s)
+    o.setBatchVector(e)
+    com_o, rep_o = o.commit(), o.reply(v)
+    H, W = G.toElementArray(h), [G.toElementArray(c) for c in w]
+    pr = nat.PoSBasicTW(G, NV, NE, NR, rand=SeedTape(b"prover", q, NR))
+    pr.precompute(g, H, pi)
+    assert pr.u.toInts() == o.u
+    WP = nat.reencrypt_native(G, pkey, W, S, pi)
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    same_msg(com, com_o)
+    same_msg(rep, rep_o)
+    ver = nat.PoSBasicTW(G, NV, NE, NR)
+    ver.precompute(g, H)
+    ver.setPermutationCommitment(pr.u)
+    ver.setInstance(pkey, W, WP)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep)
+
+
+def test_secure_random_source_is_the_default_kind(vmn, gpu_ctx, mods):
+    """mixnet.SecureRandomSource (os.urandom; arrays expanded on the device): an honest proof with it verifies, and two
+    runs differ."""
+    nat, mx = mods["native"], mods["mixnet"]
+    G, K, p, q, g = modp(vmn, gpu_ctx, 512)
+    NV, NE, NR, n = 100, 100, 50, 25
+    h, pkey, w, t = make_instance(K, g, n, 1, b"secure")
+    H = G.toElementArray(h)
+    pi, e, v = t.permutation(n), t.int_array(n, NE), t.int_array(1, NV)[0]
+    seen = []
+    for _ in range(2):
+        src = mx.SecureRandomSource(q, NR)
+        R = nat.random_ring_array_native(G, src, n, NR)
+        U = nat.permutation_commitment_native(G, g, H, R, pi)
+        pr = nat.PoSCBasicTW(G, NV, NE, NR, rand=src)
+        pr.setInstance(g, H, U, R, pi)
+        pr.setBatchVector(e)
+        com, rep = pr.commit(), pr.reply(v)
+        ver = nat.PoSCBasicTW(G, NV, NE, NR)
+        ver.setInstance(g, H, U)
+        ver.setBatchVector(e)
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        assert ver.verify(rep)
+        seen.append(rep["k_A"])
+        assert all(0 <= x < q for x in R.toInts())
+    assert seen[0] != seen[1]

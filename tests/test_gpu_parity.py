@@ -238,6 +238,72 @@ def test_helper_thread_runs_concurrently_with_main_thread(groups):
     assert len(got_helper) == 12 and all(g == want_helper for g in got_helper)
 
 
+def test_helper_lane_overlaps_with_the_protocol_thread(vmn, gpu_ctx):
+    """The helper thread announced with vmn_ctx_helper_begin gets its own stream, pool and lock: while the protocol
+    thread has ~a second of fixed-base exponentiations queued (the prover's commit), the helper's mul + permute + byte-tree
+    export (ShufflerElGamalSession.java:839-859; CCPoSW.java:114-123) finish long before that work does -- on one lane
+    they would queue behind it.  Results equal the sequential ones; fixed-base tables built by one lane serve the other."""
+    import threading
+    import time
+    import numpy as np
+    grp, _ = load_golden(2048)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=256)
+    n = 300_000
+    rng = np.random.Generator(np.random.PCG64(5))
+    def rows():
+        a = rng.integers(0, 256, size=(n, 256), dtype=np.uint8)
+        a[:, 0] &= 0x3F
+        return a.tobytes()
+    E = [G.ringArray(rows()) for _ in range(2)]
+    X, Y = G.exp(g, E[0]), G.exp(g, E[1])
+    perm = rng.permutation(n).astype(np.uint32)
+    want = X.mul(Y).permute(perm)
+    want_bt = want.toByteTree()
+    gpu_ctx.synchronize()
+    # the protocol thread's work alone
+    t0 = time.perf_counter()
+    outs = [G.exp(g, E[k % 2]) for k in range(24)]
+    gpu_ctx.synchronize()
+    t_main = time.perf_counter() - t0
+    for o in outs:
+        o.free()
+    result = {}
+
+    def helper():
+        try:
+            with gpu_ctx.helper():
+                t1 = time.perf_counter()
+                t = X.mul(Y)
+                r = t.permute(perm)
+                t.free()
+                bt = r.toByteTree()                       # blocks until the helper's own stream has produced it
+                result["t"] = time.perf_counter() - t1
+                result["ok"] = bt == want_bt and r.equals(want)
+                h = G.exp(g, E[0])                        # a table built on the main lane, used from the helper lane
+                result["fixed"] = h.equals(X)
+                h.free()
+                r.free()
+        except Exception as exc:      # pragma: no cover
+            result["error"] = exc
+
+    t0 = time.perf_counter()
+    outs = [G.exp(g, E[k % 2]) for k in range(24)]      # queued asynchronously: ~t_main of GPU work ahead
+    th = threading.Thread(target=helper)
+    th.start()
+    th.join()
+    t_helper_done = time.perf_counter() - t0
+    gpu_ctx.synchronize()
+    t_both = time.perf_counter() - t0
+    assert "error" not in result, result.get("error")
+    assert result["ok"] and result["fixed"]
+    assert all(o.equals(X if k % 2 == 0 else Y) for k, o in enumerate(outs))
+    # overlap: the helper was done well before the protocol thread's queue drained, and the whole took about as long as
+    # the protocol thread's work alone
+    assert t_helper_done < 0.6 * t_main, (t_helper_done, t_main, result["t"])
+    assert t_both < 1.35 * t_main, (t_both, t_main)
+
+
 def test_fixed_base_table_cache_is_bounded(vmn, gpu_ctx, monkeypatch):
     """Every proof brings a new fixed base (h_0): the per-group table cache drops least-recently-used tables beyond
     its byte bound instead of growing for ever.  With a bound below one table, every call rebuilds; results stay

@@ -10,7 +10,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "P-256"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 ctx = vmn.Context(0)
 G = vmn.ECqPGroup(ctx, name)
-rnd = mx.BulkRandomSource(1, G.q, G.exp_bytes)
+rnd = mx.InsecureBulkRandomSource(1, G.q, G.exp_bytes)
 E = G.ringArray(rnd.ring_array(n)); E2 = G.ringArray(rnd.ring_array(n))
 ctx.timing_enable(True)
 X = G.exp(G.g, E); ctx.synchronize()

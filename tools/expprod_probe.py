@@ -14,7 +14,7 @@ bits = int(sys.argv[2]) if len(sys.argv) > 2 else 613
 p, q, g = pyref.modp_group(2048)
 ctx = vmn.Context(0)
 G = vmn.ModPGroup(ctx, p, q, g, nbytes=256)
-rnd = mx.BulkRandomSource(1, q, 256)
+rnd = mx.InsecureBulkRandomSource(1, q, 256)
 X = G.exp(g, G.ringArray(rnd.ring_array(n)))
 E = G.ringArray(rnd.int_array(n, bits))
 for rep in range(2):

@@ -10,7 +10,7 @@ bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 p, q, g = sg.modp_group(bits)
 ctx = vmn.Context(0)
-rnd = mx.BulkRandomSource(1, q, bits // 8)
+rnd = mx.InsecureBulkRandomSource(1, q, bits // 8)
 for w in (14, 16, 17, 18, 19, 20):
     os.environ["VMN_FIXED_WINDOW"] = str(w)
     G = vmn.ModPGroup(ctx, p, q, g, nbytes=bits // 8)

@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 p, q, g = sg.modp_group(2048)
 ctx = vmn.Context(0)
 G = vmn.ModPGroup(ctx, p, q, g)
-X = G.exp(g, G.ringArray(mx.BulkRandomSource(3, q, 256).ring_array(n)))
+X = G.exp(g, G.ringArray(mx.InsecureBulkRandomSource(3, q, 256).ring_array(n)))
 for mode in ("jacobi", "power"):
     if mode == "power":
         os.environ["VMN_MEMBER_BY_POWER"] = "1"

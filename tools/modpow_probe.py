@@ -13,7 +13,7 @@ p, q, g = pyref.modp_group(bits)
 nb = bits // 8
 ctx = vmn.Context(0)
 G = vmn.ModPGroup(ctx, p, q, g, nbytes=nb)
-rnd = mx.BulkRandomSource(1, q, nb)
+rnd = mx.InsecureBulkRandomSource(1, q, nb)
 E = G.ringArray(rnd.ring_array(n))
 ctx.timing_enable(True)
 X = G.exp(g, E)

@@ -14,7 +14,7 @@ n, width = 400_000, 3
 for rep in range(3):
     grp = vmn.ECqPGroup(ctx, "P-256")
     g, q = grp.g, grp.q
-    bulk = mx.BulkRandomSource(100 + rep, q, grp.exp_bytes)
+    bulk = mx.InsecureBulkRandomSource(100 + rep, q, grp.exp_bytes)
     y = grp.k_exp(g, bulk.ring_element())
     pkey = [g] * width + [y] * width
     W = [grp.exp(g if c < width else y, grp.ringArray(bulk.ring_array(n))) for c in range(2 * width)]

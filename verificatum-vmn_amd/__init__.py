@@ -135,6 +135,26 @@ class Context:
     def num_cus(self) -> int:
         return lib().vmn_ctx_num_cus(self._h)
 
+    def helper(self):
+        """``with ctx.helper(): ...`` in the ONE helper thread of a party (ShufflerElGamalSession.java:839-859): calls made
+        inside run on the context's helper lane -- a second, high-priority stream with its own pool and lock
+        (``vmn_ctx_helper_begin`` / ``vmn_ctx_helper_end``)."""
+        ctx = self
+
+        class _Helper:
+            def __enter__(self_inner):
+                _check(lib().vmn_ctx_helper_begin(ctx._h))
+                return self_inner
+
+            def sync(self_inner):
+                """Order the helper's stream behind everything the protocol thread has queued so far."""
+                _check(lib().vmn_ctx_helper_sync(ctx._h))
+
+            def __exit__(self_inner, *exc):
+                _check(lib().vmn_ctx_helper_end(ctx._h))
+                return False
+        return _Helper()
+
     def memory_stats(self) -> dict:
         """Bytes / blocks of freed arrays cached for reuse and bytes of live allocations (arrays + temporaries)."""
         pb, nb, lb = C.c_size_t(), C.c_size_t(), C.c_size_t()

@@ -29,6 +29,8 @@ void vmn::set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vmn_last_error(void) { return g_err; }
+static thread_local vmn_ctx* tl_helper_of = nullptr;      // the context this thread is the helper of (vmn_ctx_helper_begin)
+vmn_ctx* vmn::lane_of(vmn_ctx* c) { return (c && tl_helper_of == c && c->helper) ? c->helper : c; }
 extern "C" void vmn_report_error(const char* message) { vmn::set_error("%s", message ? message : ""); }
 extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^28 lazy-carry Montgomery)"; }
 
@@ -257,6 +259,13 @@ extern "C" int vmn_ctx_create(int device, vmn_ctx** out) {
 
 extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->helper) {
+        vmn_ctx* h = ctx->helper;
+        ctx->helper = nullptr;
+        if (tl_helper_of == ctx) tl_helper_of = nullptr;
+        if (h->order_event) (void)hipEventDestroy(h->order_event);
+        vmn_ctx_destroy(h);
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& r : ctx->recs) {
@@ -280,19 +289,77 @@ extern "C" int vmn_ctx_set_stream(vmn_ctx* ctx, void* hip_stream) {
 extern "C" void* vmn_ctx_get_stream(vmn_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 extern "C" int vmn_ctx_synchronize(vmn_ctx* ctx) {
     ARG_CHECK(ctx, "null ctx");
+    ctx = LANE(ctx);
     std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_HIP(hipStreamSynchronize(ctx->stream));
     return VMN_OK;
 }
+
+// ---- the helper lane -----------------------------------------------------------------------------------------
+// order the helper stream behind everything queued on the main stream so far
+static int helper_order_behind_main(vmn_ctx* ctx) {
+    vmn_ctx* h = ctx->helper;
+    VMN_HIP(hipEventRecord(h->order_event, ctx->stream));
+    VMN_HIP(hipStreamWaitEvent(h->stream, h->order_event, 0));
+    return VMN_OK;
+}
+extern "C" int vmn_ctx_helper_begin(vmn_ctx* ctx) {
+    ARG_CHECK(ctx && !ctx->parent, "null context or a helper lane");
+    {
+        std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
+        VMN_HIP(hipSetDevice(ctx->device));
+        if (!ctx->helper) {
+            std::unique_ptr<vmn_ctx> h(new vmn_ctx());
+            h->device = ctx->device;
+            h->num_cus = ctx->num_cus;
+            h->parent = ctx;
+            int least = 0, greatest = 0;                       // numerically lowest = highest priority
+            VMN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            VMN_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, greatest));
+            h->stream = h->own_stream;
+            VMN_HIP(hipMalloc(&h->flags, 64 * sizeof(uint32_t)));
+            VMN_HIP(hipMemsetAsync(h->flags, 0, 64 * sizeof(uint32_t), h->stream));
+            VMN_HIP(hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming));
+            ctx->helper = h.release();
+        }
+    }
+    tl_helper_of = ctx;
+    std::lock_guard<std::recursive_mutex> guard__(ctx->helper->mu);
+    return helper_order_behind_main(ctx);
+}
+extern "C" int vmn_ctx_helper_sync(vmn_ctx* ctx) {
+    ARG_CHECK(ctx && ctx->helper && tl_helper_of == ctx, "not the helper thread of this context");
+    std::lock_guard<std::recursive_mutex> guard__(ctx->helper->mu);
+    VMN_HIP(hipSetDevice(ctx->device));
+    return helper_order_behind_main(ctx);
+}
+extern "C" int vmn_ctx_helper_end(vmn_ctx* ctx) {
+    ARG_CHECK(ctx && ctx->helper && tl_helper_of == ctx, "not the helper thread of this context");
+    int rc = VMN_OK;
+    {
+        std::lock_guard<std::recursive_mutex> guard__(ctx->helper->mu);
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->helper->stream) != hipSuccess) {
+            set_error("vmn_ctx_helper_end: synchronising the helper stream failed");
+            rc = VMN_ERR_DEVICE;
+        }
+    }
+    tl_helper_of = nullptr;
+    return rc;
+}
 extern "C" int vmn_ctx_num_cus(vmn_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
 extern "C" int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes) {
     ARG_CHECK(ctx, "null ctx");
-    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
-    size_t blocks = 0;
-    for (auto& kv : ctx->pool) blocks += kv.second.size();
-    if (pool_bytes) *pool_bytes = ctx->pool_bytes;
+    size_t blocks = 0, pbytes = 0, live = 0;       // an array may be freed on another lane than it came from: only the sums mean something
+    for (vmn_ctx* c : {ctx, ctx->helper}) {
+        if (!c) continue;
+        std::lock_guard<std::recursive_mutex> guard__(c->mu);
+        for (auto& kv : c->pool) blocks += kv.second.size();
+        pbytes += c->pool_bytes;
+        live += c->live_bytes;
+    }
+    if (pool_bytes) *pool_bytes = pbytes;
     if (pool_blocks) *pool_blocks = blocks;
-    if (live_bytes) *live_bytes = ctx->live_bytes;
+    if (live_bytes) *live_bytes = live;
     return VMN_OK;
 }
 
@@ -461,8 +528,10 @@ extern "C" void vmn_group_destroy(vmn_group* grp) {
     if (!grp) return;
     std::lock_guard<std::recursive_mutex> guard__(grp->ctx->mu);
     (void)hipStreamSynchronize(grp->ctx->stream);
+    if (grp->ctx->helper) (void)hipStreamSynchronize(grp->ctx->helper->stream);
     for (auto& kv : grp->fixed) {
         if (kv.second.d_tab) (void)hipFree(kv.second.d_tab);
+        if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
     }
     if (grp->curve) {
         if (grp->P.d_one) (void)hipFree(grp->P.d_one);
@@ -480,7 +549,8 @@ extern "C" size_t vmn_group_exp_bytes(const vmn_group* grp) { return grp ? grp->
 static size_t java_width(int bits) { return (size_t)bits / 8 + 1; }
 extern "C" int vmn_group_set_wire_bytes(vmn_group* grp, size_t elem_bytes, size_t exp_bytes) {
     ARG_CHECK(grp, "null group");
-    VMN_ENTER(grp->ctx);
+    VMN_ENTER(LANE(grp->ctx));
+    std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
     ARG_CHECK(grp->fixed.empty(), "wire widths must be chosen before the group is used");
     const int pbits = grp->curve ? hostbig::bit_length(grp->curve->p_words) : grp->P.nbits;
     size_t eb = elem_bytes ? elem_bytes : java_width(pbits);
@@ -933,7 +1003,7 @@ static int new_garray(vmn_group* grp, size_t n, vmn_garray** out) {
     a->grp = grp;
     a->n = n;
     a->bytes = elems_bytes(grp->P, n);
-    VMN_TRY(alloc_elems(grp->ctx, grp->P, n, &a->d));
+    VMN_TRY(alloc_elems(LANE(grp->ctx), grp->P, n, &a->d));
     *out = a.release();
     return VMN_OK;
 }
@@ -942,21 +1012,21 @@ static int new_rarray(vmn_group* grp, size_t n, vmn_rarray** out) {
     a->grp = grp;
     a->n = n;
     a->bytes = elems_bytes(grp->Q, n);
-    VMN_TRY(alloc_elems(grp->ctx, grp->Q, n, &a->d));
+    VMN_TRY(alloc_elems(LANE(grp->ctx), grp->Q, n, &a->d));
     *out = a.release();
     return VMN_OK;
 }
 
 extern "C" void vmn_garray_free(vmn_garray* a) {
     if (!a) return;
-    std::lock_guard<std::recursive_mutex> guard__(a->grp->ctx->mu);
-    pool_free(a->grp->ctx, a->d, a->bytes);
+    std::lock_guard<std::recursive_mutex> guard__(LANE(a->grp->ctx)->mu);
+    pool_free(LANE(a->grp->ctx), a->d, a->bytes);
     delete a;
 }
 extern "C" void vmn_rarray_free(vmn_rarray* a) {
     if (!a) return;
-    std::lock_guard<std::recursive_mutex> guard__(a->grp->ctx->mu);
-    pool_free(a->grp->ctx, a->d, a->bytes);
+    std::lock_guard<std::recursive_mutex> guard__(LANE(a->grp->ctx)->mu);
+    pool_free(LANE(a->grp->ctx), a->d, a->bytes);
     delete a;
 }
 extern "C" size_t vmn_garray_size(const vmn_garray* a) { return a ? a->n : 0; }
@@ -964,10 +1034,10 @@ extern "C" size_t vmn_rarray_size(const vmn_rarray* a) { return a ? a->n : 0; }
 
 extern "C" int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_garray** out, int* all_in_range) {
     ARG_CHECK(grp && out && (be || n == 0), "null argument");
-    VMN_ENTER(grp->ctx);
+    VMN_ENTER(LANE(grp->ctx));
     vmn_garray* a = nullptr;
     VMN_TRY(new_garray(grp, n, &a));
-    int rc = import_be(grp->ctx, grp->P, grp->nbytes, be, n, a->d, all_in_range);
+    int rc = import_be(LANE(grp->ctx), grp->P, grp->nbytes, be, n, a->d, all_in_range);
     if (rc != VMN_OK) {
         vmn_garray_free(a);
         return rc;
@@ -977,10 +1047,10 @@ extern "C" int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, v
 }
 extern "C" int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_rarray** out, int* all_in_range) {
     ARG_CHECK(grp && out && (be || n == 0), "null argument");
-    VMN_ENTER(grp->ctx);
+    VMN_ENTER(LANE(grp->ctx));
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
-    int rc = import_be(grp->ctx, grp->Q, grp->xbytes, be, n, a->d, all_in_range);
+    int rc = import_be(LANE(grp->ctx), grp->Q, grp->xbytes, be, n, a->d, all_in_range);
     if (rc != VMN_OK) {
         vmn_rarray_free(a);
         return rc;
@@ -992,25 +1062,25 @@ extern "C" size_t vmn_garray_bytetree_size(const vmn_garray* a) { return a ? byt
 extern "C" size_t vmn_rarray_bytetree_size(const vmn_rarray* a) { return a ? bytetree_size(a->n, a->grp->xbytes) : 0; }
 extern "C" int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
-    VMN_ENTER(a->grp->ctx);
-    return to_bytetree(a->grp->ctx, a->grp->P, a->grp->nbytes, a->d, a->n, out);
+    VMN_ENTER(LANE(a->grp->ctx));
+    return to_bytetree(LANE(a->grp->ctx), a->grp->P, a->grp->nbytes, a->d, a->n, out);
 }
 extern "C" int vmn_rarray_to_bytetree(const vmn_rarray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
-    VMN_ENTER(a->grp->ctx);
-    return to_bytetree(a->grp->ctx, a->grp->Q, a->grp->xbytes, a->d, a->n, out);
+    VMN_ENTER(LANE(a->grp->ctx));
+    return to_bytetree(LANE(a->grp->ctx), a->grp->Q, a->grp->xbytes, a->d, a->n, out);
 }
 extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_garray** out,
                                         int* format_ok, int* all_in_range) {
     ARG_CHECK(grp && bt && out && format_ok, "null argument");
-    VMN_ENTER(grp->ctx);
+    VMN_ENTER(LANE(grp->ctx));
     *out = nullptr;
     size_t n = 0;
     VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
     if (!*format_ok) return VMN_OK;
     vmn_garray* a = nullptr;
     VMN_TRY(new_garray(grp, n, &a));
-    int rc = import_be(grp->ctx, grp->P, grp->nbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
+    int rc = import_be(LANE(grp->ctx), grp->P, grp->nbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
     if (rc != VMN_OK || !*format_ok) {
         vmn_garray_free(a);
         return rc;
@@ -1021,14 +1091,14 @@ extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_
 extern "C" int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_rarray** out,
                                         int* format_ok, int* all_in_range) {
     ARG_CHECK(grp && bt && out && format_ok, "null argument");
-    VMN_ENTER(grp->ctx);
+    VMN_ENTER(LANE(grp->ctx));
     *out = nullptr;
     size_t n = 0;
     VMN_TRY(bytetree_header(bt, len, grp->xbytes, expected_n, &n, format_ok));
     if (!*format_ok) return VMN_OK;
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
-    int rc = import_be(grp->ctx, grp->Q, grp->xbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
+    int rc = import_be(LANE(grp->ctx), grp->Q, grp->xbytes, bt + 5, n, a->d, all_in_range, 1, format_ok);
     if (rc != VMN_OK || !*format_ok) {
         vmn_rarray_free(a);
         return rc;
@@ -1038,23 +1108,23 @@ extern "C" int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_
 }
 extern "C" int vmn_garray_to_be(const vmn_garray* a, uint8_t* be_out) {
     ARG_CHECK(a && (be_out || a->n == 0), "null argument");
-    VMN_ENTER(a->grp->ctx);
-    return export_be(a->grp->ctx, a->grp->P, a->grp->nbytes, a->d, a->n, be_out);
+    VMN_ENTER(LANE(a->grp->ctx));
+    return export_be(LANE(a->grp->ctx), a->grp->P, a->grp->nbytes, a->d, a->n, be_out);
 }
 extern "C" int vmn_rarray_to_be(const vmn_rarray* a, uint8_t* be_out) {
     ARG_CHECK(a && (be_out || a->n == 0), "null argument");
-    VMN_ENTER(a->grp->ctx);
-    return export_be(a->grp->ctx, a->grp->Q, a->grp->xbytes, a->d, a->n, be_out);
+    VMN_ENTER(LANE(a->grp->ctx));
+    return export_be(LANE(a->grp->ctx), a->grp->Q, a->grp->xbytes, a->d, a->n, be_out);
 }
 
 extern "C" int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out) {
     ARG_CHECK(x && y && out, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(g, x->n, &r));
-    int rc = mul_arrays(g->ctx, g->P, x->d, y->d, elem_words(g->P), x->n, r->d);
+    int rc = mul_arrays(LANE(g->ctx), g->P, x->d, y->d, elem_words(g->P), x->n, r->d);
     if (rc != VMN_OK) {
         vmn_garray_free(r);
         return rc;
@@ -1067,7 +1137,7 @@ extern "C" int vmn_garray_exp_array(const vmn_garray* x, const vmn_rarray* e, in
     ARG_CHECK(x && e && out, "null argument");
     ARG_CHECK(x->grp == e->grp && x->n == e->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
     vmn_garray* r = nullptr;
@@ -1087,7 +1157,7 @@ extern "C" int vmn_garray_exp_array(const vmn_garray* x, const vmn_rarray* e, in
 extern "C" int vmn_garray_exp_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, vmn_garray** out) {
     ARG_CHECK(x && out && (exps_be || x->n == 0) && ebytes > 0, "null argument");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     if (ebits <= 0 || (size_t)ebits > 8 * ebytes) ebits = (int)(8 * ebytes);
     int ewords = (ebits + 31) / 32;
@@ -1117,7 +1187,7 @@ extern "C" int vmn_garray_exp_ints(const vmn_garray* x, const uint8_t* exps_be, 
 extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, vmn_garray** out) {
     ARG_CHECK(x && e_be && out && ebytes > 0, "null argument");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     int ewords = (int)((ebytes + 3) / 4);
     Big e = hostbig::from_be(e_be, ebytes, ewords);
@@ -1172,22 +1242,22 @@ static int compare_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x,
 extern "C" int vmn_garray_equals(const vmn_garray* x, const vmn_garray* y, int* equal) {
     ARG_CHECK(x && y && equal, "null argument");
     ARG_CHECK(x->grp == y->grp, "arrays differ in group");
-    VMN_ENTER(x->grp->ctx);
+    VMN_ENTER(LANE(x->grp->ctx));
     if (x->n != y->n) {
         *equal = 0;
         return VMN_OK;
     }
-    return compare_arrays(x->grp->ctx, x->grp->P, x->d, y->d, x->n, equal);
+    return compare_arrays(LANE(x->grp->ctx), x->grp->P, x->d, y->d, x->n, equal);
 }
 extern "C" int vmn_rarray_equals(const vmn_rarray* x, const vmn_rarray* y, int* equal) {
     ARG_CHECK(x && y && equal, "null argument");
     ARG_CHECK(x->grp == y->grp, "arrays differ in group");
-    VMN_ENTER(x->grp->ctx);
+    VMN_ENTER(LANE(x->grp->ctx));
     if (x->n != y->n) {
         *equal = 0;
         return VMN_OK;
     }
-    return compare_arrays(x->grp->ctx, x->grp->Q, x->d, y->d, x->n, equal);
+    return compare_arrays(LANE(x->grp->ctx), x->grp->Q, x->d, y->d, x->n, equal);
 }
 
 // ---- K7 ------------------------------------------------------------------------------------------
@@ -1210,7 +1280,7 @@ static int arr_gather(const Arr* x, const vmn_modulus& m, const std::vector<uint
                       int (*mk)(vmn_group*, size_t, Arr**), void (*fr)(Arr*), Arr** out) {
     Arr* r = nullptr;
     VMN_TRY(mk(x->grp, idx.size(), &r));
-    int rc = gather_rows(x->grp->ctx, m, x->d, idx, d_fill, r->d);
+    int rc = gather_rows(LANE(x->grp->ctx), m, x->d, idx, d_fill, r->d);
     if (rc != VMN_OK) {
         fr(r);
         return rc;
@@ -1221,14 +1291,14 @@ static int arr_gather(const Arr* x, const vmn_modulus& m, const std::vector<uint
 
 extern "C" int vmn_garray_gather(const vmn_garray* x, const uint32_t* idx_host, size_t n_out, vmn_garray** out) {
     ARG_CHECK(x && out && (idx_host || n_out == 0), "null argument");
-    VMN_ENTER(x->grp->ctx);
+    VMN_ENTER(LANE(x->grp->ctx));
     std::vector<uint32_t> idx(idx_host, idx_host + n_out);
     for (uint32_t v : idx) ARG_CHECK(v < x->n, "gather index out of range");
     return arr_gather<vmn_garray>(x, x->grp->P, idx, nullptr, new_garray, vmn_garray_free, out);
 }
 extern "C" int vmn_rarray_gather(const vmn_rarray* x, const uint32_t* idx_host, size_t n_out, vmn_rarray** out) {
     ARG_CHECK(x && out && (idx_host || n_out == 0), "null argument");
-    VMN_ENTER(x->grp->ctx);
+    VMN_ENTER(LANE(x->grp->ctx));
     std::vector<uint32_t> idx(idx_host, idx_host + n_out);
     for (uint32_t v : idx) ARG_CHECK(v < x->n, "gather index out of range");
     return arr_gather<vmn_rarray>(x, x->grp->Q, idx, nullptr, new_rarray, vmn_rarray_free, out);
@@ -1244,37 +1314,37 @@ extern "C" int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host
 extern "C" int vmn_garray_shift_push(const vmn_garray* x, const uint8_t* el_be, vmn_garray** out) {
     ARG_CHECK(x && el_be && out, "null argument");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     uint32_t* d_el = nullptr;
-    VMN_TRY(import_one(g->ctx, g->P, g->nbytes, el_be, &d_el));
+    VMN_TRY(import_one(LANE(g->ctx), g->P, g->nbytes, el_be, &d_el));
     std::vector<uint32_t> idx(x->n);
     for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
     int rc = arr_gather<vmn_garray>(x, g->P, idx, d_el, new_garray, vmn_garray_free, out);
-    free_one(g->ctx, g->P, d_el);
+    free_one(LANE(g->ctx), g->P, d_el);
     return rc;
 }
 extern "C" int vmn_rarray_shift_push(const vmn_rarray* x, const uint8_t* el_be, vmn_rarray** out) {
     ARG_CHECK(x && el_be && out, "null argument");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     uint32_t* d_el = nullptr;
-    VMN_TRY(import_one(g->ctx, g->Q, g->xbytes, el_be, &d_el));
+    VMN_TRY(import_one(LANE(g->ctx), g->Q, g->xbytes, el_be, &d_el));
     std::vector<uint32_t> idx(x->n);
     for (size_t i = 0; i < x->n; ++i) idx[i] = i == 0 ? 0xffffffffu : (uint32_t)(i - 1);
     int rc = arr_gather<vmn_rarray>(x, g->Q, idx, d_el, new_rarray, vmn_rarray_free, out);
-    free_one(g->ctx, g->Q, d_el);
+    free_one(LANE(g->ctx), g->Q, d_el);
     return rc;
 }
 extern "C" int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to, vmn_garray** out) {
     ARG_CHECK(x && out, "null argument");
     ARG_CHECK(from <= to && to <= x->n, "range out of bounds");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(g, to - from, &r));
     if (to > from) {
         hipError_t he = hipMemcpyAsync(r->d, x->d + from * elem_words(g->P), (to - from) * elem_words(g->P) * sizeof(uint32_t),
-                                       hipMemcpyDeviceToDevice, g->ctx->stream);
+                                       hipMemcpyDeviceToDevice, LANE(g->ctx)->stream);
         if (he != hipSuccess) {
             vmn_garray_free(r);
             set_error("copy failed: %s", hipGetErrorString(he));
@@ -1286,7 +1356,7 @@ extern "C" int vmn_garray_copy_range(const vmn_garray* x, size_t from, size_t to
 }
 extern "C" int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host, vmn_garray** out) {
     ARG_CHECK(x && out && (keep_host || x->n == 0), "null argument");
-    VMN_ENTER(x->grp->ctx);
+    VMN_ENTER(LANE(x->grp->ctx));
     std::vector<uint32_t> idx;
     for (size_t i = 0; i < x->n; ++i) {
         if (keep_host[i]) idx.push_back((uint32_t)i);
@@ -1296,26 +1366,26 @@ extern "C" int vmn_garray_extract(const vmn_garray* x, const uint8_t* keep_host,
 extern "C" int vmn_garray_get(const vmn_garray* x, size_t i, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     ARG_CHECK(i < x->n, "index out of range");
-    VMN_ENTER(x->grp->ctx);
-    return export_be(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d + i * elem_words(x->grp->P), 1, out_be);
+    VMN_ENTER(LANE(x->grp->ctx));
+    return export_be(LANE(x->grp->ctx), x->grp->P, x->grp->nbytes, x->d + i * elem_words(x->grp->P), 1, out_be);
 }
 
 extern "C" int vmn_rarray_get(const vmn_rarray* x, size_t i, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
     ARG_CHECK(i < x->n, "index out of range");
-    VMN_ENTER(x->grp->ctx);
-    return export_be(x->grp->ctx, x->grp->Q, x->grp->xbytes, x->d + i * elem_words(x->grp->Q), 1, out_be);
+    VMN_ENTER(LANE(x->grp->ctx));
+    return export_be(LANE(x->grp->ctx), x->grp->Q, x->grp->xbytes, x->d + i * elem_words(x->grp->Q), 1, out_be);
 }
 extern "C" int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarray** out) {
     ARG_CHECK(x && out, "null argument");
     ARG_CHECK(from <= to && to <= x->n, "range out of bounds");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, to - from, &r));
     if (to > from) {
         hipError_t he = hipMemcpyAsync(r->d, x->d + from * elem_words(g->Q), (to - from) * elem_words(g->Q) * sizeof(uint32_t),
-                                       hipMemcpyDeviceToDevice, g->ctx->stream);
+                                       hipMemcpyDeviceToDevice, LANE(g->ctx)->stream);
         if (he != hipSuccess) {
             vmn_rarray_free(r);
             set_error("copy failed: %s", hipGetErrorString(he));
@@ -1390,28 +1460,28 @@ static int reduce_to_host(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, con
 
 extern "C" int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
-    VMN_ENTER(x->grp->ctx);
-    return reduce_to_host(x->grp->ctx, x->grp->P, x->grp->nbytes, x->d, x->n, true, out_be);
+    VMN_ENTER(LANE(x->grp->ctx));
+    return reduce_to_host(LANE(x->grp->ctx), x->grp->P, x->grp->nbytes, x->d, x->n, true, out_be);
 }
 extern "C" int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
-    VMN_ENTER(x->grp->ctx);
-    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->xbytes, x->d, x->n, true, out_be);
+    VMN_ENTER(LANE(x->grp->ctx));
+    return reduce_to_host(LANE(x->grp->ctx), x->grp->Q, x->grp->xbytes, x->d, x->n, true, out_be);
 }
 extern "C" int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be) {
     ARG_CHECK(x && out_be, "null argument");
-    VMN_ENTER(x->grp->ctx);
-    return reduce_to_host(x->grp->ctx, x->grp->Q, x->grp->xbytes, x->d, x->n, false, out_be);
+    VMN_ENTER(LANE(x->grp->ctx));
+    return reduce_to_host(LANE(x->grp->ctx), x->grp->Q, x->grp->xbytes, x->d, x->n, false, out_be);
 }
 extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* out_be) {
     ARG_CHECK(x && y && out_be, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
-    DevTmp prod(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
+    DevTmp prod(LANE(g->ctx));
     VMN_TRY(prod.alloc(std::max<size_t>(x->n, 1) * elem_words(g->Q) * sizeof(uint32_t)));
-    VMN_TRY(mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, prod.as<uint32_t>()));
-    return reduce_to_host(g->ctx, g->Q, g->xbytes, prod.as<uint32_t>(), x->n, false, out_be);
+    VMN_TRY(mul_arrays(LANE(g->ctx), g->Q, x->d, y->d, elem_words(g->Q), x->n, prod.as<uint32_t>()));
+    return reduce_to_host(LANE(g->ctx), g->Q, g->xbytes, prod.as<uint32_t>(), x->n, false, out_be);
 }
 
 // ---- K8 element-wise -------------------------------------------------------------------------------
@@ -1430,10 +1500,10 @@ extern "C" int vmn_rarray_mul(const vmn_rarray* x, const vmn_rarray* y, vmn_rarr
     ARG_CHECK(x && y && out, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, x->n, &r));
-    int rc = mul_arrays(g->ctx, g->Q, x->d, y->d, elem_words(g->Q), x->n, r->d);
+    int rc = mul_arrays(LANE(g->ctx), g->Q, x->d, y->d, elem_words(g->Q), x->n, r->d);
     if (rc != VMN_OK) {
         vmn_rarray_free(r);
         return rc;
@@ -1445,10 +1515,10 @@ extern "C" int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarr
     ARG_CHECK(x && y && out, "null argument");
     ARG_CHECK(x->grp == y->grp && x->n == y->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, x->n, &r));
-    int rc = ring_elementwise(g->ctx, g->Q, x->d, y->d, nullptr, 0, x->n, r->d);
+    int rc = ring_elementwise(LANE(g->ctx), g->Q, x->d, y->d, nullptr, 0, x->n, r->d);
     if (rc != VMN_OK) {
         vmn_rarray_free(r);
         return rc;
@@ -1459,10 +1529,10 @@ extern "C" int vmn_rarray_add(const vmn_rarray* x, const vmn_rarray* y, vmn_rarr
 extern "C" int vmn_rarray_neg(const vmn_rarray* x, vmn_rarray** out) {
     ARG_CHECK(x && out, "null argument");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, x->n, &r));
-    int rc = ring_elementwise(g->ctx, g->Q, x->d, nullptr, nullptr, 1, x->n, r->d);
+    int rc = ring_elementwise(LANE(g->ctx), g->Q, x->d, nullptr, nullptr, 1, x->n, r->d);
     if (rc != VMN_OK) {
         vmn_rarray_free(r);
         return rc;
@@ -1474,13 +1544,13 @@ extern "C" int vmn_rarray_mul_add(const vmn_rarray* x, const uint8_t* v_be, cons
     ARG_CHECK(x && v_be && out, "null argument");
     ARG_CHECK(!y || (x->grp == y->grp && x->n == y->n), "arrays differ in group or size");
     vmn_group* g = x->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     uint32_t* d_v = nullptr;
-    VMN_TRY(import_one(g->ctx, g->Q, g->xbytes, v_be, &d_v));
+    VMN_TRY(import_one(LANE(g->ctx), g->Q, g->xbytes, v_be, &d_v));
     vmn_rarray* r = nullptr;
     int rc = new_rarray(g, x->n, &r);
-    if (rc == VMN_OK) rc = ring_elementwise(g->ctx, g->Q, x->d, y ? y->d : nullptr, d_v, y ? 2 : 3, x->n, r->d);
-    free_one(g->ctx, g->Q, d_v);
+    if (rc == VMN_OK) rc = ring_elementwise(LANE(g->ctx), g->Q, x->d, y ? y->d : nullptr, d_v, y ? 2 : 3, x->n, r->d);
+    free_one(LANE(g->ctx), g->Q, d_v);
     if (rc != VMN_OK) {
         if (r) vmn_rarray_free(r);
         return rc;
@@ -1600,7 +1670,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
 extern "C" int vmn_rarray_max_bits(const vmn_rarray* x, int* bits) {
     ARG_CHECK(x && bits, "null argument");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     *bits = 0;
     if (x->n == 0) return VMN_OK;
@@ -1619,12 +1689,12 @@ extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_
     ARG_CHECK(b && e && out_x, "null argument");
     ARG_CHECK(b->grp == e->grp && b->n == e->n, "arrays differ in group or size");
     vmn_group* g = b->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, b->n, &r));
-    int rc = scan_affine(g->ctx, g->Q, e->d, b->d, b->n, b->n, 0, r->d);
+    int rc = scan_affine(LANE(g->ctx), g->Q, e->d, b->d, b->n, b->n, 0, r->d);
     if (rc == VMN_OK && last_be) {
-        if (b->n) rc = export_be(g->ctx, g->Q, g->xbytes, r->d + (b->n - 1) * elem_words(g->Q), 1, last_be);
+        if (b->n) rc = export_be(LANE(g->ctx), g->Q, g->xbytes, r->d + (b->n - 1) * elem_words(g->Q), 1, last_be);
         else memset(last_be, 0, g->xbytes);
     }
     if (rc != VMN_OK) {
@@ -1637,10 +1707,10 @@ extern "C" int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_
 extern "C" int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out) {
     ARG_CHECK(e && out, "null argument");
     vmn_group* g = e->grp;
-    VMN_ENTER(g->ctx);
+    VMN_ENTER(LANE(g->ctx));
     vmn_rarray* r = nullptr;
     VMN_TRY(new_rarray(g, e->n, &r));
-    int rc = scan_affine(g->ctx, g->Q, e->d, nullptr, e->n, e->n, 0, r->d);
+    int rc = scan_affine(LANE(g->ctx), g->Q, e->d, nullptr, e->n, e->n, 0, r->d);
     if (rc != VMN_OK) {
         vmn_rarray_free(r);
         return rc;
@@ -1653,7 +1723,7 @@ extern "C" int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out) {
 extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
     ARG_CHECK(x && out, "null argument");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     const size_t n = x->n;
@@ -1801,6 +1871,49 @@ static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const u
     return VMN_OK;
 }
 
+// d_out[i] = (the i-th ceil(vbits / 8) bytes of PRG(seed), leading bits cleared) mod m, as a residue row.  Values that
+// fit the modulus' bytes are imported directly (reduced by the import when they can reach m); wider ones -- bits(m) +
+// rbitlen bits: the statistically-close-to-uniform sampling of randomElementArray -- are split as hi * 2^(8 pb) + lo
+// with pb = the modulus' byte length, and recombined with one multiply-add mod m.
+static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t (&w)[8], size_t n, int vbits, uint32_t* d_out) {
+    if (n == 0) return VMN_OK;
+    const size_t Wd = elem_words(m);
+    const size_t vb = ((size_t)vbits + 7) / 8, mb = ((size_t)m.nbits + 7) / 8;
+    const size_t pb = std::min(vb, mb);
+    if (vb - pb > mb || 8 * (vb - pb) + 8 > (size_t)m.nbits) {
+        set_error("PRG values of %d bits are too wide for a %d-bit modulus", vbits, m.nbits);
+        return VMN_ERR_UNSUPPORTED;
+    }
+    DevTmp rows(ctx);
+    // low part: < 2^(8 pb) <= R, reduced by the import when it can reach the modulus
+    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, vb - pb, pb, pb, rows));
+    const int mode_lo = (vb > pb || vbits >= m.nbits) ? 2 : 0;
+    if (vb == pb) return import_dev(ctx, m, pb, rows.as<uint8_t>(), mode_lo, n, d_out, nullptr);
+    DevTmp lo(ctx), hi(ctx), cdev(ctx);
+    VMN_TRY(lo.alloc(n * Wd * sizeof(uint32_t)));
+    VMN_TRY(hi.alloc(n * Wd * sizeof(uint32_t)));
+    VMN_TRY(import_dev(ctx, m, pb, rows.as<uint8_t>(), 2, n, lo.as<uint32_t>(), nullptr));
+    const size_t hb = vb - pb;                                  // high part: < 2^(8 hb) < m
+    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, hb, hb, rows));
+    VMN_TRY(import_dev(ctx, m, hb, rows.as<uint8_t>(), 0, n, hi.as<uint32_t>(), nullptr));
+    Big c(m.NW, 0);                                             // c = 2^(8 pb) mod m as one element
+    c[0] = 1;
+    for (size_t k = 0; k < 8 * pb; ++k) hostbig::dbl_mod(c, m.n_words);
+    std::vector<uint8_t> cbe(mb);
+    hostbig::to_be(c, cbe.data(), mb);
+    VMN_TRY(cdev.alloc(Wd * sizeof(uint32_t)));
+    int ok = 1;
+    VMN_TRY(import_be(ctx, m, mb, cbe.data(), 1, cdev.as<uint32_t>(), &ok));
+    int rc = VMN_ERR_ARG;                                       // out = hi * c + lo   (ring op 2 with this modulus)
+#define X(S_, NW_, LPE_)                                                                                                      \
+    if (m.S == S_)                                                                                                            \
+        rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), d_out, (const uint32_t*)hi.as<uint32_t>(), \
+                    (const uint32_t*)lo.as<uint32_t>(), (const uint32_t*)cdev.as<uint32_t>(), 2, n, m.d_n, m.n0inv);
+    VMN_FOR_SIZES(X)
+#undef X
+    return rc;
+}
+
 extern "C" int vmn_prg_bytes(const uint8_t* seed, size_t seedlen, uint8_t* out, size_t nbytes) {
     ARG_CHECK(out || nbytes == 0, "null argument");
     uint32_t w[8];
@@ -1831,21 +1944,14 @@ extern "C" int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits,
 
 extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out) {
     ARG_CHECK(grp && out && bits > 0, "bad argument");
-    vmn_ctx* ctx = grp->ctx;
+    vmn_ctx* ctx = LANE(grp->ctx);
     VMN_ENTER(ctx);
     uint32_t w[8];
     VMN_TRY(prg_seed_words(seed, seedlen, w));
-    const size_t vb = ((size_t)bits + 7) / 8;
-    if (vb > grp->xbytes || bits > 28 * grp->Q.S) {
-        set_error("vmn_rarray_from_prg: %d-bit integers do not fit the %zu-byte exponent rows", bits, grp->xbytes);
-        return VMN_ERR_UNSUPPORTED;
-    }
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
-    DevTmp rows(ctx);
-    int rc = n ? prg_rows(ctx, w, n, vb, bits, 0, vb, grp->xbytes, rows) : VMN_OK;
-    // integers that may reach the order (bits >= bits of q) act as field elements: reduced
-    if (rc == VMN_OK) rc = import_dev(ctx, grp->Q, grp->xbytes, rows.as<uint8_t>(), bits >= grp->Q.nbits ? 2 : 0, n, a->d, nullptr);
+    // integers that may reach the order act as field elements: reduced mod q (also when wider than q)
+    int rc = prg_residues(ctx, grp->Q, w, n, bits, a->d);
     if (rc != VMN_OK) {
         vmn_rarray_free(a);
         return rc;
@@ -1856,7 +1962,7 @@ extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
 
 extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int rbitlen, vmn_garray** out) {
     ARG_CHECK(grp && out && rbitlen >= 0, "bad argument");
-    vmn_ctx* ctx = grp->ctx;
+    vmn_ctx* ctx = LANE(grp->ctx);
     VMN_ENTER(ctx);
     if (grp->curve) {
         set_error("vmn_garray_from_prg: random curve points (ECqPGroup.randomElementArray) are not implemented");
@@ -1876,11 +1982,6 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
     uint32_t w[8];
     VMN_TRY(prg_seed_words(seed, seedlen, w));
     const int vbits = m.nbits + rbitlen;
-    const size_t vb = ((size_t)vbits + 7) / 8, pb = ((size_t)m.nbits + 7) / 8;
-    if (vb - pb > grp->nbytes || pb > grp->nbytes) {
-        set_error("vmn_garray_from_prg: rbitlen too large");
-        return VMN_ERR_UNSUPPORTED;
-    }
     vmn_garray* r = nullptr;
     VMN_TRY(new_garray(grp, n, &r));
     if (n == 0) {
@@ -1888,34 +1989,9 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
         return VMN_OK;
     }
     const size_t Wd = elem_words(m);
-    DevTmp rows(ctx), lo(ctx), hi(ctx), cdev(ctx);
+    DevTmp lo(ctx);
     int rc = lo.alloc(n * Wd * sizeof(uint32_t));
-    if (rc == VMN_OK) rc = hi.alloc(n * Wd * sizeof(uint32_t));
-    // t = hi * 2^(8 pb) + lo:  lo may exceed p (reduced by the import), hi < 2^(rbitlen + 7) << p
-    if (rc == VMN_OK) rc = prg_rows(ctx, w, n, vb, vbits, vb - pb, pb, grp->nbytes, rows);
-    if (rc == VMN_OK) rc = import_dev(ctx, m, grp->nbytes, rows.as<uint8_t>(), 2, n, lo.as<uint32_t>(), nullptr);
-    if (rc == VMN_OK && vb > pb) {
-        rc = prg_rows(ctx, w, n, vb, vbits, 0, vb - pb, grp->nbytes, rows);
-        if (rc == VMN_OK) rc = import_dev(ctx, m, grp->nbytes, rows.as<uint8_t>(), 0, n, hi.as<uint32_t>(), nullptr);
-        // c = 2^(8 pb) mod p as one element (Montgomery form)
-        Big c(m.NW, 0);
-        c[0] = 1;
-        for (size_t k = 0; k < 8 * pb; ++k) hostbig::dbl_mod(c, m.n_words);
-        std::vector<uint8_t> cbe(grp->nbytes);
-        hostbig::to_be(c, cbe.data(), grp->nbytes);
-        if (rc == VMN_OK) rc = cdev.alloc(Wd * sizeof(uint32_t));
-        int ok = 1;
-        if (rc == VMN_OK) rc = import_be(ctx, m, grp->nbytes, cbe.data(), 1, cdev.as<uint32_t>(), &ok);
-        if (rc == VMN_OK) {                                  // lo := hi * c + lo   (ring op 2 with the modulus p)
-            rc = VMN_ERR_ARG;
-#define X(S_, NW_, LPE_)                                                                                                      \
-    if (m.S == S_)                                                                                                            \
-        rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), lo.as<uint32_t>(), (const uint32_t*)hi.as<uint32_t>(), \
-                    (const uint32_t*)lo.as<uint32_t>(), (const uint32_t*)cdev.as<uint32_t>(), 2, n, m.d_n, m.n0inv);
-            VMN_FOR_SIZES(X)
-#undef X
-        }
-    }
+    if (rc == VMN_OK) rc = prg_residues(ctx, m, w, n, vbits, lo.as<uint32_t>());      // t_i mod p
     // h_i = t_i^2  (cofactor 2)
     if (rc == VMN_OK) rc = mul_arrays(ctx, m, lo.as<uint32_t>(), lo.as<uint32_t>(), Wd, n, r->d);
     if (rc != VMN_OK) {
@@ -1962,7 +2038,9 @@ static size_t fixed_cache_limit() {
 }
 
 static void fixed_drop(vmn_group* g, std::map<std::string, vmn_group::FixedTable>::iterator it) {
-    (void)hipStreamSynchronize(g->ctx->stream);              // kernels reading the table may still be queued
+    (void)hipStreamSynchronize(g->ctx->stream);                    // kernels reading the table may still be queued, on either lane
+    if (g->ctx->helper) (void)hipStreamSynchronize(g->ctx->helper->stream);
+    if (it->second.ready) (void)hipEventDestroy(it->second.ready);
     if (it->second.d_tab) (void)hipFree(it->second.d_tab);
     g->fixed_bytes -= it->second.bytes;
     g->fixed.erase(it);
@@ -1989,7 +2067,7 @@ static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
 
 // Table for (base, window) cached in the group; built on the GPU from the host squaring chain.
 static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out, int reuse_hint = 1) {
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
@@ -2012,6 +2090,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         const bool grow = w_many >= ft.wbits + 2;
         if (!grow && ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
             ft.last_use = ++g->fixed_clock;
+            if (ft.built_on != ctx->stream && ft.ready) VMN_HIP(hipStreamWaitEvent(ctx->stream, ft.ready, 0));   // built by the other lane
             *out = &ft;
             return VMN_OK;
         }
@@ -2062,6 +2141,8 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         }
         ft.last_use = ++g->fixed_clock;
         ft.uses = carry_uses;
+        ft.built_on = ctx->stream;
+        if (hipEventCreateWithFlags(&ft.ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(ft.ready, ctx->stream);
         g->fixed_bytes += ft.bytes;
         auto ins = g->fixed.emplace(key, ft);
         *out = &ins.first->second;
@@ -2106,6 +2187,8 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     }
     ft.last_use = ++g->fixed_clock;
     ft.uses = carry_uses;
+    ft.built_on = ctx->stream;
+    if (hipEventCreateWithFlags(&ft.ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(ft.ready, ctx->stream);
     g->fixed_bytes += ft.bytes;
     auto ins = g->fixed.emplace(key, ft);
     *out = &ins.first->second;
@@ -2114,7 +2197,8 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
 
 extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be, size_t n_hint, int uses_hint) {
     ARG_CHECK(grp && base_be && n_hint > 0, "bad argument");
-    VMN_ENTER(grp->ctx);
+    VMN_ENTER(LANE(grp->ctx));
+    std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
     vmn_group::FixedTable* ft = nullptr;
     return fixed_table(grp, base_be, grp->Q.nbits, n_hint, &ft, uses_hint < 1 ? 1 : (uses_hint > 16 ? 16 : uses_hint));
 }
@@ -2122,7 +2206,7 @@ extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be
 extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out) {
     ARG_CHECK(grp && base_be && e && out, "null argument");
     ARG_CHECK(e->grp == grp, "exponent array belongs to another group");
-    vmn_ctx* ctx = grp->ctx;
+    vmn_ctx* ctx = LANE(grp->ctx);
     VMN_ENTER(ctx);
     const size_t n = e->n;
     vmn_garray* r = nullptr;
@@ -2134,12 +2218,15 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
     int ebits = grp->Q.nbits;
     vmn_group::FixedTable* ft = nullptr;
     DevTmp ew(ctx);
+    std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);      // until the launch is queued: the other lane may evict tables
     int rc = fixed_table(grp, base_be, ebits, n, &ft);
     if (rc == VMN_OK) rc = ew.alloc(n * (size_t)grp->Q.NW * sizeof(uint32_t));
     if (rc == VMN_OK) rc = to_words(ctx, grp->Q, e->d, n, ew.as<uint32_t>());
     if (rc == VMN_OK) {
         const vmn_modulus& m = grp->P;
-        unsigned grid = std::min<unsigned>(egrid(m, n), (unsigned)(ctx->num_cus * blocks_per_cu(m)));
+        // one workgroup per tile rather than a persistent grid: a workgroup slot frees up every ~2 ms, so kernels of
+        // the other lane (a helper's exports) are scheduled between the tiles instead of behind the whole launch
+        unsigned grid = egrid(m, n);
         rc = VMN_ERR_ARG;
         if (m.ec) {
 #define X(S_, NW_)                                                                                                   \
@@ -2194,7 +2281,7 @@ static int pick_bucket_bits(size_t n, int ebits) {
 // once and reused for every array; out_be receives k elements.
 static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, const uint32_t* e_words, int ewords,
                          int ebits, size_t n, uint8_t* out_be) {
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     const size_t ebytes_out = m.ec ? 2 * g->nbytes : g->nbytes;
@@ -2365,7 +2452,7 @@ extern "C" int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int 
     ARG_CHECK(x && e && out_be, "null argument");
     ARG_CHECK(x->grp == e->grp && x->n == e->n, "arrays differ in group or size");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
     DevTmp ew(ctx);
@@ -2377,7 +2464,7 @@ extern "C" int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int 
 extern "C" int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t ebytes, int ebits, uint8_t* out_be) {
     ARG_CHECK(x && out_be && (exps_be || x->n == 0) && ebytes > 0, "null argument");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     if (ebits <= 0 || (size_t)ebits > 8 * ebytes) ebits = (int)(8 * ebytes);
     int ewords = (ebits + 31) / 32;
@@ -2394,7 +2481,7 @@ extern "C" int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, c
     ARG_CHECK(xs && k > 0 && e && out_be, "null argument");
     vmn_group* g = e->grp;
     for (size_t a = 0; a < k; ++a) ARG_CHECK(xs[a] && xs[a]->grp == g && xs[a]->n == e->n, "arrays differ in group or size");
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
     DevTmp ew(ctx);
@@ -2409,7 +2496,7 @@ extern "C" int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, c
 extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     ARG_CHECK(x && all_members, "null argument");
     vmn_group* g = x->grp;
-    vmn_ctx* ctx = g->ctx;
+    vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
     *all_members = 1;
     if (x->n == 0) return VMN_OK;

@@ -14,6 +14,7 @@
 #include "hostbig.h"
 #include "hostnum64.h"
 
+struct vmn_ctx;
 namespace vmn {
 
 void set_error(const char* fmt, ...);
@@ -33,6 +34,9 @@ void set_error(const char* fmt, ...);
 #define VMN_ENTER(c)                                                \
     std::lock_guard<std::recursive_mutex> guard__((c)->mu);         \
     VMN_HIP(hipSetDevice((c)->device))
+// The lane a call runs on: the helper lane when the calling thread has announced itself as the helper of this context.
+vmn_ctx* lane_of(vmn_ctx* c);
+#define LANE(c) vmn::lane_of(c)
 
 #define VMN_TRY(expr)                 \
     do {                              \
@@ -48,7 +52,14 @@ struct TimingRec {
 }  // namespace vmn
 
 struct vmn_ctx {
-    std::recursive_mutex mu;              // serialises entry points (pool, scratch, flags and the stream are shared)
+    // A context is one "lane": a stream with its own pool, scratch, verdict words and mutex.  The context a caller
+    // creates is the main lane; the ONE helper thread of the reference (ShufflerElGamalSession.java:839-859: mul + permute
+    // beside a verification; the export thread of CCPoSW.java:114-123) gets a second lane on the same device
+    // (vmn_ctx_helper_begin), so that its calls neither wait for the protocol thread's mutex nor queue behind its kernels.
+    vmn_ctx* helper = nullptr;            // main lane: the helper lane, created on first use
+    vmn_ctx* parent = nullptr;            // helper lane: its main lane
+    hipEvent_t order_event = nullptr;     // helper lane: recorded on the main stream to order the helper stream behind it
+    std::recursive_mutex mu;              // serialises the entry points of this lane (pool, scratch, flags and the stream are shared)
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -117,8 +128,11 @@ struct vmn_group {
         size_t bytes = 0;
         uint64_t last_use = 0;
         int uses = 0;              // calls served (a base that keeps coming back earns a larger window)
+        hipEvent_t ready = nullptr;        // recorded behind the build; a user on another stream waits for it
+        hipStream_t built_on = nullptr;
     };
     std::map<std::string, FixedTable> fixed;
+    std::recursive_mutex tab_mu;          // the table cache is shared by the lanes of the context
     // least-recently-used tables are dropped beyond fixed_cache_limit() bytes (64 GB, env VMN_FIXED_CACHE_BYTES) (every proof brings a new base h_0)
     size_t fixed_bytes = 0;
     uint64_t fixed_clock = 0;

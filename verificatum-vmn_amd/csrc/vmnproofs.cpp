@@ -298,6 +298,32 @@ int received_bits(const vmn_rarray* a, int* bits) {
     return VMN_OK;
 }
 
+// ---- N-sized random draws: host rows, or 32 bytes expanded on the device (vmn_random_source, vmnproofs.h) ----------
+int random_ring_array(vmn_group* grp, const vmn_random_source& rs, size_t n, int qbits, int rbitlen, RA& out) {
+    if (rs.array_seed && n > 1) {
+        uint8_t seed[32];
+        if (rs.array_seed(rs.user, seed) != 0) return fail(VMN_ERR_ARG, "random source failed");
+        return vmn_rarray_from_prg(grp, seed, 32, n, qbits + rbitlen, out.out());
+    }
+    const uint8_t* rows = nullptr;
+    if (!rs.ring_elements || rs.ring_elements(rs.user, n, &rows) != 0 || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
+    int ok = 1;
+    TRY(vmn_rarray_from_be(grp, rows, n, out.out(), &ok));
+    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+}
+int random_integer_array(vmn_group* grp, const vmn_random_source& rs, size_t n, int bits, RA& out) {
+    if (rs.array_seed && n > 1) {
+        uint8_t seed[32];
+        if (rs.array_seed(rs.user, seed) != 0) return fail(VMN_ERR_ARG, "random source failed");
+        return vmn_rarray_from_prg(grp, seed, 32, n, bits, out.out());
+    }
+    const uint8_t* rows = nullptr;
+    if (!rs.integers || rs.integers(rs.user, n, bits, &rows) != 0 || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
+    int ok = 1;
+    TRY(vmn_rarray_from_be(grp, rows, n, out.out(), &ok));
+    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+}
+
 // ---- what the three proofs share -----------------------------------------------------------------------------
 struct ProofBase {
     HostGroup G;
@@ -326,19 +352,11 @@ struct ProofBase {
     int need_rs() const { return has_rs ? VMN_OK : fail(VMN_ERR_ARG, "this proof object was created without a random source (verifier)"); }
     int draw_ring_array(size_t n, RA& out) {
         TRY(need_rs());
-        const uint8_t* rows = nullptr;
-        if (rs.ring_elements(rs.user, n, &rows) != 0 || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
-        int ok = 1;
-        TRY(vmn_rarray_from_be(G.grp, rows, n, out.out(), &ok));
-        return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+        return random_ring_array(G.grp, rs, n, G.qbits, rbitlen, out);
     }
     int draw_integers(size_t n, int bits, RA& out) {
         TRY(need_rs());
-        const uint8_t* rows = nullptr;
-        if (rs.integers(rs.user, n, bits, &rows) != 0 || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
-        int ok = 1;
-        TRY(vmn_rarray_from_be(G.grp, rows, n, out.out(), &ok));
-        return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+        return random_integer_array(G.grp, rs, n, bits, out);
     }
     int draw_ring_element(Num& out) {
         TRY(need_rs());
@@ -1492,6 +1510,16 @@ int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_ga
     TRY(vmn_garray_mul(h, tmp1, tmp2.out()));                                     // generators.mul(tmp) :201
     tmp1.reset();
     return vmn_garray_permute(tmp2, pi, u_out);                                   // :215
+}
+
+int vmn_rarray_random(vmn_group* grp, const vmn_random_source* rs, size_t n, int rbitlen, vmn_rarray** out) {
+    if (!grp || !rs || !out || rbitlen < 0 || (!rs->ring_elements && !rs->array_seed)) return fail(VMN_ERR_ARG, "vmn_rarray_random: bad argument");
+    HostGroup G;
+    TRY(G.init(grp));
+    RA a;
+    TRY(random_ring_array(grp, *rs, n, G.qbits, rbitlen, a));
+    *out = a.release();
+    return VMN_OK;
 }
 
 int vmn_permutation_shrink(const uint32_t* pi, size_t n_max, size_t n, uint8_t* keep_out, uint32_t* pi_out) {

@@ -103,8 +103,44 @@ class PermutationCommitment:
         return keepList
 
 
-class ShaRandomSource:
-    """Deterministic random source for the benchmark and the tests (SHA-256 counter stream).  VCR's
+class SecureRandomSource:
+    """The random source a prover uses by default: the operating system's CSPRNG (``os.urandom``), the counterpart of
+    the reference's ``RandomDevice /dev/urandom`` (demo/mixnet/.checkbaseconf:124).  Single ring elements are drawn
+    with ``rbitlen`` bits of slack and reduced (statistical distance 2^-rbitlen from uniform); the N-sized draws of a
+    proof are expanded on the GPU from 32 fresh bytes each (``array_seed``, see ``vmn_random_source`` in
+    include/vmnproofs.h), so no N-sized host buffer exists.  ``ring_array`` / ``int_array`` remain for drivers that
+    want host rows (the Python mirror)."""
+
+    def __init__(self, q: int, rbitlen: int = 100):
+        import os
+        self._urandom = os.urandom
+        self.q, self.rbitlen = q, rbitlen
+
+    def array_seed(self) -> bytes:
+        return self._urandom(32)
+
+    def ring_element(self) -> int:
+        nb = (self.q.bit_length() + self.rbitlen + 7) // 8
+        return int.from_bytes(self._urandom(nb), "big") % self.q
+
+    def ring_array(self, n: int) -> List[int]:
+        return [self.ring_element() for _ in range(n)]
+
+    def int_array(self, n: int, bits: int) -> List[int]:
+        nb = (bits + 7) // 8
+        mask = (1 << bits) - 1
+        return [int.from_bytes(self._urandom(nb), "big") & mask for _ in range(n)]
+
+    def permutation(self, n: int) -> List[int]:
+        import random
+        pi = list(range(n))
+        random.SystemRandom().shuffle(pi)
+        return pi
+
+
+class InsecureShaRandomSource:
+    """NOT FOR PRODUCTION: a fixed-seed, reproducible stream (tests, benchmark).
+    Deterministic random source for the benchmark and the tests (SHA-256 counter stream).  VCR's
     own ``randomElementArray`` sampling is not part of the reference tree; any source works for the
     arithmetic, and parity tests feed the same tape to the oracle."""
 
@@ -137,8 +173,9 @@ class ShaRandomSource:
         return sorted(range(n), key=lambda i: (keys[i], i))
 
 
-class BulkRandomSource:
-    """numpy-backed random source for large N (benchmark): hands out big-endian byte blocks of the
+class InsecureBulkRandomSource:
+    """NOT FOR PRODUCTION: numpy's PCG64 is not a cryptographic generator (benchmark inputs only).
+    numpy-backed random source for large N (benchmark): hands out big-endian byte blocks of the
     group's wire width instead of Python integers, so that no per-element Python work happens.
     Ring elements are uniform below 2^(bits(q)-1) <= q (top bit cleared): statistically as good for
     a throughput run, and always in range."""
@@ -170,3 +207,7 @@ class BulkRandomSource:
 
     def permutation(self, n: int):
         return self.rng.permutation(n).astype(self.np.uint32)
+
+    def array_seed(self) -> bytes:
+        """32 bytes for a device-expanded array draw (vmn_random_source.array_seed)."""
+        return self.rng.integers(0, 256, size=32, dtype=self.np.uint8).tobytes()

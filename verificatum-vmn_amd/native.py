@@ -25,8 +25,11 @@ _ROWS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p))
 _INTS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p))
 
 
+_SEED_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8))
+
+
 class _RandomSourceStruct(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("ring_elements", _ROWS_CB), ("integers", _INTS_CB)]
+    _fields_ = [("user", C.c_void_p), ("ring_elements", _ROWS_CB), ("integers", _INTS_CB), ("array_seed", _SEED_CB)]
 
 
 def plib() -> C.CDLL:
@@ -48,7 +51,7 @@ class RandomSource:
     """Adapter from a tape object (``ring_array(n)``, ``ring_element()``, ``int_array(n, bits)``; ints or
     big-endian blocks) to ``vmn_random_source``.  Buffers stay alive until the next call, as the ABI requires."""
 
-    def __init__(self, group, tape):
+    def __init__(self, group, tape, device_arrays: bool = True):
         # the callbacks close over this small state object only (no reference back to the RandomSource or to the
         # group: a reference cycle would hand finalisation order to the garbage collector)
         class _State:
@@ -81,8 +84,22 @@ class RandomSource:
                 st.error = exc
                 return 1
 
-        self._cbs = (_ROWS_CB(ring_cb), _INTS_CB(ints_cb))
-        self.struct = _RandomSourceStruct(None, self._cbs[0], self._cbs[1])
+        def seed_cb(_user, out):
+            try:
+                seed = bytes(st.tape.array_seed())
+                if len(seed) != 32:
+                    raise ValueError("array_seed() must return 32 bytes")
+                C.memmove(out, seed, 32)
+                return 0
+            except Exception as exc:       # pragma: no cover
+                st.error = exc
+                return 1
+
+        # N-sized draws are expanded on the device when the tape offers 32-byte seeds (``array_seed()``) and
+        # ``device_arrays`` is not switched off; otherwise they come as host rows
+        use_seed = device_arrays and hasattr(tape, "array_seed")
+        self._cbs = (_ROWS_CB(ring_cb), _INTS_CB(ints_cb), _SEED_CB(seed_cb) if use_seed else _SEED_CB())
+        self.struct = _RandomSourceStruct(None, self._cbs[0], self._cbs[1], self._cbs[2])
 
     @property
     def error(self):
@@ -420,6 +437,18 @@ def keep_list_sanitize_native(keep, n_max: int, n: int):
     replaced = C.c_int()
     _check(plib().vmn_keep_list_sanitize(buf, C.c_size_t(len(keep)), C.c_size_t(n_max), C.c_size_t(n), C.byref(replaced)))
     return [b != 0 for b in buf.raw[:n_max]], bool(replaced.value)
+
+
+def random_ring_array_native(group, tape, n: int, rbitlen: int):
+    """``vmn_rarray_random``: pRing.randomElementArray(n, randomSource, rbitlen) -- expanded on the device from 32 bytes of
+    the tape when it offers ``array_seed()`` (the re-encryption exponents, ShufflerElGamalSession.java:408-409)."""
+    rs = RandomSource(group, tape)
+    out = C.c_void_p()
+    rc = plib().vmn_rarray_random(group._h, C.byref(rs.struct), C.c_size_t(n), C.c_int(rbitlen), C.byref(out))
+    if rc != 0 and rs.error is not None:
+        raise rs.error
+    _check(rc)
+    return PRingElementArray(group, out)
 
 
 # ---- verifiable threshold decryption (the interface of elgamal.py over the C++ drivers) -------------------------------
