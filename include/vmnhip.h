@@ -71,11 +71,14 @@ int vmn_ctx_synchronize(vmn_ctx* ctx);
  * or writes byte trees (P/hvzk/CCPoSW.java:114-123).  A thread that calls vmn_ctx_helper_begin(ctx) becomes that helper
  * until vmn_ctx_helper_end(ctx): its calls on arrays / groups of ctx run on a second, high-priority stream with its own
  * pool, scratch and lock, so they neither wait for the protocol thread's calls nor queue behind its kernels (the long
- * fixed-base launches are one workgroup per tile so that slots free up every few milliseconds).  Ordering: begin() and
- * helper_sync() order the helper's stream behind everything the protocol thread has queued so far (call helper_sync
- * before touching an array the protocol thread queued work on after begin); end() waits for the helper's work, so
- * the protocol thread may use its results after joining the thread.  An array must not be freed by one thread while
+ * fixed-base launches are one workgroup per tile so that slots free up every few milliseconds).
+ * Ordering.  vmn_ctx_helper_mark (either thread) records "everything the protocol thread has queued up to here"; begin()
+ * and helper_sync() order the helper's stream behind the LATEST mark (begin() sets one if there has never been any) --
+ * not behind work queued after it, which is what lets the helper run beside that work.  The protocol thread marks right
+ * after queueing what the helper needs (typically just before it starts the thread); end() waits for the helper's work,
+ * so the protocol thread may use its results after joining the thread.  An array must not be freed by one thread while
  * the other still uses it -- the reference's rule for its own arrays.  One helper per context. */
+int vmn_ctx_helper_mark(vmn_ctx* ctx);
 int vmn_ctx_helper_begin(vmn_ctx* ctx);
 int vmn_ctx_helper_sync(vmn_ctx* ctx);
 int vmn_ctx_helper_end(vmn_ctx* ctx);

@@ -287,6 +287,7 @@ def test_helper_lane_overlaps_with_the_protocol_thread(vmn, gpu_ctx):
         except Exception as exc:      # pragma: no cover
             result["error"] = exc
 
+    gpu_ctx.helper_mark()                                # X, Y, E are complete: what the helper relies on
     t0 = time.perf_counter()
     outs = [G.exp(g, E[k % 2]) for k in range(24)]      # queued asynchronously: ~t_main of GPU work ahead
     th = threading.Thread(target=helper)

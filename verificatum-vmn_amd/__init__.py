@@ -135,6 +135,10 @@ class Context:
     def num_cus(self) -> int:
         return lib().vmn_ctx_num_cus(self._h)
 
+    def helper_mark(self) -> None:
+        """Protocol thread: what is queued up to here is what the helper may rely on (``vmn_ctx_helper_mark``)."""
+        _check(lib().vmn_ctx_helper_mark(self._h))
+
     def helper(self):
         """``with ctx.helper(): ...`` in the ONE helper thread of a party (ShufflerElGamalSession.java:839-859): calls made
         inside run on the context's helper lane -- a second, high-priority stream with its own pool and lock
@@ -147,7 +151,7 @@ class Context:
                 return self_inner
 
             def sync(self_inner):
-                """Order the helper's stream behind everything the protocol thread has queued so far."""
+                """Order the helper's stream behind the protocol thread's latest ``helper_mark()``."""
                 _check(lib().vmn_ctx_helper_sync(ctx._h))
 
             def __exit__(self_inner, *exc):

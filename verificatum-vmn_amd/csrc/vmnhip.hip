@@ -296,42 +296,57 @@ extern "C" int vmn_ctx_synchronize(vmn_ctx* ctx) {
 }
 
 // ---- the helper lane -----------------------------------------------------------------------------------------
-// order the helper stream behind everything queued on the main stream so far
-static int helper_order_behind_main(vmn_ctx* ctx) {
+static int helper_create(vmn_ctx* ctx) {
+    std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
+    VMN_HIP(hipSetDevice(ctx->device));
+    if (ctx->helper) return VMN_OK;
+    std::unique_ptr<vmn_ctx> h(new vmn_ctx());
+    h->device = ctx->device;
+    h->num_cus = ctx->num_cus;
+    h->parent = ctx;
+    int least = 0, greatest = 0;                       // numerically lowest = highest priority
+    VMN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    VMN_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, greatest));
+    h->stream = h->own_stream;
+    VMN_HIP(hipMalloc(&h->flags, 64 * sizeof(uint32_t)));
+    VMN_HIP(hipMemsetAsync(h->flags, 0, 64 * sizeof(uint32_t), h->stream));
+    VMN_HIP(hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming));
+    ctx->helper = h.release();
+    return VMN_OK;
+}
+// "what the protocol thread has queued so far is what the helper may rely on": an event on the main stream
+static int helper_mark_locked(vmn_ctx* ctx) {
     vmn_ctx* h = ctx->helper;
     VMN_HIP(hipEventRecord(h->order_event, ctx->stream));
+    h->marked = true;
+    return VMN_OK;
+}
+// order the helper stream behind the latest mark (recording one now if there has never been any)
+static int helper_wait_mark(vmn_ctx* ctx) {
+    vmn_ctx* h = ctx->helper;
+    std::lock_guard<std::mutex> og(h->order_mu);
+    if (!h->marked) VMN_TRY(helper_mark_locked(ctx));
     VMN_HIP(hipStreamWaitEvent(h->stream, h->order_event, 0));
     return VMN_OK;
 }
+extern "C" int vmn_ctx_helper_mark(vmn_ctx* ctx) {
+    ARG_CHECK(ctx && !ctx->parent, "null context or a helper lane");
+    VMN_TRY(helper_create(ctx));
+    VMN_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> og(ctx->helper->order_mu);
+    return helper_mark_locked(ctx);
+}
 extern "C" int vmn_ctx_helper_begin(vmn_ctx* ctx) {
     ARG_CHECK(ctx && !ctx->parent, "null context or a helper lane");
-    {
-        std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
-        VMN_HIP(hipSetDevice(ctx->device));
-        if (!ctx->helper) {
-            std::unique_ptr<vmn_ctx> h(new vmn_ctx());
-            h->device = ctx->device;
-            h->num_cus = ctx->num_cus;
-            h->parent = ctx;
-            int least = 0, greatest = 0;                       // numerically lowest = highest priority
-            VMN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            VMN_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, greatest));
-            h->stream = h->own_stream;
-            VMN_HIP(hipMalloc(&h->flags, 64 * sizeof(uint32_t)));
-            VMN_HIP(hipMemsetAsync(h->flags, 0, 64 * sizeof(uint32_t), h->stream));
-            VMN_HIP(hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming));
-            ctx->helper = h.release();
-        }
-    }
+    VMN_TRY(helper_create(ctx));
+    VMN_HIP(hipSetDevice(ctx->device));
     tl_helper_of = ctx;
-    std::lock_guard<std::recursive_mutex> guard__(ctx->helper->mu);
-    return helper_order_behind_main(ctx);
+    return helper_wait_mark(ctx);
 }
 extern "C" int vmn_ctx_helper_sync(vmn_ctx* ctx) {
     ARG_CHECK(ctx && ctx->helper && tl_helper_of == ctx, "not the helper thread of this context");
-    std::lock_guard<std::recursive_mutex> guard__(ctx->helper->mu);
     VMN_HIP(hipSetDevice(ctx->device));
-    return helper_order_behind_main(ctx);
+    return helper_wait_mark(ctx);
 }
 extern "C" int vmn_ctx_helper_end(vmn_ctx* ctx) {
     ARG_CHECK(ctx && ctx->helper && tl_helper_of == ctx, "not the helper thread of this context");
@@ -346,6 +361,7 @@ extern "C" int vmn_ctx_helper_end(vmn_ctx* ctx) {
     tl_helper_of = nullptr;
     return rc;
 }
+
 extern "C" int vmn_ctx_num_cus(vmn_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
 extern "C" int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes) {
     ARG_CHECK(ctx, "null ctx");

@@ -58,7 +58,9 @@ struct vmn_ctx {
     // (vmn_ctx_helper_begin), so that its calls neither wait for the protocol thread's mutex nor queue behind its kernels.
     vmn_ctx* helper = nullptr;            // main lane: the helper lane, created on first use
     vmn_ctx* parent = nullptr;            // helper lane: its main lane
-    hipEvent_t order_event = nullptr;     // helper lane: recorded on the main stream to order the helper stream behind it
+    hipEvent_t order_event = nullptr;     // helper lane: the latest "mark" on the main stream; the helper stream is ordered behind it
+    bool marked = false;                  // helper lane: a mark has been recorded
+    std::mutex order_mu;                  // helper lane: guards order_event / marked (both threads touch them)
     std::recursive_mutex mu;              // serialises the entry points of this lane (pool, scratch, flags and the stream are shared)
     int device = 0;
     hipStream_t own_stream = nullptr;
