@@ -115,6 +115,12 @@ int vmn_pos_set_batch_vector(vmn_pos* p, const uint8_t* e_be);    /* N rows of e
 /* setBatchVector(byte[] prgSeed) as the reference has it (:533-538): e is derived on the GPU from the 32-byte seed
  * (vmn_rarray_from_prg: PRGHeuristic over SHA-256, N integers of ebitlen bits).  Same for PoSC / CCPoS below. */
 int vmn_pos_set_batch_vector_seed(vmn_pos* p, const uint8_t* seed, size_t seedlen);
+/* Optional: the part of commit() that does not depend on the batching vector -- its random draws (same order and values)
+ * and the multi-exponentiations with epsilon.  The reference derives the batching vector by hashing the whole instance
+ * (hvzk/PoSTW.java:118-130, hvzk/ChallengerRO.java:96-116: 1.5 GB of byte trees at N = 10^6, ~0.7 s of SHA-256 on one
+ * core); a caller runs this part on the GPU while its hash thread -- the helper thread of vmn_ctx_helper_begin, which
+ * exports the byte trees on its own stream -- computes the seed.  commit() runs it itself when it was not called. */
+int vmn_pos_commit_prepare(vmn_pos* p);
 int vmn_pos_commit(vmn_pos* p, vmn_msg** commitment);             /* :546-700 */
 int vmn_pos_reply(vmn_pos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);   /* :856-888 */
 int vmn_pos_compute_af(vmn_pos* p);                               /* :407-410 */
@@ -132,6 +138,7 @@ int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h,
                           const vmn_rarray* r, const uint32_t* pi);
 int vmn_posc_set_batch_vector(vmn_posc* p, const uint8_t* e_be);
 int vmn_posc_set_batch_vector_seed(vmn_posc* p, const uint8_t* seed, size_t seedlen);    /* :350-355 */
+int vmn_posc_commit_prepare(vmn_posc* p);                         /* see vmn_pos_commit_prepare */
 int vmn_posc_commit(vmn_posc* p, vmn_msg** commitment);           /* :363-529 */
 int vmn_posc_reply(vmn_posc* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :607-636 */
 int vmn_posc_set_commitment(vmn_posc* p, const vmn_msg* commitment);
@@ -149,6 +156,7 @@ int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* 
                            const vmn_rarray* const* s);
 int vmn_ccpos_set_batch_vector(vmn_ccpos* p, const uint8_t* e_be);
 int vmn_ccpos_set_batch_vector_seed(vmn_ccpos* p, const uint8_t* seed, size_t seedlen);  /* :330-335 */
+int vmn_ccpos_commit_prepare(vmn_ccpos* p);                       /* see vmn_pos_commit_prepare */
 int vmn_ccpos_commit(vmn_ccpos* p, vmn_msg** commitment);         /* :344-396 */
 int vmn_ccpos_reply(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :462-485 */
 int vmn_ccpos_set_commitment(vmn_ccpos* p, const vmn_msg* commitment);

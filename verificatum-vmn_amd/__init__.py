@@ -318,7 +318,8 @@ class ModPGroup:
     def _from_bytetree(self, fn: str, cls, bt: bytes, expected_n: int):
         h = C.c_void_p()
         fmt, rng = C.c_int(0), C.c_int(1)
-        _check(getattr(lib(), fn)(self._h, bytes(bt), C.c_size_t(len(bt)), C.c_size_t(expected_n), C.byref(h),
+        blk = host_block(bt) or host_block(bytes(bt))      # bytes, or a host buffer object (pinned tensor): no copy
+        _check(getattr(lib(), fn)(self._h, blk[0], C.c_size_t(blk[1]), C.c_size_t(expected_n), C.byref(h),
                                    C.byref(fmt), C.byref(rng)))
         if not fmt.value:
             raise ValueError("EIOException: not a byte tree of %d-byte leaves" % self.nbytes)

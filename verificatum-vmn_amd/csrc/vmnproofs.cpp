@@ -516,8 +516,15 @@ struct vmn_pos : ProofBase {
         }
         return VMN_OK;
     }
-    int commit(vmn_msg** out) {
-        REQUIRE(out && prover && e.p && width, "commit needs a prover with instance and batching vector set");
+    // The part of commit() that does not depend on the batching vector: all its random draws (same order, same values)
+    // and F' = pk^(-phi) prod (w'_i)^(eps_i).  A caller that derives the batching vector by hashing the instance
+    // (PoSTW.java:118-130: ~1.5 GB of byte trees at N = 10^6) runs this while the hash is computed; commit() does it
+    // itself otherwise.
+    bool prepared = false;
+    Bytes Cp_, Dp_;
+    std::vector<Bytes> Fp_;
+    int commit_prepare() {
+        REQUIRE(prover && width && !prepared, "commit_prepare needs a prover with the instance set, once per proof");
         // randomness in the reference's order: b :583, beta :612, gamma :667, delta :673, phi :687
         TRY(draw_ring_array(N, b));
         TRY(draw_ring_array(N, beta));
@@ -525,6 +532,17 @@ struct vmn_pos : ProofBase {
         TRY(draw_ring_element(delta));
         phi.resize(width);
         for (auto& ph : phi) TRY(draw_ring_element(ph));
+        std::vector<Bytes> prods;
+        TRY(expprod_multi(wp, epsilon, eps_bits, prods));                         // :690
+        TRY(gexp(g, gamma, Cp_));                                                 // :667-679
+        TRY(gexp(g, delta, Dp_));
+        TRY(pk_side(pkey, phi, prods, Fp_));                                      // :687-690
+        prepared = true;
+        return VMN_OK;
+    }
+    int commit(vmn_msg** out) {
+        REQUIRE(out && prover && e.p && width, "commit needs a prover with instance and batching vector set");
+        if (!prepared) TRY(commit_prepare());
         TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :552-554
         Bytes h0(G.eb), dbytes(G.xb);
         TRY(vmn_garray_get(h, 0, h0.data()));
@@ -532,15 +550,10 @@ struct vmn_pos : ProofBase {
         TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dbytes.data()));                  // :583-598
         d = G.ring_from(dbytes.data());
         TRY(vmn_rarray_prods(ipe, y.out()));                                      // :600-604
-        std::vector<Bytes> prods;
-        TRY(expprod_multi(wp, epsilon, eps_bits, prods));                         // :690
         GA B, Bp;
         TRY(bridging_commitments(g, h0, x, y, beta, epsilon, B, Bp));             // :606-648 (queued)
-        Bytes Cp, Dp;
-        TRY(gexp(g, gamma, Cp));                                                  // :667-679
-        TRY(gexp(g, delta, Dp));
-        std::vector<Bytes> Fp;
-        TRY(pk_side(pkey, phi, prods, Fp));                                       // :687-690
+        const Bytes &Cp = Cp_, &Dp = Dp_;
+        const std::vector<Bytes>& Fp = Fp_;
         std::unique_ptr<vmn_msg> m(new vmn_msg());
         m->push(B);
         m->push_element(Ap);
@@ -704,8 +717,11 @@ struct vmn_posc : ProofBase {
         }
         return VMN_OK;
     }
-    int commit(vmn_msg** out) {
-        REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
+    // the part of commit() that does not depend on the batching vector (see vmn_pos::commit_prepare)
+    bool prepared = false;
+    Bytes Ap_, Cp_, Dp_;
+    int commit_prepare() {
+        REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
         // randomness in the reference's order: b, alpha, epsilon, beta, gamma, delta (PoSCBasicTW.java:400-500)
         TRY(draw_ring_array(N, b));
         TRY(draw_ring_element(alpha));
@@ -713,21 +729,28 @@ struct vmn_posc : ProofBase {
         TRY(draw_ring_array(N, beta));
         TRY(draw_ring_element(gamma));
         TRY(draw_ring_element(delta));
+        Bytes hp(G.eb), ga;
+        TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        TRY(gexp(g, alpha, ga));
+        TRY(G.el_mul(ga, hp, Ap_));
+        TRY(gexp(g, gamma, Cp_));
+        TRY(gexp(g, delta, Dp_));
+        prepared = true;
+        return VMN_OK;
+    }
+    int commit(vmn_msg** out) {
+        REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
+        if (!prepared) TRY(commit_prepare());
         TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));
-        Bytes h0(G.eb), dbytes(G.xb), hp(G.eb);
+        Bytes h0(G.eb), dbytes(G.xb);
         TRY(vmn_garray_get(h, 0, h0.data()));
         RA x, y;
         TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dbytes.data()));
         d = G.ring_from(dbytes.data());
         TRY(vmn_rarray_prods(ipe, y.out()));
-        TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
         GA B, Bp;
         TRY(bridging_commitments(g, h0, x, y, beta, epsilon, B, Bp));
-        Bytes ga, Ap, Cp, Dp;
-        TRY(gexp(g, alpha, ga));
-        TRY(G.el_mul(ga, hp, Ap));
-        TRY(gexp(g, gamma, Cp));
-        TRY(gexp(g, delta, Dp));
+        const Bytes &Ap = Ap_, &Cp = Cp_, &Dp = Dp_;
         std::unique_ptr<vmn_msg> m(new vmn_msg());
         m->push(B);
         m->push_element(Ap);
@@ -871,22 +894,35 @@ struct vmn_ccpos : ProofBase {
         }
         return VMN_OK;
     }
-    int commit(vmn_msg** out) {
-        REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
+    // the part of commit() that does not depend on the batching vector -- here all of its arithmetic: the two
+    // multi-exponentiations with epsilon (see vmn_pos::commit_prepare)
+    bool prepared = false;
+    Bytes Ap_;
+    std::vector<Bytes> Bp_;
+    int commit_prepare() {
+        REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
         TRY(draw_ring_element(alpha));                                            // :360-375
         TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
         beta.resize(width);
         for (auto& bt : beta) TRY(draw_ring_element(bt));
-        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :350
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
         std::vector<Bytes> eps_prods;
         TRY(expprod_multi(xs, epsilon, eps_bits, eps_prods));                     // :377, :391 — one sort of epsilon
-        Bytes ga, Ap;
+        Bytes ga;
         TRY(gexp(g, alpha, ga));
-        TRY(G.el_mul(ga, eps_prods[0], Ap));
-        std::vector<Bytes> prods(eps_prods.begin() + 1, eps_prods.end()), Bp;
-        TRY(pk_side(pkey, beta, prods, Bp));
+        TRY(G.el_mul(ga, eps_prods[0], Ap_));
+        std::vector<Bytes> prods(eps_prods.begin() + 1, eps_prods.end());
+        TRY(pk_side(pkey, beta, prods, Bp_));
+        prepared = true;
+        return VMN_OK;
+    }
+    int commit(vmn_msg** out) {
+        REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
+        if (!prepared) TRY(commit_prepare());
+        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :350
+        const Bytes& Ap = Ap_;
+        const std::vector<Bytes>& Bp = Bp_;
         std::unique_ptr<vmn_msg> m(new vmn_msg());
         m->push_element(Ap);
         m->push_bytes(VMN_ITEM_ELEMENTS, Bp);
@@ -1585,6 +1621,18 @@ int vmn_pos_set_batch_vector(vmn_pos* p, const uint8_t* e_be) {
 int vmn_pos_set_batch_vector_seed(vmn_pos* p, const uint8_t* seed, size_t seedlen) {
     NONNULL(p);
     return p->batch_vector_seed(seed, seedlen, p->e);
+}
+int vmn_pos_commit_prepare(vmn_pos* p) {
+    NONNULL(p);
+    return p->commit_prepare();
+}
+int vmn_posc_commit_prepare(vmn_posc* p) {
+    NONNULL(p);
+    return p->commit_prepare();
+}
+int vmn_ccpos_commit_prepare(vmn_ccpos* p) {
+    NONNULL(p);
+    return p->commit_prepare();
 }
 int vmn_pos_commit(vmn_pos* p, vmn_msg** commitment) {
     NONNULL(p);

@@ -144,13 +144,31 @@ class Message:
         _check(plib().vmn_msg_to_bytetree(self._h, out))
         return out.raw
 
+    def byteTreeSize(self) -> int:
+        return plib().vmn_msg_bytetree_size(self._h)
+
+    def toByteTreeInto(self, host_buffer) -> int:
+        """The byte tree written into a caller-owned host buffer (a pinned ``torch`` uint8 tensor / uint8 array): the
+        arrays inside are framed on the GPU and downloaded straight into it."""
+        blk = host_block(host_buffer)
+        size = self.byteTreeSize()
+        if blk is None or blk[1] < size:
+            raise ValueError("host buffer too small for the byte tree")
+        _check(plib().vmn_msg_to_bytetree(self._h, blk[0]))
+        return size
+
     @staticmethod
     def fromByteTree(group, bt: bytes, layout: Sequence[int], counts: Sequence[int]) -> Optional["Message"]:
         """None when the bytes are not a message of that layout (the caller substitutes trivial values)."""
         h, ok = C.c_void_p(), C.c_int(0)
         lay = (C.c_int * len(layout))(*layout)
         cnt = (C.c_size_t * len(counts))(*counts)
-        _check(plib().vmn_msg_from_bytetree(group._h, bytes(bt), C.c_size_t(len(bt)), lay, cnt, C.c_size_t(len(layout)),
+        if isinstance(bt, tuple):                      # (host buffer object, length): no copy (pinned: PCIe speed)
+            blk = host_block(bt[0])
+            ptr, length = blk[0], bt[1]
+        else:
+            ptr, length = bytes(bt), len(bt)
+        _check(plib().vmn_msg_from_bytetree(group._h, ptr, C.c_size_t(length), lay, cnt, C.c_size_t(len(layout)),
                                             C.byref(h), C.byref(ok)))
         return Message(group, h) if ok.value else None
 
@@ -273,6 +291,11 @@ class _NativeProof:
         b = _be(v)
         self._call("set_challenge", b, C.c_size_t(len(b)))
 
+    def commitPrepare(self):
+        """The part of ``commit()`` that does not depend on the batching vector (``vmn_*_commit_prepare``): run it while
+        the Fiat-Shamir seed is being hashed."""
+        self._call("commit_prepare")
+
     def _commit(self):
         h = C.c_void_p()
         self._call("commit", C.byref(h))
@@ -324,16 +347,24 @@ class PoSBasicTW(_NativeProof):
         self._call("compute_af")
 
     def setCommitment(self, msg):
-        self._com = self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
+        self._com = msg if isinstance(msg, Message) else self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
         self._call("set_commitment", self._com._h)
 
     def verify(self, reply) -> bool:
-        m = self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
+        m = reply if isinstance(reply, Message) else self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
         verdict = C.c_int(0)
         five = (C.c_int * 5)()
         self._call("verify", m._h, C.byref(verdict), five)
         self.verdicts = tuple(bool(x) for x in five)
         return bool(verdict.value)
+
+    def readCommitment(self, bt, n: int, width: int):
+        """``setCommitment(ByteTreeReader)`` (:780-823): parse the published byte tree (framing, range and subgroup
+        membership of every element, on the GPU); malformed input gives None -- the caller substitutes trivial values."""
+        return Message.fromByteTree(self.G, bt, self._com_kinds, [n, 1, n, 1, 1, 2 * width])
+
+    def readReply(self, bt, n: int, width: int):
+        return Message.fromByteTree(self.G, bt, self._rep_kinds, [1, n, 1, 1, n, width])
 
 
 class PoSCBasicTW(_NativeProof):
@@ -355,7 +386,7 @@ class PoSCBasicTW(_NativeProof):
         return self._commit()
 
     def setCommitment(self, msg):
-        self._com = self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
+        self._com = msg if isinstance(msg, Message) else self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
         self._call("set_commitment", self._com._h)
 
     def verify(self, reply) -> bool:
@@ -386,7 +417,7 @@ class CCPoSBasicW(_NativeProof):
         return self._commit()
 
     def setCommitment(self, msg):
-        self._com = self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
+        self._com = msg if isinstance(msg, Message) else self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
         self._call("set_commitment", self._com._h)
 
     def computeAB(self, raisedu=None):
