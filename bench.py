@@ -42,6 +42,52 @@ PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3
 HBM_PEAK_GBS = 8000.0
 
 
+def leg_roofline(fam: dict, wall_ms: float) -> dict:
+    """Roofline object of a proof leg from the work its kernels EXECUTED: the library counts, per launch, the
+    v_mad_u64_u32 multiply-adds its lanes perform (Montgomery products x 2 S^2, squarings, point additions as field
+    products; csrc/vmnhip.hip note_work) -- not SURVEY.md's canonical count, which prices a fixed-base exponentiation at
+    256 products where the radix-2^16 .. 2^19 tables need 108-128.  peak = the integer-VALU issue rate (one
+    multiply-add per lane per 4 cycles: 39.3 T/s); `frac` is against the wall clock of the leg (host gaps, HBM-bound
+    kernels and sorting included), `frac_kernel_time` against the summed kernel durations."""
+    mads = sum(v[2] for v in fam.values())
+    kernel_ms = sum(v[1] for v in fam.values())
+    by = {k: {"ms": round(v[1], 3), "T_mads": round(v[2] / 1e12, 4),
+              "frac": round(v[2] / (v[1] / 1e3) / 1e12 / PEAK_TMACS, 4) if v[1] > 0 else None}
+          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]) if v[2] > 0}
+    return {"bound": "valu-int", "unit": "T multiply-adds/s (v_mad_u64_u32 executed; 28-bit limbs)", "peak": PEAK_TMACS,
+            "executed_T_mads": mads / 1e12, "achieved": mads / (wall_ms / 1e3) / 1e12, "frac": mads / (wall_ms / 1e3) / 1e12 / PEAK_TMACS,
+            "kernel_ms": kernel_ms, "achieved_kernel_time": mads / (kernel_ms / 1e3) / 1e12 if kernel_ms else None,
+            "frac_kernel_time": mads / (kernel_ms / 1e3) / 1e12 / PEAK_TMACS if kernel_ms else None,
+            "by_family": by, "profiles": "profiles/r02_pmc_*.json (rocprofv3 --pmc passes of the dominant kernels)"}
+
+
+def source_fingerprint() -> str:
+    """sha256 (16 hex digits) over the kernel sources: PMC summaries under profiles/ carry the fingerprint of the build
+    they were measured on, and are used only when it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "verificatum-vmn_amd", "csrc")
+    for name in ("mont28.h", "modp_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
+        with open(os.path.join(base, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_valu_peak():
+    """T instr/s the hardware sustains for independent v_mad_u64_u32 at two waves per SIMD (tools/valu_rate.hip ->
+    profiles/valu_rate_r01.csv), or None when the file is missing."""
+    import csv
+    try:
+        best = None
+        with open(os.path.join(ROOT, "profiles", "valu_rate_r01.csv")) as f:
+            for row in csv.DictReader(f):
+                if row.get("instr", "").startswith("v_mad_u64_u32 indep") and row.get("waves_per_simd") == "2":
+                    best = float(row["Tlaneops_per_s"])
+        return best
+    except Exception:
+        return None
+
+
 def make_inputs(n: int, seed: int, nbytes: int):
     """n random bases (< 2^2047 < p) and exponents (2047-bit, < q) as big-endian bytes."""
     import numpy as np
@@ -218,7 +264,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
                "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
                "kernel_launches": sum(v[0] for v in fam.values()),
                "reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
-               "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok)}
+               "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "roofline": leg_roofline(fam, (t3 - t0) * 1e3)}
         if best is None or cur["total_ms"] < best["total_ms"]:
             best = cur
         for a in WP + S + [com["B"], com["Bp"], rep["k_B"], rep["k_E"], prover.u]:
@@ -239,7 +285,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
     best["fiat_shamir_host_ms"] = fs_ms
     best["fiat_shamir_bytes"] = fs_bytes
     # canonical cost, SURVEY.md §8d: ~3280 M(64) = 2.7e7 MAC per ciphertext (PoS path, n = 2048, width 1)
-    best["algorithmic_TMACs"] = 3280 * 8256 * n / (best["total_ms"] / 1e3) / 1e12
+    best["canonical_TMACs_survey_8d"] = 3280 * 8256 * n / (best["total_ms"] / 1e3) / 1e12      # NOT a roofline fraction: see `roofline`
     return best
 
 
@@ -372,7 +418,7 @@ def mix_prove_e2e(entry, vmn, ctx, grp, n: int, seed: int, sync):
            "verifier_phases_ms": {"seed_known": (t_vseed - t1) * 1e3, "verified": (t2 - t1) * 1e3},
            "hashed_bytes_per_party": hasher_p.bytes_hashed + com_n + 37,
            "instance_hash_thread_busy_ms": [hasher_p.busy_s * 1e3, hasher_v.busy_s * 1e3],
-           "gpu_kernel_ms": kernel_ms,
+           "gpu_kernel_ms": kernel_ms, "roofline": leg_roofline(fam, (t2 - t0) * 1e3),
            "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
     for a in WP + S + [U, H] + W:
         a.free()
@@ -469,7 +515,8 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
             "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
             "ciphertexts_per_s_online": n / online, "ciphertexts_per_s_total": n / (t4 - t0),
             # SURVEY.md §8d canonical cost: 1090 M(96) per ciphertext online (M(96) = 18528 MAC)
-            "algorithmic_TMACs_online": 1090 * 18528 * n / online / 1e12,
+            "canonical_TMACs_online_survey_8d": 1090 * 18528 * n / online / 1e12,      # NOT a roofline fraction: see `roofline`
+            "roofline": leg_roofline(fam, (t4 - t0) * 1e3),          # offline + online: the counters cover the whole pass
             "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
@@ -543,6 +590,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
             "n": n, "drivers": drivers, "accepted": bool(ok), "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3,
             "ccpos_prove_ms": (t3 - t2) * 1e3, "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
             "ciphertexts_per_s_online": n / online,
+            "roofline": leg_roofline(fam, (t4 - t0) * 1e3),
             "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
@@ -613,7 +661,7 @@ def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dis
             "precompute_and_reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
             "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "n": n,
             "ciphertexts_per_s": n / (t3 - t0),
-            "algorithmic_TMACs": 3280 * 8256 * n / (t3 - t0) / 1e12}
+            "canonical_TMACs_survey_8d": 3280 * 8256 * n / (t3 - t0) / 1e12, "roofline": leg_roofline(fam, (t3 - t0) * 1e3)}
 
 
 def cpu_mix_prove(p, q, g, n: int, cores: int):
@@ -666,12 +714,13 @@ def main() -> None:
     ap.add_argument("--cpu-sample-elements", dest="cpu_sample", type=int, default=0, help="elements of the CPU baseline sample (0 = auto)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--mix-elements", dest="mix_n", type=int, default=1_000_000, help="ciphertexts of the mix+prove leg (0 = skip)")
-    ap.add_argument("--ec-elements", dest="ec_n", type=int, default=400_000,
+    ap.add_argument("--ec-elements", dest="ec_n", type=int, default=1_000_000,
                     help="ciphertexts of the P-256 width-3 leg (BASELINE configs[4]; 0 = skip; single GPU only)")
     ap.add_argument("--drivers", choices=["native", "python"], default="native",
                     help="proof drivers of the mix legs: the C++ drivers behind include/vmnproofs.h, or their Python mirror")
-    ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=400_000,
+    ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=1_000_000,
                     help="ciphertexts of the 3072-bit CCPoS leg (BASELINE configs[2]; 0 = skip; single GPU only)")
+    ap.add_argument("--no-e2e", dest="no_e2e", action="store_true", help="skip the end-to-end pass of the mix + prove leg (profiling runs)")
     args = ap.parse_args()
 
     # Build (only if a prebuilt library is missing) BEFORE anything touches the GPU: a process that has
@@ -761,14 +810,23 @@ def main() -> None:
     valu_busy = None
     pmc_instr = None
     n_launch = n
+    pmc_file = "profiles/r02_pmc_kernels.json"
+    pmc_note = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_modpow_v11.json")) as f:
-            pmc = json.load(f)
-        traffic = pmc["hbm_bytes_per_element"] * n
-        valu_busy = pmc["valu_busy_frac"]
-        pmc_instr = pmc["valu_instr_per_element_lane"]
-    except Exception:
-        pass
+        with open(os.path.join(ROOT, pmc_file)) as f:
+            pmc_all = json.load(f)
+        if pmc_all.get("source_fingerprint") != source_fingerprint():
+            pmc_note = (f"{pmc_file} was measured on another build of the kernels (fingerprint {pmc_all.get('source_fingerprint')} != "
+                        f"{source_fingerprint()}): its counters are not used; rerun tools/profile_pmc.sh")
+            print("bench.py: " + pmc_note, file=sys.stderr)
+        else:
+            pmc = pmc_all["kernels"]["k_modpow<vmn::Cfg<74, 1>"]
+            traffic = pmc["hbm_bytes_per_unit"] * n
+            valu_busy = pmc["valu_busy_frac"]
+            pmc_instr = pmc["valu_instr_per_unit"]
+    except Exception as exc:
+        pmc_note = f"{pmc_file} not usable ({type(exc).__name__}: {exc})"
+        print("bench.py: " + pmc_note, file=sys.stderr)
 
     result = {
         "metric": "modexps/sec (batched variable-base modPow, 2048-bit ModPGroup, full-length exponents)",
@@ -789,11 +847,11 @@ def main() -> None:
         "roofline": {"bound": "valu-int", "kernel": "k_modpow<74>", "achieved": achieved, "peak": PEAK_TMACS,
                      "unit": "TMAC/s (32x32->64-bit multiply-accumulate)", "frac": achieved / PEAK_TMACS,
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
-                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_modpow_v11.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per element x n)",
+                     "traffic": traffic, "traffic_source": pmc_note or f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build, bytes per element x n)",
                      "valu_busy_pmc": valu_busy,
                      # what the hardware sustains for v_mad_u64_u32 at this kernel's two waves per SIMD
                      # (profiles/valu_rate_r01.txt), and the kernel's issue rate from the PMC instruction count
-                     "peak_measured": 33.1,
+                     "peak_measured": measured_valu_peak(), "peak_measured_source": "profiles/valu_rate_r01.csv: independent v_mad_u64_u32, two waves per SIMD",
                      "issued_Tlaneinstr_per_s": (pmc_instr * n_launch / avg_kernel_s / 1e12) if pmc_instr else None,
                      "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                              "achieved_GBs": alg_bytes / avg_kernel_s / 1e9, "peak_GBs": HBM_PEAK_GBS}},
@@ -821,7 +879,7 @@ def main() -> None:
             mp["ciphertexts_per_s"] = mp["n"] / (mp["total_ms"] / 1e3)
         else:
             mp = mix_prove(entry, vmn, ctx, grp, args.mix_n, 777 + rank, barrier, steps=2, drivers=args.drivers)
-        if not distributed:
+        if not distributed and not args.no_e2e:
             try:
                 runs = [mix_prove_e2e(entry, vmn, ctx, grp, args.mix_n, 4321 + k, barrier) for k in range(2)]
                 mp["end_to_end"] = min(runs, key=lambda r: r["total_ms"])
@@ -872,6 +930,7 @@ def main() -> None:
                                   "bit_exact_vs_gpu": got == want}
         if got != want:
             result["parity_error"] = "GPU output differs from the GMP oracle on the sample"
+            result["value"] = None                         # a wrong result has no throughput
         if "mix_prove" in result and "error" not in result["mix_prove"] and not distributed:
             try:
                 result["mix_prove"]["cpu_baseline"] = cpu_mix_prove(p, q, g, 3000, cores)
@@ -881,6 +940,9 @@ def main() -> None:
         print(json.dumps(result))
     if distributed:
         dist.destroy_process_group()
+    if "parity_error" in result:
+        print("bench.py: " + result["parity_error"], file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

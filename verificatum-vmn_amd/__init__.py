@@ -172,13 +172,13 @@ class Context:
         _check(lib().vmn_ctx_timing_reset(self._h))
 
     def timing_report(self) -> dict:
-        """{family: (launches, total_ms)} of every kernel family since the last reset."""
-        buf = C.create_string_buffer(8192)
+        """{family: (launches, total_ms, executed multiply-adds)} of every kernel family since the last reset."""
+        buf = C.create_string_buffer(16384)
         _check(lib().vmn_ctx_timing_report(self._h, buf, C.c_size_t(len(buf))))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            out[name] = (int(cnt), float(ms))
+            name, cnt, ms, mads = line.split()
+            out[name] = (int(cnt), float(ms), float(mads))       # mads: v_mad_u64_u32 multiply-adds executed (work accounting)
         return out
 
     def timing_get(self, family: str):

@@ -83,10 +83,12 @@ static int launch(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), un
     TimingRec rec;
     if (ctx->timing) {
         rec.family = family;
+        rec.mads = ctx->next_mads;
         VMN_HIP(hipEventCreate(&rec.start));
         VMN_HIP(hipEventCreate(&rec.stop));
         VMN_HIP(hipEventRecord(rec.start, ctx->stream));
     }
+    ctx->next_mads = 0;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, ctx->stream, static_cast<KArgs>(args)...);
     VMN_HIP(hipGetLastError());
     if (ctx->timing) {
@@ -95,6 +97,20 @@ static int launch(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), un
     }
     return VMN_OK;
 }
+
+// Work accounting for the roofline of the proof legs (bench.py): the number of v_mad_u64_u32 multiply-adds the NEXT
+// launch executes, from the number of Montgomery products / squarings its lanes perform.  A product of S limbs is 2 S^2
+// multiply-adds (multiplication + reduction half); a squaring S^2 (reduction) + S (S + SQR_BLK) / 2 (block-symmetric
+// multiplication half) in the one-lane geometry and a full product in the multi-lane ones.  Curve points: field products
+// (S = 10 / 15), 16 per addition (11M + 5S), 8 per doubling (3M + 5S).  Only recorded while timing is on.
+static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double squarings = 0) {
+    if (!ctx->timing) return 0;
+    const double S = m.ec ? (double)m.ec->S : (double)m.S;
+    const double sq = (m.ec || m.LPE > 1) ? 2 * S * S : S * S + S * (S + SQR_BLK) / 2;
+    ctx->next_mads = products * 2 * S * S + squarings * sq;
+    return 0;                                   // (an int so that a launch inside a macro can be written  note_work(..) ? 0 : launch(..))
+}
+static const double EC_ADD = 16, EC_DBL = 8;
 
 static unsigned light_grid(vmn_ctx* ctx, size_t work_items) {
     size_t blocks = (work_items + BLOCK - 1) / BLOCK;
@@ -108,10 +124,12 @@ static int launch_light(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs..
     TimingRec rec;
     if (ctx->timing) {
         rec.family = family;
+        rec.mads = ctx->next_mads;
         VMN_HIP(hipEventCreate(&rec.start));
         VMN_HIP(hipEventCreate(&rec.stop));
         VMN_HIP(hipEventRecord(rec.start, ctx->stream));
     }
+    ctx->next_mads = 0;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, static_cast<KArgs>(args)...);
     VMN_HIP(hipGetLastError());
     if (ctx->timing) {
@@ -388,6 +406,7 @@ static int timing_collect(vmn_ctx* ctx) {
         auto& acc = ctx->timing_acc[r.family];
         acc.first += 1;
         acc.second += ms;
+        ctx->work_acc[r.family] += r.mads;
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
@@ -406,6 +425,7 @@ extern "C" int vmn_ctx_timing_reset(vmn_ctx* ctx) {
     std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_TRY(timing_collect(ctx));
     ctx->timing_acc.clear();
+    ctx->work_acc.clear();
     return VMN_OK;
 }
 extern "C" int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launches, double* total_ms) {
@@ -425,7 +445,7 @@ extern "C" int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len) {
     std::string out;
     for (auto& kv : ctx->timing_acc) {
         char line[160];
-        snprintf(line, sizeof(line), "%s %ld %.4f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        snprintf(line, sizeof(line), "%s %ld %.4f %.6e\n", kv.first.c_str(), kv.second.first, kv.second.second, ctx->work_acc[kv.first]);
         out += line;
     }
     size_t k = std::min(out.size(), len - 1);
@@ -824,6 +844,7 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     VMN_TRY(raw.alloc(n * stride + 8));
     VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
     VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    note_work(ctx, m, (m.ec ? 7.0 : 1.0) * (double)n);
     int rc = VMN_ERR_ARG;
     if (m.ec) {
 #define X(S_, NW_)                                                                                                   \
@@ -859,6 +880,7 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     const size_t stride = m.ec ? 2 * nbytes : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
+    note_work(ctx, m, m.ec ? 8.0 * (double)n : (double)n, m.ec ? (double)m.nbits * (double)n : 0.0);     // curves: one Fermat inversion per point
     int rc = VMN_ERR_ARG;
     if (m.ec) {
 #define X(S_, NW_)                                                                                               \
@@ -924,6 +946,7 @@ static void free_one(vmn_ctx* ctx, const vmn_modulus& m, uint32_t* d) { pool_fre
 static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, size_t ystride, size_t n,
                       uint32_t* out) {
     if (n == 0) return VMN_OK;
+    note_work(ctx, m, (m.ec ? EC_ADD : 1.0) * (double)n);
     int rc = VMN_ERR_ARG;
     if (m.ec) {
 #define X(S_, NW_) \
@@ -942,6 +965,7 @@ static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, con
 // M28 residues -> packed words (n * NW words)
 static int to_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* in, size_t n, uint32_t* out_words) {
     if (n == 0) return VMN_OK;
+    note_work(ctx, m, (double)n);
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = launch(ctx, "to_words", k_to_words<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), out_words, in, n, m.d_n, m.n0inv);
@@ -974,6 +998,7 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, c
         unsigned grid = std::min<unsigned>(grid_for(n), (unsigned)(ctx->num_cus * 2));
         size_t tab_bytes = (size_t)grid * BLOCK * ((size_t)1 << wb) * elem_words(m) * sizeof(uint32_t);
         VMN_TRY(ensure_scratch(ctx, tab_bytes));
+        note_work(ctx, m, (double)n * (EC_DBL * ebits + EC_ADD * ((ebits + wb - 1) / wb + (1 << wb))));
         int rc = VMN_ERR_ARG;
 #define X(S_, NW_)                                                                                                  \
     if (m.ec->S == S_)                                                                                              \
@@ -988,6 +1013,10 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, c
     unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
     size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);
     VMN_TRY(ensure_scratch(ctx, tab_bytes));
+    {
+        const int nwin = (ebits + wbits - 1) / wbits;
+        note_work(ctx, m, (double)n * (nwin - 1 + (1 << wbits) - 2), (double)n * (nwin - 1) * wbits);
+    }
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
@@ -1439,6 +1468,7 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
     size_t cur = len;
     while (true) {
         uint32_t* dst = (L == 1) ? d_out : ping;
+        if (mul || m.ec) note_work(ctx, m, (m.ec ? EC_ADD : 1.0) * (double)nseg * (double)(cur - L));
         int rc = VMN_ERR_ARG;
         if (m.ec) {
 #define X(S_, NW_) \
@@ -1504,6 +1534,7 @@ extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y
 static int ring_elementwise(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, const uint32_t* v,
                             int op, size_t n, uint32_t* out) {
     if (n == 0) return VMN_OK;
+    if (op >= 2) note_work(ctx, m, (double)n);
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), out, x, y, v, op, n, m.d_n, m.n0inv);
@@ -1608,7 +1639,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
         if (seglen <= Cc) {
 #define X(S_, NW_)                                                                                                 \
     if (m.ec->S == S_)                                                                                             \
-        rc = launch_light(ctx, "scan", k_ec_scan_apply<S_>, grid_for(nchunks), out, e, (const uint32_t*)nullptr, n, \
+        rc = note_work(ctx, m, EC_ADD * (double)n) ? 0 : launch_light(ctx, "scan", k_ec_scan_apply<S_>, grid_for(nchunks), out, e, (const uint32_t*)nullptr, n, \
                           Cc, seglen, rev, ecdev(m.ec));
             VMN_FOR_CURVES(X)
 #undef X
@@ -1619,7 +1650,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
         uint32_t* Etot = tot.as<uint32_t>();
         uint32_t* inc = Etot + nchunks * Wd;
 #define X(S_, NW_) \
-    if (m.ec->S == S_) rc = launch_light(ctx, "scan", k_ec_scan_totals<S_>, grid_for(nchunks), Etot, e, n, Cc, seglen, rev, ecdev(m.ec));
+    if (m.ec->S == S_) rc = note_work(ctx, m, EC_ADD * (double)n) ? 0 : launch_light(ctx, "scan", k_ec_scan_totals<S_>, grid_for(nchunks), Etot, e, n, Cc, seglen, rev, ecdev(m.ec));
         VMN_FOR_CURVES(X)
 #undef X
         VMN_TRY(rc);
@@ -1628,7 +1659,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
         rc = VMN_ERR_ARG;
 #define X(S_, NW_)                                                                                                       \
     if (m.ec->S == S_)                                                                                                   \
-        rc = launch_light(ctx, "scan", k_ec_scan_apply<S_>, grid_for(nchunks), out, e, (const uint32_t*)inc, n, Cc, seglen, \
+        rc = note_work(ctx, m, EC_ADD * (double)n) ? 0 : launch_light(ctx, "scan", k_ec_scan_apply<S_>, grid_for(nchunks), out, e, (const uint32_t*)inc, n, Cc, seglen, \
                           rev, ecdev(m.ec));
         VMN_FOR_CURVES(X)
 #undef X
@@ -1646,7 +1677,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
         size_t nchunks = (n + Cs - 1) / Cs;
 #define X(S_, NW_, LPE_)                                                                                                        \
     if (m.S == S_)                                                                                                        \
-        rc = launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)nullptr, \
+        rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)nullptr, \
                     n, Cs, seglen, rev, m.d_n, m.n0inv, m.d_one);
         VMN_FOR_SIZES(X)
 #undef X
@@ -1661,10 +1692,10 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
-        rc = launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, false>, egrid(m, nchunks), lds_bytes(m), Etot, e, b, n, C, seglen,  \
+        rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, false>, egrid(m, nchunks), lds_bytes(m), Etot, e, b, n, C, seglen,  \
                     rev, m.d_n, m.n0inv, m.d_one);                                                                      \
         if (rc == VMN_OK && b)                                                                                          \
-            rc = launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, true>, egrid(m, nchunks), lds_bytes(m), Xtot, e, b, n, C,       \
+            rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, true>, egrid(m, nchunks), lds_bytes(m), Xtot, e, b, n, C,       \
                         seglen, rev, m.d_n, m.n0inv, m.d_one);                                                          \
     }
     VMN_FOR_SIZES(X)
@@ -1676,7 +1707,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                  \
     if (m.S == S_)                                                                                                  \
-        rc = launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)inc, n, \
+        rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)inc, n, \
                     C, seglen, rev, m.d_n, m.n0inv, m.d_one);
     VMN_FOR_SIZES(X)
 #undef X
@@ -2146,7 +2177,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         for (int l = 1; l < w && rc == VMN_OK; ++l) {
             size_t lanes = (((size_t)1 << l) - 1) * nwin;
 #define X(S_, NW_) \
-    if (m.ec->S == S_) rc = launch_light(ctx, "fixed_table", k_ec_fixed_level<S_>, grid_for(lanes), ft.d_tab, w, nwin, l, ecdev(m.ec));
+    if (m.ec->S == S_) rc = note_work(ctx, m, EC_ADD * (double)lanes) ? 0 : launch_light(ctx, "fixed_table", k_ec_fixed_level<S_>, grid_for(lanes), ft.d_tab, w, nwin, l, ecdev(m.ec));
             VMN_FOR_CURVES(X)
 #undef X
         }
@@ -2193,7 +2224,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     for (int l = 1; l < w && rc == VMN_OK; ++l) {
         size_t lanes = (((size_t)1 << l) - 1) * nwin;
 #define X(S_, NW_, LPE_) \
-    if (m.S == S_) rc = launch(ctx, "fixed_table", k_fixed_level<Cfg<S_, LPE_>>, egrid(m, lanes), lds_bytes(m), ft.d_tab, w, nwin, l, m.d_n, m.n0inv);
+    if (m.S == S_) rc = note_work(ctx, m, (double)lanes) ? 0 : launch(ctx, "fixed_table", k_fixed_level<Cfg<S_, LPE_>>, egrid(m, lanes), lds_bytes(m), ft.d_tab, w, nwin, l, m.d_n, m.n0inv);
         VMN_FOR_SIZES(X)
 #undef X
     }
@@ -2247,14 +2278,14 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
         if (m.ec) {
 #define X(S_, NW_)                                                                                                   \
     if (m.ec->S == S_)                                                                                               \
-        rc = launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+        rc = note_work(ctx, m, EC_ADD * (double)n * (ft->nwin - 1)) ? 0 : launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                           ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, ecdev(m.ec));
             VMN_FOR_CURVES(X)
 #undef X
         } else {
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
-        rc = launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+        rc = note_work(ctx, m, (double)n * (ft->nwin - 1)) ? 0 : launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                     ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, m.d_n, m.n0inv);
         VMN_FOR_SIZES(X)
 #undef X
@@ -2380,11 +2411,13 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
             level_cache.emplace_back(hm2[0], hm2[1]);
         }
         const size_t total_out = hm2[0];
+        const double level_in = level == 0 ? (double)nwin * (double)n : (double)level_cache[level - 1].first;
+        const double level_products = std::max(0.0, level_in - (double)total_out);
         if (total_out > 0 && m.ec) {
             rc = VMN_ERR_ARG;
 #define X(S_, NW_)                                                                                                     \
     if (m.ec->S == S_) {                                                                                               \
-        rc = first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, grid_for(total_out), items_out, items_in, \
+        rc = note_work(ctx, m, EC_ADD * level_products) ? 0 : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, grid_for(total_out), items_out, items_in, \
                                   (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out,    \
                                   nbuckets, total_out, F, ecdev(m.ec))                                                 \
                    : launch_light(ctx, "expprod", k_ec_bucket_level<S_, false>, grid_for(total_out), items_out,        \
@@ -2398,7 +2431,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
             rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
-        rc = first ? launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, true>, egrid(m, total_out), lds_bytes(m), items_out,    \
+        rc = note_work(ctx, m, level_products) ? 0 : first ? launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, true>, egrid(m, total_out), lds_bytes(m), items_out,    \
                             items_in, (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out, \
                             nbuckets, total_out, F, m.d_n, m.n0inv)                                                     \
                    : launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, false>, egrid(m, total_out), lds_bytes(m), items_out,   \

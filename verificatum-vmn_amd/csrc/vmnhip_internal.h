@@ -47,6 +47,7 @@ vmn_ctx* lane_of(vmn_ctx* c);
 struct TimingRec {
     std::string family;
     hipEvent_t start, stop;
+    double mads = 0;           // v_mad_u64_u32 multiply-adds the launch executes (products x 2 S^2 ...), noted by the launch site
 };
 
 }  // namespace vmn
@@ -79,6 +80,8 @@ struct vmn_ctx {
     bool timing = false;
     std::vector<vmn::TimingRec> recs;
     std::map<std::string, std::pair<long, double>> timing_acc;
+    std::map<std::string, double> work_acc;    // executed multiply-adds per kernel family (while timing is on)
+    double next_mads = 0;                      // set by note_work() just before a launch, consumed by it
 };
 
 // Elliptic-curve group data (ECqPGroup): field constants on the device, see ec_kernels.h.
