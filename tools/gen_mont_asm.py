@@ -151,8 +151,9 @@ def gen(S: int) -> str:
 PAIR_P0, PAIR_PT, PAIR_C = 2, 4, 6      # v[2:3] column 0, v[4:5] column L-1, v[6:7] c
 
 
-def _row_pair(L: int, first: bool, lanes: int = 2):
-    """lanes = 2: the pair row described above.  lanes = 4 (moduli > 3080 bits): lane h = lane & 3 holds columns
+def _row_pair(L: int, first: bool, lanes: int = 2, j0: int = 0, blk: int = 0):
+    """blk > 0: SQUARING row of the block of local rows [j0, j0 + blk) -- see the note below the function.
+    lanes = 2: the pair row described above.  lanes = 4 (moduli > 3080 bits): lane h = lane & 3 holds columns
     [h*L, (h+1)*L); m is taken from lane 0 of the quad (quad_perm [0,0,0,0]); every lane hands its c to the lane
     below (quad_perm [1,2,3,3]; the top lane receives the fresh zero); only lane 0 carries c >> 28 into its new
     column 0.  Two masks: LOW = all ones on lane 0 of the element, NOTTOP = all ones on every lane but the last."""
@@ -164,6 +165,8 @@ def _row_pair(L: int, first: bool, lanes: int = 2):
     NI = f"%{3 * L + 3}"                  # n0inv (SGPR)
     EM = f"%{3 * L + 4}"                  # LOW mask: 0xffffffff on lane 0 of the element (pair: the even lane)
     NT = f"%{3 * L + 5}"                  # NOTTOP mask: 0xffffffff on all lanes but the last (pair: the even lane)
+    B2 = f"%{3 * L + 6}"                  # 2*b (squaring rows only)
+    sqr = blk > 0
     bcast = "[0,0,2,2]" if lanes == 2 else "[0,0,0,0]"
     from_above = "[1,1,3,3]" if lanes == 2 else "[1,2,3,3]"
     C = f"%{L + 1}"
@@ -175,7 +178,10 @@ def _row_pair(L: int, first: bool, lanes: int = 2):
         if j in emitted or j >= L:
             return
         emitted.add(j)
-        out.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {B}, " + ("0" if first else P(j)))
+        if sqr and j < j0:
+            return                                    # no product for this local column in this block of rows
+        mult = B2 if (sqr and j >= j0 + blk) else B
+        out.append(f"v_mad_u64_u32 {P(j)}, vcc, {A(j)}, {mult}, " + ("0" if first else P(j)))
 
     ab(0)
     ab(1)
@@ -206,6 +212,59 @@ def _row_pair(L: int, first: bool, lanes: int = 2):
     out.append(f"v_and_b32 v{PAIR_C + 1}, {EM}, v{PAIR_C + 1}")
     out.append(f"v_lshl_add_u64 {P(0)}, {P(0)}, 0, {C}")
     return out
+
+
+# Squaring with several lanes per element.  Lane h holds the limbs a_h = a[hL .. (h+1)L) (contiguous shares), so
+#     a^2 = sum_h a_h^2 B^(2hL)  +  2 sum_{u<h} a_u a_h B^((u+h)L),          B = 2^28.
+# The rows are the general ones (row i: every lane multiplies its own limbs by b = a_i from LDS, local columns, the
+# cross-lane shift of the reduction), but the SAME local columns are skipped on every lane, which is what saves time
+# in a wave: with i' = i mod L the row's local index and J0 the first row of its block of SQR_BLK rows, every lane
+#     skips its local columns j < J0,  multiplies the columns J0 <= j < J0 + SQR_BLK by b,  the later ones by 2b.
+# Why this is a^2: take row i = uL + i' (the multiplier limb belongs to share u) on lane h.
+#   h == u  the symmetric rule of the one-lane squaring: a_j a_i' is formed once, doubled, when j is in a later block;
+#           twice, plain, inside the block (rows i' and j); the square a_i'^2 once.
+#   h != u  the lane forms the cross products a_h[j] * a_u[i'], column (h + u)L + j + i'.  The same pair is also within
+#           reach of lane u in row hL + j (its limb a_u[i'] times b = a_h[j]).  Splitting the pairs by blocks of the local
+#           indices -- block(j) > block(i'): here, doubled; block(j) < block(i'): there, doubled; same block: both, plain
+#           -- forms every cross product exactly twice, and is the very same rule.
+# Per lane a squaring is LPE * (L^2 / 2 + L * SQR_BLK / 2) products instead of LPE * L^2.  Column bound: a column lives
+# S rows and receives one product per row -- none, plain (< 2^56) or doubled (< 2^57), about half of each -- plus one
+# m * N < 2^56: S * 2^57 + LPE * SQR_BLK * 2^56 < 2^64 for S = 110; S = 148 is relieved half way (mont28.h).
+def gen_pair_sqr(S: int, lanes: int) -> str:
+    L = S // lanes
+    parts = []
+    variants = [(True, 0)] + [(False, j0) for j0 in range(0, L, SQR_BLK)]
+    for first, j0 in variants:
+        lines = _row_pair(L, first, lanes, j0, SQR_BLK)
+        o = []
+        if first:
+            o.append(f"template <> __device__ __forceinline__ void mont_lanes_sqr_row_asm_first<{L}, {lanes}>(u64 (&P)[{L}], const u32 (&a)[{L}], u32 b, u32 b2,\n"
+                     f"        const u32 (&n)[{L}], u32 n0inv, u32 lowmask, u32 nottopmask) {{")
+        else:
+            o.append(f"template <> __device__ __forceinline__ void mont_lanes_sqr_row_asm<{L}, {lanes}, {j0}>(u64 (&P)[{L}], const u32 (&a)[{L}], u32 b, u32 b2,\n"
+                     f"        const u32 (&n)[{L}], u32 n0inv, u32 lowmask, u32 nottopmask) {{")
+        o.append("    u32 m; u64 c;")
+        o.append("    asm volatile(")
+        for l in lines:
+            o.append(f'        "{l}\\n\\t"')
+
+        def cons(j):
+            pre = "=&" if first else "+"
+            if j == 0:
+                return pre + "{v[%d:%d]}" % (PAIR_P0, PAIR_P0 + 1)
+            if j == L - 1:
+                return pre + "{v[%d:%d]}" % (PAIR_PT, PAIR_PT + 1)
+            return pre + "v"
+        outs = ", ".join([f'"{cons(j)}"(P[{j}])' for j in range(L)] + ['"=&v"(m)', '"=&{v[%d:%d]}"(c)' % (PAIR_C, PAIR_C + 1)])
+        ins = ", ".join([f'"v"(a[{j}])' for j in range(L)] + ['"v"(b)'] + [f'"v"(n[{j}])' for j in range(L)]
+                        + ['"s"(n0inv)', '"v"(lowmask)', '"v"(nottopmask)', '"v"(b2)'])
+        o.append(f"        : {outs}")
+        o.append(f"        : {ins}")
+        o.append('        : "vcc");')
+        o.append("}")
+        o.append("")
+        parts.append("\n".join(o))
+    return "\n".join(parts)
 
 
 def gen_pair(S: int, lanes: int = 2) -> str:
@@ -250,9 +309,11 @@ def render(sizes, pair_sizes=(), quad_sizes=()) -> str:
     for S in pair_sizes:
         parts.append(f"// two lanes per element, S = {S} limbs ({S // 2} per lane)")
         parts.append(gen_pair(S))
+        parts.append(gen_pair_sqr(S, 2))
     for S in quad_sizes:
         parts.append(f"// four lanes per element, S = {S} limbs ({S // 4} per lane)")
         parts.append(gen_pair(S, 4))
+        parts.append(gen_pair_sqr(S, 4))
     return "\n".join(parts) + "\n"
 
 

@@ -261,7 +261,7 @@ __device__ __forceinline__ void mont_sqr(u32 (&r)[C::L], const u32 (&a)[C::L], c
     if constexpr (C::LPE == 1) {
         mont_sqr_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
     } else {
-        mont_mul_columns_lanes<C::L, C::LPE>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);   // general product
+        mont_sqr_columns_lanes<C::L, C::LPE>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);
     }
     normalize<C>(r, T, ln);
 }

@@ -58,6 +58,9 @@ template <int S, int J0> __device__ __forceinline__ void mont_sqr_row_asm(u64 (&
 // element, nottopmask = all ones on every lane of the element but the last.
 template <int L, int LPE> __device__ __forceinline__ void mont_lanes_row_asm_first(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask);
 template <int L, int LPE> __device__ __forceinline__ void mont_lanes_row_asm_next(u64 (&P)[L], const u32 (&a)[L], u32 b, const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask);
+// Squaring rows of the multi-lane geometries (see the generator: every lane skips the same LOCAL columns).
+template <int L, int LPE> __device__ __forceinline__ void mont_lanes_sqr_row_asm_first(u64 (&P)[L], const u32 (&a)[L], u32 b, u32 b2, const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask);
+template <int L, int LPE, int J0> __device__ __forceinline__ void mont_lanes_sqr_row_asm(u64 (&P)[L], const u32 (&a)[L], u32 b, u32 b2, const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask);
 #include "gen/mont_rows.inc"
 
 // T (S lazy columns, value < 2N when a, b < 2N and R > 4N) = a * b / R mod N.
@@ -154,6 +157,40 @@ __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&
             bn = b_lds[(i < S ? i : 0) * bstride];
             mont_lanes_row_asm_next<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
         }
+    }
+}
+
+// Multi-lane squaring: T = a^2 / R mod N with every cross product formed once.  The rows whose multiplier limb belongs
+// to share u (rows uL .. uL + L - 1) run the block pattern of their LOCAL index on every lane (gen_mont_asm.py,
+// gen_pair_sqr): per lane LPE * (L^2 / 2 + 4 L) products instead of LPE * L^2.  a_lds holds a copy of a.
+template <int L, int LPE, int J0>
+__device__ __forceinline__ void mont_sqr_lanes_share(u64 (&T)[L], const u32 (&a)[L], const u32* a_lds, int bstride, const u32 (&n)[L],
+                                                     u32 n0inv, u32 lowmask, u32 nottopmask, u32& bn, int base, int skip_first) {
+    constexpr int S = LPE * L;
+    constexpr int END = J0 + SQR_BLK < L ? J0 + SQR_BLK : L;
+#pragma unroll 2
+    for (int ip = (J0 == 0 ? skip_first : J0); ip < END; ++ip) {
+        const int i = base + ip;
+        u32 bi = bn;
+        bn = a_lds[(i + 1 < S ? i + 1 : 0) * bstride];            // prefetch the next row's limb under this row
+        mont_lanes_sqr_row_asm<L, LPE, J0>(T, a, bi, bi << 1, n, n0inv, lowmask, nottopmask);
+    }
+    if constexpr (END < L) mont_sqr_lanes_share<L, LPE, END>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, base, skip_first);
+}
+template <int L, int LPE>
+__device__ __forceinline__ void mont_sqr_columns_lanes(u64 (&T)[L], const u32 (&a)[L], const u32* a_lds, int bstride,
+                                                       const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask) {
+    constexpr int S = LPE * L;
+    static_assert(S <= 256, "one relief is not enough beyond 256 limbs");
+    u32 b0 = a_lds[0];
+    u32 bn = a_lds[bstride];
+    mont_lanes_sqr_row_asm_first<L, LPE>(T, a, b0, b0 << 1, n, n0inv, lowmask, nottopmask);
+#pragma unroll 1
+    for (int u = 0; u < LPE; ++u) {
+        if constexpr (2 * S > 256) {
+            if (u == LPE / 2) relieve_columns<L, LPE>(T, lowmask, nottopmask);      // half way, as in the general product
+        }
+        mont_sqr_lanes_share<L, LPE, 0>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, u * L, u == 0 ? 1 : 0);
     }
 }
 
