@@ -168,7 +168,7 @@ __device__ __forceinline__ void mont_sqr_lanes_share(u64 (&T)[L], const u32 (&a)
                                                      u32 n0inv, u32 lowmask, u32 nottopmask, u32& bn, int base, int skip_first) {
     constexpr int S = LPE * L;
     constexpr int END = J0 + SQR_BLK < L ? J0 + SQR_BLK : L;
-#pragma unroll 2
+#pragma unroll 8
     for (int ip = (J0 == 0 ? skip_first : J0); ip < END; ++ip) {
         const int i = base + ip;
         u32 bi = bn;
