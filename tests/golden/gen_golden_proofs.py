@@ -185,7 +185,116 @@ def proof_records():
     return {"modp512": {"p": hx(p), "q": hx((p - 1) // 2), "g": "4"}, "records": recs}
 
 
+def config_records():
+    """Transcripts on the BASELINE.json configurations' own groups (tests/golden/proofs_configs.json):
+      configs[2]  3072-bit ModPGroup (RFC 3526 group 15), width 1: permutation commitment precomputed for N_max = 8,
+                  PoSC on it, shrink to N = 6 (keep list, PermutationCommitment.java:390-471), re-encryption, CCPoS with the
+                  plain and the raised verifier (CCPoSBasicW.java:493-506, 571-580);
+      configs[4]  ECqPGroup P-256, width 3: PoS and CCPoS.
+    Group-generic restatement (oracle/pyref_proofs.py GPoS / GCCPoS, PoSC over integers)."""
+    NV, NE, NR = 256, 256, 100
+    recs = []
+    # ---- configs[2]
+    p, q, g = pyref.modp_group(3072)
+    K = P.ModPAdapter(p, q)
+    n_max, n = 8, 6
+    t = Tape(b"golden-cfg2", q)
+    h = K.exp_fixed(g, t.ring_array(n_max))
+    y = K.exp(g, t.ring_element())
+    pkey = [g, y]
+    w = [K.exp_fixed(g, t.ring_array(n)) for _ in range(2)]
+    pi, r, rho = t.permutation(n_max), t.ring_array(n_max), t.int_array(1, 50)[0]
+    e_max, v1 = t.int_array(n_max, NE), t.int_array(1, NV)[0]
+    u = P.permutation_commitment(g, h, r, pi, p)
+    oc = P.PoSC(p, q, NV, NE, NR, rand=Tape(b"golden-cfg2-posc", q))
+    oc.setInstance(g, h, u, r, pi)
+    oc.setBatchVector(e_max)
+    com1, rep1 = oc.commit(), oc.reply(v1)
+    vc = P.PoSC(p, q, NV, NE, NR)
+    vc.setInstance(g, h, u)
+    vc.setBatchVector(e_max)
+    vc.setCommitment(com1)
+    assert vc.verify(rep1, v1)
+    keep, pi_s = P.shrink_permutation(pi, n)
+    u_s = P.extract(u, keep)
+    assert u_s == P.permutation_commitment(g, h[:n], r[:n], pi_s, p)
+    s = [t.ring_array(n)]
+    e, v2 = t.int_array(n, NE), t.int_array(1, NV)[0]
+    wp = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi_s)
+    cc = P.GCCPoS(K, NV, NE, NR, rand=Tape(b"golden-cfg2-ccpos", q))
+    cc.setInstance(g, h[:n], u_s, pkey, w, wp, r[:n], pi_s, s)
+    cc.setBatchVector(e)
+    com2, rep2 = cc.commit(), cc.reply(v2)
+    for raised in (False, True):
+        cv = P.GCCPoS(K, NV, NE, NR)
+        cv.setInstance(g, h[:n], u_s, pkey, w, wp)
+        cv.setBatchVector(e)
+        cv.setCommitment(com2)
+        if raised:
+            cv.computeAB(K.exp_scalar(u_s, rho))
+            assert cv.verify(rep2, v2, K.exp_scalar(h[:n], rho), rho)
+        else:
+            cv.computeAB()
+            assert cv.verify(rep2, v2)
+    L = lambda xs: list(map(hx, xs))
+    recs.append({"config": 2, "group": "modp3072", "width": 1, "nbits": [NV, NE, NR], "n_max": n_max, "n": n, "g": hx(g), "h": L(h),
+                 "pkey": L(pkey), "w": [L(c) for c in w], "wp": [L(c) for c in wp], "pi": pi, "r": L(r), "rho": hx(rho), "u": L(u),
+                 "e_max": L(e_max), "v_posc": hx(v1), "tape_posc": "golden-cfg2-posc", "posc_commitment": enc_msg(com1, hx),
+                 "posc_reply": enc_msg(rep1, hx), "keep": [int(k) for k in keep], "pi_shrunk": pi_s, "u_shrunk": L(u_s),
+                 "s": [L(c) for c in s], "e": L(e), "v": hx(v2), "tape_ccpos": "golden-cfg2-ccpos", "ccpos_commitment": enc_msg(com2, hx),
+                 "ccpos_reply": enc_msg(rep2, hx), "verdict": True})
+    # ---- configs[4]
+    c = Curve("P-256")
+    K = P.ECAdapter(c)
+    q, g = c.n, c.g
+    n, width = 8, 3
+    t = Tape(b"golden-cfg4", q)
+    h = K.exp_fixed(g, t.ring_array(n))
+    y = K.exp(g, t.ring_element())
+    pkey = [g] * width + [y] * width
+    w = [K.exp_fixed(g, t.ring_array(n)) for _ in range(2 * width)]
+    pi, r = t.permutation(n), t.ring_array(n)
+    s = [t.ring_array(n) for _ in range(width)]
+    e, v = t.int_array(n, NE), t.int_array(1, NV)[0]
+    wp = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    o = P.GPoS(K, NV, NE, NR, rand=Tape(b"golden-cfg4-pos", q))
+    o.precompute(g, h, pi)
+    o.setInstance(pkey, w, wp, s)
+    o.setBatchVector(e)
+    com, rep = o.commit(), o.reply(v)
+    ov = P.GPoS(K, NV, NE, NR)
+    ov.precompute(g, h)
+    ov.u = o.u
+    ov.setInstance(pkey, w, wp)
+    ov.setBatchVector(e)
+    ov.computeAF()
+    ov.setCommitment(com)
+    assert ov.verify(rep, v)
+    u = P.g_permutation_commitment(K, g, h, r, pi)
+    cc = P.GCCPoS(K, NV, NE, NR, rand=Tape(b"golden-cfg4-ccpos", q))
+    cc.setInstance(g, h, u, pkey, w, wp, r, pi, s)
+    cc.setBatchVector(e)
+    com2, rep2 = cc.commit(), cc.reply(v)
+    cv = P.GCCPoS(K, NV, NE, NR)
+    cv.setInstance(g, h, u, pkey, w, wp)
+    cv.setBatchVector(e)
+    cv.setCommitment(com2)
+    cv.computeAB()
+    assert cv.verify(rep2, v)
+    recs.append({"config": 4, "group": "P-256", "width": width, "nbits": [NV, NE, NR], "n": n, "g": pt(g), "h": pts(h), "pkey": pts(pkey),
+                 "w": [pts(col) for col in w], "wp": [pts(col) for col in wp], "pi": pi, "s": [L(col) for col in s], "r": L(r),
+                 "e": L(e), "v": hx(v), "tape_pos": "golden-cfg4-pos", "pos_u": pts(o.u), "pos_commitment": enc_msg(com, pt),
+                 "pos_reply": enc_msg(rep, pt), "u": pts(u), "tape_ccpos": "golden-cfg4-ccpos", "ccpos_commitment": enc_msg(com2, pt),
+                 "ccpos_reply": enc_msg(rep2, pt), "verdict": True})
+    return {"records": recs}
+
+
 def main():
+    rec = config_records()
+    path = os.path.join(HERE, "proofs_configs.json")
+    with open(path, "w") as f:
+        json.dump(rec, f, separators=(",", ":"))
+    print(path, len(rec["records"]), "records", os.path.getsize(path), "bytes")
     for name, fname in (("P-256", "ec_p256.json"), ("P-384", "ec_p384.json")):
         rec = ec_cases(name, [1, 2, 9, 64] if name == "P-256" else [1, 7, 33])
         path = os.path.join(HERE, fname)
