@@ -1,0 +1,120 @@
+/* vmnjni_rs.c -- see vmnjni_rs.h.  Plain C; needs a JDK's jni.h (not available where this repository is developed). */
+#include "vmnjni_rs.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct vmn_jrs {
+    JavaVM* vm;
+    jobject bridge;                 /* global reference */
+    jmethodID ring, ints, seed;
+    jbyteArray rows;                /* global reference to the rows handed out last, pinned through rows_ptr */
+    jbyte* rows_ptr;
+    void* owner;
+    struct vmn_jrs* next;           /* owner table */
+};
+
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static struct vmn_jrs* g_owned = NULL;
+
+static JNIEnv* env_of(struct vmn_jrs* h) {
+    JNIEnv* env = NULL;
+    if ((*h->vm)->GetEnv(h->vm, (void**)&env, JNI_VERSION_1_6) != JNI_OK) return NULL;   /* callbacks come on a Java thread */
+    return env;
+}
+static void drop_rows(JNIEnv* env, struct vmn_jrs* h) {
+    if (h->rows) {
+        (*env)->ReleaseByteArrayElements(env, h->rows, h->rows_ptr, JNI_ABORT);
+        (*env)->DeleteGlobalRef(env, h->rows);
+        h->rows = NULL;
+        h->rows_ptr = NULL;
+    }
+}
+/* keep `arr` (n rows) alive and pinned; returns 0 on success */
+static int hand_over(JNIEnv* env, struct vmn_jrs* h, jbyteArray arr, const uint8_t** rows) {
+    if ((*env)->ExceptionCheck(env) || !arr) return 1;          /* the Java exception stays pending and surfaces in the caller */
+    drop_rows(env, h);
+    h->rows = (jbyteArray)(*env)->NewGlobalRef(env, arr);
+    (*env)->DeleteLocalRef(env, arr);
+    if (!h->rows) return 1;
+    h->rows_ptr = (*env)->GetByteArrayElements(env, h->rows, NULL);
+    if (!h->rows_ptr) return 1;
+    *rows = (const uint8_t*)h->rows_ptr;
+    return 0;
+}
+static int cb_ring(void* user, size_t n, const uint8_t** rows) {
+    struct vmn_jrs* h = (struct vmn_jrs*)user;
+    JNIEnv* env = env_of(h);
+    if (!env) return 1;
+    return hand_over(env, h, (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->ring, (jlong)n), rows);
+}
+static int cb_ints(void* user, size_t n, int bits, const uint8_t** rows) {
+    struct vmn_jrs* h = (struct vmn_jrs*)user;
+    JNIEnv* env = env_of(h);
+    if (!env) return 1;
+    return hand_over(env, h, (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->ints, (jlong)n, (jint)bits), rows);
+}
+static int cb_seed(void* user, uint8_t seed_out[32]) {
+    struct vmn_jrs* h = (struct vmn_jrs*)user;
+    JNIEnv* env = env_of(h);
+    if (!env) return 1;
+    jbyteArray arr = (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->seed);
+    if ((*env)->ExceptionCheck(env) || !arr || (*env)->GetArrayLength(env, arr) != 32) return 1;
+    (*env)->GetByteArrayRegion(env, arr, 0, 32, (jbyte*)seed_out);
+    (*env)->DeleteLocalRef(env, arr);
+    return 0;
+}
+
+vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge) {
+    struct vmn_jrs* h = (struct vmn_jrs*)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    jclass c = (*env)->GetObjectClass(env, bridge);
+    h->ring = (*env)->GetMethodID(env, c, "ringElements", "(J)[B");
+    h->ints = (*env)->GetMethodID(env, c, "integers", "(JI)[B");
+    h->seed = (*env)->GetMethodID(env, c, "arraySeed", "()[B");
+    if (!h->ring || !h->ints || !h->seed || (*env)->GetJavaVM(env, &h->vm) != JNI_OK) {
+        free(h);
+        return NULL;
+    }
+    h->bridge = (*env)->NewGlobalRef(env, bridge);
+    /* does this source offer seeds?  RandomSourceBridge.deviceArrays() says so without drawing randomness */
+    jmethodID dev = (*env)->GetMethodID(env, c, "deviceArrays", "()Z");
+    if (dev && !(*env)->CallBooleanMethod(env, bridge, dev)) h->seed = NULL;
+    return h;
+}
+void vmn_jrs_fill(vmn_jrs* h, vmn_random_source* out) {
+    out->user = h;
+    out->ring_elements = cb_ring;
+    out->integers = cb_ints;
+    out->array_seed = h->seed ? cb_seed : NULL;
+}
+void vmn_jrs_free(JNIEnv* env, vmn_jrs* h) {
+    if (!h) return;
+    drop_rows(env, h);
+    if (h->bridge) (*env)->DeleteGlobalRef(env, h->bridge);
+    free(h);
+}
+void vmn_jrs_set_owner(vmn_jrs* h, void* owner) {
+    h->owner = owner;
+    pthread_mutex_lock(&g_mu);
+    h->next = g_owned;
+    g_owned = h;
+    pthread_mutex_unlock(&g_mu);
+}
+void vmn_jrs_release_owner(void* owner) {
+    struct vmn_jrs* found = NULL;
+    pthread_mutex_lock(&g_mu);
+    for (struct vmn_jrs** pp = &g_owned; *pp; pp = &(*pp)->next) {
+        if ((*pp)->owner == owner) {
+            found = *pp;
+            *pp = found->next;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+    if (found) {
+        JNIEnv* env = env_of(found);
+        if (env) vmn_jrs_free(env, found);
+    }
+}

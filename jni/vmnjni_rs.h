@@ -1,0 +1,21 @@
+/* vmnjni_rs.h -- bridge from vmn_random_source (include/vmnproofs.h) to a Java object implementing
+ * com.verificatum.vmnhip.RandomSourceBridge:
+ *     byte[] ringElements(long n)          n rows of exp_bytes, big-endian, each < q
+ *     byte[] integers(long n, int bits)    n rows of exp_bytes holding `bits`-bit integers (as field elements)
+ *     byte[] arraySeed()                   32 bytes for one device-expanded array draw, or null: host rows for arrays too
+ * The callbacks run on the thread that called into the library (the party's protocol thread), so the JNIEnv of that
+ * call is used.  Rows handed to the library stay pinned until the next callback or until the bridge is freed, as the C
+ * ABI requires.  A proof object created with a bridge owns it: the table below maps the object's handle to the bridge,
+ * and the object's _free wrapper releases it. */
+#ifndef VMNJNI_RS_H
+#define VMNJNI_RS_H
+#include <jni.h>
+#include "../include/vmnproofs.h"
+
+typedef struct vmn_jrs vmn_jrs;
+vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge);
+void vmn_jrs_fill(vmn_jrs* h, vmn_random_source* out);
+void vmn_jrs_free(JNIEnv* env, vmn_jrs* h);
+void vmn_jrs_set_owner(vmn_jrs* h, void* owner);       /* owner = the proof object created with this source */
+void vmn_jrs_release_owner(void* owner);               /* called by the owner's _free wrapper (no-op for verifiers) */
+#endif
