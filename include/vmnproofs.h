@@ -98,11 +98,43 @@ int vmn_msg_to_bytetree(const vmn_msg* m, uint8_t* out);
 int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const int* layout, const size_t* counts,
                           size_t items, vmn_msg** out, int* format_ok);
 
+/* ---- one proof over several GPUs (BASELINE.json configs[3], [4]) ---------------------------------------
+ * One process per GPU.  Every rank creates the same proof object, sets the same communicator (its own rank), and makes
+ * the SAME calls in the same order with random sources that return the SAME values on every rank (one party owns all
+ * ranks: it seeds them alike).  Position-indexed arrays are split into contiguous shards (vmn_shard_bounds); each rank
+ * computes and keeps its shard of u, w', B, B', k_B, k_E.  Arguments:
+ *   h                       always the WHOLE array, replicated on every rank (provers read it through the permutation;
+ *                           its size is the size of the proof);
+ *   u, w, w', r, s, raised  the whole array or this rank's shard -- told apart by their size;
+ *   pi                      the whole permutation table;
+ *   messages                scalars are identical on every rank, array items are this rank's shard.
+ * The batching vector and the prover's N-sized random arrays are generated in full on every rank (a PRG pass), so
+ * permuted reads are local gathers and no element crosses a link; the exchanges are fixed-size all-gathers of scalars:
+ * partial products of expProd / prod, partial sums, scan carries, each shard's last B, verdict bits -- at most one per
+ * phase and a few hundred bytes per rank ("all-reduce" of north_star: modular multiplication is not a reduction operator
+ * of RCCL, so it is all-gather + local multiplication).
+ * all_gather: every rank contributes `bytes` bytes; recv receives world * bytes in rank order; 0 on success. */
+typedef struct vmn_comm {
+    void* user;
+    int rank, world;
+    int (*all_gather)(void* user, const uint8_t* send, size_t bytes, uint8_t* recv);
+} vmn_comm;
+/* shard k of n positions over `world` ranks: [lo, hi), sizes differ by at most one (possibly empty) */
+void vmn_shard_bounds(size_t n, int world, int rank, size_t* lo, size_t* hi);
+/* this rank's positions of the shuffler's two arrays, gathered out of the whole inputs (no exchange):
+ * w'[lo, hi) of permute(w * pk^s, pi^-1) and u[lo, hi) of permute(h * g^r, pi). */
+int vmn_shuffle_reencrypt_shard(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w_full,
+                                const vmn_rarray* const* s_full, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** wp_out);
+int vmn_permutation_commitment_shard(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_rarray* r_full,
+                                     const uint32_t* pi, size_t lo, size_t hi, vmn_garray** u_out);
+
 /* ---- PoSBasicTW --------------------------------------------------------------------------------------------- */
 typedef struct vmn_pos vmn_pos;
 /* rs = NULL for a verifier.  ref: constructor PoSBasicTW.java:300-330 (vbitlen, ebitlen, rbitlen). */
 int vmn_pos_create(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, vmn_pos** out);
 void vmn_pos_free(vmn_pos* p);                                    /* free() :1088-1101 */
+/* sharded proof: before precompute (see vmn_comm above) */
+int vmn_pos_set_comm(vmn_pos* p, const vmn_comm* comm);
 /* prover (pi != NULL, :436-482): draws r, computes u = permute(h g^r, pi), alpha, epsilon, A'.
  * verifier (pi == NULL, :394-402): records g, h. */
 int vmn_pos_precompute(vmn_pos* p, const uint8_t* g_be, const vmn_garray* h, const uint32_t* pi);
@@ -133,6 +165,7 @@ int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts
 typedef struct vmn_posc vmn_posc;
 int vmn_posc_create(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, vmn_posc** out);
 void vmn_posc_free(vmn_posc* p);
+int vmn_posc_set_comm(vmn_posc* p, const vmn_comm* comm);          /* before set_instance */
 /* setInstance :306-340; r, pi = NULL for a verifier */
 int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u,
                           const vmn_rarray* r, const uint32_t* pi);
@@ -149,6 +182,7 @@ int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict);           
 typedef struct vmn_ccpos vmn_ccpos;
 int vmn_ccpos_create(vmn_group* grp, int vbitlen, int ebitlen, int rbitlen, const vmn_random_source* rs, vmn_ccpos** out);
 void vmn_ccpos_free(vmn_ccpos* p);
+int vmn_ccpos_set_comm(vmn_ccpos* p, const vmn_comm* comm);        /* before set_instance */
 /* setInstance :290-330; r, pi, s = NULL for a verifier */
 int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u,
                            const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,

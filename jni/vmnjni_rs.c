@@ -102,7 +102,76 @@ void vmn_jrs_set_owner(vmn_jrs* h, void* owner) {
     g_owned = h;
     pthread_mutex_unlock(&g_mu);
 }
+struct vmn_jcomm {
+    JavaVM* vm;
+    jobject bridge;
+    jmethodID gather;
+    int rank, world;
+    void* owner;
+    struct vmn_jcomm* next;
+};
+static struct vmn_jcomm* g_comms = NULL;
+
+static int cb_gather(void* user, const uint8_t* send, size_t bytes, uint8_t* recv) {
+    struct vmn_jcomm* h = (struct vmn_jcomm*)user;
+    JNIEnv* env = NULL;
+    if ((*h->vm)->GetEnv(h->vm, (void**)&env, JNI_VERSION_1_6) != JNI_OK) return 1;
+    jbyteArray mine = (*env)->NewByteArray(env, (jsize)bytes);
+    if (!mine) return 1;
+    (*env)->SetByteArrayRegion(env, mine, 0, (jsize)bytes, (const jbyte*)send);
+    jbyteArray all = (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->gather, mine);
+    (*env)->DeleteLocalRef(env, mine);
+    if ((*env)->ExceptionCheck(env) || !all || (size_t)(*env)->GetArrayLength(env, all) != bytes * (size_t)h->world) return 1;
+    (*env)->GetByteArrayRegion(env, all, 0, (jsize)(bytes * (size_t)h->world), (jbyte*)recv);
+    (*env)->DeleteLocalRef(env, all);
+    return 0;
+}
+vmn_jcomm* vmn_jcomm_new(JNIEnv* env, jobject bridge, void* owner) {
+    struct vmn_jcomm* h = (struct vmn_jcomm*)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    jclass c = (*env)->GetObjectClass(env, bridge);
+    jmethodID rank = (*env)->GetMethodID(env, c, "rank", "()I"), world = (*env)->GetMethodID(env, c, "world", "()I");
+    h->gather = (*env)->GetMethodID(env, c, "allGather", "([B)[B");
+    if (!rank || !world || !h->gather || (*env)->GetJavaVM(env, &h->vm) != JNI_OK) {
+        free(h);
+        return NULL;
+    }
+    h->rank = (*env)->CallIntMethod(env, bridge, rank);
+    h->world = (*env)->CallIntMethod(env, bridge, world);
+    h->bridge = (*env)->NewGlobalRef(env, bridge);
+    h->owner = owner;
+    pthread_mutex_lock(&g_mu);
+    h->next = g_comms;
+    g_comms = h;
+    pthread_mutex_unlock(&g_mu);
+    return h;
+}
+void vmn_jcomm_fill(vmn_jcomm* h, vmn_comm* out) {
+    out->user = h;
+    out->rank = h->rank;
+    out->world = h->world;
+    out->all_gather = cb_gather;
+}
+static void release_comms(void* owner) {
+    struct vmn_jcomm* found = NULL;
+    pthread_mutex_lock(&g_mu);
+    for (struct vmn_jcomm** pp = &g_comms; *pp; pp = &(*pp)->next) {
+        if ((*pp)->owner == owner) {
+            found = *pp;
+            *pp = found->next;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+    if (found) {
+        JNIEnv* env = NULL;
+        if ((*found->vm)->GetEnv(found->vm, (void**)&env, JNI_VERSION_1_6) == JNI_OK) (*env)->DeleteGlobalRef(env, found->bridge);
+        free(found);
+    }
+}
+
 void vmn_jrs_release_owner(void* owner) {
+    release_comms(owner);
     struct vmn_jrs* found = NULL;
     pthread_mutex_lock(&g_mu);
     for (struct vmn_jrs** pp = &g_owned; *pp; pp = &(*pp)->next) {

@@ -17,5 +17,13 @@ vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge);
 void vmn_jrs_fill(vmn_jrs* h, vmn_random_source* out);
 void vmn_jrs_free(JNIEnv* env, vmn_jrs* h);
 void vmn_jrs_set_owner(vmn_jrs* h, void* owner);       /* owner = the proof object created with this source */
-void vmn_jrs_release_owner(void* owner);               /* called by the owner's _free wrapper (no-op for verifiers) */
+void vmn_jrs_release_owner(void* owner);               /* called by the owner's _free wrapper (no-op for verifiers): random
+                                                          source AND communicator bridges of that object */
+
+/* vmn_comm over a Java object implementing com.verificatum.vmnhip.CommBridge:
+ *     int rank(); int world(); byte[] allGather(byte[] mine)     (world * mine.length bytes, in rank order)
+ * owned by the proof object it was set on (vmn_*_set_comm) and released with it. */
+typedef struct vmn_jcomm vmn_jcomm;
+vmn_jcomm* vmn_jcomm_new(JNIEnv* env, jobject bridge, void* owner);
+void vmn_jcomm_fill(vmn_jcomm* h, vmn_comm* out);
 #endif

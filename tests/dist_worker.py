@@ -1,6 +1,9 @@
 """Worker of the multi-process tests: runs the sharded proof of a shuffle on this rank and, on rank 0,
 checks the gathered transcript against the single-process oracle.  Backend "fake" = integer arrays on
-the CPU (gloo); backend "hip" = the real library on this rank's GPU (nccl)."""
+the CPU (gloo) under the Python mirror of the sharded drivers; backend "hip..." = the real library on this rank's GPU
+under the sharded C++ drivers (vmn_*_set_comm), or -- with "-mirror" -- under the Python mirror.
+
+argv: backend bits n width out_path [flow]      flow = pos (default) | ccpos | posc"""
 import importlib.util
 import json
 import os
@@ -27,8 +30,143 @@ def load_parallel():
     return m
 
 
+def load_native():
+    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.native", os.path.join(entry.PKG_DIR, "native.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def gather_and_check(dist, rank, world, mine, expect, out_path):
+    """All ranks' shards to rank 0; compare with the oracle's transcript."""
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        checks = {}
+        for key, want in expect["arrays"].items():
+            checks[key] = [x for gsh in gathered for x in gsh["arrays"][key]] == want
+        checks["scalars"] = all(gsh["scalars"] == expect["scalars"] for gsh in gathered)
+        for key, want in expect["flags"].items():
+            checks[key] = all(gsh["flags"][key] == want for gsh in gathered)
+        with open(out_path, "w") as f:
+            json.dump({"pass": all(checks.values()), "why": json.dumps(checks), "world": world,
+                       "exchanges": [gsh.get("exchanges") for gsh in gathered]}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
+
+
+def flow_ccpos_or_posc(flow, native, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, t, q, n, width, bits3, out_path):
+    """CCPoS (plain + raised) or PoSC on a permutation commitment, sharded; transcript vs the oracle."""
+    NV, NE, NR = bits3
+    pi, r, s = t.permutation(n), t.ring_array(n), [t.ring_array(n) for _ in range(width)]
+    e, v, rho = t.int_array(n, NE), t.int_array(1, NV)[0], t.int_array(1, 50)[0]
+    u = P.g_permutation_commitment(K, g, h, r, pi)
+    wp = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    lo, hi = par.shard_bounds(n, world, rank)
+    H, W = G.toElementArray(h), [G.toElementArray(c) for c in w]
+    R, S = G.ringArray(r), [G.ringArray(c) for c in s]
+    ints = lambda a: a.toInts() if hasattr(a, "toInts") else a
+    if native:
+        ncomm = nat.NativeComm(comm)
+        U = nat.permutation_commitment_shard_native(G, g, H, R, pi, lo, hi)          # this rank's shard, from the whole h and r
+        WP = nat.reencrypt_shard_native(G, pkey, W, S, pi, lo, hi)
+    else:
+        ncomm = None
+        U = G.toElementArray(u[lo:hi])
+        WP = [G.toElementArray(c[lo:hi]) for c in wp]
+    arrays = {"u": ints(U)}
+    for c in range(2 * width):
+        arrays["wp%d" % c] = ints(WP[c])
+    expect = {"arrays": {"u": u}, "flags": {}}
+    for c in range(2 * width):
+        expect["arrays"]["wp%d" % c] = wp[c]
+    if flow == "posc":
+        if K.__class__.__name__ != "ModPAdapter":
+            raise SystemExit("the PoSC oracle is integer-only")
+        o = P.PoSC(K.p, q, NV, NE, NR, rand=Tape(b"prover", q))
+        o.setInstance(g, h, u, r, pi)
+        o.setBatchVector(e)
+        com_o, rep_o = o.commit(), o.reply(v)
+        pr = nat.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"prover", q))
+        pr.setComm(ncomm)
+        pr.setInstance(g, H, U, R, pi)
+        pr.setBatchVector(e)
+        com, rep = pr.commit(), pr.reply(v)
+        ver = nat.PoSCBasicTW(G, NV, NE, NR)
+        ver.setComm(ncomm)
+        ver.setInstance(g, H, U)
+        ver.setBatchVector(e)
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        ok = ver.verify(rep)
+        bad = dict(rep)
+        if rank == world - 1 and hi > lo:
+            kb = rep["k_B"].toInts()
+            kb[-1] = (kb[-1] + 1) % q
+            bad["k_B"] = G.ringArray(kb)
+        bad_ok = ver.verify(bad)
+        arrays.update({"B": ints(com["B"]), "Bp": ints(com["Bp"]), "k_B": ints(rep["k_B"]), "k_E": ints(rep["k_E"])})
+        expect["arrays"].update({"B": com_o["B"], "Bp": com_o["Bp"], "k_B": rep_o["k_B"], "k_E": rep_o["k_E"]})
+        scal = [com["Ap"], com["Cp"], com["Dp"], rep["k_A"], rep["k_C"], rep["k_D"]]
+        expect["scalars"] = [com_o["Ap"], com_o["Cp"], com_o["Dp"], rep_o["k_A"], rep_o["k_C"], rep_o["k_D"]]
+        expect["flags"] = {"ok": True, "bad_ok": False}
+        mine = {"arrays": arrays, "scalars": scal, "flags": {"ok": ok, "bad_ok": bad_ok}, "exchanges": ncomm.exchanges}
+        gather_and_check(dist, rank, world, mine, expect, out_path)
+    oc = P.GCCPoS(K, NV, NE, NR, rand=Tape(b"prover", q))
+    oc.setInstance(g, h, u, pkey, w, wp, r, pi, s)
+    oc.setBatchVector(e)
+    com_o, rep_o = oc.commit(), oc.reply(v)
+    if native:
+        pr = nat.CCPoSBasicW(G, NV, NE, NR, rand=Tape(b"prover", q))
+        pr.setComm(ncomm)
+        mk = lambda: nat.CCPoSBasicW(G, NV, NE, NR)
+    else:
+        pr = par.ShardedCCPoSBasicW(G, NV, NE, NR, comm, rand=Tape(b"prover", q))
+        mk = lambda: par.ShardedCCPoSBasicW(G, NV, NE, NR, comm)
+    pr.setInstance(g, H, U, pkey, W, WP, R, pi, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    flags = {}
+    RU_full = G.toElementArray(K.exp_scalar(u, rho))              # raised arrays handed over whole: the drivers cut their shard
+    RH_full = G.toElementArray(K.exp_scalar(h, rho))
+    for raised in (False, True):
+        ver = mk()
+        if native:
+            ver.setComm(ncomm)
+        ver.setInstance(g, H, U, pkey, W, WP)
+        ver.setBatchVector(e)
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        bad = dict(rep)
+        if rank == 0 and hi > lo:
+            ke = ints(rep["k_E"])
+            ke[0] = (ke[0] + 1) % q
+            bad["k_E"] = G.ringArray(ke)
+        if raised:
+            ver.computeAB(RU_full)
+            flags["ok_raised"] = ver.verify(rep, RH_full, rho)
+            flags["bad_raised"] = ver.verify(bad, RH_full, rho)
+        else:
+            ver.computeAB()
+            flags["ok_plain"] = ver.verify(rep)
+            flags["bad_plain"] = ver.verify(bad)
+    arrays["k_E"] = ints(rep["k_E"])
+    expect["arrays"]["k_E"] = rep_o["k_E"]
+    expect["scalars"] = [com_o["Ap"], com_o["Bp"], rep_o["k_A"], rep_o["k_B"]]
+    expect["flags"] = {"ok_plain": True, "bad_plain": False, "ok_raised": True, "bad_raised": False}
+    mine = {"arrays": arrays, "scalars": [com["Ap"], com["Bp"], rep["k_A"], rep["k_B"]], "flags": flags,
+            "exchanges": ncomm.exchanges if ncomm else None}
+    gather_and_check(dist, rank, world, mine, expect, out_path)
+
+
 def main():
     backend, bits, n, width, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    flow = sys.argv[6] if len(sys.argv) > 6 else "pos"
+    mirror = backend.endswith("-mirror")
+    if mirror:
+        backend = backend[: -len("-mirror")]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
@@ -42,6 +180,8 @@ def main():
     par = load_parallel()
     comm = par.Comm(dist, device)
     ec = backend.endswith("-ec")
+    native = backend.startswith("hip") and not mirror
+    nat = load_native() if native else None
     if ec:
         from oracle.pyref_ec import Curve
         curve = Curve("P-256")
@@ -76,17 +216,33 @@ def main():
     else:
         from fake_backend import FakeGroup
         G = FakeGroup(p, q, g)
+    if flow != "pos":
+        t2 = Tape(b"dist-%s%d" % (flow.encode(), bits), q)
+        flow_ccpos_or_posc(flow, native, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, t2, q, n, width, (NV, NE, NR), out_path)
     H = G.toElementArray(h)
     W = [G.toElementArray(c) for c in w]
 
-    pr = par.ShardedPoSBasicTW(G, NV, NE, NR, comm, rand=Tape(b"prover", q))
-    pr.precompute(g, H, pi)
-    WP = pr.reencrypt(pkey, W, s)
-    pr.setInstance(pkey, W, WP)
+    if native:
+        ncomm = nat.NativeComm(comm)
+        lo, hi = par.shard_bounds(n, world, rank)
+        assert (lo, hi) == nat.shard_bounds_native(n, world, rank)
+        S = [G.ringArray(c) for c in s]
+        pr = nat.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prover", q))
+        pr.setComm(ncomm)
+        pr.precompute(g, H, pi)
+        WP = nat.reencrypt_shard_native(G, pkey, W, S, pi, lo, hi)
+        pr.setInstance(pkey, W, WP, S)                 # w, s: whole arrays, w': this rank's shard
+        ver = nat.PoSBasicTW(G, NV, NE, NR)
+        ver.setComm(ncomm)
+    else:
+        pr = par.ShardedPoSBasicTW(G, NV, NE, NR, comm, rand=Tape(b"prover", q))
+        pr.precompute(g, H, pi)
+        WP = pr.reencrypt(pkey, W, s)
+        pr.setInstance(pkey, W, WP)
+        ver = par.ShardedPoSBasicTW(G, NV, NE, NR, comm)
     pr.setBatchVector(e)
     com = pr.commit()
     rep = pr.reply(v)
-    ver = par.ShardedPoSBasicTW(G, NV, NE, NR, comm)
     ver.precompute(g, H)
     ver.setPermutationCommitment(pr.u)
     ver.setInstance(pkey, W, WP)

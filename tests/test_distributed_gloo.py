@@ -20,11 +20,11 @@ def free_port():
     return port
 
 
-def run_world(world, backend, bits, n, width, tmp_path, timeout=600):
-    out = tmp_path / f"dist_{backend}_{world}_{n}.json"
+def run_world(world, backend, bits, n, width, tmp_path, timeout=600, flow="pos"):
+    out = tmp_path / f"dist_{backend}_{flow}_{world}_{n}.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), backend, str(bits), str(n), str(width), str(out)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), backend, str(bits), str(n), str(width), str(out), flow]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, env=env)
     assert proc.returncode == 0, proc.stdout.decode()[-3000:]
@@ -83,15 +83,44 @@ def test_more_ranks_than_elements(tmp_path):
     assert res["pass"], res["why"]
 
 
+@pytest.mark.parametrize("world,n,width,backend", [(2, 13, 1, "fake"), (3, 8, 2, "fake"), (3, 2, 1, "fake"), (2, 6, 3, "fake-ec")])
+def test_sharded_ccpos_matches_oracle_on_gloo(world, n, width, backend, tmp_path):
+    """BASELINE configs[4] is a CCPoS over P-256 at width 3 on 8 GPUs: the sharded commitment-consistent proof, plain and
+    raised verifier, ragged and empty shards included, against the single-process oracle."""
+    res = run_world(world, backend, 512 if backend == "fake" else 256, n, width, tmp_path, flow="ccpos")
+    assert res["pass"], res["why"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flow,backend,bits,n,width", [("pos", "hip-gloo", 2048, 150, 1), ("ccpos", "hip-gloo", 2048, 90, 2),
+                                                       ("posc", "hip-gloo", 512, 77, 1), ("ccpos", "hip-gloo-ec", 256, 40, 3),
+                                                       ("pos", "hip-gloo-ec", 256, 60, 1)])
+def test_sharded_cxx_drivers_two_ranks_one_gpu(flow, backend, bits, n, width, tmp_path):
+    """The sharded C++ drivers (vmn_pos / vmn_posc / vmn_ccpos with a communicator, include/vmnproofs.h) on the real
+    kernels: two ranks share the one GPU of the test box, gloo carries the all-gather callback (on an 8-GPU node the
+    backend is nccl = RCCL).  P-256 at width 3 is BASELINE configs[4]'s shape."""
+    res = run_world(2, backend, bits, n, width, tmp_path, timeout=900, flow=flow)
+    assert res["pass"], res["why"]
+    assert all(x is None or x <= 12 for x in res["exchanges"]), res["exchanges"]      # a handful of exchanges per proof
+
+
+@pytest.mark.gpu
+def test_sharded_cxx_drivers_three_ranks_ragged_and_empty(tmp_path):
+    res = run_world(3, "hip-gloo", 512, 2, 1, tmp_path, timeout=900, flow="pos")      # one rank owns nothing
+    assert res["pass"], res["why"]
+    res = run_world(3, "hip-gloo", 512, 10, 2, tmp_path, timeout=900, flow="ccpos")
+    assert res["pass"], res["why"]
+
+
 @pytest.mark.gpu
 def test_sharded_pos_real_kernels_two_ranks_one_gpu(tmp_path):
     """The same sharded proof with the HIP library doing the arithmetic: two ranks share the one GPU of
     the test box (gloo carries the small exchanges; on an 8-GPU node the backend is nccl = RCCL)."""
-    res = run_world(2, "hip-gloo", 2048, 150, 1, tmp_path, timeout=900)
+    res = run_world(2, "hip-gloo-mirror", 2048, 150, 1, tmp_path, timeout=900)         # the Python mirror on the real kernels
     assert res["pass"], res["why"]
 
 
 @pytest.mark.gpu
 def test_sharded_pos_p256_real_kernels_two_ranks_one_gpu(tmp_path):
-    res = run_world(2, "hip-gloo-ec", 256, 60, 1, tmp_path, timeout=900)
+    res = run_world(2, "hip-gloo-ec-mirror", 256, 60, 1, tmp_path, timeout=900)
     assert res["pass"], res["why"]

@@ -17,6 +17,7 @@ The wrappers are mechanical (the C ABI was designed for it: opaque pointers, pla
     const char* / char*                 String / byte[]
     void*                               long        (hipStream_t)
     const vmn_random_source*            RandomSourceBridge  (callbacks into the party's RandomSource)
+    const vmn_comm*                     CommBridge          (the all-gather of a sharded proof: byte[] allGather(byte[]))
     int / size_t                        int / long
 
 plus, for the calls that move whole arrays (…_from_be, …_to_be, …_bytetree, vmn_msg_to/from_bytetree), a second
@@ -36,7 +37,7 @@ PKG_PATH = PKG.replace(".", "/")
 PKG_JNI = PKG.replace(".", "_")
 
 HANDLES = ("vmn_ctx", "vmn_group", "vmn_garray", "vmn_rarray", "vmn_msg", "vmn_pos", "vmn_posc", "vmn_ccpos", "vmn_decproof",
-           "vmn_igen", "vmn_spos", "vmn_sccpos", "vmn_sposc")
+           "vmn_igen")
 BULK = {"vmn_garray_from_be": ["be"], "vmn_rarray_from_be": ["be"], "vmn_garray_to_be": ["be_out"], "vmn_rarray_to_be": ["be_out"],
         "vmn_garray_to_bytetree": ["out"], "vmn_rarray_to_bytetree": ["out"], "vmn_garray_from_bytetree": ["bt"],
         "vmn_rarray_from_bytetree": ["bt"], "vmn_msg_to_bytetree": ["out"], "vmn_msg_from_bytetree": ["bt"]}
@@ -75,6 +76,8 @@ def kind(ptype):
     const = "const" in ptype
     if t == "vmn_random_source*":
         return "rs"
+    if t == "vmn_comm*":
+        return "comm"
     for h in HANDLES:
         if t == h + "*":
             return "handle"
@@ -92,11 +95,12 @@ def kind(ptype):
 
 JAVA_T = {"handle": "long", "handles_in": "long[]", "handles_out": "long[]", "bytes_in": "byte[]", "bytes_out": "byte[]",
           "ints_in": "int[]", "ints_out": "int[]", "longs_in": "long[]", "longs_out": "long[]", "doubles_out": "double[]",
-          "chars_in": "String", "chars_out": "byte[]", "ptr": "long", "int": "int", "size": "long", "rs": "RandomSourceBridge"}
+          "chars_in": "String", "chars_out": "byte[]", "ptr": "long", "int": "int", "size": "long", "rs": "RandomSourceBridge",
+          "comm": "CommBridge"}
 JNI_T = {"handle": "jlong", "handles_in": "jlongArray", "handles_out": "jlongArray", "bytes_in": "jbyteArray", "bytes_out": "jbyteArray",
          "ints_in": "jintArray", "ints_out": "jintArray", "longs_in": "jlongArray", "longs_out": "jlongArray",
          "doubles_out": "jdoubleArray", "chars_in": "jstring", "chars_out": "jbyteArray", "ptr": "jlong", "int": "jint", "size": "jlong",
-         "rs": "jobject"}
+         "rs": "jobject", "comm": "jobject"}
 
 
 def ret_types(ret):
@@ -174,6 +178,13 @@ def c_wrapper(cls, ret, name, plist, direct=()):
             pre.append(f"    vmn_jrs* h_{pname} = {pname} ? vmn_jrs_new(env, {pname}) : NULL;")
             pre.append(f"    vmn_random_source s_{pname};")
             pre.append(f"    if (h_{pname}) vmn_jrs_fill(h_{pname}, &s_{pname});")
+            call.append(f"h_{pname} ? &s_{pname} : NULL")
+        elif k == "comm":
+            # the proof object keeps calling the communicator: the bridge is owned by it (first parameter) until its _free
+            args.append(f"jobject {pname}")
+            pre.append(f"    vmn_jcomm* h_{pname} = {pname} ? vmn_jcomm_new(env, {pname}, (void*)(intptr_t){plist[0][1]}) : NULL;")
+            pre.append(f"    vmn_comm s_{pname};")
+            pre.append(f"    if (h_{pname}) vmn_jcomm_fill(h_{pname}, &s_{pname});")
             call.append(f"h_{pname} ? &s_{pname} : NULL")
         else:
             raise SystemExit(f"gen_jni: no wrapper rule for {k} ({name}.{pname})")

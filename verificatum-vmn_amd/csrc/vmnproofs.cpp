@@ -57,6 +57,7 @@ struct GA {
     GA() {}
     GA(const GA&) = delete;
     GA& operator=(const GA&) = delete;
+    GA(GA&& o) noexcept : p(o.p) { o.p = nullptr; }
     ~GA() { reset(); }
     void reset() {
         if (p) vmn_garray_free(p);
@@ -78,6 +79,7 @@ struct RA {
     RA() {}
     RA(const RA&) = delete;
     RA& operator=(const RA&) = delete;
+    RA(RA&& o) noexcept : p(o.p) { o.p = nullptr; }
     ~RA() { reset(); }
     void reset() {
         if (p) vmn_rarray_free(p);
@@ -325,15 +327,27 @@ int random_integer_array(vmn_group* grp, const vmn_random_source& rs, size_t n, 
 }
 
 // ---- what the three proofs share -----------------------------------------------------------------------------
+// Sharding (include/vmnproofs.h vmn_comm): with a communicator set, every rank runs the SAME call sequence
+// with random sources that return the SAME values; position-indexed arrays live as contiguous shards [lo, hi) of the N
+// positions.  Public inputs that are read through the permutation (h for u = permute(h g^r, pi), the batching vector for
+// e' = permute(e, pi^-1)) and the N-sized random arrays are held in full on every rank -- generating them is a PRG
+// pass, cheap beside the exponentiations -- so the permuted arrays are local gathers and no element ever crosses a
+// link.  What crosses: one fixed-size all-gather per group of scalars -- partial products of expProd / prod, partial
+// sums of the inner products, the carries of the two scans, each shard's last B, verdict bits.
 struct ProofBase {
     HostGroup G;
     int vbitlen, ebitlen, rbitlen;
     int e_bits, eps_bits;              // prover-side bounds of values this object made itself (e from the PRG, epsilon)
     bool has_rs = false;
     vmn_random_source rs{};
-    size_t N = 0;
+    size_t N = 0;                      // size of THIS rank's arrays (= Ntot without a communicator)
     Bytes v_be;                        // the challenge as handed in (exponent of single elements)
     Num v;                             // ... and reduced mod q
+    // sharding
+    bool sharded = false;
+    vmn_comm comm{};
+    size_t Ntot = 0, lo = 0, hi = 0;
+    RA e_full_own;                     // the whole batching vector (sharded provers permute it)
 
     int init(vmn_group* grp, int vb, int ebl, int rb, const vmn_random_source* r) {
         TRY(G.init(grp));
@@ -349,14 +363,74 @@ struct ProofBase {
         }
         return VMN_OK;
     }
-    int need_rs() const { return has_rs ? VMN_OK : fail(VMN_ERR_ARG, "this proof object was created without a random source (verifier)"); }
-    int draw_ring_array(size_t n, RA& out) {
-        TRY(need_rs());
-        return random_ring_array(G.grp, rs, n, G.qbits, rbitlen, out);
+    int set_comm(const vmn_comm* c) {
+        if (!c || !c->all_gather || c->world < 1 || c->rank < 0 || c->rank >= c->world) return fail(VMN_ERR_ARG, "bad communicator");
+        if (N) return fail(VMN_ERR_ARG, "the communicator must be set before the instance");
+        comm = *c;
+        sharded = true;
+        return VMN_OK;
     }
-    int draw_integers(size_t n, int bits, RA& out) {
+    // the N positions of the whole proof and this rank's share of them
+    void set_total(size_t ntot) {
+        Ntot = ntot;
+        if (sharded) {
+            vmn_shard_bounds(ntot, comm.world, comm.rank, &lo, &hi);
+        } else {
+            lo = 0;
+            hi = ntot;
+        }
+        N = hi - lo;
+    }
+    // An array argument of a sharded proof is either this rank's shard (N elements) or the whole array (Ntot elements,
+    // replicated), of which the shard is cut here.  `own` keeps a cut alive.
+    int local_garray(const vmn_garray* a, GA& own, const vmn_garray** out, const char* what) {
+        const size_t n = vmn_garray_size(a);
+        if (n == N && (!sharded || N == Ntot)) {
+            *out = a;
+            return VMN_OK;
+        }
+        if (sharded && n == Ntot) {
+            TRY(vmn_garray_copy_range(a, lo, hi, own.out()));
+            *out = own;
+            return VMN_OK;
+        }
+        if (n == N) {
+            *out = a;
+            return VMN_OK;
+        }
+        return fail(VMN_ERR_ARG, "%s: %zu elements, expected this rank's %zu or all %zu", what, n, N, Ntot);
+    }
+    int local_rarray(const vmn_rarray* a, RA& own, const vmn_rarray** out, const char* what) {
+        const size_t n = vmn_rarray_size(a);
+        if (sharded && n == Ntot && N != Ntot) {
+            TRY(vmn_rarray_copy_range(a, lo, hi, own.out()));
+            *out = own;
+            return VMN_OK;
+        }
+        if (n == N) {
+            *out = a;
+            return VMN_OK;
+        }
+        return fail(VMN_ERR_ARG, "%s: %zu elements, expected this rank's %zu or all %zu", what, n, N, Ntot);
+    }
+    int need_rs() const { return has_rs ? VMN_OK : fail(VMN_ERR_ARG, "this proof object was created without a random source (verifier)"); }
+    // N-sized draws: the whole array on every rank (same source values everywhere), of which `out` is this rank's shard;
+    // `full` (may be null) keeps the whole array for draws that are read through the permutation.
+    int draw_ring_array(RA& out, RA* full = nullptr) {
         TRY(need_rs());
-        return random_integer_array(G.grp, rs, n, bits, out);
+        if (!sharded) return random_ring_array(G.grp, rs, Ntot, G.qbits, rbitlen, out);
+        RA all;
+        TRY(random_ring_array(G.grp, rs, Ntot, G.qbits, rbitlen, all));
+        TRY(vmn_rarray_copy_range(all, lo, hi, out.out()));
+        if (full) full->p = all.release();
+        return VMN_OK;
+    }
+    int draw_integers(int bits, RA& out) {
+        TRY(need_rs());
+        if (!sharded) return random_integer_array(G.grp, rs, Ntot, bits, out);
+        RA all;
+        TRY(random_integer_array(G.grp, rs, Ntot, bits, all));
+        return vmn_rarray_copy_range(all, lo, hi, out.out());
     }
     int draw_ring_element(Num& out) {
         TRY(need_rs());
@@ -372,28 +446,187 @@ struct ProofBase {
         v = G.reduce(vb, n);
         return VMN_OK;
     }
-    int batch_vector_seed(const uint8_t* seed, size_t seedlen, RA& e) {
-        if (!N) return fail(VMN_ERR_ARG, "batching vector before the instance (size unknown)");
-        return vmn_rarray_from_prg(G.grp, seed, seedlen, N, ebitlen, e.out());
+    // the batching vector: this rank's shard in e; sharded objects keep the whole vector as well (e' = permute(e, pi^-1))
+    int keep_batch_vector(RA& all, RA& e) {
+        if (!sharded) {
+            e.reset();
+            e.p = all.release();
+            return VMN_OK;
+        }
+        TRY(vmn_rarray_copy_range(all, lo, hi, e.out()));
+        e_full_own.reset();
+        e_full_own.p = all.release();
+        return VMN_OK;
     }
-    int batch_vector(const uint8_t* e_be, RA& e) { return import_batch_vector(G.grp, e_be, N, ebitlen, e); }
+    int batch_vector_seed(const uint8_t* seed, size_t seedlen, RA& e) {
+        if (!Ntot) return fail(VMN_ERR_ARG, "batching vector before the instance (size unknown)");
+        RA all;
+        TRY(vmn_rarray_from_prg(G.grp, seed, seedlen, Ntot, ebitlen, all.out()));
+        return keep_batch_vector(all, e);
+    }
+    int batch_vector(const uint8_t* e_be, RA& e) {
+        RA all;
+        TRY(import_batch_vector(G.grp, e_be, Ntot, ebitlen, all));
+        return keep_batch_vector(all, e);
+    }
+    // e' = permute(e, pi^-1), this rank's positions
+    int permuted_batch_vector(const RA& e, const std::vector<uint32_t>& piinv, RA& ipe) {
+        if (!sharded) return vmn_rarray_permute(e, piinv.data(), ipe.out());
+        return vmn_rarray_gather(e_full_own, piinv.data() + lo, N, ipe.out());
+    }
     // g^a for a ring scalar; through the cached fixed-base table when the group is a curve (one launch), on the
     // host for ModPGroup
     int gexp(const Bytes& base, const Num& e, Bytes& out) const { return G.el_exp(base, e, out); }
 
-    // the commitments B, B' of PoS and PoSC (PoSBasicTW.java:583-648, PoSCBasicTW.java:400-470): x, y are consumed
-    int bridging_commitments(const Bytes& g, const Bytes& h0, RA& x, RA& y, const RA& beta, const RA& epsilon, GA& B, GA& Bp) {
+    // ---- exchanges between the ranks: every rank contributes `mine` (same length everywhere) -----------------------
+    int exchange(const Bytes& mine, std::vector<Bytes>& all) {
+        all.clear();
+        if (!sharded) {
+            all.push_back(mine);
+            return VMN_OK;
+        }
+        Bytes recv((size_t)comm.world * mine.size());
+        if (comm.all_gather(comm.user, mine.data(), mine.size(), recv.data()) != 0) return fail(VMN_ERR_DEVICE, "all-gather failed");
+        for (int k = 0; k < comm.world; ++k) all.emplace_back(recv.begin() + (size_t)k * mine.size(), recv.begin() + (size_t)(k + 1) * mine.size());
+        return VMN_OK;
+    }
+    bool rank_nonempty(int k) const {
+        size_t a, b;
+        vmn_shard_bounds(Ntot, sharded ? comm.world : 1, k, &a, &b);
+        return b > a;
+    }
+    // One exchange for a phase: group elements to multiply over the ranks (partial products), ring scalars to add or to
+    // multiply, values to collect per rank (scan carries, last elements), flags to AND.
+    struct Round {
+        ProofBase& pb;
+        std::vector<Bytes*> mul_el;
+        std::vector<Num*> sum_r, mul_r;
+        std::vector<std::pair<Bytes, std::vector<Bytes>*>> per_rank;     // (mine, all ranks' values)
+        std::vector<int*> flags;
+        explicit Round(ProofBase& p) : pb(p) {}
+        void product(Bytes& el) { mul_el.push_back(&el); }
+        void products(std::vector<Bytes>& els) {
+            for (auto& e : els) mul_el.push_back(&e);
+        }
+        void sum(Num& x) { sum_r.push_back(&x); }
+        void ring_product(Num& x) { mul_r.push_back(&x); }
+        void collect(const Bytes& mine, std::vector<Bytes>& all) { per_rank.emplace_back(mine, &all); }
+        void all_true(int& flag) { flags.push_back(&flag); }
+        int run() {
+            const HostGroup& G = pb.G;
+            Bytes mine;
+            for (Bytes* e : mul_el) mine.insert(mine.end(), e->begin(), e->end());
+            for (Num* x : sum_r) {
+                Bytes b = G.ring_bytes(*x);
+                mine.insert(mine.end(), b.begin(), b.end());
+            }
+            for (Num* x : mul_r) {
+                Bytes b = G.ring_bytes(*x);
+                mine.insert(mine.end(), b.begin(), b.end());
+            }
+            for (auto& pr : per_rank) mine.insert(mine.end(), pr.first.begin(), pr.first.end());
+            for (int* f : flags) mine.push_back(*f ? 1 : 0);
+            if (mine.empty()) return VMN_OK;
+            std::vector<Bytes> all;
+            TRY(pb.exchange(mine, all));
+            size_t off = 0;
+            for (Bytes* e : mul_el) {
+                Bytes acc(all[0].begin() + off, all[0].begin() + off + G.eb);
+                for (size_t k = 1; k < all.size(); ++k) {
+                    Bytes t;
+                    TRY(G.el_mul(acc, Bytes(all[k].begin() + off, all[k].begin() + off + G.eb), t));
+                    acc.swap(t);
+                }
+                *e = acc;
+                off += G.eb;
+            }
+            for (Num* x : sum_r) {
+                Num acc = G.ring_from(all[0].data() + off);
+                for (size_t k = 1; k < all.size(); ++k) acc = G.Zq.add(acc, G.ring_from(all[k].data() + off));
+                *x = acc;
+                off += G.xb;
+            }
+            for (Num* x : mul_r) {
+                Num acc = G.ring_from(all[0].data() + off);
+                for (size_t k = 1; k < all.size(); ++k) acc = G.Zq.mul(acc, G.ring_from(all[k].data() + off));
+                *x = acc;
+                off += G.xb;
+            }
+            for (auto& pr : per_rank) {
+                pr.second->clear();
+                for (auto& a : all) pr.second->emplace_back(a.begin() + off, a.begin() + off + pr.first.size());
+                off += pr.first.size();
+            }
+            for (int* f : flags) {
+                int ok = 1;
+                for (auto& a : all) ok = ok && a[off];
+                *f = ok;
+                off += 1;
+            }
+            return VMN_OK;
+        }
+    };
+
+    // x = b.recLin(e'), y = e'.prods() over ALL positions: local scans, one exchange of the carries (the map of a shard is
+    // x -> x E + X with E = the product of its e', X = its local result), a multiply-add fix-up on the ranks above 0.
+    // x_in / y_in: the values entering this shard (x_{lo-1}, y_{lo-1}; 0 and 1 on the first).
+    int scans(const RA& b, const RA& ipe, RA& x, RA& y, Num& d, Bytes& x_in, Bytes& y_in) {
+        Bytes dloc(G.xb, 0);
+        TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dloc.data()));
+        TRY(vmn_rarray_prods(ipe, y.out()));
+        x_in.assign(G.xb, 0);
+        y_in.assign(G.xb, 0);
+        y_in[G.xb - 1] = 1;
+        if (!sharded) {
+            d = G.ring_from(dloc.data());
+            return VMN_OK;
+        }
+        Bytes mine(2 * G.xb, 0);                                   // (E, X) of this shard; an empty shard is the identity map (1, 0)
+        mine[G.xb - 1] = 1;
+        if (N) {
+            TRY(vmn_rarray_get(y, N - 1, mine.data()));
+            memcpy(mine.data() + G.xb, dloc.data(), G.xb);
+        }
+        std::vector<Bytes> all;
+        TRY(exchange(mine, all));
+        Num xin(G.ql, 0), yin(G.ql, 0), dd(G.ql, 0);
+        yin[0] = 1;
+        for (int k = 0; k < comm.world; ++k) {
+            const Num E = G.ring_from(all[k].data()), X = G.ring_from(all[k].data() + G.xb);
+            if (k < comm.rank) {
+                xin = G.mul_add(xin, E, X);
+                yin = G.Zq.mul(yin, E);
+            }
+            dd = G.mul_add(dd, E, X);
+        }
+        d = dd;
+        x_in = G.ring_bytes(xin);
+        y_in = G.ring_bytes(yin);
+        if (comm.rank > 0 && N) {                                  // x_i = x_i^loc + x_in * P_i,  y_i = y_in * P_i  (P = local prods)
+            RA xf, yf;
+            TRY(vmn_rarray_mul_add(y, x_in.data(), x, xf.out()));
+            TRY(vmn_rarray_mul_add(y, y_in.data(), nullptr, yf.out()));
+            x.reset();
+            y.reset();
+            x.p = xf.release();
+            y.p = yf.release();
+        }
+        return VMN_OK;
+    }
+
+    // the commitments B, B' of PoS and PoSC (PoSBasicTW.java:583-648, PoSCBasicTW.java:400-470): x, y are consumed;
+    // x_in / y_in are what shiftPush pushes in front: (0, 1), or the carries into this shard
+    int bridging_commitments(const Bytes& g, const Bytes& h0, RA& x, RA& y, const Bytes& x_in, const Bytes& y_in, const RA& beta,
+                             const RA& epsilon, GA& B, GA& Bp) {
         GA g_exp_x, h0_exp_y;
         TRY(vmn_group_exp_fixed(G.grp, g.data(), x, g_exp_x.out()));
         TRY(vmn_group_exp_fixed(G.grp, h0.data(), y, h0_exp_y.out()));
         TRY(vmn_garray_mul(g_exp_x, h0_exp_y, B.out()));
         g_exp_x.reset();
         h0_exp_y.reset();
-        Bytes zero(G.xb, 0), one(G.xb, 0);
-        one[G.xb - 1] = 1;
         RA xp, yp, xp_mul_eps, beta_add_prod, yp_mul_eps;
-        TRY(vmn_rarray_shift_push(x, zero.data(), xp.out()));
-        TRY(vmn_rarray_shift_push(y, one.data(), yp.out()));
+        TRY(vmn_rarray_shift_push(x, x_in.data(), xp.out()));
+        TRY(vmn_rarray_shift_push(y, y_in.data(), yp.out()));
         x.reset();
         y.reset();
         TRY(vmn_rarray_mul(xp, epsilon, xp_mul_eps.out()));
@@ -406,17 +639,35 @@ struct ProofBase {
         return VMN_OK;
     }
     // check (B): B_i^v B'_i == g^{k_B,i} B_{i-1}^{k_E,i}, B_{-1} = h0 (PoSBasicTW.java:1023-1042).  Queues the
-    // element-wise work and returns the two sides; the comparison (which blocks) is left to the caller.
-    int bridging_sides(const Bytes& g, const Bytes& h0, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
+    // element-wise work and returns the two sides; the comparison (which blocks) is left to the caller.  `prev` = the
+    // element in front of this shard's B (h0, or the last B of the shard below).
+    int bridging_sides(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
                        const vmn_rarray* k_E, int kE_bits, GA& left, GA& right) {
         GA B_exp_v, g_exp_k_B, B_shift, B_shift_exp_k_E;
         TRY(vmn_garray_exp_scalar(B, v_be.data(), v_be.size(), B_exp_v.out()));
         TRY(vmn_garray_mul(B_exp_v, Bp, left.out()));
         B_exp_v.reset();
         TRY(vmn_group_exp_fixed(G.grp, g.data(), k_B, g_exp_k_B.out()));
-        TRY(vmn_garray_shift_push(B, h0.data(), B_shift.out()));
+        TRY(vmn_garray_shift_push(B, prev.data(), B_shift.out()));
         TRY(vmn_garray_exp_array(B_shift, k_E, kE_bits, B_shift_exp_k_E.out()));
         TRY(vmn_garray_mul(g_exp_k_B, B_shift_exp_k_E, right.out()));
+        return VMN_OK;
+    }
+    // the last B of the whole proof and the element in front of this shard's B, from every rank's last local B
+    void pick_B(const std::vector<Bytes>& lasts, const Bytes& h0, Bytes& Blast, Bytes& prev) const {
+        prev = h0;
+        Blast = h0;
+        const int world = sharded ? comm.world : 1, me = sharded ? comm.rank : 0;
+        for (int k = 0; k < world; ++k) {
+            if (!rank_nonempty(k)) continue;
+            if (k < me) prev = lasts[k];
+            Blast = lasts[k];
+        }
+    }
+    // this rank's last B (the unit when its shard is empty: never used then)
+    int last_local(const vmn_garray* B, Bytes& out) const {
+        out = G.one();
+        if (N) TRY(vmn_garray_get(B, N - 1, out.data()));
         return VMN_OK;
     }
     // pk_c^{-k_c mod width} * t_c for the 2w components of a ciphertext-shaped value
@@ -430,6 +681,7 @@ struct ProofBase {
         }
         return VMN_OK;
     }
+    // this rank's partial products (the caller completes them over the ranks in its phase's Round)
     int expprod_multi(const std::vector<const vmn_garray*>& xs, const vmn_rarray* e, int bits, std::vector<Bytes>& out) const {
         Bytes flat(xs.size() * G.eb);
         TRY(vmn_garray_expprod_multi(xs.data(), xs.size(), e, bits, flat.data()));
@@ -437,10 +689,25 @@ struct ProofBase {
         for (size_t k = 0; k < xs.size(); ++k) out.emplace_back(flat.begin() + k * G.eb, flat.begin() + (k + 1) * G.eb);
         return VMN_OK;
     }
-    int check_arrays(const vmn_garray* const* arr, size_t k, const char* what) const {
+    // the 2w components of a ciphertext array, each this rank's shard (cut from whole arrays where those were handed in)
+    int local_components(const vmn_garray* const* arr, size_t k, std::vector<GA>& own, std::vector<const vmn_garray*>& out, const char* what) {
         if (!arr) return fail(VMN_ERR_ARG, "%s: null", what);
+        own.clear();
+        own.resize(k);
+        out.assign(k, nullptr);
         for (size_t c = 0; c < k; ++c) {
-            if (!arr[c] || vmn_garray_size(arr[c]) != N) return fail(VMN_ERR_ARG, "%s: component %zu is null or not of size N", what, c);
+            if (!arr[c]) return fail(VMN_ERR_ARG, "%s: component %zu is null", what, c);
+            TRY(local_garray(arr[c], own[c], &out[c], what));
+        }
+        return VMN_OK;
+    }
+    int local_columns(const vmn_rarray* const* arr, size_t k, std::vector<RA>& own, std::vector<const vmn_rarray*>& out, const char* what) {
+        own.clear();
+        own.resize(k);
+        out.assign(k, nullptr);
+        for (size_t c = 0; c < k; ++c) {
+            if (!arr[c]) return fail(VMN_ERR_ARG, "%s: column %zu is null", what, c);
+            TRY(local_rarray(arr[c], own[c], &out[c], what));
         }
         return VMN_OK;
     }
@@ -452,8 +719,9 @@ struct ProofBase {
 // PoSBasicTW
 // ================================================================================================================
 struct vmn_pos : ProofBase {
-    Bytes g;
-    const vmn_garray* h = nullptr;
+    Bytes g, h0;
+    const vmn_garray* h = nullptr;           // this rank's generators
+    GA h_own;
     std::vector<uint32_t> pi, piinv;
     bool prover = false;
     RA r, epsilon, e, ipe, b, beta;
@@ -465,7 +733,9 @@ struct vmn_pos : ProofBase {
     size_t width = 0;
     std::vector<Bytes> pkey;
     std::vector<const vmn_garray*> w, wp;
+    std::vector<GA> w_own, wp_own;
     std::vector<const vmn_rarray*> s;
+    std::vector<RA> s_own;
     // verifier
     Bytes A;
     std::vector<Bytes> F;
@@ -476,44 +746,48 @@ struct vmn_pos : ProofBase {
 
     int precompute(const uint8_t* g_be, const vmn_garray* h_, const uint32_t* pi_) {
         REQUIRE(g_be && h_, "null argument");
-        N = vmn_garray_size(h_);
-        REQUIRE(N > 0, "empty generator array");
-        g.assign(g_be, g_be + G.eb);
-        h = h_;
+        REQUIRE(vmn_garray_size(h_) > 0, "empty generator array");
         prover = pi_ != nullptr;
+        // h is always the whole array (a prover reads it through the permutation; every rank needs h_0 and the size)
+        set_total(vmn_garray_size(h_));
+        g.assign(g_be, g_be + G.eb);
+        h0.assign(G.eb, 0);
+        TRY(vmn_garray_get(h_, 0, h0.data()));                   // (with a communicator h is always the whole array)
+        TRY(local_garray(h_, h_own, &h, "h"));
         if (!prover) return VMN_OK;                              // verifier :394-402
-        REQUIRE(is_permutation(pi_, N), "pi is not a permutation of [0, N)");
-        pi.assign(pi_, pi_ + N);
-        piinv = inverse_permutation(pi_, N);
+        REQUIRE(is_permutation(pi_, Ntot), "pi is not a permutation of [0, N)");
+        pi.assign(pi_, pi_ + Ntot);
+        piinv = inverse_permutation(pi_, Ntot);
         // :446-465  u_i = g^{r_pi(i)} h_pi(i)
-        TRY(draw_ring_array(N, r));
+        RA r_full;
+        TRY(draw_ring_array(r, sharded ? &r_full : nullptr));
         TRY(draw_ring_element(alpha));
-        TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
-        TRY(vmn_permutation_commitment(G.grp, g.data(), h, r, pi.data(), u_own.out()));
+        TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
+        if (!sharded) {
+            TRY(vmn_permutation_commitment(G.grp, g.data(), h_, r, pi.data(), u_own.out()));
+        } else {
+            TRY(vmn_permutation_commitment_shard(G.grp, g.data(), h_, r_full, pi.data(), lo, hi, u_own.out()));
+        }
         u = u_own;
         // :481  A' = g^alpha prod h_i^eps_i
         Bytes hp(G.eb), ga;
         TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        Round rd(*this);
+        rd.product(hp);
+        TRY(rd.run());
         TRY(gexp(g, alpha, ga));
         return G.el_mul(ga, hp, Ap);
     }
     int set_instance(const uint8_t* pkey_be, size_t width_, const vmn_garray* const* w_, const vmn_garray* const* wp_,
                      const vmn_rarray* const* s_) {
-        REQUIRE(pkey_be && width_ > 0 && N > 0, "null argument or precompute not called");
+        REQUIRE(pkey_be && width_ > 0 && Ntot > 0, "null argument or precompute not called");
         width = width_;
-        TRY(check_arrays(w_, 2 * width, "w"));
-        TRY(check_arrays(wp_, 2 * width, "w'"));
+        TRY(local_components(w_, 2 * width, w_own, w, "w"));
+        TRY(local_components(wp_, 2 * width, wp_own, wp, "w'"));
         pkey.clear();
         for (size_t c = 0; c < 2 * width; ++c) pkey.emplace_back(pkey_be + c * G.eb, pkey_be + (c + 1) * G.eb);
-        w.assign(w_, w_ + 2 * width);
-        wp.assign(wp_, wp_ + 2 * width);
         s.clear();
-        if (s_) {
-            for (size_t c = 0; c < width; ++c) {
-                REQUIRE(s_[c] && vmn_rarray_size(s_[c]) == N, "re-encryption exponents: null or not of size N");
-                s.push_back(s_[c]);
-            }
-        }
+        if (s_) TRY(local_columns(s_, width, s_own, s, "re-encryption exponents"));
         return VMN_OK;
     }
     // The part of commit() that does not depend on the batching vector: all its random draws (same order, same values)
@@ -526,14 +800,17 @@ struct vmn_pos : ProofBase {
     int commit_prepare() {
         REQUIRE(prover && width && !prepared, "commit_prepare needs a prover with the instance set, once per proof");
         // randomness in the reference's order: b :583, beta :612, gamma :667, delta :673, phi :687
-        TRY(draw_ring_array(N, b));
-        TRY(draw_ring_array(N, beta));
+        TRY(draw_ring_array(b));
+        TRY(draw_ring_array(beta));
         TRY(draw_ring_element(gamma));
         TRY(draw_ring_element(delta));
         phi.resize(width);
         for (auto& ph : phi) TRY(draw_ring_element(ph));
         std::vector<Bytes> prods;
         TRY(expprod_multi(wp, epsilon, eps_bits, prods));                         // :690
+        Round rd(*this);
+        rd.products(prods);
+        TRY(rd.run());
         TRY(gexp(g, gamma, Cp_));                                                 // :667-679
         TRY(gexp(g, delta, Dp_));
         TRY(pk_side(pkey, phi, prods, Fp_));                                      // :687-690
@@ -543,51 +820,59 @@ struct vmn_pos : ProofBase {
     int commit(vmn_msg** out) {
         REQUIRE(out && prover && e.p && width, "commit needs a prover with instance and batching vector set");
         if (!prepared) TRY(commit_prepare());
-        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :552-554
-        Bytes h0(G.eb), dbytes(G.xb);
-        TRY(vmn_garray_get(h, 0, h0.data()));
+        TRY(permuted_batch_vector(e, piinv, ipe));                                // :552-554
         RA x, y;
-        TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dbytes.data()));                  // :583-598
-        d = G.ring_from(dbytes.data());
-        TRY(vmn_rarray_prods(ipe, y.out()));                                      // :600-604
+        Bytes x_in, y_in;
+        TRY(scans(b, ipe, x, y, d, x_in, y_in));                                  // :583-604
         GA B, Bp;
-        TRY(bridging_commitments(g, h0, x, y, beta, epsilon, B, Bp));             // :606-648 (queued)
-        const Bytes &Cp = Cp_, &Dp = Dp_;
-        const std::vector<Bytes>& Fp = Fp_;
+        TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp)); // :606-648 (queued)
         std::unique_ptr<vmn_msg> m(new vmn_msg());
         m->push(B);
         m->push_element(Ap);
         m->push(Bp);
-        m->push_element(Cp);
-        m->push_element(Dp);
-        m->push_bytes(VMN_ITEM_ELEMENTS, Fp);
+        m->push_element(Cp_);
+        m->push_element(Dp_);
+        m->push_bytes(VMN_ITEM_ELEMENTS, Fp_);
         *out = m.release();
         return VMN_OK;
     }
     int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
         REQUIRE(out && prover && ipe.p && s.size() == width, "reply needs commit() and the re-encryption exponents");
         TRY(set_challenge(vb, vbytes));
-        Bytes a(G.xb), c(G.xb), f(G.xb);
-        TRY(vmn_rarray_inner_product(r, ipe, a.data()));
-        TRY(vmn_rarray_sum(r, c.data()));
-        std::vector<Bytes> kF;
+        Bytes ab(G.xb), cb(G.xb), fb(G.xb);
+        TRY(vmn_rarray_inner_product(r, ipe, ab.data()));
+        TRY(vmn_rarray_sum(r, cb.data()));
+        Num a = G.ring_from(ab.data()), c = G.ring_from(cb.data());
+        std::vector<Num> f(width);
         for (size_t col = 0; col < width; ++col) {                               // product-ring inner product: per column
-            TRY(vmn_rarray_inner_product(s[col], e, f.data()));
-            kF.push_back(G.ring_bytes(G.mul_add(G.ring_from(f.data()), v, phi[col])));
+            TRY(vmn_rarray_inner_product(s[col], e, fb.data()));
+            f[col] = G.ring_from(fb.data());
         }
+        Round rd(*this);
+        rd.sum(a);
+        rd.sum(c);
+        for (auto& fc : f) rd.sum(fc);
+        TRY(rd.run());
+        std::vector<Bytes> kF;
+        for (size_t col = 0; col < width; ++col) kF.push_back(G.ring_bytes(G.mul_add(f[col], v, phi[col])));
         Bytes vq = G.ring_bytes(v);
         RA k_B, k_E;
         TRY(vmn_rarray_mul_add(b, vq.data(), beta, k_B.out()));
         TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
         std::unique_ptr<vmn_msg> m(new vmn_msg());
-        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(a.data()), v, alpha)));
+        m->push_ring(G.ring_bytes(G.mul_add(a, v, alpha)));
         m->push(k_B);
-        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(c.data()), v, gamma)));
+        m->push_ring(G.ring_bytes(G.mul_add(c, v, gamma)));
         m->push_ring(G.ring_bytes(G.mul_add(d, v, delta)));
         m->push(k_E);
         m->push_bytes(VMN_ITEM_RING, kF);
         *out = m.release();
         return VMN_OK;
+    }
+    GA u_cut;
+    int set_permutation_commitment(const vmn_garray* u_) {
+        REQUIRE(u_, "null argument");
+        return local_garray(u_, u_cut, &u, "u");
     }
     int compute_af() {
         REQUIRE(u && e.p && width, "computeAF needs u, the instance and the batching vector");
@@ -595,6 +880,9 @@ struct vmn_pos : ProofBase {
         xs.insert(xs.end(), w.begin(), w.end());
         std::vector<Bytes> res;
         TRY(expprod_multi(xs, e, e_bits, res));                                   // one sort of e for u and w
+        Round rd(*this);
+        rd.products(res);
+        TRY(rd.run());
         A = res[0];
         F.assign(res.begin() + 1, res.end());
         return VMN_OK;
@@ -635,25 +923,36 @@ struct vmn_pos : ProofBase {
         std::vector<Num> k_F;
         for (auto& bts : split(*ikF)) k_F.push_back(G.ring_from(bts.data()));
         // scalars that come back from the GPU first (each blocks on the stream) ...
-        Bytes h0(G.eb), uprod(G.eb), hprod(G.eb), Blast(G.eb), eprod(G.xb);
-        TRY(vmn_garray_get(h, 0, h0.data()));
+        Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb);
         TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
         TRY(vmn_garray_prod(h, hprod.data()));
-        TRY(vmn_garray_get(cB, N - 1, Blast.data()));
-        TRY(vmn_rarray_prod(e, eprod.data()));                                    // :1014
+        TRY(last_local(cB, mylast));
+        TRY(vmn_rarray_prod(e, eprod_b.data()));                                  // :1014
+        Num eprod = G.ring_from(eprod_b.data());
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
         std::vector<Bytes> kE_prods;
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
         TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));                       // :1021, :1063 — one sort of k_E
+        // ... completed over the ranks in ONE exchange ...
+        std::vector<Bytes> lasts;
+        Round rd(*this);
+        rd.product(uprod);
+        rd.product(hprod);
+        rd.products(kE_prods);
+        rd.ring_product(eprod);
+        rd.collect(mylast, lasts);
+        TRY(rd.run());
+        Bytes Blast, prev;
+        pick_B(lasts, h0, Blast, prev);
         // ... then the element-wise work of check (B) is queued ...
         GA left, right;
-        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // :1023-1042
+        TRY(bridging_sides(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // :1023-1042
         // ... and the single-element checks run on the host while the GPU works
         Bytes C, D, t, lhs, rhs;
         TRY(G.el_div(uprod, hprod, C));
-        TRY(G.el_exp(h0, eprod.data(), eprod.size(), t));
+        TRY(G.el_exp(h0, eprod, t));
         TRY(G.el_div(Blast, t, D));
         TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :1016-1021
         TRY(gexp(g, k_A, t));
@@ -674,6 +973,9 @@ struct vmn_pos : ProofBase {
         }
         int vB = 0;
         TRY(vmn_garray_equals(left, right, &vB));
+        Round rv(*this);
+        rv.all_true(vB);
+        if (sharded) TRY(rv.run());
         if (five) {
             five[0] = vA;
             five[1] = vB;
@@ -690,10 +992,12 @@ struct vmn_pos : ProofBase {
 // PoSCBasicTW
 // ================================================================================================================
 struct vmn_posc : ProofBase {
-    Bytes g;
+    Bytes g, h0;
     const vmn_garray* h = nullptr;
     const vmn_garray* u = nullptr;
     const vmn_rarray* r = nullptr;
+    GA h_own, u_own;
+    RA r_own;
     std::vector<uint32_t> piinv;
     RA epsilon, e, ipe, b, beta;
     Num alpha, gamma, delta, d;
@@ -701,19 +1005,23 @@ struct vmn_posc : ProofBase {
     const vmn_garray* cBp = nullptr;
     Bytes cAp, cCp, cDp;
 
+    // h: the whole array; u / r: whole arrays or this rank's shards (a prover's pi is always the whole permutation)
     int set_instance(const uint8_t* g_be, const vmn_garray* h_, const vmn_garray* u_, const vmn_rarray* r_, const uint32_t* pi_) {
         REQUIRE(g_be && h_ && u_, "null argument");
-        N = vmn_garray_size(h_);
-        REQUIRE(N > 0 && vmn_garray_size(u_) == N, "h / u empty or of different size");
+        set_total(vmn_garray_size(h_));
+        REQUIRE(Ntot > 0, "h / u empty");
         g.assign(g_be, g_be + G.eb);
-        h = h_;
-        u = u_;
-        r = r_;
+        h0.assign(G.eb, 0);
+        TRY(vmn_garray_get(h_, 0, h0.data()));
+        TRY(local_garray(h_, h_own, &h, "h"));
+        TRY(local_garray(u_, u_own, &u, "u"));
+        r = nullptr;
         piinv.clear();
         if (pi_) {
-            REQUIRE(r_ && vmn_rarray_size(r_) == N, "prover needs the commitment exponents r");
-            REQUIRE(is_permutation(pi_, N), "pi is not a permutation of [0, N)");
-            piinv = inverse_permutation(pi_, N);
+            REQUIRE(r_, "prover needs the commitment exponents r");
+            TRY(local_rarray(r_, r_own, &r, "r"));
+            REQUIRE(is_permutation(pi_, Ntot), "pi is not a permutation of [0, N)");
+            piinv = inverse_permutation(pi_, Ntot);
         }
         return VMN_OK;
     }
@@ -723,14 +1031,17 @@ struct vmn_posc : ProofBase {
     int commit_prepare() {
         REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
         // randomness in the reference's order: b, alpha, epsilon, beta, gamma, delta (PoSCBasicTW.java:400-500)
-        TRY(draw_ring_array(N, b));
+        TRY(draw_ring_array(b));
         TRY(draw_ring_element(alpha));
-        TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
-        TRY(draw_ring_array(N, beta));
+        TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
+        TRY(draw_ring_array(beta));
         TRY(draw_ring_element(gamma));
         TRY(draw_ring_element(delta));
         Bytes hp(G.eb), ga;
         TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        Round rd(*this);
+        rd.product(hp);
+        TRY(rd.run());
         TRY(gexp(g, alpha, ga));
         TRY(G.el_mul(ga, hp, Ap_));
         TRY(gexp(g, gamma, Cp_));
@@ -741,39 +1052,40 @@ struct vmn_posc : ProofBase {
     int commit(vmn_msg** out) {
         REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
         if (!prepared) TRY(commit_prepare());
-        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));
-        Bytes h0(G.eb), dbytes(G.xb);
-        TRY(vmn_garray_get(h, 0, h0.data()));
+        TRY(permuted_batch_vector(e, piinv, ipe));
         RA x, y;
-        TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dbytes.data()));
-        d = G.ring_from(dbytes.data());
-        TRY(vmn_rarray_prods(ipe, y.out()));
+        Bytes x_in, y_in;
+        TRY(scans(b, ipe, x, y, d, x_in, y_in));
         GA B, Bp;
-        TRY(bridging_commitments(g, h0, x, y, beta, epsilon, B, Bp));
-        const Bytes &Ap = Ap_, &Cp = Cp_, &Dp = Dp_;
+        TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp));
         std::unique_ptr<vmn_msg> m(new vmn_msg());
         m->push(B);
-        m->push_element(Ap);
+        m->push_element(Ap_);
         m->push(Bp);
-        m->push_element(Cp);
-        m->push_element(Dp);
+        m->push_element(Cp_);
+        m->push_element(Dp_);
         *out = m.release();
         return VMN_OK;
     }
     int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
         REQUIRE(out && ipe.p && r, "reply needs commit()");
         TRY(set_challenge(vb, vbytes));
-        Bytes a(G.xb), c(G.xb);
-        TRY(vmn_rarray_inner_product(r, ipe, a.data()));
-        TRY(vmn_rarray_sum(r, c.data()));
+        Bytes ab(G.xb), cb(G.xb);
+        TRY(vmn_rarray_inner_product(r, ipe, ab.data()));
+        TRY(vmn_rarray_sum(r, cb.data()));
+        Num a = G.ring_from(ab.data()), c = G.ring_from(cb.data());
+        Round rd(*this);
+        rd.sum(a);
+        rd.sum(c);
+        TRY(rd.run());
         Bytes vq = G.ring_bytes(v);
         RA k_B, k_E;
         TRY(vmn_rarray_mul_add(b, vq.data(), beta, k_B.out()));
         TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
         std::unique_ptr<vmn_msg> m(new vmn_msg());
-        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(a.data()), v, alpha)));
+        m->push_ring(G.ring_bytes(G.mul_add(a, v, alpha)));
         m->push(k_B);
-        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(c.data()), v, gamma)));
+        m->push_ring(G.ring_bytes(G.mul_add(c, v, gamma)));
         m->push_ring(G.ring_bytes(G.mul_add(d, v, delta)));
         m->push(k_E);
         *out = m.release();
@@ -808,25 +1120,36 @@ struct vmn_posc : ProofBase {
         REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
         *verdict = 0;
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
-        Bytes h0(G.eb), A(G.eb), uprod(G.eb), hprod(G.eb), Blast(G.eb), eprod(G.xb), hk(G.eb);
-        TRY(vmn_garray_get(h, 0, h0.data()));
+        Bytes A(G.eb), uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), hk(G.eb);
         TRY(vmn_garray_expprod(u, e, e_bits, A.data()));                          // :660
         TRY(vmn_garray_prod(u, uprod.data()));
         TRY(vmn_garray_prod(h, hprod.data()));
-        TRY(vmn_garray_get(cB, N - 1, Blast.data()));
-        TRY(vmn_rarray_prod(e, eprod.data()));
+        TRY(last_local(cB, mylast));
+        TRY(vmn_rarray_prod(e, eprod_b.data()));
+        Num eprod = G.ring_from(eprod_b.data());
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
         TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, hk.data()));
+        std::vector<Bytes> lasts;
+        Round rd(*this);
+        rd.product(A);
+        rd.product(uprod);
+        rd.product(hprod);
+        rd.product(hk);
+        rd.ring_product(eprod);
+        rd.collect(mylast, lasts);
+        TRY(rd.run());
+        Bytes Blast, prev;
+        pick_B(lasts, h0, Blast, prev);
         Bytes t, lhs, rhs, C, D;
         TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :676-682
         TRY(gexp(g, k_A, t));
         TRY(G.el_mul(t, hk, rhs));
-        if (lhs != rhs) return VMN_OK;                                            // short-circuit :682
+        if (lhs != rhs) return VMN_OK;                                            // short-circuit :682 (the same on every rank)
         GA left, right;
-        TRY(bridging_sides(g, h0, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // (B) :685-715
+        TRY(bridging_sides(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // (B) :685-715
         TRY(G.el_div(uprod, hprod, C));
-        TRY(G.el_exp(h0, eprod.data(), eprod.size(), t));
+        TRY(G.el_exp(h0, eprod, t));
         TRY(G.el_div(Blast, t, D));
         TRY(G.el_expmul(C, v_be, cCp, lhs));                                      // (C) :718-723
         TRY(gexp(g, k_C, rhs));
@@ -836,6 +1159,9 @@ struct vmn_posc : ProofBase {
         const int vD = lhs == rhs;
         int vB = 0;
         TRY(vmn_garray_equals(left, right, &vB));
+        Round rv(*this);
+        rv.all_true(vB);
+        if (sharded) TRY(rv.run());
         *verdict = vB && vC && vD;
         return VMN_OK;
     }
@@ -849,11 +1175,15 @@ struct vmn_ccpos : ProofBase {
     const vmn_garray* h = nullptr;
     const vmn_garray* u = nullptr;
     const vmn_rarray* r = nullptr;
+    GA h_own, u_own;
+    RA r_own;
     std::vector<uint32_t> piinv;
     size_t width = 0;
     std::vector<Bytes> pkey;
     std::vector<const vmn_garray*> w, wp;
+    std::vector<GA> w_own, wp_own;
     std::vector<const vmn_rarray*> s;
+    std::vector<RA> s_own;
     RA epsilon, e, ipe;
     Num alpha;
     std::vector<Num> beta;
@@ -868,29 +1198,25 @@ struct vmn_ccpos : ProofBase {
                      const vmn_garray* const* w_, const vmn_garray* const* wp_, const vmn_rarray* r_, const uint32_t* pi_,
                      const vmn_rarray* const* s_) {
         REQUIRE(g_be && h_ && u_ && pkey_be && width_ > 0, "null argument");
-        N = vmn_garray_size(h_);
-        REQUIRE(N > 0 && vmn_garray_size(u_) == N, "h / u empty or of different size");
+        set_total(vmn_garray_size(h_));
+        REQUIRE(Ntot > 0, "h / u empty");
         width = width_;
-        TRY(check_arrays(w_, 2 * width, "w"));
-        TRY(check_arrays(wp_, 2 * width, "w'"));
         g.assign(g_be, g_be + G.eb);
-        h = h_;
-        u = u_;
-        r = r_;
+        TRY(local_garray(h_, h_own, &h, "h"));
+        TRY(local_garray(u_, u_own, &u, "u"));
+        TRY(local_components(w_, 2 * width, w_own, w, "w"));
+        TRY(local_components(wp_, 2 * width, wp_own, wp, "w'"));
         pkey.clear();
         for (size_t c = 0; c < 2 * width; ++c) pkey.emplace_back(pkey_be + c * G.eb, pkey_be + (c + 1) * G.eb);
-        w.assign(w_, w_ + 2 * width);
-        wp.assign(wp_, wp_ + 2 * width);
         piinv.clear();
         s.clear();
+        r = nullptr;
         if (pi_) {
-            REQUIRE(r_ && vmn_rarray_size(r_) == N && s_, "prover needs r and s");
-            REQUIRE(is_permutation(pi_, N), "pi is not a permutation of [0, N)");
-            piinv = inverse_permutation(pi_, N);
-            for (size_t c = 0; c < width; ++c) {
-                REQUIRE(s_[c] && vmn_rarray_size(s_[c]) == N, "re-encryption exponents: null or not of size N");
-                s.push_back(s_[c]);
-            }
+            REQUIRE(r_ && s_, "prover needs r and s");
+            TRY(local_rarray(r_, r_own, &r, "r"));
+            REQUIRE(is_permutation(pi_, Ntot), "pi is not a permutation of [0, N)");
+            piinv = inverse_permutation(pi_, Ntot);
+            TRY(local_columns(s_, width, s_own, s, "re-encryption exponents"));
         }
         return VMN_OK;
     }
@@ -902,13 +1228,16 @@ struct vmn_ccpos : ProofBase {
     int commit_prepare() {
         REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
         TRY(draw_ring_element(alpha));                                            // :360-375
-        TRY(draw_integers(N, ebitlen + vbitlen + rbitlen, epsilon));
+        TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
         beta.resize(width);
         for (auto& bt : beta) TRY(draw_ring_element(bt));
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
         std::vector<Bytes> eps_prods;
         TRY(expprod_multi(xs, epsilon, eps_bits, eps_prods));                     // :377, :391 — one sort of epsilon
+        Round rd(*this);
+        rd.products(eps_prods);
+        TRY(rd.run());
         Bytes ga;
         TRY(gexp(g, alpha, ga));
         TRY(G.el_mul(ga, eps_prods[0], Ap_));
@@ -920,30 +1249,35 @@ struct vmn_ccpos : ProofBase {
     int commit(vmn_msg** out) {
         REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
         if (!prepared) TRY(commit_prepare());
-        TRY(vmn_rarray_permute(e, piinv.data(), ipe.out()));                      // :350
-        const Bytes& Ap = Ap_;
-        const std::vector<Bytes>& Bp = Bp_;
+        TRY(permuted_batch_vector(e, piinv, ipe));                                // :350
         std::unique_ptr<vmn_msg> m(new vmn_msg());
-        m->push_element(Ap);
-        m->push_bytes(VMN_ITEM_ELEMENTS, Bp);
+        m->push_element(Ap_);
+        m->push_bytes(VMN_ITEM_ELEMENTS, Bp_);
         *out = m.release();
         return VMN_OK;
     }
     int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
         REQUIRE(out && ipe.p && r && s.size() == width, "reply needs commit()");
         TRY(set_challenge(vb, vbytes));
-        Bytes a(G.xb), bsum(G.xb);
-        TRY(vmn_rarray_inner_product(r, ipe, a.data()));
-        std::vector<Bytes> kB;
+        Bytes ab(G.xb), bsum(G.xb);
+        TRY(vmn_rarray_inner_product(r, ipe, ab.data()));
+        Num a = G.ring_from(ab.data());
+        std::vector<Num> f(width);
         for (size_t col = 0; col < width; ++col) {
             TRY(vmn_rarray_inner_product(s[col], e, bsum.data()));
-            kB.push_back(G.ring_bytes(G.mul_add(G.ring_from(bsum.data()), v, beta[col])));
+            f[col] = G.ring_from(bsum.data());
         }
+        Round rd(*this);
+        rd.sum(a);
+        for (auto& fc : f) rd.sum(fc);
+        TRY(rd.run());
+        std::vector<Bytes> kB;
+        for (size_t col = 0; col < width; ++col) kB.push_back(G.ring_bytes(G.mul_add(f[col], v, beta[col])));
         Bytes vq = G.ring_bytes(v);
         RA k_E;
         TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
         std::unique_ptr<vmn_msg> m(new vmn_msg());
-        m->push_ring(G.ring_bytes(G.mul_add(G.ring_from(a.data()), v, alpha)));
+        m->push_ring(G.ring_bytes(G.mul_add(a, v, alpha)));
         m->push_bytes(VMN_ITEM_RING, kB);
         m->push(k_E);
         *out = m.release();
@@ -963,6 +1297,7 @@ struct vmn_ccpos : ProofBase {
         have_commitment = true;
         return VMN_OK;
     }
+    GA ru_own;
     int compute_ab(const vmn_garray* raisedu) {
         REQUIRE(u && e.p && width, "computeAB needs the instance and the batching vector");
         raised = raisedu != nullptr;
@@ -971,18 +1306,25 @@ struct vmn_ccpos : ProofBase {
             xs.insert(xs.end(), w.begin(), w.end());
             std::vector<Bytes> res;
             TRY(expprod_multi(xs, e, e_bits, res));
+            Round rd(*this);
+            rd.products(res);
+            TRY(rd.run());
             A = res[0];
             B.assign(res.begin() + 1, res.end());
         } else {
-            REQUIRE(vmn_garray_size(raisedu) == N, "raised commitment not of size N");
+            const vmn_garray* ru = nullptr;
+            TRY(local_garray(raisedu, ru_own, &ru, "raised commitment"));
             // w.mul(raisedu): the base-group array multiplies every component (:502); then one sort of e
             std::vector<GA> tmp(2 * width);
             std::vector<const vmn_garray*> xs;
             for (size_t c = 0; c < 2 * width; ++c) {
-                TRY(vmn_garray_mul(w[c], raisedu, tmp[c].out()));
+                TRY(vmn_garray_mul(w[c], ru, tmp[c].out()));
                 xs.push_back(tmp[c]);
             }
             TRY(expprod_multi(xs, e, e_bits, AB));
+            Round rd(*this);
+            rd.products(AB);
+            TRY(rd.run());
         }
         have_ab = true;
         return VMN_OK;
@@ -1006,6 +1348,9 @@ struct vmn_ccpos : ProofBase {
             xs.insert(xs.end(), wp.begin(), wp.end());
             std::vector<Bytes> kE_prods;
             TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));
+            Round rd(*this);
+            rd.products(kE_prods);
+            TRY(rd.run());
             TRY(G.el_expmul(A, v_be, cAp, lhs));
             TRY(gexp(g, k_A, t));
             TRY(G.el_mul(t, kE_prods[0], rhs));
@@ -1021,15 +1366,21 @@ struct vmn_ccpos : ProofBase {
             return VMN_OK;
         }
         // raised, single-equation form :571-580:  AB^v (B' A'^rho) = pk^{-k_B} prod (w'_i h_i^rho)^{k_E,i} g^{k_A rho}
-        REQUIRE(vmn_garray_size(raisedh) == N && rho_bytes > 0, "raised generators not of size N");
+        GA rh_own;
+        const vmn_garray* rh = nullptr;
+        REQUIRE(rho_bytes > 0, "empty raised exponent");
+        TRY(local_garray(raisedh, rh_own, &rh, "raised generators"));
         std::vector<GA> tmp(2 * width);
         std::vector<const vmn_garray*> xs;
         for (size_t c = 0; c < 2 * width; ++c) {
-            TRY(vmn_garray_mul(wp[c], raisedh, tmp[c].out()));
+            TRY(vmn_garray_mul(wp[c], rh, tmp[c].out()));
             xs.push_back(tmp[c]);
         }
         std::vector<Bytes> prods, rB;
         TRY(expprod_multi(xs, ikE->ra, kE_bits, prods));
+        Round rd(*this);
+        rd.products(prods);
+        TRY(rd.run());
         Num rho = G.reduce(rho_be, rho_bytes);
         Bytes Ap_rho, g_term;
         TRY(G.el_exp(cAp, rho_be, rho_bytes, Ap_rho));
@@ -1548,6 +1899,48 @@ int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_ga
     return vmn_garray_permute(tmp2, pi, u_out);                                   // :215
 }
 
+void vmn_shard_bounds(size_t n, int world, int rank, size_t* lo, size_t* hi) {
+    const size_t base = n / (size_t)world, rem = n % (size_t)world, k = (size_t)rank;
+    const size_t a = k * base + (k < rem ? k : rem);
+    if (lo) *lo = a;
+    if (hi) *hi = a + base + (k < rem ? 1 : 0);
+}
+
+// this rank's positions [lo, hi) of u = permute(h g^r, pi): u_i = h_pi(i) g^(r_pi(i)), gathered out of the whole h and r
+int vmn_permutation_commitment_shard(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_rarray* r_full,
+                                     const uint32_t* pi, size_t lo, size_t hi, vmn_garray** u_out) {
+    if (!grp || !g_be || !h_full || !r_full || !pi || !u_out || lo > hi || hi > vmn_garray_size(h_full) ||
+        vmn_rarray_size(r_full) != vmn_garray_size(h_full))
+        return fail(VMN_ERR_ARG, "vmn_permutation_commitment_shard: bad argument");
+    GA hsel, gr;
+    RA rsel;
+    TRY(vmn_rarray_gather(r_full, pi + lo, hi - lo, rsel.out()));
+    TRY(vmn_group_exp_fixed(grp, g_be, rsel, gr.out()));
+    TRY(vmn_garray_gather(h_full, pi + lo, hi - lo, hsel.out()));
+    return vmn_garray_mul(hsel, gr, u_out);
+}
+
+// this rank's positions [lo, hi) of w' = permute(w pk^s, pi^-1), gathered out of the whole w and s
+int vmn_shuffle_reencrypt_shard(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w_full,
+                                const vmn_rarray* const* s_full, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** wp_out) {
+    if (!grp || !pkey_be || !width || !w_full || !s_full || !pi || !wp_out || lo > hi) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt_shard: null argument");
+    const size_t eb = vmn_group_elem_bytes(grp);
+    const size_t n = vmn_garray_size(w_full[0]);
+    if (hi > n || !is_permutation(pi, n)) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt_shard: pi is not a permutation of [0, N) or the range is outside it");
+    std::vector<uint32_t> inv = inverse_permutation(pi, n);
+    std::vector<GA> res(2 * width);
+    for (size_t c = 0; c < 2 * width; ++c) {
+        RA ssel;
+        GA factors, wsel;
+        TRY(vmn_rarray_gather(s_full[c % width], inv.data() + lo, hi - lo, ssel.out()));
+        TRY(vmn_group_exp_fixed(grp, pkey_be + c * eb, ssel, factors.out()));
+        TRY(vmn_garray_gather(w_full[c], inv.data() + lo, hi - lo, wsel.out()));
+        TRY(vmn_garray_mul(wsel, factors, res[c].out()));
+    }
+    for (size_t c = 0; c < 2 * width; ++c) wp_out[c] = res[c].release();
+    return VMN_OK;
+}
+
 int vmn_rarray_random(vmn_group* grp, const vmn_random_source* rs, size_t n, int rbitlen, vmn_rarray** out) {
     if (!grp || !rs || !out || rbitlen < 0 || (!rs->ring_elements && !rs->array_seed)) return fail(VMN_ERR_ARG, "vmn_rarray_random: bad argument");
     HostGroup G;
@@ -1605,9 +1998,19 @@ int vmn_pos_precompute(vmn_pos* p, const uint8_t* g_be, const vmn_garray* h, con
 const vmn_garray* vmn_pos_permutation_commitment(const vmn_pos* p) { return p ? p->u : nullptr; }
 int vmn_pos_set_permutation_commitment(vmn_pos* p, const vmn_garray* u) {
     NONNULL(p);
-    if (!u || vmn_garray_size(u) != p->N) return fail(VMN_ERR_ARG, "vmn_pos_set_permutation_commitment: u null or not of size N");
-    p->u = u;
-    return VMN_OK;
+    return p->set_permutation_commitment(u);
+}
+int vmn_pos_set_comm(vmn_pos* p, const vmn_comm* comm) {
+    NONNULL(p);
+    return p->set_comm(comm);
+}
+int vmn_posc_set_comm(vmn_posc* p, const vmn_comm* comm) {
+    NONNULL(p);
+    return p->set_comm(comm);
+}
+int vmn_ccpos_set_comm(vmn_ccpos* p, const vmn_comm* comm) {
+    NONNULL(p);
+    return p->set_comm(comm);
 }
 int vmn_pos_set_instance(vmn_pos* p, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w, const vmn_garray* const* wp,
                          const vmn_rarray* const* s) {

@@ -32,6 +32,44 @@ class _RandomSourceStruct(C.Structure):
     _fields_ = [("user", C.c_void_p), ("ring_elements", _ROWS_CB), ("integers", _INTS_CB), ("array_seed", _SEED_CB)]
 
 
+_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class _CommStruct(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("all_gather", _GATHER_CB)]
+
+
+class NativeComm:
+    """``vmn_comm`` over a ``parallel.Comm`` (torch.distributed: RCCL on the GPU box, gloo in the tests): the proof
+    drivers call back for their few fixed-size all-gathers of scalars."""
+
+    def __init__(self, comm):
+        self.comm = comm
+        self.error = None
+        self.exchanges = 0
+        self.bytes_sent = 0
+
+        def gather_cb(_user, send, nbytes, recv):
+            try:
+                parts = comm.all_gather_bytes(C.string_at(send, nbytes))
+                C.memmove(recv, b"".join(parts), nbytes * comm.world)
+                self.exchanges += 1
+                self.bytes_sent += nbytes
+                return 0
+            except Exception as exc:       # pragma: no cover - re-raised by the caller
+                self.error = exc
+                return 1
+
+        self._cb = _GATHER_CB(gather_cb)
+        self.struct = _CommStruct(None, comm.rank, comm.world, self._cb)
+
+
+def shard_bounds_native(n: int, world: int, rank: int):
+    lo, hi = C.c_size_t(), C.c_size_t()
+    plib().vmn_shard_bounds(C.c_size_t(n), C.c_int(world), C.c_int(rank), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
 def plib() -> C.CDLL:
     """Load ``libvmnproofs.so`` (g++, built by ``__graft_entry__.build()``); it links against ``libvmnhip.so``."""
     global _plib
@@ -44,6 +82,7 @@ def plib() -> C.CDLL:
             getattr(_plib, name).restype = C.c_size_t
         for name in ("vmn_msg_item_garray", "vmn_msg_item_rarray", "vmn_pos_permutation_commitment"):
             getattr(_plib, name).restype = C.c_void_p
+        _plib.vmn_shard_bounds.restype = None
     return _plib
 
 
@@ -232,10 +271,18 @@ class _NativeProof:
     def _fn(self, name):
         return getattr(plib(), f"vmn_{self._prefix}_{name}")
 
+    def setComm(self, ncomm: "NativeComm"):
+        """Shard this proof over the ranks of ``ncomm`` (``vmn_*_set_comm``; before the instance is set): every rank
+        makes the same calls, array items of the messages are this rank's shard (include/vmnproofs.h, vmn_comm)."""
+        self._ncomm = ncomm
+        _check(self._fn("set_comm")(self._h, C.byref(ncomm.struct)))
+
     def _call(self, name, *args):
         rc = self._fn(name)(self._h, *args)
         if rc != 0 and self._rs is not None and self._rs.error is not None:
             raise self._rs.error
+        if rc != 0 and getattr(self, "_ncomm", None) is not None and self._ncomm.error is not None:
+            raise self._ncomm.error
         _check(rc)
 
     def free(self):
@@ -442,6 +489,25 @@ def reencrypt_native(group, pkey, w, s, pi):
     ptr, keep = _u32_array(pi)
     _check(plib().vmn_shuffle_reencrypt(group._h, group.enc_els(pkey), C.c_size_t(width), _ptr_array(w), _ptr_array(s), ptr, out))
     return [PGroupElementArray(group, C.c_void_p(h)) for h in out]
+
+
+def reencrypt_shard_native(group, pkey, w_full, s_full, pi, lo: int, hi: int):
+    """``vmn_shuffle_reencrypt_shard``: positions [lo, hi) of w' = permute(w * pk^s, pi^-1), out of the whole w and s."""
+    width = len(pkey) // 2
+    out = (C.c_void_p * (2 * width))()
+    ptr, keep = _u32_array(pi)
+    _check(plib().vmn_shuffle_reencrypt_shard(group._h, group.enc_els(pkey), C.c_size_t(width), _ptr_array(w_full), _ptr_array(s_full),
+                                              ptr, C.c_size_t(lo), C.c_size_t(hi), out))
+    return [PGroupElementArray(group, C.c_void_p(h)) for h in out]
+
+
+def permutation_commitment_shard_native(group, g, h_full, r_full, pi, lo: int, hi: int):
+    """``vmn_permutation_commitment_shard``: positions [lo, hi) of u = permute(h * g^r, pi)."""
+    out = C.c_void_p()
+    ptr, keep = _u32_array(pi)
+    _check(plib().vmn_permutation_commitment_shard(group._h, group.enc_el(g), h_full._h, r_full._h, ptr, C.c_size_t(lo), C.c_size_t(hi),
+                                                   C.byref(out)))
+    return PGroupElementArray(group, out)
 
 
 def permutation_commitment_native(group, g, h, r, pi):

@@ -61,6 +61,20 @@ class Comm:
             res.append([int.from_bytes(raw[i * nbytes:(i + 1) * nbytes], "big") for i in range(len(values))])
         return res
 
+    def all_gather_bytes(self, data: bytes) -> List[bytes]:
+        """Every rank contributes ``len(data)`` bytes (the same length everywhere); the per-rank blocks in rank order.
+        This is the one primitive the C++ proof drivers call back for (``vmn_comm.all_gather``, include/vmnproofs.h)."""
+        if not self.dist:
+            return [bytes(data)]
+        import torch
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        if self.device is not None:
+            t = t.to(self.device)
+        out = torch.empty(self.world * len(data), dtype=torch.uint8, device=t.device)
+        self.dist.all_gather_into_tensor(out, t)
+        raw = out.cpu().numpy().tobytes()
+        return [raw[k * len(data):(k + 1) * len(data)] for k in range(self.world)]
+
     def all_true(self, flag: bool) -> bool:
         return all(v[0] == 1 for v in self.all_gather_ints([1 if flag else 0], 1))
 
@@ -98,13 +112,8 @@ def _take_rows(arr, idx, nbytes: int):
     return _take(arr, idx)
 
 
-class ShardedPoSBasicTW:
-    """Proof of a shuffle with every array sharded by position; see the module docstring.
-
-    ``group`` is a ``ModPGroup`` (or any object with the same interface).  Replicated public inputs are
-    handed over as full arrays on this rank's GPU; secrets and the batching vector come from host
-    tapes shared by all ranks.
-    """
+class _ShardedBase:
+    """What the sharded mirrors share: the exchanges of single elements / ring scalars and the slicing of host tapes."""
 
     def __init__(self, group, vbitlen: int, ebitlen: int, rbitlen: int, comm: Comm, rand=None):
         self.G, self.comm, self.rand = group, comm, rand
@@ -154,14 +163,33 @@ class ShardedPoSBasicTW:
             rows = [x % self.q for x in rows]        # integers longer than q (epsilon over a 256-bit curve order) act mod q
         return self.G.ringArray(rows)
 
+    def _set_size(self, size: int):
+        self.size = size
+        self.lo, self.hi = shard_bounds(size, self.comm.world, self.comm.rank)
+        self.local = range(self.lo, self.hi)
+
+    def _local(self, arr):
+        """An array argument is the whole array (replicated) or already this rank's shard -- told apart by size."""
+        if arr.size() == self.size and (self.hi - self.lo) != self.size:
+            return arr.copyOfRange(self.lo, self.hi)
+        return arr
+
+
+class ShardedPoSBasicTW(_ShardedBase):
+    """Proof of a shuffle with every array sharded by position; see the module docstring.
+
+    ``group`` is a ``ModPGroup`` (or any object with the same interface).  Replicated public inputs are
+    handed over as full arrays on this rank's GPU; secrets and the batching vector come from host
+    tapes shared by all ranks.  (Python mirror of the sharded C++ driver, ``vmn_pos_set_comm``: the CPU suite runs it
+    on gloo ranks over tests/fake_backend.py; the product path is ``native.PoSBasicTW.setComm``.)
+    """
+
     # ---- setup --------------------------------------------------------------------------------
     def precompute(self, g: int, h_full, pi=None):
         """h_full: the N independent generators, replicated.  Prover (pi given): draws r, alpha, epsilon
         from the shared tape and computes its shard of u and the global A'."""
         G = self.G
-        self.size = h_full.size()
-        self.lo, self.hi = shard_bounds(self.size, self.comm.world, self.comm.rank)
-        self.local = range(self.lo, self.hi)
+        self._set_size(h_full.size())
         self.g, self.h_full = g, h_full
         self.h = h_full.copyOfRange(self.lo, self.hi)
         self.h0 = h_full.get(0)
@@ -344,6 +372,80 @@ class ShardedPoSBasicTW:
                        for c, (Fc, Fpc, pk, t) in enumerate(zip(self.F, self.Fp, self.pkey, wp_kE)))
         self.verdicts = (verdictA, verdictB, verdictC, verdictD, verdictF)
         return all(self.verdicts)
+
+
+class ShardedCCPoSBasicW(_ShardedBase):
+    """Commitment-consistent proof of a shuffle, sharded by position (mirror of ``vmn_ccpos_set_comm``;
+    ref: hvzk/CCPoSBasicW.java:344-396, 462-506, 519-584).  h is the whole array; u, w, w', r, s may be whole arrays or
+    shards; the batching vector and epsilon come from tapes shared by all ranks."""
+
+    def setInstance(self, g, h_full, u, pkey, w, wp, r=None, pi=None, s=None):
+        self._set_size(h_full.size())
+        self.g, self.pkey = g, list(pkey)
+        self.h = self._local(h_full)
+        self.u = self._local(u)
+        self.w = [self._local(c) for c in w]
+        self.wp = [self._local(c) for c in wp]
+        self.r = self._local(r) if r is not None else None
+        self.s = [self._local(c) for c in s] if s is not None else None
+        self.piinv = _inv(pi) if pi is not None else None
+
+    def setBatchVector(self, e_full):
+        self.e_full = e_full
+        self.e = self._ring_rows(e_full, self.local)
+
+    def commit(self):
+        G, g = self.G, self.g
+        self.ipe = self._ring_rows(self.e_full, _slice_idx(self.piinv, self.lo, self.hi))
+        self.alpha = self.rand.ring_element()
+        eps_full = self.rand.int_array(self.size, self.ebitlen + self.vbitlen + self.rbitlen)
+        self.epsilon = self._ring_rows(eps_full, self.local)
+        width = len(self.pkey) // 2
+        self.beta = [self.rand.ring_element() for _ in range(width)]
+        parts = [self.h.expProd(self.epsilon, self.eps_bits)] + [c.expProd(self.epsilon, self.eps_bits) for c in self.wp]
+        tot = self._prod_all(parts)
+        self.Ap = G.k_mul(self._gexp(g, self.alpha), tot[0])
+        self.Bp = [G.k_mul(self._gexp(pk, -self.beta[c % width]), t) for c, (pk, t) in enumerate(zip(self.pkey, tot[1:]))]
+        return {"Ap": self.Ap, "Bp": self.Bp}
+
+    def reply(self, v: int):
+        q = self.q
+        tot = self._sum_all([self.r.innerProduct(self.ipe)] + [si.innerProduct(self.e) for si in self.s])
+        self.k_E = self.ipe.mulAdd(v % q, self.epsilon)
+        return {"k_A": (tot[0] * v + self.alpha) % q, "k_B": [(b * v + bt) % q for b, bt in zip(tot[1:], self.beta)], "k_E": self.k_E}
+
+    def setCommitment(self, msg):
+        self.Ap, self.Bp = msg["Ap"], msg["Bp"]
+
+    def setChallenge(self, v: int):
+        self.v = int(v)
+
+    def computeAB(self, raisedu=None):
+        if raisedu is None:
+            tot = self._prod_all([self.u.expProd(self.e, self.e_bits)] + [c.expProd(self.e, self.e_bits) for c in self.w])
+            self.A, self.B = tot[0], tot[1:]
+        else:
+            ru = self._local(raisedu)
+            self.AB = self._prod_all([c.mul(ru).expProd(self.e, self.e_bits) for c in self.w])
+
+    def verify(self, reply, raisedh=None, raisedExponent=None) -> bool:
+        G, g, v = self.G, self.g, self.v
+        k_A, k_B, k_E = reply["k_A"], reply["k_B"], reply["k_E"]
+        width = len(self.pkey) // 2
+        kE_bits = max(1, k_E.maxBits())
+        if raisedExponent is None:
+            tot = self._prod_all([self.h.expProd(k_E, kE_bits)] + [c.expProd(k_E, kE_bits) for c in self.wp])
+            if self._expmul(self.A, v, self.Ap) != G.k_mul(self._gexp(g, k_A), tot[0]):
+                return False
+            return all(self._expmul(Bc, v, Bpc) == G.k_mul(self._gexp(pk, -k_B[c % width]), t)
+                       for c, (Bc, Bpc, pk, t) in enumerate(zip(self.B, self.Bp, self.pkey, tot[1:])))
+        rho = raisedExponent
+        rh = self._local(raisedh)
+        tot = self._prod_all([c.mul(rh).expProd(k_E, kE_bits) for c in self.wp])
+        Ap_rho = self._gexp(self.Ap, rho)
+        g_term = self._gexp(g, k_A * rho % self.q)
+        return all(self._expmul(ABc, v, G.k_mul(Bpc, Ap_rho)) == G.k_mul(G.k_mul(self._gexp(pk, -k_B[c % width]), t), g_term)
+                   for c, (ABc, Bpc, pk, t) in enumerate(zip(self.AB, self.Bp, self.pkey, tot)))
 
 
 def _inv(pi):
