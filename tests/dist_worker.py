@@ -31,6 +31,7 @@ def load_parallel():
 
 
 def load_native():
+    entry.load_package()                       # native.py imports from its package
     spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.native", os.path.join(entry.PKG_DIR, "native.py"))
     m = importlib.util.module_from_spec(spec)
     sys.modules[spec.name] = m
@@ -266,7 +267,7 @@ def main():
     mine = {"u": ints(pr.u), "wp": [ints(c) for c in WP], "B": ints(com["B"]), "Bp": ints(com["Bp"]),
             "k_B": ints(rep["k_B"]), "k_E": ints(rep["k_E"]),
             "scalars": [com["Ap"], com["Cp"], com["Dp"], com["Fp"], rep["k_A"], rep["k_C"], rep["k_D"], rep["k_F"]],
-            "ok": ok, "bad_ok": bad_ok, "bad_verdicts": list(bad_verdicts)}
+            "ok": ok, "bad_ok": bad_ok, "bad_verdicts": list(bad_verdicts), "exchanges": ncomm.exchanges if native else None}
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     result = {"pass": True, "why": ""}
@@ -289,7 +290,8 @@ def main():
             "accept": all(gsh["ok"] for gsh in gathered),
             "reject_tampered": all(not gsh["bad_ok"] and gsh["bad_verdicts"] == [True, False, True, True, True] for gsh in gathered),
         }
-        result = {"pass": all(checks.values()), "why": json.dumps(checks), "world": world}
+        result = {"pass": all(checks.values()), "why": json.dumps(checks), "world": world,
+                  "exchanges": [gsh.get("exchanges") for gsh in gathered]}
         with open(out_path, "w") as f:
             json.dump(result, f)
     dist.barrier()
