@@ -595,21 +595,25 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
 
 
 def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dist, device):
-    """The same workload sharded over the ranks: N = n_per_gpu x world ciphertexts (at most BASELINE.json
-    configs[3]'s 4 194 304: every rank holds the replicated public arrays and the whole shared tape in host
-    memory), one proof, every array split by position (verificatum-vmn_amd/parallel.py); public inputs
-    replicated per GPU; the only collectives are all-gathers of partial products / scan carries / verdicts (RCCL)."""
-    par, mx = load_sub(entry, "parallel"), load_sub(entry, "mixnet")
+    """The same workload sharded over the ranks: N = n_per_gpu x world ciphertexts (at most BASELINE.json configs[3]'s
+    4 194 304), ONE proof through the sharded C++ drivers (vmn_pos_set_comm, include/vmnproofs.h): every
+    position-indexed array is split by position; the public inputs h, w and the prover's N-sized random arrays -- expanded
+    on every GPU from the same 32-byte seeds -- are held whole, so the permuted arrays are local gathers; the only
+    collectives are all-gathers of a few hundred bytes (partial products, partial sums, scan carries, verdict bits;
+    RCCL over xGMI) -- one per phase."""
+    par, mx, nat = load_sub(entry, "parallel"), load_sub(entry, "mixnet"), load_sub(entry, "native")
     comm = par.Comm(dist, device)
+    ncomm = nat.NativeComm(comm)
     NV = NE = 256
     NR = 100
     n = min(n_per_gpu * comm.world, 4_194_304)
+    lo, hi = nat.shard_bounds_native(n, comm.world, comm.rank)
     p, q, g = grp.p, grp.q, grp.g
     pub = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)             # same seed on every rank: replicated public instance
     y = pow(g, pub.ring_element(), p)
     pkey = [g, y]
     for base in pkey:                      # session setup (tables sized for this rank's shard)
-        grp.precomputeFixed(base, max(1, n // comm.world), 16)
+        grp.precomputeFixed(base, max(1, hi - lo), 16)
     H = grp.exp(g, grp.ringArray(pub.ring_array(n)))
     T = grp.ringArray(pub.ring_array(n))
     M = grp.exp(g, grp.ringArray(pub.ring_array(n)))
@@ -617,38 +621,33 @@ def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dis
     W = [grp.exp(g, T), M.mul(YT)]
     for a in (T, M, YT):
         a.free()
-    EB = NE + NV + NR
-    tape = ReplaySource(pub, [("permutation", n), ("ring_array", n),                          # pi, s
-                              ("ring_array", n), ("ring_element",), ("int_array", n, EB),      # r, alpha, epsilon
-                              ("int_array", n, NE),                                            # e
-                              ("ring_array", n), ("ring_array", n),                            # b, beta
-                              ("ring_element",), ("ring_element",), ("ring_element",),         # gamma, delta, phi
-                              ("int_array", 1, NV)], pin=False)    # shards are gathered out of the tape on the host
     ctx.timing_reset()
     ctx.timing_enable(True)
     gc.collect()            # release the previous pass's arrays into the pool before the clock starts
     sync()
     t0 = time.perf_counter()
-    pi = tape.permutation(n)
-    s_full = [tape.ring_array(n)]
-    prover = par.ShardedPoSBasicTW(grp, NV, NE, NR, comm, rand=tape)
+    pi = pub.permutation(n)                                                # the same on every rank
+    S = [nat.random_ring_array_native(grp, pub, n, NR)]                    # whole array on every rank, from one 32-byte seed
+    prover = nat.PoSBasicTW(grp, NV, NE, NR, rand=pub)
+    prover.setComm(ncomm)
     prover.precompute(g, H, pi)
-    WP = prover.reencrypt(pkey, W, s_full)
+    WP = nat.reencrypt_shard_native(grp, pkey, W, S, pi, lo, hi)           # this rank's shard of w'
     sync()
     t1 = time.perf_counter()
-    prover.setInstance(pkey, W, WP)
-    e = tape.int_array(n, NE)
-    prover.setBatchVector(e)
+    prover.setInstance(pkey, W, WP, S)
+    e_seed = pub.array_seed()
+    prover.setBatchVectorSeed(e_seed)
     com = prover.commit()
-    v = int.from_bytes(tape.int_array(1, NV), "big")
+    v = int.from_bytes(pub.int_array(1, NV), "big")
     rep = prover.reply(v)
     sync()
     t2 = time.perf_counter()
-    ver = par.ShardedPoSBasicTW(grp, NV, NE, NR, comm)
+    ver = nat.PoSBasicTW(grp, NV, NE, NR)
+    ver.setComm(ncomm)
     ver.precompute(g, H)
     ver.setPermutationCommitment(prover.u)
     ver.setInstance(pkey, W, WP)
-    ver.setBatchVector(e)
+    ver.setBatchVectorSeed(e_seed)
     ver.computeAF()
     ver.setCommitment(com)
     ver.setChallenge(v)
@@ -659,7 +658,9 @@ def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dis
     fam = ctx.timing_report()
     return {"kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
             "precompute_and_reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
-            "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "n": n,
+            "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "n": n, "ciphertexts_per_rank": hi - lo,
+            "collective": {"backend": dist.get_backend() if dist.is_initialized() else None, "world": comm.world,
+                           "all_gathers_per_proof": ncomm.exchanges, "bytes_sent_per_rank": ncomm.bytes_sent},
             "ciphertexts_per_s": n / (t3 - t0),
             "canonical_TMACs_survey_8d": 3280 * 8256 * n / (t3 - t0) / 1e12, "roofline": leg_roofline(fam, (t3 - t0) * 1e3)}
 
@@ -843,7 +844,9 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: batched modPow, RFC 3526 group 14 (2048-bit safe prime), "
                                "random bases, random 2047-bit exponents, device-resident in/out",
-                   "elements_per_gpu": n, "parallelism": f"shard{world}" if world > 1 else "single"},
+                   "elements_per_gpu": n, "parallelism": f"shard{world}" if world > 1 else "single",
+                   "world_size": world, "collective_backend": (backend if distributed else None),
+                   "note": "element-wise op: contiguous shards, no data-path collective (weak scaling)"},
         "roofline": {"bound": "valu-int", "kernel": "k_modpow<74>", "achieved": achieved, "peak": PEAK_TMACS,
                      "unit": "TMAC/s (32x32->64-bit multiply-accumulate)", "frac": achieved / PEAK_TMACS,
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
