@@ -131,7 +131,8 @@ int vmn_garray_from_be(vmn_group* grp, const uint8_t* be, size_t n, vmn_garray**
  * P/hvzk/PoSBasicTW.java:694-699. */
 int vmn_garray_to_be(const vmn_garray* a, uint8_t* be_out);
 /* The same in the reference's byte-tree framing: node(N leaves of elem_bytes) =
- * 00 | uint32_be(N) | N x (01 | uint32_be(elem_bytes) | value).  Leaf headers are written / checked on the
+ * 00 | uint32_be(N) | N x (01 | uint32_be(elem_bytes) | value); over a curve group N x node(leaf(x), leaf(y)), the point at
+ * infinity as two leaves of 0xff bytes (= -1) [NOT-IN-REF: VCR's form, from the verifier specification].  Headers are written / checked on the
  * GPU.  from_bytetree: expected_n = 0 accepts any size (pGroup.toElementArray(0, reader)); *format_ok = 0
  * (and no array) when the tree is not a node of leaves of the right width (the reference's
  * ArithmFormatException / EIOException, which its callers catch: P/hvzk/PoSBasicTW.java:505-513). */
@@ -237,13 +238,16 @@ int vmn_rarray_copy_range(const vmn_rarray* x, size_t from, size_t to, vmn_rarra
 int vmn_rarray_max_bits(const vmn_rarray* x, int* bits);
 
 /* ---- pseudo-random derivations ---------------------------------------------
- * VCR's PRGHeuristic and RandomOracle over SHA-256, restated from their published definition (the classes are not
- * in the reference tree): PRG(seed) = H(seed || uint32_be(0)) || H(seed || uint32_be(1)) || ...;
+ * VCR's PRGHeuristic and RandomOracle over SHA-256 / SHA-384 / SHA-512 (the three the reference offers,
+ * ref: P/elgamal/ProtocolElGamal.java:352-371 PRG, :413-434 random-oracle hash), restated from their published definition
+ * (the classes are not in the reference tree): PRG(seed) = H(seed || uint32_be(0)) || H(seed || uint32_be(1)) || ...;
  * RO_nout(d) = first ceil(nout/8) bytes of PRG(H(uint32_be(nout) || d)) with the superfluous leading bits cleared.
- * Seeds are 32 bytes (PRGHeuristic.minNoSeedBytes of SHA-256).  Both constructions are pinned by the published
- * known-answer vectors (tests/test_prg.py). */
+ * A PRG seed has the digest's length (PRGHeuristic.minNoSeedBytes), so seedlen = 32 / 48 / 64 selects the hash everywhere
+ * a seed is taken.  The SHA-256 constructions are pinned by the published known-answer vectors, SHA-384 / SHA-512 by
+ * hashlib (tests/test_prg.py). */
 int vmn_prg_bytes(const uint8_t* seed, size_t seedlen, uint8_t* out, size_t nbytes);              /* host */
-int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits, uint8_t* out);            /* host, small inputs */
+int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits, uint8_t* out);            /* host, SHA-256 */
+int vmn_random_oracle_hash(int hash_bits, const uint8_t* data, size_t len, int nout_bits, uint8_t* out);   /* 256 / 384 / 512 */
 /* The random vector of a proof, generated on the device: prg.setSeed(seed); LargeIntegerArray.random(n, bits, prg)
  * as field elements.  ref: P/hvzk/PoSBasicTW.java:533-538, PoSCBasicTW.java:350-355, CCPoSBasicW.java:330-335.
  * Value i = the i-th ceil(bits/8) bytes of the stream, leading bits cleared; reduced mod q when it can reach q. */
@@ -251,7 +255,10 @@ int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, siz
 /* Independent generators: pGroup.randomElementArray(n, prg, rbitlen) of a safe-prime ModPGroup, generated on the
  * device.  ref: P/distr/IndependentGeneratorsRO.java:117-130 (seed = RO(globalPrefix || bytetree(sid))).
  * t_i = the i-th ceil((bits(p) + rbitlen)/8) bytes, leading bits cleared; h_i = t_i^((p-1)/q) = t_i^2 mod p.
- * The derivation follows the specification's text; it is not pinned by a vector of the reference. */
+ * ECqPGroup (P-256 is the reference's default group, demo/mixnet/.conf:153): the values are candidates for x = t mod p,
+ * kept when x^3 - 3x + b is a square, with the smaller root as y; element i is the i-th kept candidate (candidates are
+ * tested in parallel, the kept ones compacted in order).
+ * The derivations follow the specification's text; they are not pinned by a vector of the reference [NOT-IN-REF]. */
 int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int rbitlen, vmn_garray** out);
 
 /* ---- partial results for multi-GPU sharding --------------------------------

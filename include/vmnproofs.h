@@ -75,6 +75,9 @@ int vmn_rarray_random(vmn_group* grp, const vmn_random_source* rs, size_t n, int
 typedef struct vmn_msg vmn_msg;
 enum { VMN_ITEM_GARRAY = 1, VMN_ITEM_RARRAY = 2, VMN_ITEM_ELEMENTS = 3, VMN_ITEM_RING = 4 };
 int vmn_msg_create(vmn_msg** out);
+/* the same for a message whose group elements belong to grp: over a curve group the single elements of the wire form are
+ * node(leaf(x), leaf(y)) instead of a leaf (messages made by the drivers and by vmn_msg_from_bytetree know their group) */
+int vmn_msg_create_for(vmn_group* grp, vmn_msg** out);
 void vmn_msg_free(vmn_msg* m);                                   /* frees the arrays it owns */
 size_t vmn_msg_items(const vmn_msg* m);
 int vmn_msg_item_kind(const vmn_msg* m, size_t i);
@@ -88,7 +91,9 @@ int vmn_msg_push_elements(vmn_msg* m, const uint8_t* be, size_t count, size_t wi
 int vmn_msg_push_ring(vmn_msg* m, const uint8_t* be, size_t count, size_t width);
 /* Wire form: node(items); an array item is the array's byte tree, one element a leaf, k > 1
  * elements of a ciphertext-shaped item node(node(k/2 leaves), node(k/2 leaves)) (k = 2: node(leaf, leaf)), k > 1
- * ring elements node(k leaves).  ModPGroup only (byte trees of curve points are not built). */
+ * ring elements node(k leaves).  Over ECqPGroup an element is node(leaf(x), leaf(y)) (infinity: both -1) and an array
+ * node(N such nodes): [NOT-IN-REF] -- VCR's ECqPGroupElement / BPGroupElementArray, restated from the verifier
+ * specification, not pinned by a reference fixture. */
 size_t vmn_msg_bytetree_size(const vmn_msg* m);
 int vmn_msg_to_bytetree(const vmn_msg* m, uint8_t* out);
 /* `layout` lists the expected item kinds (VMN_ITEM_*), `counts[i]` the element count of items of kind 3 / 4 and

@@ -48,6 +48,25 @@ def test_library_host_functions_reproduce_the_published_vectors(entry):
     assert lib.vmn_prg_bytes(SEED, ctypes.c_size_t(31), out, ctypes.c_size_t(32)) == -5          # VMN_ERR_UNSUPPORTED
 
 
+def test_sha384_and_sha512_variants_of_prg_and_random_oracle(entry):
+    """The reference lets the operator pick SHA-256, SHA-384 or SHA-512 for the PRG and for the random oracles
+    (elgamal/ProtocolElGamal.java:352-371, 413-434).  A seed has the digest's length, which selects the hash; the library's
+    host functions against the Python restatement over hashlib."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "verificatum-vmn_amd", "libvmnhip.so"))
+    for name, bits in (("sha384", 384), ("sha512", 512), ("sha256", 256)):
+        seed = bytes(range(bits // 8))
+        out = ctypes.create_string_buffer(1000)
+        assert lib.vmn_prg_bytes(seed, ctypes.c_size_t(len(seed)), out, ctypes.c_size_t(1000)) == 0
+        assert out.raw == pyref_prg.prg_bytes(seed, 1000, name)
+        for data in (b"", b"abc", bytes(range(256)) * 3, b"x" * 111, b"y" * 112, b"z" * 127, b"w" * 128):     # padding boundaries of the 128-byte block
+            for nout in (8 * (bits // 8), 65, 1000):
+                nb = (nout + 7) // 8
+                out = ctypes.create_string_buffer(nb)
+                assert lib.vmn_random_oracle_hash(ctypes.c_int(bits), data, ctypes.c_size_t(len(data)), ctypes.c_int(nout), out) == 0
+                assert out.raw == pyref_prg.random_oracle(data, nout, name), (name, len(data), nout)
+    assert lib.vmn_random_oracle_hash(ctypes.c_int(224), b"", ctypes.c_size_t(0), ctypes.c_int(8), out) == -1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits", [512, 2048, 3072])
 def test_device_random_vector_and_generators(bits, vmn, gpu_ctx):
@@ -67,13 +86,47 @@ def test_device_random_vector_and_generators(bits, vmn, gpu_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hashname,seedlen", [("sha384", 48), ("sha512", 64)])
+def test_device_generators_with_sha384_and_sha512_seeds(hashname, seedlen, vmn, gpu_ctx):
+    grp, _ = load_golden(2048)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    seed = pyref_prg.random_oracle(b"wide-hash", 8 * seedlen, hashname)
+    assert len(seed) == seedlen
+
+    def ints(n, bits):
+        vb = (bits + 7) // 8
+        stream = pyref_prg.prg_bytes(seed, n * vb, hashname)
+        return [int.from_bytes(stream[i * vb:(i + 1) * vb], "big") & ((1 << bits) - 1) for i in range(n)]
+    for n, ebits in ((1, 256), (91, 256), (40, 613), (17, 2047 + 100)):
+        assert G.ringArrayFromPRG(seed, n, ebits).toInts() == [x % q for x in ints(n, ebits)]
+    H = G.elementArrayFromPRG(seed, 33, 100)
+    assert H.toInts() == [pow(t % p, 2, p) for t in ints(33, p.bit_length() + 100)]
+
+
+@pytest.mark.gpu
 def test_random_vector_over_a_curve_order(vmn, gpu_ctx):
     G = vmn.ECqPGroup(gpu_ctx, "P-256")
     seed = pyref_prg.random_oracle(b"curve", 256)
     assert G.ringArrayFromPRG(seed, 200, 128).toInts() == pyref_prg.random_integers(seed, 200, 128)
     assert G.ringArrayFromPRG(seed, 200, 256).toInts() == [x % G.q for x in pyref_prg.random_integers(seed, 200, 256)]
-    with pytest.raises(vmn.VmnError):
-        G.elementArrayFromPRG(seed, 4, 100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,hashname,seedlen", [("P-256", "sha256", 32), ("P-384", "sha256", 32), ("P-256", "sha512", 64)])
+def test_independent_generators_over_curves(curve_name, hashname, seedlen, vmn, gpu_ctx):
+    """IndependentGeneratorsRO over ECqPGroup (P-256 is the reference's default group): random points derived on the GPU,
+    candidates tested in parallel and compacted in order, against the sequential Python restatement."""
+    from oracle.pyref_ec import Curve
+    c = Curve(curve_name)
+    G = vmn.ECqPGroup(gpu_ctx, curve_name)
+    seed = pyref_prg.random_oracle(b"curve-generators", 8 * seedlen, hashname)
+    for n, rbitlen in ((1, 100), (2, 100), (257, 100), (1000, 50), (33, 0)):
+        H = G.elementArrayFromPRG(seed, n, rbitlen)
+        want = pyref_prg.ec_generators(seed, n, c, rbitlen, hashname)
+        assert H.toInts() == want, (n, rbitlen)
+        assert all(c.on_curve(P) for P in want)
+    assert G.elementArrayFromPRG(seed, 0, 100).size() == 0
 
 
 @pytest.mark.gpu

@@ -30,6 +30,7 @@ struct ECDev {
     const u32* mp;     // 64 * p, normalised limbs (added before a subtraction so the result stays positive)
     const u32* mp2;    // 256 * p, for the few subtractions whose subtrahend is itself a difference (< 256 p)
     const u32* pm2;    // p - 2 as packed 32-bit words (Fermat inversion)
+    const u32* pp14;   // (p + 1) / 4 as packed words: square roots (p = 3 mod 4 for P-256 and P-384)
     u32 n0inv;         // -p^{-1} mod 2^28
     int pwords;        // words of pm2
 };
@@ -151,16 +152,20 @@ __device__ __forceinline__ bool f_is_zero(const u32 (&a)[S], const ECDev& E) {
 }
 // r = a^(p-2): Fermat inversion, left-to-right binary (uniform exponent: no divergence).  Export only.
 template <int S>
-__device__ void f_inv(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
+__device__ void f_pow_words(u32 (&r)[S], const u32 (&a)[S], const u32* __restrict__ ewords, int nwords, const ECDev& E) {
     u32 acc[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) acc[j] = E.one[j];
-    for (int bit = E.pwords * 32 - 1; bit >= 0; --bit) {
+    for (int bit = nwords * 32 - 1; bit >= 0; --bit) {
         f_sqr<S>(acc, acc, E);
-        if ((E.pm2[bit >> 5] >> (bit & 31)) & 1) f_mul<S>(acc, acc, a, E);
+        if ((ewords[bit >> 5] >> (bit & 31)) & 1) f_mul<S>(acc, acc, a, E);
     }
 #pragma unroll
     for (int j = 0; j < S; ++j) r[j] = acc[j];
+}
+template <int S>
+__device__ void f_inv(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
+    f_pow_words<S>(r, a, E.pm2, E.pwords, E);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -318,12 +323,31 @@ __device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q,
 // curve (replaced by the identity, the reference's "trivial value" convention).
 template <int S, int NW>
 __global__ void __launch_bounds__(BLOCK) k_ec_import(u32* __restrict__ out, const uint8_t* __restrict__ be, size_t nbytes,
-                                                     size_t stride, size_t n, ECDev E, u32* __restrict__ flags) {
+                                                     size_t stride, int framed, size_t n, ECDev E, u32* __restrict__ flags) {
+    // framed: every point is the byte tree node(leaf(x), leaf(y)) = 00 00000002 | 01 len x | 01 len y (the form VCR gives a
+    // curve point; [NOT-IN-REF]: restated from the verifier specification); the coordinates are moved together first
     using C1 = Cfg<S, 1>;
     constexpr int ROW = ECfg<S>::ROW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (el >= n) return;
-    const uint8_t* src = be + el * stride;
+    const uint8_t* rec = be + el * stride;
+    uint8_t packed[2 * (4 * NW + 4)];
+    const uint8_t* src = rec;
+    if (framed) {
+        auto hdr_ok = [&](const uint8_t* h, uint8_t tag, size_t len) {
+            return h[0] == tag && h[1] == (uint8_t)(len >> 24) && h[2] == (uint8_t)(len >> 16) && h[3] == (uint8_t)(len >> 8) && h[4] == (uint8_t)len;
+        };
+        if (!(hdr_ok(rec, 0, 2) && hdr_ok(rec + 5, 1, nbytes) && hdr_ok(rec + 10 + nbytes, 1, nbytes))) atomicOr(flags, 4u);
+        if (nbytes <= sizeof(packed) / 2) {
+            for (size_t i = 0; i < nbytes; ++i) {
+                packed[i] = rec[10 + i];
+                packed[nbytes + i] = rec[15 + nbytes + i];
+            }
+            src = packed;
+        } else {
+            atomicOr(flags, 4u);
+        }
+    }
     u32 allff = 0xff;
     for (size_t i = 0; i < 2 * nbytes; ++i) allff &= src[i];
     Pt<S> P;
@@ -367,7 +391,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_import(u32* __restrict__ out, cons
 }
 
 template <int S, int NW>
-__global__ void __launch_bounds__(BLOCK) k_ec_export(uint8_t* __restrict__ be, size_t nbytes, size_t stride,
+__global__ void __launch_bounds__(BLOCK) k_ec_export(uint8_t* __restrict__ be, size_t nbytes, size_t stride, int framed,
                                                      const u32* __restrict__ in, size_t n, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -375,8 +399,23 @@ __global__ void __launch_bounds__(BLOCK) k_ec_export(uint8_t* __restrict__ be, s
     Pt<S> P;
     pt_load<S>(P, in + el * ROW);
     uint8_t* dst = be + el * stride;
-    if (P.inf) {
-        for (size_t i = 0; i < 2 * nbytes; ++i) dst[i] = 0xff;
+    uint8_t* dsty = dst + nbytes;
+    if (framed) {                                      // node(leaf(x), leaf(y)), see k_ec_import
+        auto hdr = [&](uint8_t* h, uint8_t tag, size_t len) {
+            h[0] = tag;
+            h[1] = (uint8_t)(len >> 24);
+            h[2] = (uint8_t)(len >> 16);
+            h[3] = (uint8_t)(len >> 8);
+            h[4] = (uint8_t)len;
+        };
+        hdr(dst, 0, 2);
+        hdr(dst + 5, 1, nbytes);
+        hdr(dst + 10 + nbytes, 1, nbytes);
+        dsty = dst + 15 + nbytes;
+        dst += 10;
+    }
+    if (P.inf) {                                       // the point at infinity: both coordinates -1 (all 0xff)
+        for (size_t i = 0; i < nbytes; ++i) dst[i] = dsty[i] = 0xff;
         return;
     }
     u32 zi[S], zi2[S], zi3[S], xa[S], ya[S], one1[S], t[S];
@@ -406,7 +445,7 @@ __global__ void __launch_bounds__(BLOCK) k_ec_export(uint8_t* __restrict__ be, s
         for (long o = (long)nbytes - 4L * NW - 1; o >= 0; --o) d[o] = 0;
     };
     out_coord(xa, dst);
-    out_coord(ya, dst + nbytes);
+    out_coord(ya, dsty);
 }
 
 // K4: out[i] = x[i] + y[i]   (ystride = 0: one shared point)

@@ -13,6 +13,7 @@
 #include "modp_kernels.h"
 #include "vmnhip_internal.h"
 #include "sha256.h"
+#include "sha512.h"
 #include "hostnum64.h"
 
 using namespace vmn;
@@ -633,6 +634,7 @@ static ECDev ecdev(const vmn_curve* c) {
     E.mp = c->d_mp;
     E.mp2 = c->d_mp2;
     E.pm2 = c->d_pm2;
+    E.pp14 = c->d_pp14;
     E.n0inv = c->n0inv;
     E.pwords = c->NW;
     return E;
@@ -740,6 +742,19 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     size_t o_mp = put(limbs_of(times_small(pw, 64, NW + 1), S), FW);
     size_t o_mp2 = put(limbs_of(times_small(pw, 256, NW + 1), S), FW);
     size_t o_pm2 = put(std::vector<uint32_t>(pm2.begin(), pm2.end()), (NW + 3) & ~3);
+    Big pp14(NW + 1, 0);                                  // (p + 1) / 4: p = 3 mod 4 for both curves
+    {
+        uint64_t c = 1;
+        for (int i = 0; i < NW; ++i) {
+            c += pw[i];
+            pp14[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        pp14[NW] = (uint32_t)c;
+        for (int i = 0; i < NW; ++i) pp14[i] = (pp14[i] >> 2) | (pp14[i + 1] << 30);
+        pp14.resize(NW);
+    }
+    size_t o_pp14 = put(std::vector<uint32_t>(pp14.begin(), pp14.end()), (NW + 3) & ~3);
     VMN_TRY(upload_words(ctx, &c->d_consts, blob));
     c->d_p = c->d_consts + o_p;
     c->d_one = c->d_consts + o_one;
@@ -748,6 +763,7 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     c->d_mp = c->d_consts + o_mp;
     c->d_mp2 = c->d_consts + o_mp2;
     c->d_pm2 = c->d_consts + o_pm2;
+    c->d_pp14 = c->d_consts + o_pp14;
     *out = c.release();
     return VMN_OK;
 }
@@ -835,11 +851,8 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (all_in_range) *all_in_range = 1;
     if (format_ok) *format_ok = 1;
     if (n == 0) return VMN_OK;
-    if (m.ec && leaf_hdr) {
-        set_error("byte-tree framing of curve points is not implemented");
-        return VMN_ERR_UNSUPPORTED;
-    }
-    const size_t stride = m.ec ? 2 * nbytes : nbytes + (leaf_hdr ? 5 : 0);
+    // a curve point in a byte tree is node(leaf(x), leaf(y)): 15 framing bytes around the two coordinates
+    const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
@@ -850,7 +863,7 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 #define X(S_, NW_)                                                                                                   \
     if (m.ec->S == S_)                                                                                               \
         rc = launch_light(ctx, "import", k_ec_import<S_, NW_>, grid_for(n), d_out, (const uint8_t*)raw.as<uint8_t>(), \
-                          nbytes, stride, n, ecdev(m.ec), ctx->flags);
+                          nbytes, stride, leaf_hdr, n, ecdev(m.ec), ctx->flags);
         VMN_FOR_CURVES(X)
 #undef X
     } else {
@@ -873,11 +886,8 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be,
                      int leaf_hdr = 0) {
     if (n == 0) return VMN_OK;
-    if (m.ec && leaf_hdr) {
-        set_error("byte-tree framing of curve points is not implemented");
-        return VMN_ERR_UNSUPPORTED;
-    }
-    const size_t stride = m.ec ? 2 * nbytes : nbytes + (leaf_hdr ? 5 : 0);
+    // a curve point in a byte tree is node(leaf(x), leaf(y)): 15 framing bytes around the two coordinates
+    const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     note_work(ctx, m, m.ec ? 8.0 * (double)n : (double)n, m.ec ? (double)m.nbits * (double)n : 0.0);     // curves: one Fermat inversion per point
@@ -886,7 +896,7 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 #define X(S_, NW_)                                                                                               \
     if (m.ec->S == S_)                                                                                           \
         rc = launch_light(ctx, "export", k_ec_export<S_, NW_>, grid_for(n), raw.as<uint8_t>(), nbytes, stride,   \
-                          d_in, n, ecdev(m.ec));
+                          leaf_hdr, d_in, n, ecdev(m.ec));
         VMN_FOR_CURVES(X)
 #undef X
     } else {
@@ -904,7 +914,8 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 }
 
 // byte tree of an array: node header on the host, leaves framed on the device
-static size_t bytetree_size(size_t n, size_t nbytes) { return 5 + n * (5 + nbytes); }
+// node(N leaves of nbytes) for residues; node(N x node(leaf(x), leaf(y))) for curve points (nbytes = one coordinate)
+static size_t bytetree_size(size_t n, size_t nbytes, bool ec = false) { return 5 + n * (ec ? 15 + 2 * nbytes : 5 + nbytes); }
 static int to_bytetree(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* out) {
     out[0] = 0;
     out[1] = (uint8_t)(n >> 24);
@@ -914,12 +925,12 @@ static int to_bytetree(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const 
     return export_be(ctx, m, nbytes, d_in, n, out + 5, 1);
 }
 // returns the element count through *n_out; *format_ok = 0 if the buffer is not node(N leaves of nbytes)
-static int bytetree_header(const uint8_t* bt, size_t len, size_t nbytes, size_t expected_n, size_t* n_out, int* format_ok) {
+static int bytetree_header(const uint8_t* bt, size_t len, size_t nbytes, size_t expected_n, size_t* n_out, int* format_ok, bool ec = false) {
     *format_ok = 0;
     *n_out = 0;
     if (len < 5 || bt[0] != 0) return VMN_OK;
     size_t n = ((size_t)bt[1] << 24) | ((size_t)bt[2] << 16) | ((size_t)bt[3] << 8) | bt[4];
-    if (len != bytetree_size(n, nbytes)) return VMN_OK;
+    if (len != bytetree_size(n, nbytes, ec)) return VMN_OK;
     if (expected_n != 0 && n != expected_n) return VMN_OK;
     *n_out = n;
     *format_ok = 1;
@@ -1103,7 +1114,7 @@ extern "C" int vmn_rarray_from_be(vmn_group* grp, const uint8_t* be, size_t n, v
     *out = a;
     return VMN_OK;
 }
-extern "C" size_t vmn_garray_bytetree_size(const vmn_garray* a) { return a ? bytetree_size(a->n, a->grp->nbytes) : 0; }
+extern "C" size_t vmn_garray_bytetree_size(const vmn_garray* a) { return a ? bytetree_size(a->n, a->grp->nbytes, a->grp->curve != nullptr) : 0; }
 extern "C" size_t vmn_rarray_bytetree_size(const vmn_rarray* a) { return a ? bytetree_size(a->n, a->grp->xbytes) : 0; }
 extern "C" int vmn_garray_to_bytetree(const vmn_garray* a, uint8_t* out) {
     ARG_CHECK(a && out, "null argument");
@@ -1121,7 +1132,7 @@ extern "C" int vmn_garray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_
     VMN_ENTER(LANE(grp->ctx));
     *out = nullptr;
     size_t n = 0;
-    VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok));
+    VMN_TRY(bytetree_header(bt, len, grp->nbytes, expected_n, &n, format_ok, grp->curve != nullptr));
     if (!*format_ok) return VMN_OK;
     vmn_garray* a = nullptr;
     VMN_TRY(new_garray(grp, n, &a));
@@ -1848,52 +1859,192 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
 // ================================================================================================
 // N1: PRGHeuristic(SHA-256) on the device, the random vector of a proof and independent generators
 // ================================================================================================
+// A PRG seed: PRGHeuristic over SHA-256 / SHA-384 / SHA-512 takes a seed of the digest's length (minNoSeedBytes), so
+// the seed length says which hash it is (elgamal/ProtocolElGamal.java:352-371).  Big-endian 32-bit words.
+struct PrgSeed {
+    int hash = 256;               // 256, 384, 512
+    uint32_t w[16] = {0};
+    int digest_bytes() const { return hash / 8; }
+};
+// digest bytes of block `blk` of PRG(seed): H(seed || uint32_be(blk))
+template <int HASH>
+__host__ __device__ inline void prg_block_bytes(uint8_t (&dg)[HASH / 8], const uint32_t* seed_words, uint32_t blk) {
+    if constexpr (HASH == 256) {
+        uint32_t sw[8], d[8];
+        for (int k = 0; k < 8; ++k) sw[k] = seed_words[k];
+        sha256::prg_block(d, sw, blk);
+        for (int b = 0; b < 32; ++b) dg[b] = (uint8_t)(d[b >> 2] >> (24 - 8 * (b & 3)));
+    } else {
+        uint64_t d[8];
+        sha512::prg_block<HASH>(d, seed_words, blk);
+        for (int b = 0; b < HASH / 8; ++b) dg[b] = (uint8_t)(d[b >> 3] >> (56 - 8 * (b & 7)));
+    }
+}
 // Row i = bytes [part_off, part_off + part_len) of the i-th val_bytes-byte value of the PRG stream (value i =
 // stream bytes [i*val_bytes, (i+1)*val_bytes), first byte masked with top_mask), right-aligned in row_bytes bytes.
-// One lane per row; a lane hashes the 32-byte blocks its value overlaps (<= val_bytes/32 + 2 compressions).
+// One lane per row; a lane hashes the digest-sized blocks its value overlaps (<= val_bytes / digest + 2 compressions).
+template <int HASH>
 __global__ void __launch_bounds__(256) k_prg_rows(uint8_t* __restrict__ out, size_t row_bytes, size_t val_bytes, uint32_t top_mask,
                                                   size_t part_off, size_t part_len, const uint32_t* __restrict__ seed_words,
                                                   size_t n) {
+    constexpr int DB = HASH / 8;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t seed[8];
+    uint32_t seed[HASH / 32];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) seed[k] = seed_words[k];
+    for (int k = 0; k < HASH / 32; ++k) seed[k] = seed_words[k];
     uint8_t* row = out + i * row_bytes;
     const size_t pad = row_bytes - part_len;
     for (size_t k = 0; k < pad; ++k) row[k] = 0;
     const size_t v0 = i * val_bytes;                       // stream offset of the value
     const size_t lo = v0 + part_off, hi = lo + part_len;   // stream range wanted
-    for (size_t blk = lo / 32; blk * 32 < hi; ++blk) {
-        uint32_t dg[8];
-        sha256::prg_block(dg, seed, (uint32_t)blk);
-        for (int b = 0; b < 32; ++b) {
-            size_t pos = blk * 32 + b;
+    for (size_t blk = lo / DB; blk * DB < hi; ++blk) {
+        uint8_t dg[DB];
+        prg_block_bytes<HASH>(dg, seed, (uint32_t)blk);
+        for (int b = 0; b < DB; ++b) {
+            size_t pos = blk * DB + b;
             if (pos < lo || pos >= hi) continue;
-            uint8_t byte = (uint8_t)(dg[b >> 2] >> (24 - 8 * (b & 3)));
+            uint8_t byte = dg[b];
             if (pos == v0) byte &= (uint8_t)top_mask;
             row[pad + (pos - lo)] = byte;
         }
     }
 }
 
-static int prg_seed_words(const uint8_t* seed, size_t seedlen, uint32_t (&w)[8]) {
-    if (!seed || seedlen != 32) {
-        set_error("PRG seed must be 32 bytes (a SHA-256 digest; PRGHeuristic.minNoSeedBytes)");
+// ECqPGroup.randomElementArray(n, prg, rbitlen), candidate by candidate (the reference derives its independent generators
+// with it, P/distr/IndependentGeneratorsRO.java:117-130; the procedure itself is VCR's and is restated from the published
+// verifier specification [NOT-IN-REF]): candidate j = the j-th ceil((bits(p) + rbitlen) / 8) bytes of the PRG stream with
+// the leading bits cleared, reduced mod p, taken as an x coordinate; it is KEPT when x^3 - 3x + b is a square, and then
+// the point is (x, y) with y the SMALLER of the two roots; the i-th element of the array is the i-th kept candidate.
+// One lane per candidate: x from the PRG, z = (x^3 - 3x + b)^((p+1)/4) (p = 3 mod 4), kept iff z^2 is that value; the
+// caller compacts the kept rows in order.  c_m = 2^(8 cb) mod p in Montgomery form (the value is hi * 2^(8 cb) + lo).
+template <int S, int NW, int HASH>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW)
+k_ec_random_points(u32* __restrict__ rows, u32* __restrict__ keep, const uint32_t* __restrict__ seed_words, size_t first, size_t m,
+                   size_t vb, uint32_t top_mask, size_t cb, const u32* __restrict__ c_m, ECDev E) {
+    constexpr int DB = HASH / 8;
+    constexpr int ROW = ECfg<S>::ROW;
+    using C1 = Cfg<S, 1>;
+    size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    uint32_t seed[HASH / 32];
+#pragma unroll
+    for (int k = 0; k < HASH / 32; ++k) seed[k] = seed_words[k];
+    // the candidate's bytes: hi = the vb - cb leading ones (right-aligned in 4 NW bytes), lo = the last cb
+    uint8_t hi_b[4 * NW], lo_b[4 * NW];
+    for (int k = 0; k < 4 * NW; ++k) hi_b[k] = lo_b[k] = 0;
+    const size_t v0 = (first + j) * vb, hb = vb - cb;
+    for (size_t blk = v0 / DB; blk * DB < v0 + vb; ++blk) {
+        uint8_t dg[DB];
+        prg_block_bytes<HASH>(dg, seed, (uint32_t)blk);
+        for (int b = 0; b < DB; ++b) {
+            size_t pos = blk * DB + b;
+            if (pos < v0 || pos >= v0 + vb) continue;
+            uint8_t byte = dg[b];
+            if (pos == v0) byte &= (uint8_t)top_mask;
+            size_t k = pos - v0;                       // index inside the value, big-endian
+            if (k < hb) hi_b[4 * NW - hb + k] = byte;
+            else lo_b[4 * NW - cb + (k - hb)] = byte;
+        }
+    }
+    Lane<C1> ln(nullptr);
+    u32 hi[S], lo[S], rr[S], cm[S], x[S], t[S], t2[S], rhs[S], z[S], bb[S];
+    limbs_from_be<C1, NW>(hi, hi_b, 4L * NW, ln);
+    limbs_from_be<C1, NW>(lo, lo_b, 4L * NW, ln);
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        rr[k] = E.rr[k];
+        cm[k] = c_m[k];
+        bb[k] = E.b[k];
+    }
+    f_mul<S>(lo, lo, rr, E);                           // Montgomery form (any value below R is reduced on the way)
+    f_mul<S>(hi, hi, rr, E);
+    f_mul<S>(t, hi, cm, E);
+    f_add<S>(x, t, lo);                                // x = hi * 2^(8 cb) + lo  mod p
+    f_canon<S>(x, x, E);
+    f_sqr<S>(t, x, E);
+    f_mul<S>(t2, t, x, E);                             // x^3
+    f_small<S, 3>(t, x);
+    f_add<S>(rhs, t2, bb);
+    f_sub<S>(rhs, rhs, t, E);                          // x^3 - 3x + b
+    f_canon<S>(rhs, rhs, E);
+    f_pow_words<S>(z, rhs, E.pp14, E.pwords, E);
+    f_sqr<S>(t, z, E);
+    f_sub<S, true>(t2, t, rhs, E);
+    const bool ok = f_is_zero<S>(t2, E);
+    // the smaller root: compare the standard representatives of z and p - z
+    u32 one1[S], zs[S], zn[S], pp[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        one1[k] = k == 0 ? 1u : 0u;
+        pp[k] = E.p[k];
+    }
+    f_mul<S>(zs, z, one1, E);                          // z / R: standard representative, < 2p
+    {
+        u32 d[S];
+        if (borrow_sweep<S>(d, zs, pp, 0) == 0) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) zs[k] = d[k];
+        }
+    }
+    borrow_sweep<S>(zn, pp, zs, 0);                    // p - z  (z != 0 unless rhs = 0: then both are 0 mod p)
+    bool neg_smaller = false;
+    for (int k = S - 1; k >= 0; --k) {
+        if (zn[k] != zs[k]) {
+            neg_smaller = zn[k] < zs[k];
+            break;
+        }
+    }
+    u32 znz = 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) znz |= zs[k];
+    Pt<S> P;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        P.X[k] = x[k];
+        P.Z[k] = E.one[k];
+    }
+    u32 ysel[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) ysel[k] = (neg_smaller && znz) ? zn[k] : zs[k];
+    f_mul<S>(P.Y, ysel, rr, E);                        // back to Montgomery form
+    f_canon<S>(P.Y, P.Y, E);
+    P.inf = 0;
+    pt_store<S>(rows + j * ROW, P);
+    keep[j] = ok ? 1u : 0u;
+}
+// idx[pos[j]] = j for the kept candidates (pos = exclusive prefix sums of keep): the gather table of the compaction
+__global__ void __launch_bounds__(BLOCK) k_compact_index(u32* __restrict__ idx, const u32* __restrict__ keep, const u32* __restrict__ pos,
+                                                         size_t m, size_t limit) {
+    size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < m && keep[j] && pos[j] < limit) idx[pos[j]] = (u32)j;
+}
+
+static int prg_seed_words(const uint8_t* seed, size_t seedlen, PrgSeed& ps) {
+    if (!seed || (seedlen != 32 && seedlen != 48 && seedlen != 64)) {
+        set_error("PRG seed must be 32, 48 or 64 bytes (PRGHeuristic.minNoSeedBytes of SHA-256 / SHA-384 / SHA-512)");
         return VMN_ERR_UNSUPPORTED;
     }
-    for (int i = 0; i < 8; ++i) w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+    ps.hash = (int)seedlen * 8;
+    for (size_t i = 0; i < seedlen / 4; ++i)
+        ps.w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
     return VMN_OK;
 }
 // device rows of one part of the PRG values (see k_prg_rows)
-static int prg_rows(vmn_ctx* ctx, const uint32_t (&seedw)[8], size_t n, size_t val_bytes, int val_bits, size_t part_off, size_t part_len,
+static int prg_rows(vmn_ctx* ctx, const PrgSeed& ps, size_t n, size_t val_bytes, int val_bits, size_t part_off, size_t part_len,
                     size_t row_bytes, DevTmp& rows) {
     DevTmp dseed(ctx);
-    VMN_TRY(dseed.alloc(32));
-    VMN_TRY(h2d(ctx, dseed.p, seedw, 32));
+    VMN_TRY(dseed.alloc(64));
+    VMN_TRY(h2d(ctx, dseed.p, ps.w, 64));
     VMN_TRY(rows.alloc(n * row_bytes + 8));
     uint32_t top_mask = val_bits % 8 ? (1u << (val_bits % 8)) - 1 : 0xffu;
-    return launch_light(ctx, "prg", k_prg_rows, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
+    if (ps.hash == 256)
+        return launch_light(ctx, "prg", k_prg_rows<256>, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
+                            (const uint32_t*)dseed.as<uint32_t>(), n);
+    if (ps.hash == 384)
+        return launch_light(ctx, "prg", k_prg_rows<384>, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
+                            (const uint32_t*)dseed.as<uint32_t>(), n);
+    return launch_light(ctx, "prg", k_prg_rows<512>, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
                         (const uint32_t*)dseed.as<uint32_t>(), n);
 }
 // rows already on the device -> residues (mode: see k_import_be)
@@ -1922,7 +2073,7 @@ static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const u
 // fit the modulus' bytes are imported directly (reduced by the import when they can reach m); wider ones -- bits(m) +
 // rbitlen bits: the statistically-close-to-uniform sampling of randomElementArray -- are split as hi * 2^(8 pb) + lo
 // with pb = the modulus' byte length, and recombined with one multiply-add mod m.
-static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t (&w)[8], size_t n, int vbits, uint32_t* d_out) {
+static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, size_t n, int vbits, uint32_t* d_out) {
     if (n == 0) return VMN_OK;
     const size_t Wd = elem_words(m);
     const size_t vb = ((size_t)vbits + 7) / 8, mb = ((size_t)m.nbits + 7) / 8;
@@ -1963,37 +2114,59 @@ static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t (&w)[
 
 extern "C" int vmn_prg_bytes(const uint8_t* seed, size_t seedlen, uint8_t* out, size_t nbytes) {
     ARG_CHECK(out || nbytes == 0, "null argument");
-    uint32_t w[8];
-    VMN_TRY(prg_seed_words(seed, seedlen, w));
-    for (size_t blk = 0; blk * 32 < nbytes; ++blk) {
-        uint32_t dg[8];
-        sha256::prg_block(dg, w, (uint32_t)blk);
-        for (size_t b = 0; b < 32 && blk * 32 + b < nbytes; ++b) out[blk * 32 + b] = (uint8_t)(dg[b >> 2] >> (24 - 8 * (b & 3)));
+    PrgSeed ps;
+    VMN_TRY(prg_seed_words(seed, seedlen, ps));
+    const size_t db = (size_t)ps.digest_bytes();
+    for (size_t blk = 0; blk * db < nbytes; ++blk) {
+        uint8_t d256[32], d384[48], d512[64];
+        const uint8_t* dg = d256;
+        if (ps.hash == 256) {
+            prg_block_bytes<256>(d256, ps.w, (uint32_t)blk);
+        } else if (ps.hash == 384) {
+            prg_block_bytes<384>(d384, ps.w, (uint32_t)blk);
+            dg = d384;
+        } else {
+            prg_block_bytes<512>(d512, ps.w, (uint32_t)blk);
+            dg = d512;
+        }
+        for (size_t b = 0; b < db && blk * db + b < nbytes; ++b) out[blk * db + b] = dg[b];
     }
     return VMN_OK;
 }
 
-extern "C" int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits, uint8_t* out) {
+extern "C" int vmn_random_oracle_hash(int hash_bits, const uint8_t* data, size_t len, int nout_bits, uint8_t* out) {
     ARG_CHECK((data || len == 0) && out && nout_bits > 0, "bad argument");
+    ARG_CHECK(hash_bits == 256 || hash_bits == 384 || hash_bits == 512, "hash must be 256, 384 or 512 (SHA-2)");
     std::vector<uint8_t> msg(4 + len);
     msg[0] = (uint8_t)((uint32_t)nout_bits >> 24);
     msg[1] = (uint8_t)((uint32_t)nout_bits >> 16);
     msg[2] = (uint8_t)((uint32_t)nout_bits >> 8);
     msg[3] = (uint8_t)nout_bits;
     if (len) memcpy(msg.data() + 4, data, len);
-    uint8_t seed[32];
-    sha256::hash(msg.data(), msg.size(), seed);
+    uint8_t seed[64];
+    if (hash_bits == 256) {
+        uint8_t d[32];
+        sha256::hash(msg.data(), msg.size(), d);
+        memcpy(seed, d, 32);
+    } else if (hash_bits == 384) {
+        sha512::hash<384>(msg.data(), msg.size(), seed);
+    } else {
+        sha512::hash<512>(msg.data(), msg.size(), seed);
+    }
     size_t nb = ((size_t)nout_bits + 7) / 8;
-    VMN_TRY(vmn_prg_bytes(seed, 32, out, nb));
+    VMN_TRY(vmn_prg_bytes(seed, (size_t)hash_bits / 8, out, nb));
     if (nout_bits % 8) out[0] &= (uint8_t)((1u << (nout_bits % 8)) - 1);
     return VMN_OK;
+}
+extern "C" int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits, uint8_t* out) {
+    return vmn_random_oracle_hash(256, data, len, nout_bits, out);
 }
 
 extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out) {
     ARG_CHECK(grp && out && bits > 0, "bad argument");
     vmn_ctx* ctx = LANE(grp->ctx);
     VMN_ENTER(ctx);
-    uint32_t w[8];
+    PrgSeed w;
     VMN_TRY(prg_seed_words(seed, seedlen, w));
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
@@ -2007,14 +2180,106 @@ extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
     return VMN_OK;
 }
 
+// Random curve points from a PRG seed (see k_ec_random_points): candidates in batches, kept rows compacted in order.
+static int ec_random_points(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int rbitlen, vmn_garray** out) {
+    vmn_ctx* ctx = LANE(grp->ctx);
+    const vmn_modulus& m = grp->P;
+    const vmn_curve* cv = grp->curve;
+    PrgSeed ps;
+    VMN_TRY(prg_seed_words(seed, seedlen, ps));
+    const int pbits = hostbig::bit_length(cv->p_words);
+    const int vbits = pbits + rbitlen;
+    const size_t vb = ((size_t)vbits + 7) / 8, cb = ((size_t)pbits + 7) / 8;
+    if (vb - cb + 1 > cb) {
+        set_error("vmn_garray_from_prg: rbitlen too large for this curve");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    vmn_garray* r = nullptr;
+    VMN_TRY(new_garray(grp, n, &r));
+    if (n == 0) {
+        *out = r;
+        return VMN_OK;
+    }
+    const size_t Wd = elem_words(m);
+    // c_m = 2^(8 cb) * R mod p as field limbs
+    Big c(cv->NW, 0);
+    c[0] = 1;
+    for (size_t k = 0; k < 8 * cb + 28 * (size_t)cv->S; ++k) hostbig::dbl_mod(c, cv->p_words);
+    std::vector<uint32_t> cl = limbs_of(c, cv->S);
+    cl.resize(stride_for_limbs(cv->S), 0);
+    DevTmp dc(ctx), dseed(ctx);
+    int rc = dc.alloc(cl.size() * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = h2d(ctx, dc.p, cl.data(), cl.size() * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = dseed.alloc(64);
+    if (rc == VMN_OK) rc = h2d(ctx, dseed.p, ps.w, 64);
+    const uint32_t top_mask = vbits % 8 ? (1u << (vbits % 8)) - 1 : 0xffu;
+    size_t have = 0, first = 0;                       // points kept so far, candidates consumed so far
+    while (rc == VMN_OK && have < n) {
+        const size_t need = n - have;
+        const size_t mcand = 2 * need + need / 8 + 64;        // about half of the candidates are kept
+        const size_t scan_blocks = (mcand + (size_t)BLOCK * SCAN_ITEMS - 1) / ((size_t)BLOCK * SCAN_ITEMS);
+        DevTmp cand(ctx), meta(ctx);
+        rc = cand.alloc(mcand * Wd * sizeof(uint32_t));
+        if (rc == VMN_OK) rc = meta.alloc((3 * (mcand + 1) + scan_blocks + 8) * sizeof(uint32_t));
+        if (rc != VMN_OK) break;
+        uint32_t* keep = meta.as<uint32_t>();
+        uint32_t* pos = keep + (mcand + 1);
+        uint32_t* idx = pos + (mcand + 1);
+        uint32_t* bsum = idx + (mcand + 1);
+        uint32_t* total = bsum + scan_blocks;
+        rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                            \
+    if (cv->S == S_) {                                                                                                        \
+        if (ps.hash == 256)                                                                                                   \
+            rc = launch_light(ctx, "prg", k_ec_random_points<S_, NW_, 256>, grid_for(mcand), cand.as<uint32_t>(), keep,       \
+                              (const uint32_t*)dseed.as<uint32_t>(), first, mcand, vb, top_mask, cb, (const uint32_t*)dc.as<uint32_t>(), ecdev(cv)); \
+        else if (ps.hash == 384)                                                                                              \
+            rc = launch_light(ctx, "prg", k_ec_random_points<S_, NW_, 384>, grid_for(mcand), cand.as<uint32_t>(), keep,       \
+                              (const uint32_t*)dseed.as<uint32_t>(), first, mcand, vb, top_mask, cb, (const uint32_t*)dc.as<uint32_t>(), ecdev(cv)); \
+        else                                                                                                                  \
+            rc = launch_light(ctx, "prg", k_ec_random_points<S_, NW_, 512>, grid_for(mcand), cand.as<uint32_t>(), keep,       \
+                              (const uint32_t*)dseed.as<uint32_t>(), first, mcand, vb, top_mask, cb, (const uint32_t*)dc.as<uint32_t>(), ecdev(cv)); \
+    }
+        VMN_FOR_CURVES(X)
+#undef X
+        if (rc != VMN_OK) break;
+        // exclusive prefix sums of the keep flags, then the kept rows in candidate order
+        rc = launch_light(ctx, "prg", k_u32_blocksum, (unsigned)scan_blocks, bsum, (const uint32_t*)keep, mcand);
+        if (rc == VMN_OK) {
+            hipLaunchKernelGGL(k_u32_scan_top, dim3(1), dim3(64), 0, ctx->stream, bsum, scan_blocks, total);
+            rc = hipGetLastError() == hipSuccess ? VMN_OK : VMN_ERR_DEVICE;
+        }
+        if (rc == VMN_OK) rc = launch_light(ctx, "prg", k_u32_scan_apply, (unsigned)scan_blocks, pos, (uint32_t*)nullptr, (const uint32_t*)keep, (const uint32_t*)bsum, mcand);
+        uint32_t kept = 0;
+        if (rc == VMN_OK) rc = d2h(ctx, &kept, total, sizeof(kept));
+        if (rc != VMN_OK) break;
+        size_t take = std::min<size_t>(kept, need);
+        // the candidates consumed: all of them when more points are needed; otherwise up to the last one taken (not needed
+        // afterwards: the array is complete)
+        if (take) {
+            rc = launch_light(ctx, "prg", k_compact_index, grid_for(mcand), idx, (const uint32_t*)keep, (const uint32_t*)pos, mcand, take);
+            int cpr = (int)(Wd / 4);
+            if (rc == VMN_OK)
+                rc = launch_light(ctx, "gather", k_gather, light_grid(ctx, take * cpr), reinterpret_cast<uint4*>(r->d + have * Wd),
+                                  reinterpret_cast<const uint4*>(cand.as<uint32_t>()), (const uint32_t*)idx,
+                                  reinterpret_cast<const uint4*>(m.d_one), take, cpr);
+        }
+        have += take;
+        first += mcand;
+    }
+    if (rc != VMN_OK) {
+        vmn_garray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
 extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int rbitlen, vmn_garray** out) {
     ARG_CHECK(grp && out && rbitlen >= 0, "bad argument");
     vmn_ctx* ctx = LANE(grp->ctx);
     VMN_ENTER(ctx);
-    if (grp->curve) {
-        set_error("vmn_garray_from_prg: random curve points (ECqPGroup.randomElementArray) are not implemented");
-        return VMN_ERR_UNSUPPORTED;
-    }
+    if (grp->curve) return ec_random_points(grp, seed, seedlen, n, rbitlen, out);
     const vmn_modulus& m = grp->P;
     {   // the cofactor (p-1)/q must be 2 (safe-prime groups: the elements are squared)
         Big twoq = grp->Q.n_words;
@@ -2026,7 +2291,7 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
             return VMN_ERR_UNSUPPORTED;
         }
     }
-    uint32_t w[8];
+    PrgSeed w;
     VMN_TRY(prg_seed_words(seed, seedlen, w));
     const int vbits = m.nbits + rbitlen;
     vmn_garray* r = nullptr;

@@ -97,6 +97,7 @@ struct vmn_curve {
     const uint32_t* d_mp = nullptr;
     const uint32_t* d_mp2 = nullptr;
     const uint32_t* d_pm2 = nullptr;
+    const uint32_t* d_pp14 = nullptr;
     uint32_t n0inv = 0;
 };
 

@@ -232,6 +232,9 @@ struct vmn_msg {
         size_t count = 0, width = 0;
     };
     std::vector<Item> items;
+    bool ec = false;                   // group elements are curve points: an element is node(leaf(x), leaf(y)) on the wire
+    vmn_msg() {}
+    explicit vmn_msg(bool ec_) : ec(ec_) {}
     ~vmn_msg() {
         for (auto& it : items) {
             if (it.ga) vmn_garray_free(it.ga);
@@ -826,7 +829,7 @@ struct vmn_pos : ProofBase {
         TRY(scans(b, ipe, x, y, d, x_in, y_in));                                  // :583-604
         GA B, Bp;
         TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp)); // :606-648 (queued)
-        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push(B);
         m->push_element(Ap);
         m->push(Bp);
@@ -859,7 +862,7 @@ struct vmn_pos : ProofBase {
         RA k_B, k_E;
         TRY(vmn_rarray_mul_add(b, vq.data(), beta, k_B.out()));
         TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
-        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push_ring(G.ring_bytes(G.mul_add(a, v, alpha)));
         m->push(k_B);
         m->push_ring(G.ring_bytes(G.mul_add(c, v, gamma)));
@@ -1058,7 +1061,7 @@ struct vmn_posc : ProofBase {
         TRY(scans(b, ipe, x, y, d, x_in, y_in));
         GA B, Bp;
         TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp));
-        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push(B);
         m->push_element(Ap_);
         m->push(Bp);
@@ -1082,7 +1085,7 @@ struct vmn_posc : ProofBase {
         RA k_B, k_E;
         TRY(vmn_rarray_mul_add(b, vq.data(), beta, k_B.out()));
         TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
-        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push_ring(G.ring_bytes(G.mul_add(a, v, alpha)));
         m->push(k_B);
         m->push_ring(G.ring_bytes(G.mul_add(c, v, gamma)));
@@ -1250,7 +1253,7 @@ struct vmn_ccpos : ProofBase {
         REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
         if (!prepared) TRY(commit_prepare());
         TRY(permuted_batch_vector(e, piinv, ipe));                                // :350
-        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push_element(Ap_);
         m->push_bytes(VMN_ITEM_ELEMENTS, Bp_);
         *out = m.release();
@@ -1276,7 +1279,7 @@ struct vmn_ccpos : ProofBase {
         Bytes vq = G.ring_bytes(v);
         RA k_E;
         TRY(vmn_rarray_mul_add(ipe, vq.data(), epsilon, k_E.out()));
-        std::unique_ptr<vmn_msg> m(new vmn_msg());
+        std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push_ring(G.ring_bytes(G.mul_add(a, v, alpha)));
         m->push_bytes(VMN_ITEM_RING, kB);
         m->push(k_E);
@@ -1676,6 +1679,11 @@ int vmn_msg_create(vmn_msg** out) {
     *out = new vmn_msg();
     return VMN_OK;
 }
+int vmn_msg_create_for(vmn_group* grp, vmn_msg** out) {
+    if (!out || !grp) return fail(VMN_ERR_ARG, "vmn_msg_create_for: null argument");
+    *out = new vmn_msg(vmn_group_kind(grp) == 1);
+    return VMN_OK;
+}
 void vmn_msg_free(vmn_msg* m) { delete m; }
 size_t vmn_msg_items(const vmn_msg* m) { return m ? m->items.size() : 0; }
 int vmn_msg_item_kind(const vmn_msg* m, size_t i) { return m && i < m->items.size() ? m->items[i].kind : 0; }
@@ -1736,8 +1744,9 @@ static void put_header(uint8_t*& o, uint8_t tag, size_t n) {
     *o++ = (uint8_t)(n >> 8);
     *o++ = (uint8_t)n;
 }
-static size_t scalar_item_size(const vmn_msg::Item& it) {
-    const size_t leaf = 5 + it.width;
+static size_t scalar_item_size(const vmn_msg::Item& it, bool ec) {
+    // one element: a leaf, or -- a curve point -- node(leaf(x), leaf(y))
+    const size_t leaf = (ec && it.kind == VMN_ITEM_ELEMENTS) ? 15 + it.width : 5 + it.width;
     if (it.count == 1) return leaf;
     if (it.kind == VMN_ITEM_RING) return 5 + it.count * leaf;
     if (it.count == 2) return 5 + 2 * leaf;
@@ -1749,7 +1758,7 @@ size_t vmn_msg_bytetree_size(const vmn_msg* m) {
     for (auto& it : m->items) {
         if (it.kind == VMN_ITEM_GARRAY) total += vmn_garray_bytetree_size(it.ga);
         else if (it.kind == VMN_ITEM_RARRAY) total += vmn_rarray_bytetree_size(it.ra);
-        else total += scalar_item_size(it);
+        else total += scalar_item_size(it, m->ec);
     }
     return total;
 }
@@ -1769,8 +1778,19 @@ int vmn_msg_to_bytetree(const vmn_msg* m, uint8_t* out) {
             continue;
         }
         auto leaf = [&](size_t k) {
+            const uint8_t* src = it.bytes.data() + k * it.width;
+            if (m->ec && it.kind == VMN_ITEM_ELEMENTS) {            // a curve point: node(leaf(x), leaf(y))
+                const size_t cb = it.width / 2;
+                put_header(o, 0, 2);
+                for (int half = 0; half < 2; ++half) {
+                    put_header(o, 1, cb);
+                    memcpy(o, src + half * cb, cb);
+                    o += cb;
+                }
+                return;
+            }
             put_header(o, 1, it.width);
-            memcpy(o, it.bytes.data() + k * it.width, it.width);
+            memcpy(o, src, it.width);
             o += it.width;
         };
         if (it.count == 1) {
@@ -1806,6 +1826,12 @@ struct Reader {
         p += width;
         return true;
     }
+    // one group element: a leaf, or -- a curve point -- node(leaf(x), leaf(y)) appended as x || y
+    bool element(size_t width, bool point, Bytes& sink) {
+        if (!point) return leaf(width, sink);
+        size_t n;
+        return header(0, &n) && n == 2 && leaf(width / 2, sink) && leaf(width / 2, sink);
+    }
 };
 }  // namespace
 
@@ -1818,11 +1844,12 @@ int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const i
     Reader rd{bt, bt + len};
     size_t n;
     if (!rd.header(0, &n) || n != items) return VMN_OK;
-    std::unique_ptr<vmn_msg> m(new vmn_msg());
+    const bool ec = vmn_group_kind(grp) == 1;
+    std::unique_ptr<vmn_msg> m(new vmn_msg(ec));
     for (size_t i = 0; i < items; ++i) {
         if (layout[i] == VMN_ITEM_GARRAY || layout[i] == VMN_ITEM_RARRAY) {
             const size_t width = layout[i] == VMN_ITEM_GARRAY ? eb : xb;
-            const size_t need = 5 + counts[i] * (5 + width);
+            const size_t need = 5 + counts[i] * ((ec && layout[i] == VMN_ITEM_GARRAY) ? 15 + width : 5 + width);
             if ((size_t)(rd.end - rd.p) < need) return VMN_OK;
             int ok = 0, in_range = 1;
             if (layout[i] == VMN_ITEM_GARRAY) {
@@ -1848,16 +1875,17 @@ int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const i
         it.count = counts[i];
         it.width = layout[i] == VMN_ITEM_ELEMENTS ? eb : xb;
         bool good = true;
+        const bool point = ec && it.kind == VMN_ITEM_ELEMENTS;
         if (it.count == 1) {
-            good = rd.leaf(it.width, it.bytes);
+            good = rd.element(it.width, point, it.bytes);
         } else if (it.kind == VMN_ITEM_RING || it.count == 2) {
             good = rd.header(0, &n) && n == it.count;
-            for (size_t k = 0; good && k < it.count; ++k) good = rd.leaf(it.width, it.bytes);
+            for (size_t k = 0; good && k < it.count; ++k) good = rd.element(it.width, point, it.bytes);
         } else {
             good = rd.header(0, &n) && n == 2;
             for (size_t half = 0; good && half < 2; ++half) {
                 good = rd.header(0, &n) && n == it.count / 2;
-                for (size_t k = 0; good && k < it.count / 2; ++k) good = rd.leaf(it.width, it.bytes);
+                for (size_t k = 0; good && k < it.count / 2; ++k) good = rd.element(it.width, point, it.bytes);
             }
         }
         if (!good) return VMN_OK;

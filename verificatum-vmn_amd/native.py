@@ -437,7 +437,7 @@ class PoSCBasicTW(_NativeProof):
         self._call("set_commitment", self._com._h)
 
     def verify(self, reply) -> bool:
-        m = self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
+        m = reply if isinstance(reply, Message) else self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
         verdict = C.c_int(0)
         self._call("verify", m._h, C.byref(verdict))
         return bool(verdict.value)
@@ -471,7 +471,7 @@ class CCPoSBasicW(_NativeProof):
         self._call("compute_ab", raisedu._h if raisedu is not None else None)
 
     def verify(self, reply, raisedh=None, raisedExponent: Optional[int] = None) -> bool:
-        m = self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
+        m = reply if isinstance(reply, Message) else self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
         verdict = C.c_int(0)
         if raisedExponent is None:
             self._call("verify", m._h, None, None, C.c_size_t(0), C.byref(verdict))
