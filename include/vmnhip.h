@@ -84,6 +84,12 @@ int vmn_ctx_helper_sync(vmn_ctx* ctx);
 int vmn_ctx_helper_end(vmn_ctx* ctx);
 /* Number of compute units of the context's device (used by the benchmark to state the roofline). */
 int vmn_ctx_num_cus(vmn_ctx* ctx);
+/* Small arrays.  One element per lane fills the device only from ~1.3 x 10^5 elements on; real elections (the
+ * reference's demo: 10^4 ciphertexts, BASELINE.json configs[0]) are far below.  For 2048-bit moduli every launch over at
+ * most `items` elements therefore runs in the WIDE geometry -- the same rows, same results, four lanes per element, so
+ * that each chain of dependent products is ~2.5 times shorter.  Default 40960 (the measured crossover; env
+ * VMN_WIDE_MAX overrides it); 0 = never, SIZE_MAX = always.  A tuning knob: results never depend on it. */
+int vmn_ctx_set_small_array_threshold(vmn_ctx* ctx, size_t items);
 /* Memory accounting (operations / leak hunting): bytes and blocks of freed arrays cached for reuse, bytes of live
  * allocations handed out and not yet freed (arrays + temporaries), and a group's cached fixed-base tables. */
 int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes);

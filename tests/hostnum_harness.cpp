@@ -43,7 +43,20 @@ static int ec_main(char** argv) {
     return 0;
 }
 
+// "jac n a [a ...]": the Jacobi symbols (a / n)
+static int jac_main(int argc, char** argv) {
+    Bytes nb = from_hex(argv[2]);
+    size_t nl = (nb.size() + 7) / 8;
+    Mod M(from_be(nb.data(), nb.size(), nl));
+    for (int i = 3; i < argc; ++i) {
+        Bytes ab = from_hex(argv[i]);
+        printf("%d\n", M.jacobi(from_be(ab.data(), ab.size(), nl)));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 4 && !strcmp(argv[1], "jac")) return jac_main(argc, argv);
     if (argc == 6 && !strcmp(argv[1], "ec")) return ec_main(argv);
     if (argc != 5) return 2;
     Bytes nb = from_hex(argv[1]), ab = from_hex(argv[2]), bb = from_hex(argv[3]), eb = from_hex(argv[4]);

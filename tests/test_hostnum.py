@@ -39,6 +39,37 @@ def test_order_of_p256_and_edge_values(harness):
         assert got == [a * b % n, pow(a, e, n), pow(a, -1, n), e % n, (a + b) % n, (-a) % n]
 
 
+def _jacobi(a, n):
+    a %= n
+    t = 1
+    while a:
+        while a % 2 == 0:
+            a //= 2
+            if n % 8 in (3, 5):
+                t = -t
+        a, n = n, a
+        if a % 4 == 3 and n % 4 == 3:
+            t = -t
+        a %= n
+    return t if n == 1 else 0
+
+
+@pytest.mark.parametrize("bits", [2048, 3072])
+def test_jacobi_symbol_is_subgroup_membership_for_safe_primes(bits, harness):
+    """The membership test of the single elements of a commitment (HostGroup::check_elements): symbol 1 <=> x^q = 1."""
+    p, q, g = pyref.modp_group(bits)
+    vals = [1, p - 1, 2, 1 << 64, (1 << 640) + (1 << 64), 0] + pyref.stream_ints(b"jac%d" % bits, 14, p)
+    out = subprocess.run([harness, "jac", "%x" % p] + ["%x" % v for v in vals], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(x) for x in out]
+    assert got == [_jacobi(v, p) for v in vals]
+    assert got[:5] == [1 if pow(v, q, p) == 1 else -1 for v in vals[:5]] and got[5] == 0
+    # a composite modulus: 0 when not coprime
+    n = 3 * 5 * 7 * 11 * 13 * 17
+    vals = list(range(0, 60))
+    out = subprocess.run([harness, "jac", "%x" % n] + ["%x" % v for v in vals], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in out] == [_jacobi(v, n) for v in vals]
+
+
 @pytest.mark.parametrize("name", ["P-256", "P-384"])
 def test_host_curve_points_against_the_affine_reference(name, harness):
     """csrc/hostcurve.h (single points of the C++ proof drivers) against oracle/pyref_ec.py, with the exceptional

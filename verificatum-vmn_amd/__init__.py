@@ -135,6 +135,11 @@ class Context:
     def num_cus(self) -> int:
         return lib().vmn_ctx_num_cus(self._h)
 
+    def set_small_array_threshold(self, items: int) -> None:
+        """Launches over at most ``items`` elements use the wide (four lanes per element) geometry for 2048-bit moduli
+        (``vmn_ctx_set_small_array_threshold``); 0 = never.  A tuning knob: results never depend on it."""
+        _check(lib().vmn_ctx_set_small_array_threshold(self._h, C.c_size_t(min(int(items), 2 ** 64 - 1))))
+
     def helper_mark(self) -> None:
         """Protocol thread: what is queued up to here is what the helper may rely on (``vmn_ctx_helper_mark``)."""
         _check(lib().vmn_ctx_helper_mark(self._h))

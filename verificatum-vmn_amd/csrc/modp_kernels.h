@@ -23,16 +23,27 @@ namespace vmn {
 
 constexpr int BLOCK = 256;   // threads per workgroup: 4 waves, one per SIMD
 
+// "Wide" geometries for SMALL arrays (fewer elements than the chip has lanes at one element per lane): the same
+// element rows -- same R, same words in memory -- are worked on by four lanes, so that a chain of dependent products is
+// ~4 times shorter and four times as many waves are in flight.  S_ = 76 is the wide form of S = 74 (2048-bit moduli):
+// four shares of 19 columns = 76 columns, the two above the 74 limbs are zero; a product still takes ROWS = 74
+// reduction rows, so R = 2^(28*74) as in Cfg<74, 1>.  The shares are PACKED in memory (share h = words 19h .. 19h+18
+// of the 76-word row, the two padding words of the one-lane layout being the two zero columns).
+__host__ __device__ constexpr int rows_for(int S, int LPE) { return (S == 76 && LPE == 4) ? 74 : S; }
+
 template <int S_, int LPE_>
 struct Cfg {
-    static constexpr int S = S_;                        // limbs per element
+    static constexpr int S = S_;                        // columns per element (limbs, plus the zero columns of a wide geometry)
     static constexpr int LPE = LPE_;                    // lanes per element
     static constexpr int L = S_ / LPE_;                 // limbs per lane
-    static constexpr int LW = stride_for_limbs(L);      // words of one lane's share in memory
-    static constexpr int W = LPE_ * LW;                 // words per element in memory
+    static constexpr int ROWS = rows_for(S_, LPE_);     // reduction rows of a product: R = 2^(28 ROWS)
+    static constexpr bool PACKED = ROWS != S_;          // wide geometry on the rows of the one-lane layout
+    static constexpr int LW = PACKED ? L : stride_for_limbs(L);      // words of one lane's share in memory
+    static constexpr int W = PACKED ? stride_for_limbs(ROWS) : LPE_ * LW;   // words per element in memory
     static constexpr int EPB = BLOCK / LPE_;            // elements per workgroup
     static constexpr int MINW = 2;                      // waves per SIMD the kernels are built for
     static_assert(S_ % LPE_ == 0, "limbs must split evenly over the lanes of an element");
+    static_assert(!PACKED || W == S_, "a packed geometry covers the whole row");
 };
 
 // What a lane needs to know about its place: element slot in the workgroup, which half it holds, its
@@ -75,6 +86,12 @@ __device__ __forceinline__ u32 or_all(u32 x) {
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void load_elem(u32 (&a)[C::L], const u32* __restrict__ p, const Lane<C>& ln) {
+    if constexpr (C::PACKED) {                          // shares of L words, not 16-byte aligned: dword loads
+        const u32* q = p + ln.half * C::L;
+#pragma unroll
+        for (int j = 0; j < C::L; ++j) a[j] = q[j];
+        return;
+    }
     const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
 #pragma unroll
     for (int k = 0; k < C::LW / 4; ++k) {
@@ -87,6 +104,12 @@ __device__ __forceinline__ void load_elem(u32 (&a)[C::L], const u32* __restrict_
 }
 template <class C>
 __device__ __forceinline__ void store_elem(u32* __restrict__ p, const u32 (&a)[C::L], const Lane<C>& ln) {
+    if constexpr (C::PACKED) {                          // (the columns above the limbs are zero: value < 2N < 2^(28 ROWS))
+        u32* q = p + ln.half * C::L;
+#pragma unroll
+        for (int j = 0; j < C::L; ++j) q[j] = a[j];
+        return;
+    }
     uint4* q = reinterpret_cast<uint4*>(p + ln.half * C::LW);
 #pragma unroll
     for (int k = 0; k < C::LW / 4; ++k) {
@@ -101,8 +124,14 @@ __device__ __forceinline__ void store_elem(u32* __restrict__ p, const u32 (&a)[C
 // global element -> the element's LDS column (multiplier operand); each lane moves its own share
 template <class C>
 __device__ __forceinline__ void load_elem_to_lds(const Lane<C>& ln, const u32* __restrict__ p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
     u32* dst = ln.bl + ln.half * C::L * C::EPB;
+    if constexpr (C::PACKED) {
+        const u32* q = p + ln.half * C::L;
+#pragma unroll
+        for (int j = 0; j < C::L; ++j) dst[j * C::EPB] = q[j];
+        return;
+    }
+    const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
 #pragma unroll
     for (int k = 0; k < C::LW / 4; ++k) {
         uint4 v = q[k];
@@ -250,7 +279,7 @@ __device__ __forceinline__ void mont_mul(u32 (&r)[C::L], const u32 (&a)[C::L], c
     if constexpr (C::LPE == 1) {
         mont_mul_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
     } else {
-        mont_mul_columns_lanes<C::L, C::LPE>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);
+        mont_mul_columns_lanes<C::L, C::LPE, C::ROWS>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);
     }
     normalize<C>(r, T, ln);
 }
@@ -261,7 +290,7 @@ __device__ __forceinline__ void mont_sqr(u32 (&r)[C::L], const u32 (&a)[C::L], c
     if constexpr (C::LPE == 1) {
         mont_sqr_columns<C::L>(T, a, ln.bl, C::EPB, n, n0inv);
     } else {
-        mont_sqr_columns_lanes<C::L, C::LPE>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);
+        mont_sqr_columns_lanes<C::L, C::LPE, C::ROWS>(T, a, ln.bl, C::EPB, n, n0inv, ln.lowmask, ln.nottopmask);
     }
     normalize<C>(r, T, ln);
 }

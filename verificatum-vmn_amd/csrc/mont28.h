@@ -134,12 +134,14 @@ __device__ __forceinline__ void relieve_columns(u64 (&T)[L], u32 lowmask, u32 no
     const u32 lo = lane_below<LPE>((u32)cout) & ~lowmask, hi = lane_below<LPE>((u32)(cout >> 32)) & ~lowmask;
     T[0] += ((u64)hi << 32) | lo;
 }
-template <int L, int LPE>
+// ROWS <= S = LPE * L is the number of reduction rows (R = 2^(28 ROWS)): the limbs of the multiplier above ROWS are zero
+// (the wide geometries of modp_kernels.h), their rows are not run.
+template <int L, int LPE, int ROWS = LPE * L>
 __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&a)[L], const u32* b_lds, int bstride,
                                                        const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask) {
-    constexpr int S = LPE * L;
+    constexpr int S = ROWS;
     constexpr int HALF = 2 * S > 256 ? S / 2 : S;       // rows before the relief (S: none)
-    static_assert(S <= 256, "one relief is not enough beyond 256 limbs");
+    static_assert(S <= 256 && ROWS <= LPE * L, "one relief is not enough beyond 256 limbs");
     u32 bi = b_lds[0];
     u32 bn = b_lds[bstride];
     mont_lanes_row_asm_first<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
@@ -163,35 +165,38 @@ __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&
 // Multi-lane squaring: T = a^2 / R mod N with every cross product formed once.  The rows whose multiplier limb belongs
 // to share u (rows uL .. uL + L - 1) run the block pattern of their LOCAL index on every lane (gen_mont_asm.py,
 // gen_pair_sqr): per lane LPE * (L^2 / 2 + 4 L) products instead of LPE * L^2.  a_lds holds a copy of a.
-template <int L, int LPE, int J0>
+// LIM = the share's number of rows (L, or what is left of ROWS for the last share of a wide geometry: the limbs above
+// are zero, so are all the products the skipped rows would have formed).
+template <int L, int LPE, int ROWS, int LIM, int J0>
 __device__ __forceinline__ void mont_sqr_lanes_share(u64 (&T)[L], const u32 (&a)[L], const u32* a_lds, int bstride, const u32 (&n)[L],
                                                      u32 n0inv, u32 lowmask, u32 nottopmask, u32& bn, int base, int skip_first) {
-    constexpr int S = LPE * L;
-    constexpr int END = J0 + SQR_BLK < L ? J0 + SQR_BLK : L;
+    constexpr int END = J0 + SQR_BLK < LIM ? J0 + SQR_BLK : LIM;
 #pragma unroll 8
     for (int ip = (J0 == 0 ? skip_first : J0); ip < END; ++ip) {
         const int i = base + ip;
         u32 bi = bn;
-        bn = a_lds[(i + 1 < S ? i + 1 : 0) * bstride];            // prefetch the next row's limb under this row
+        bn = a_lds[(i + 1 < ROWS ? i + 1 : 0) * bstride];         // prefetch the next row's limb under this row
         mont_lanes_sqr_row_asm<L, LPE, J0>(T, a, bi, bi << 1, n, n0inv, lowmask, nottopmask);
     }
-    if constexpr (END < L) mont_sqr_lanes_share<L, LPE, END>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, base, skip_first);
+    if constexpr (END < LIM) mont_sqr_lanes_share<L, LPE, ROWS, LIM, END>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, base, skip_first);
 }
-template <int L, int LPE>
+template <int L, int LPE, int ROWS = LPE * L>
 __device__ __forceinline__ void mont_sqr_columns_lanes(u64 (&T)[L], const u32 (&a)[L], const u32* a_lds, int bstride,
                                                        const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask) {
-    constexpr int S = LPE * L;
-    static_assert(S <= 256, "one relief is not enough beyond 256 limbs");
+    constexpr int LAST = ROWS - (LPE - 1) * L;          // rows of the last share
+    static_assert(ROWS <= 256 && LAST >= 1 && LAST <= L, "one relief is not enough beyond 256 limbs");
     u32 b0 = a_lds[0];
     u32 bn = a_lds[bstride];
     mont_lanes_sqr_row_asm_first<L, LPE>(T, a, b0, b0 << 1, n, n0inv, lowmask, nottopmask);
 #pragma unroll 1
-    for (int u = 0; u < LPE; ++u) {
-        if constexpr (2 * S > 256) {
+    for (int u = 0; u < LPE - (LAST < L ? 1 : 0); ++u) {
+        if constexpr (2 * ROWS > 256) {
             if (u == LPE / 2) relieve_columns<L, LPE>(T, lowmask, nottopmask);      // half way, as in the general product
         }
-        mont_sqr_lanes_share<L, LPE, 0>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, u * L, u == 0 ? 1 : 0);
+        mont_sqr_lanes_share<L, LPE, ROWS, L, 0>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, u * L, u == 0 ? 1 : 0);
     }
+    if constexpr (LAST < L)
+        mont_sqr_lanes_share<L, LPE, ROWS, LAST, 0>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, (LPE - 1) * L, 0);
 }
 
 // Resolve the lazy columns into 28-bit limbs (value unchanged, < 2N < 2^(28*S)).

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <future>
 #include <memory>
 #include <utility>
 
@@ -49,7 +50,9 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // (modulus bits) -> (S limbs, NW words).  One template instantiation per supported size.
 // X(limbs, packed words, lanes per element).  3072-bit moduli (110 limbs) run two lanes per element, 4096-bit
 // moduli (148 limbs: R = 2^4144) four.
-#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(110, 96, 2) X(148, 128, 4)
+// X(76, 64, 4) is the WIDE geometry of 2048-bit moduli (modp_kernels.h, struct Cfg): the rows of X(74, 64, 1) worked on by
+// four lanes each; launches over few elements are routed there (geom() below).
+#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(110, 96, 2) X(148, 128, 4)
 // elliptic curves: X(field limbs, packed words)
 // (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
 #define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
@@ -67,6 +70,33 @@ static bool size_for_bits(int nbits, int* S, int* NW, int* LPE) {
     }
     return false;
 }
+
+// The geometry a launch over `items` independent elements (chains, tiles ...) runs in: one element per lane fills the chip
+// from ~1.3 x 10^5 elements on (2 waves x 4 SIMDs x 256 CUs x 64 lanes); up to ctx->wide_max elements (default 40960: the
+// measured crossover of k_modpow / k_fixed_exp, tools/sweep_small_n.sh) the same rows are handed to four lanes each,
+// which shortens every chain of dependent products ~2.5 times.  The two geometries share R and the memory layout, so the
+// choice is made per launch.  Scans and the tails of reductions are latency-bound at every size (three passes of one
+// product per element): they always run wide (`always`).  vmn_ctx_set_small_array_threshold(ctx, 0) turns the wide
+// geometry off, a huge value routes everything through it (the test-suite does both); VMN_WIDE_MAX sets the default.
+static size_t default_wide_max() {
+    static const size_t v = [] {
+        const char* env = getenv("VMN_WIDE_MAX");
+        return env ? (size_t)strtoull(env, nullptr, 10) : (size_t)40960;
+    }();
+    return v;
+}
+static const vmn_modulus& geom(const vmn_ctx* ctx, const vmn_modulus& m, size_t items, bool always = false) {
+    const vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
+    if (!m.wide || root->wide_max == 0) return m;
+    return (always || items <= root->wide_max) ? *m.wide : m;
+}
+// the non-curve launch sites: X sees `m` = the geometry chosen for `items`
+#define VMN_DISPATCH(items, X)                              \
+    {                                                       \
+        const vmn_modulus& m_base__ = m;                    \
+        const vmn_modulus& m = geom(ctx, m_base__, (items)); \
+        VMN_FOR_SIZES(X)                                    \
+    }
 
 static size_t lds_bytes(const vmn_modulus& m) { return (size_t)m.S * (BLOCK / m.LPE) * sizeof(u32); }
 static int blocks_per_cu(const vmn_modulus&) { return 2; }
@@ -101,14 +131,15 @@ static int launch(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), un
 
 // Work accounting for the roofline of the proof legs (bench.py): the number of v_mad_u64_u32 multiply-adds the NEXT
 // launch executes, from the number of Montgomery products / squarings its lanes perform.  A product of S limbs is 2 S^2
-// multiply-adds (multiplication + reduction half); a squaring S^2 (reduction) + S (S + SQR_BLK) / 2 (block-symmetric
-// multiplication half) in the one-lane geometry and a full product in the multi-lane ones.  Curve points: field products
+// multiply-adds (multiplication + reduction half); a squaring S^2 (reduction) + S (S + LPE SQR_BLK) / 2 (block-symmetric
+// multiplication half, summed over the LPE lanes of the element).  Curve points: field products
 // (S = 10 / 15), 16 per addition (11M + 5S), 8 per doubling (3M + 5S).  Only recorded while timing is on.
 static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double squarings = 0) {
     if (!ctx->timing) return 0;
-    const double S = m.ec ? (double)m.ec->S : (double)m.S;
-    const double sq = (m.ec || m.LPE > 1) ? 2 * S * S : S * S + S * (S + SQR_BLK) / 2;
-    ctx->next_mads = products * 2 * S * S + squarings * sq;
+    const double S = m.ec ? (double)m.ec->S : (double)m.S;              // columns
+    const double Rw = m.ec ? S : (double)m.rows;                         // rows (< S in a wide geometry)
+    const double sq = m.ec ? 2 * S * S : Rw * S + Rw * (S + SQR_BLK * m.LPE) / 2;      // block-symmetric in every geometry
+    ctx->next_mads = products * 2 * Rw * S + squarings * sq;
     return 0;                                   // (an int so that a launch inside a macro can be written  note_work(..) ? 0 : launch(..))
 }
 static const double EC_ADD = 16, EC_DBL = 8;
@@ -155,6 +186,7 @@ static int ensure_scratch(vmn_ctx* ctx, size_t bytes) {
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
     }
+    VMN_TRACE("scratch:hipMalloc");
     VMN_HIP(hipMalloc(&ctx->scratch, bytes));
     ctx->scratch_bytes = bytes;
     return VMN_OK;
@@ -163,34 +195,43 @@ static int ensure_scratch(vmn_ctx* ctx, size_t bytes) {
 // ---- stream-ordered caching allocator ------------------------------------------------------------
 static const size_t POOL_LIMIT = (size_t)96 << 30;      // keep at most 96 GB of freed blocks cached
 
+static size_t block_class_of(vmn_ctx* ctx, const void* p, size_t fallback, bool forget);
 static void pool_release_all(vmn_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool) {
-        for (void* q : kv.second) (void)hipFree(q);
+        for (void* q : kv.second) {
+            (void)hipFree(q);
+            (void)block_class_of(ctx, q, 0, true);
+        }
     }
     ctx->pool.clear();
     ctx->pool_bytes = 0;
 }
-// Size classes of the pool: multiples of 256 B below 1 MB; above, eight classes per power of two (<= 12.5 % slack).
+// Size classes of the pool: multiples of 256 B below 4 KB; above, eight classes per power of two (<= 12.5 % slack).
 // Temporaries whose size depends on the data (the level buffers of a multi-exponentiation) would otherwise add a
 // new exact size -- and a block that is never reused -- with every call (found by tools/soak.py).
 static size_t pool_round(size_t bytes) {
     if (bytes < 256) return 256;
-    if (bytes < ((size_t)1 << 20)) return (bytes + 255) & ~(size_t)255;
+    if (bytes < ((size_t)1 << 12)) return (bytes + 255) & ~(size_t)255;
     int top = 63 - __builtin_clzll((unsigned long long)bytes);
     size_t gran = (size_t)1 << (top - 3);
     return (bytes + gran - 1) & ~(gran - 1);
 }
+// A request is served by the smallest cached block of its class or of a class up to twice as large: a data-dependent
+// size that crosses a class boundary from one proof to the next must not cost a hipMalloc (which maps memory: 20 ms
+// were measured for a few MB, as long as all the kernels of a proof of 10^4 ciphertexts).  The block remembers its own
+// class (ctx->block_class), so that it returns to the list it came from.
 static int pool_alloc(vmn_ctx* ctx, size_t bytes, void** out) {
     bytes = pool_round(bytes);
-    auto it = ctx->pool.find(bytes);
-    if (it != ctx->pool.end() && !it->second.empty()) {
+    for (auto it = ctx->pool.lower_bound(bytes); it != ctx->pool.end() && it->first <= 2 * bytes; ++it) {
+        if (it->second.empty()) continue;
         *out = it->second.back();
         it->second.pop_back();
-        ctx->pool_bytes -= bytes;
-        ctx->live_bytes += bytes;
+        ctx->pool_bytes -= it->first;
+        ctx->live_bytes += it->first;
         return VMN_OK;
     }
+    VMN_TRACE("pool:hipMalloc");
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -201,14 +242,30 @@ static int pool_alloc(vmn_ctx* ctx, size_t bytes, void** out) {
         set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? VMN_ERR_NOMEM : VMN_ERR_DEVICE;
     }
+    {
+        vmn_ctx* root = ctx->parent ? ctx->parent : ctx;         // one table for the lanes of a context: a block may be freed on the other lane
+        std::lock_guard<std::mutex> g(root->block_mu);
+        root->block_class[*out] = bytes;
+    }
     ctx->live_bytes += bytes;
     return VMN_OK;
 }
+static size_t block_class_of(vmn_ctx* ctx, const void* p, size_t fallback, bool forget) {
+    vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
+    std::lock_guard<std::mutex> g(root->block_mu);
+    auto bc = root->block_class.find(p);
+    if (bc == root->block_class.end()) return fallback;
+    size_t c = bc->second;
+    if (forget) root->block_class.erase(bc);
+    return c;
+}
 static void pool_free(vmn_ctx* ctx, void* p, size_t bytes) {
     if (!p) return;
-    bytes = pool_round(bytes);
+    const bool drop = ctx->pool_bytes + pool_round(bytes) > POOL_LIMIT;
+    bytes = block_class_of(ctx, p, pool_round(bytes), drop);
     ctx->live_bytes -= bytes;
-    if (ctx->pool_bytes + bytes > POOL_LIMIT) {
+    if (drop) {
+        VMN_TRACE("pool:hipFree");
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
         return;
@@ -268,6 +325,7 @@ extern "C" int vmn_ctx_create(int device, vmn_ctx** out) {
     std::unique_ptr<vmn_ctx> ctx(new vmn_ctx());
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    ctx->wide_max = default_wide_max();
     VMN_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     VMN_HIP(hipMalloc(&ctx->flags, 64 * sizeof(uint32_t)));
@@ -382,6 +440,13 @@ extern "C" int vmn_ctx_helper_end(vmn_ctx* ctx) {
 }
 
 extern "C" int vmn_ctx_num_cus(vmn_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+extern "C" int vmn_ctx_set_small_array_threshold(vmn_ctx* ctx, size_t items) {
+    ARG_CHECK(ctx, "null ctx");
+    vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
+    std::lock_guard<std::recursive_mutex> guard__(root->mu);
+    root->wide_max = items;
+    return VMN_OK;
+}
 extern "C" int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes) {
     ARG_CHECK(ctx, "null ctx");
     size_t blocks = 0, pbytes = 0, live = 0;       // an array may be freed on another lane than it came from: only the sums mean something
@@ -483,6 +548,7 @@ static int upload_words(vmn_ctx* ctx, uint32_t** dst, const std::vector<uint32_t
 }
 
 static void modulus_destroy(vmn_modulus& m) {
+    delete m.wide;                         // a view: plain data, owns nothing
     if (m.d_n) (void)hipFree(m.d_n);
     if (m.d_rr) (void)hipFree(m.d_rr);
     if (m.d_one) (void)hipFree(m.d_one);
@@ -497,6 +563,7 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
     m.S = S;
     m.NW = NW;
     m.LPE = LPE;
+    m.rows = S;
     m.W = LPE * stride_for_limbs(S / LPE);
     m.n_words = hostbig::from_be(be, nbytes, NW);
     // bytes beyond NW words must be zero
@@ -530,6 +597,13 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
         std::vector<uint8_t> nbe((size_t)NW * 4);
         hostbig::to_be(m.n_words, nbe.data(), nbe.size());
         m.hm64 = new num64::Mod(num64::from_be(nbe.data(), nbe.size(), ((size_t)NW * 4 + 7) / 8));
+    }
+    if (S == 74 && LPE == 1) {             // the wide geometry of the same rows (Cfg<76, 4>: 74 rows, four packed shares of 19 columns)
+        static_assert(Cfg<76, 4>::W == Cfg<74, 1>::W && Cfg<76, 4>::ROWS == 74, "the wide geometry reads the one-lane rows");
+        m.wide = new vmn_modulus(m);
+        m.wide->S = 76;
+        m.wide->LPE = 4;
+        m.wide->wide = nullptr;
     }
     return VMN_OK;
 }
@@ -871,7 +945,7 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (m.S == S_)                                                                                              \
         rc = launch(ctx, "import", k_import_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), d_out, raw.as<uint8_t>(), \
                     nbytes, stride, leaf_hdr, n, m.d_n, m.n0inv, m.d_rr, ctx->flags);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     }
     VMN_TRY(rc);
@@ -904,7 +978,7 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (m.S == S_)                                                                                          \
         rc = launch(ctx, "export", k_export_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), raw.as<uint8_t>(),    \
                     nbytes, stride, leaf_hdr, d_in, n, m.d_n, m.n0inv);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     }
     VMN_TRY(rc);
@@ -968,7 +1042,7 @@ static int mul_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, con
     }
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = launch(ctx, "modmul", k_mul<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), out, x, y, ystride, n, m.d_n, m.n0inv);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     return rc;
 }
@@ -980,7 +1054,7 @@ static int to_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* in, size
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = launch(ctx, "to_words", k_to_words<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), out_words, in, n, m.d_n, m.n0inv);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     return rc;
 }
@@ -1000,11 +1074,12 @@ static int pick_window(int ebits) {
 }
 
 // out[i] = x[i]^e[i] with packed-word exponents already on the device
-static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* e_words, int ewords,
+static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x, const uint32_t* e_words, int ewords,
                         size_t estride, int ebits, size_t n, uint32_t* out) {
     if (n == 0) return VMN_OK;
     if (ebits < 1) ebits = 1;
-    if (m.ec) {
+    if (m0.ec) {
+        const vmn_modulus& m = m0;
         int wb = std::min(pick_window(ebits), 5);
         unsigned grid = std::min<unsigned>(grid_for(n), (unsigned)(ctx->num_cus * 2));
         size_t tab_bytes = (size_t)grid * BLOCK * ((size_t)1 << wb) * elem_words(m) * sizeof(uint32_t);
@@ -1020,6 +1095,7 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, c
         return rc;
     }
     int wbits = pick_window(ebits);
+    const vmn_modulus& m = geom(ctx, m0, n);
     unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
     unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
     size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);
@@ -1494,7 +1570,7 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
                  : launch(ctx, "reduce", k_reduce_strided<Cfg<S_, LPE_>, false>, egrid(m, nseg * L), lds_bytes(m), dst, src, cur, \
                           L, nseg, m.d_n, m.n0inv);                                                                     \
     }
-        VMN_FOR_SIZES(X)
+        VMN_DISPATCH((nseg * L) / 8, X)        /* the tail levels of a reduction are latency-bound: wide up to 8 x the threshold */
 #undef X
         }
         VMN_TRY(rc);
@@ -1549,7 +1625,7 @@ static int ring_elementwise(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* 
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), out, x, y, v, op, n, m.d_n, m.n0inv);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     return rc;
 }
@@ -1633,9 +1709,10 @@ static size_t scan_chunk(size_t n, size_t lanes_wanted) {
     return c;
 }
 
-static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, const uint32_t* b, size_t n, size_t seglen,
+static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* e, const uint32_t* b, size_t n, size_t seglen,
                        int rev, uint32_t* out) {
     if (n == 0) return VMN_OK;
+    const vmn_modulus& m = geom(ctx, m0, n, true);     // (the chunk length below depends on the geometry's lanes per element)
     const size_t Wd = elem_words(m);
     if (seglen == 0 || seglen > n) seglen = n;
     if (m.ec) {                                        // running sums of curve points (b must be null)
@@ -1690,7 +1767,7 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
     if (m.S == S_)                                                                                                        \
         rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)nullptr, \
                     n, Cs, seglen, rev, m.d_n, m.n0inv, m.d_one);
-        VMN_FOR_SIZES(X)
+        VMN_DISPATCH(nchunks, X)
 #undef X
         return rc;
     }
@@ -1709,18 +1786,18 @@ static int scan_affine(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* e, co
             rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_totals<Cfg<S_, LPE_>, true>, egrid(m, nchunks), lds_bytes(m), Xtot, e, b, n, C,       \
                         seglen, rev, m.d_n, m.n0inv, m.d_one);                                                          \
     }
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(nchunks, X)
 #undef X
     VMN_TRY(rc);
     // inclusive scan over the chunk totals with the same recurrence (segments shrink by C)
     size_t seg_chunks = seglen == n ? nchunks : seglen / C;
-    VMN_TRY(scan_affine(ctx, m, Etot, b ? Xtot : nullptr, nchunks, seg_chunks, 0, inc));
+    VMN_TRY(scan_affine(ctx, m0, Etot, b ? Xtot : nullptr, nchunks, seg_chunks, 0, inc));
     rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                  \
     if (m.S == S_)                                                                                                  \
         rc = note_work(ctx, m, (double)n) ? 0 : launch(ctx, "scan", k_scan_apply<Cfg<S_, LPE_>>, egrid(m, nchunks), lds_bytes(m), out, e, b, (const uint32_t*)inc, n, \
                     C, seglen, rev, m.d_n, m.n0inv, m.d_one);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(nchunks, X)
 #undef X
     return rc;
 }
@@ -2058,7 +2135,7 @@ static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const u
     if (m.S == S_)                                                                                                     \
         rc = launch(ctx, "import", k_import_be<Cfg<S_, LPE_>, NW_>, egrid(m, n), lds_bytes(m), d_out, d_rows, nbytes, nbytes, mode, n, \
                     m.d_n, m.n0inv, m.d_rr, ctx->flags);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     VMN_TRY(rc);
     if (all_in_range) {
@@ -2107,7 +2184,7 @@ static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, si
     if (m.S == S_)                                                                                                            \
         rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), d_out, (const uint32_t*)hi.as<uint32_t>(), \
                     (const uint32_t*)lo.as<uint32_t>(), (const uint32_t*)cdev.as<uint32_t>(), 2, n, m.d_n, m.n0inv);
-    VMN_FOR_SIZES(X)
+    VMN_DISPATCH(n, X)
 #undef X
     return rc;
 }
@@ -2466,6 +2543,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         set_error("fixed base out of range");
         return VMN_ERR_FORMAT;
     }
+    VMN_TRACE("fixed_table:build");
     const num64::Mod& hm = *m.hm64;                      // 64-bit limbs: the chain is sequential host work per new base
     num64::Num cur = hm.to_m(num64::from_be(base_be, g->nbytes, hm.nl));
     const size_t chain = (size_t)nwin * w;
@@ -2490,7 +2568,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         size_t lanes = (((size_t)1 << l) - 1) * nwin;
 #define X(S_, NW_, LPE_) \
     if (m.S == S_) rc = note_work(ctx, m, (double)lanes) ? 0 : launch(ctx, "fixed_table", k_fixed_level<Cfg<S_, LPE_>>, egrid(m, lanes), lds_bytes(m), ft.d_tab, w, nwin, l, m.d_n, m.n0inv);
-        VMN_FOR_SIZES(X)
+        VMN_DISPATCH(lanes, X)
 #undef X
     }
     if (rc != VMN_OK) {
@@ -2535,7 +2613,7 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
     if (rc == VMN_OK) rc = ew.alloc(n * (size_t)grp->Q.NW * sizeof(uint32_t));
     if (rc == VMN_OK) rc = to_words(ctx, grp->Q, e->d, n, ew.as<uint32_t>());
     if (rc == VMN_OK) {
-        const vmn_modulus& m = grp->P;
+        const vmn_modulus& m = geom(ctx, grp->P, n);
         // one workgroup per tile rather than a persistent grid: a workgroup slot frees up every ~2 ms, so kernels of
         // the other lane (a helper's exports) are scheduled between the tiles instead of behind the whole launch
         unsigned grid = egrid(m, n);
@@ -2703,7 +2781,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
                             items_in, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_out, nbuckets,     \
                             total_out, F, m.d_n, m.n0inv);                                                              \
     }
-            VMN_FOR_SIZES(X)
+            VMN_DISPATCH(total_out, X)
 #undef X
             VMN_TRY(rc);
         }
@@ -2749,8 +2827,9 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     }
     std::vector<uint8_t> wbe(k * (size_t)nwin * g->nbytes);
     VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, wbe.data()));
+    VMN_TRACE("expprod:horner_host");
     const num64::Mod& hm = *m.hm64;
-    for (size_t arr = 0; arr < k; ++arr) {
+    auto horner = [&](size_t arr) {
         num64::Num acc = hm.one_m;
         for (int w = nwin - 1; w >= 0; --w) {
             for (int s2 = 0; s2 < c; ++s2) hm.mmul(acc, acc, acc);
@@ -2758,7 +2837,11 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
             hm.mmul(acc, acc, ww);
         }
         num64::to_be(hm.from_m(acc), out_be + arr * ebytes_out, g->nbytes);
-    }
+    };
+    std::vector<std::future<void>> others;                 // one chain per array: the arrays beyond the first on threads of their own
+    for (size_t arr = 1; arr < k; ++arr) others.emplace_back(std::async(std::launch::async, horner, arr));
+    horner(0);
+    for (auto& f : others) f.get();
     return VMN_OK;
 }
 

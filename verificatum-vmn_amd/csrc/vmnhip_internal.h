@@ -13,6 +13,7 @@
 #include "../../include/vmnhip.h"
 #include "hostbig.h"
 #include "hostnum64.h"
+#include "hosttrace.h"
 
 struct vmn_ctx;
 namespace vmn {
@@ -32,6 +33,7 @@ void set_error(const char* fmt, ...);
 // its one helper thread, ShufflerElGamalSession.java:839-859, may call concurrently on distinct arrays); the
 // mutex is recursive because entry points compose (permute -> gather, mul_partials -> from_be / prod).
 #define VMN_ENTER(c)                                                \
+    VMN_TRACE(__func__);                                            \
     std::lock_guard<std::recursive_mutex> guard__((c)->mu);         \
     VMN_HIP(hipSetDevice((c)->device))
 // The lane a call runs on: the helper lane when the calling thread has announced itself as the helper of this context.
@@ -67,6 +69,7 @@ struct vmn_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int num_cus = 0;
+    size_t wide_max = 0;                  // main lane: launches over at most this many elements use the wide geometry (vmnhip.hip: geom())
     // grow-only scratch (window tables, temporaries)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -74,6 +77,8 @@ struct vmn_ctx {
     // stream-ordered caching allocator: freed device blocks are kept by size and handed out again
     // (all work of a context is on one stream, so reuse is ordered after the previous user)
     std::map<size_t, std::vector<void*>> pool;
+    std::map<const void*, size_t> block_class;     // main lane: every pooled block of the context -> the size class it belongs to
+    std::mutex block_mu;                           //   (both lanes look blocks up: an array may be freed on the other lane)
     size_t pool_bytes = 0;
     size_t live_bytes = 0;                // handed out by pool_alloc and not yet returned
     std::unordered_set<const void*> lds_attr_set;
@@ -106,6 +111,9 @@ struct vmn_modulus {
     int S = 0;                 // 28-bit limbs
     int NW = 0;                // 32-bit words of the packed form
     int LPE = 1;               // lanes per element (2 for 3072-bit moduli)
+    int rows = 0;              // reduction rows of a product: R = 2^(28 rows); = S except in a wide geometry
+    vmn_modulus* wide = nullptr;     // the wide geometry of the same rows (2048-bit moduli: 4 lanes per element), a view:
+                                     // it shares every pointer of this object and owns nothing
     int W = 0;                 // words per element row in device memory
     const vmn_curve* ec = nullptr;   // non-null: the "elements" are curve points (rows of 3 field elements)
     int nbits = 0;

@@ -16,12 +16,14 @@
 #include <string.h>
 
 #include <algorithm>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "hostcurve.h"
 #include "hostnum64.h"
+#include "hosttrace.h"
 
 using vmn::num64::Bytes;
 using vmn::num64::Mod;
@@ -112,6 +114,36 @@ bool is_permutation(const uint32_t* pi, size_t n) {
 }
 
 // ---- the group as the host sees it: sizes, Z_q scalars, single group elements ---------------------------------
+// The exponentiations of SINGLE elements of a proof (g^alpha, pk^(-phi), A^v A' ...: 16 in a proof of a shuffle, a full-length
+// one ~2 ms on one host core) are independent of each other within a phase: each runs on a worker thread of its own,
+// started as soon as its operands exist -- beside the GPU calls of the phase, which block the calling thread -- and the
+// phase joins them right before it uses the values.  At N = 10^6 this hides 30 ms of 1 s; at N = 10^4 it is a third of
+// the proof.  Declare a HostJobs AFTER the objects its jobs write: it joins in its destructor, so an early return
+// (TRY) never leaves a job writing into a dead object.  The jobs only call const members of HostGroup.
+struct HostJobs {
+    std::vector<std::future<int>> pending;
+    template <class F>
+    void start(F&& f) {
+        if (pending.size() >= 32) {                 // (a very wide ciphertext: bounded number of threads, the rest inline)
+            int rc = f();
+            pending.emplace_back(std::async(std::launch::deferred, [rc] { return rc; }));
+            return;
+        }
+        pending.emplace_back(std::async(std::launch::async, std::forward<F>(f)));
+    }
+    int join() {
+        VMN_TRACE("host:jobs_join");
+        int rc = VMN_OK;
+        for (auto& f : pending) {
+            int r = f.get();
+            if (rc == VMN_OK) rc = r;
+        }
+        pending.clear();
+        return rc;
+    }
+    ~HostJobs() { (void)join(); }
+};
+
 struct HostGroup {
     vmn_group* grp = nullptr;
     bool ec = false;
@@ -121,6 +153,7 @@ struct HostGroup {
     Mod Zq, Zp;                       // Z_q scalars; Z_p = the modulus (ModPGroup) or the coordinate field (curves)
     HostCurve curve;
     int qbits = 0;
+    bool safe_prime = false;          // ModPGroup with p = 2q + 1: membership of a single element = Jacobi symbol 1
     Bytes g;
 
     int init(vmn_group* g_) {
@@ -137,6 +170,16 @@ struct HostGroup {
         Zq = Mod(vmn::num64::from_be(qb.data(), xb, ql));
         qbits = vmn::num64::bit_length(Zq.n);
         Zp = Mod(vmn::num64::from_be(pb.data(), cw, pl));
+        if (!ec) {                                  // p = 2q + 1 ?
+            Num t = Zq.n;
+            t.resize(pl, 0);
+            Num d = t;
+            vmn::num64::add_in(t, d);
+            Num o(pl, 0);
+            o[0] = 1;
+            vmn::num64::add_in(t, o);
+            safe_prime = vmn::num64::cmp(t, Zp.n) == 0;
+        }
         curve.F = &Zp;                 // (HostGroup objects are not copied after init)
         curve.cb = cw;
         curve.fl = pl;
@@ -157,6 +200,7 @@ struct HostGroup {
         return o;
     }
     int el_exp(const Bytes& base, const uint8_t* e_be, size_t ebytes, Bytes& out) const {
+        VMN_TRACE("host:el_exp");
         if (ec) {
             out = curve.exp(base, e_be, ebytes);
             return VMN_OK;
@@ -194,16 +238,28 @@ struct HostGroup {
         *ok = 1;
         TRY(vmn_garray_from_be(grp, flat.data(), els.size(), x.out(), ok));
         if (!*ok || ec) return VMN_OK;                 // curves: on the curve = in the group (cofactor 1)
-        // ModPGroup: in range is not yet in the subgroup of order q: x^q = 1 on the host (a handful of elements)
-        Bytes qb = vmn::num64::to_bytes(Zq.n, xb);
+        // ModPGroup: in range is not yet in the subgroup of order q (a handful of elements, on the host): the Jacobi
+        // symbol when p = 2q + 1 (~0.1 ms each); x^q = 1 otherwise, every power on a thread of its own
+        if (safe_prime) {
+            for (const Bytes* e : els) {
+                if (Zp.jacobi(vmn::num64::from_be(e->data(), eb, pl)) != 1) *ok = 0;
+            }
+            return VMN_OK;
+        }
+        const Bytes qb = vmn::num64::to_bytes(Zq.n, xb);
         Num one(pl, 0);
         one[0] = 1;
-        for (const Bytes* e : els) {
-            if (vmn::num64::cmp(Zp.pow(vmn::num64::from_be(e->data(), eb, pl), qb.data(), qb.size()), one) != 0) {
-                *ok = 0;
-                break;
+        std::vector<int> member(els.size(), 0);
+        {
+            HostJobs jobs;
+            for (size_t k = 0; k < els.size(); ++k) {
+                jobs.start([this, k, &els, &qb, &one, &member] {
+                    member[k] = vmn::num64::cmp(Zp.pow(vmn::num64::from_be(els[k]->data(), eb, pl), qb.data(), qb.size()), one) == 0;
+                    return (int)VMN_OK;
+                });
             }
         }
+        for (int mbr : member) if (!mbr) *ok = 0;
         return VMN_OK;
     }
     int el_div(const Bytes& a, const Bytes& b, Bytes& out) const {
@@ -218,6 +274,7 @@ struct HostGroup {
         return el_mul(t, b, out);
     }
 };
+
 
 }  // namespace vmnp
 using namespace vmnp;
@@ -420,6 +477,7 @@ struct ProofBase {
     // N-sized draws: the whole array on every rank (same source values everywhere), of which `out` is this rank's shard;
     // `full` (may be null) keeps the whole array for draws that are read through the permutation.
     int draw_ring_array(RA& out, RA* full = nullptr) {
+        VMN_TRACE("proof:draw_ring_array");
         TRY(need_rs());
         if (!sharded) return random_ring_array(G.grp, rs, Ntot, G.qbits, rbitlen, out);
         RA all;
@@ -429,6 +487,7 @@ struct ProofBase {
         return VMN_OK;
     }
     int draw_integers(int bits, RA& out) {
+        VMN_TRACE("proof:draw_integers");
         TRY(need_rs());
         if (!sharded) return random_integer_array(G.grp, rs, Ntot, bits, out);
         RA all;
@@ -474,6 +533,7 @@ struct ProofBase {
     }
     // e' = permute(e, pi^-1), this rank's positions
     int permuted_batch_vector(const RA& e, const std::vector<uint32_t>& piinv, RA& ipe) {
+        VMN_TRACE("proof:permuted_batch_vector");
         if (!sharded) return vmn_rarray_permute(e, piinv.data(), ipe.out());
         return vmn_rarray_gather(e_full_own, piinv.data() + lo, N, ipe.out());
     }
@@ -574,6 +634,7 @@ struct ProofBase {
     // x -> x E + X with E = the product of its e', X = its local result), a multiply-add fix-up on the ranks above 0.
     // x_in / y_in: the values entering this shard (x_{lo-1}, y_{lo-1}; 0 and 1 on the first).
     int scans(const RA& b, const RA& ipe, RA& x, RA& y, Num& d, Bytes& x_in, Bytes& y_in) {
+        VMN_TRACE("proof:scans");
         Bytes dloc(G.xb, 0);
         TRY(vmn_rarray_rec_lin(b, ipe, x.out(), dloc.data()));
         TRY(vmn_rarray_prods(ipe, y.out()));
@@ -621,6 +682,7 @@ struct ProofBase {
     // x_in / y_in are what shiftPush pushes in front: (0, 1), or the carries into this shard
     int bridging_commitments(const Bytes& g, const Bytes& h0, RA& x, RA& y, const Bytes& x_in, const Bytes& y_in, const RA& beta,
                              const RA& epsilon, GA& B, GA& Bp) {
+        VMN_TRACE("proof:bridging_commitments");
         GA g_exp_x, h0_exp_y;
         TRY(vmn_group_exp_fixed(G.grp, g.data(), x, g_exp_x.out()));
         TRY(vmn_group_exp_fixed(G.grp, h0.data(), y, h0_exp_y.out()));
@@ -646,6 +708,7 @@ struct ProofBase {
     // element in front of this shard's B (h0, or the last B of the shard below).
     int bridging_sides(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
                        const vmn_rarray* k_E, int kE_bits, GA& left, GA& right) {
+        VMN_TRACE("proof:bridging_sides");
         GA B_exp_v, g_exp_k_B, B_shift, B_shift_exp_k_E;
         TRY(vmn_garray_exp_scalar(B, v_be.data(), v_be.size(), B_exp_v.out()));
         TRY(vmn_garray_mul(B_exp_v, Bp, left.out()));
@@ -673,15 +736,21 @@ struct ProofBase {
         if (N) TRY(vmn_garray_get(B, N - 1, out.data()));
         return VMN_OK;
     }
-    // pk_c^{-k_c mod width} * t_c for the 2w components of a ciphertext-shaped value
-    int pk_side(const std::vector<Bytes>& pkey, const std::vector<Num>& k, const std::vector<Bytes>& t, std::vector<Bytes>& out) const {
+    // pk_c^{-k_c mod width} * t_c for the 2w components of a ciphertext-shaped value: the powers do not need t (started
+    // early, one job each), the products do
+    void pk_powers(HostJobs& jobs, const std::vector<Bytes>& pkey, const std::vector<Num>& k, std::vector<Bytes>& pw) const {
         const size_t width = pkey.size() / 2;
-        out.resize(pkey.size());
+        pw.assign(pkey.size(), Bytes());
         for (size_t c = 0; c < pkey.size(); ++c) {
-            Bytes pw;
-            TRY(G.el_exp(pkey[c], G.Zq.neg(k[c % width]), pw));
-            TRY(G.el_mul(pw, t[c], out[c]));
+            const Bytes* base = &pkey[c];
+            Bytes* out = &pw[c];
+            const Num kc = G.Zq.neg(k[c % width]);
+            jobs.start([this, base, out, kc] { return G.el_exp(*base, kc, *out); });
         }
+    }
+    int pk_finish(const std::vector<Bytes>& pw, const std::vector<Bytes>& t, std::vector<Bytes>& out) const {
+        out.resize(pw.size());
+        for (size_t c = 0; c < pw.size(); ++c) TRY(G.el_mul(pw[c], t[c], out[c]));
         return VMN_OK;
     }
     // this rank's partial products (the caller completes them over the ranks in its phase's Round)
@@ -748,6 +817,7 @@ struct vmn_pos : ProofBase {
     std::vector<Bytes> cFp;
 
     int precompute(const uint8_t* g_be, const vmn_garray* h_, const uint32_t* pi_) {
+        VMN_TRACE("pos:precompute");
         REQUIRE(g_be && h_, "null argument");
         REQUIRE(vmn_garray_size(h_) > 0, "empty generator array");
         prover = pi_ != nullptr;
@@ -766,6 +836,9 @@ struct vmn_pos : ProofBase {
         TRY(draw_ring_array(r, sharded ? &r_full : nullptr));
         TRY(draw_ring_element(alpha));
         TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
+        Bytes hp(G.eb), ga;
+        HostJobs jobs;
+        jobs.start([&] { return gexp(g, alpha, ga); });
         if (!sharded) {
             TRY(vmn_permutation_commitment(G.grp, g.data(), h_, r, pi.data(), u_own.out()));
         } else {
@@ -773,12 +846,11 @@ struct vmn_pos : ProofBase {
         }
         u = u_own;
         // :481  A' = g^alpha prod h_i^eps_i
-        Bytes hp(G.eb), ga;
         TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
         Round rd(*this);
         rd.product(hp);
         TRY(rd.run());
-        TRY(gexp(g, alpha, ga));
+        TRY(jobs.join());
         return G.el_mul(ga, hp, Ap);
     }
     int set_instance(const uint8_t* pkey_be, size_t width_, const vmn_garray* const* w_, const vmn_garray* const* wp_,
@@ -801,6 +873,7 @@ struct vmn_pos : ProofBase {
     Bytes Cp_, Dp_;
     std::vector<Bytes> Fp_;
     int commit_prepare() {
+        VMN_TRACE("pos:commit_prepare");
         REQUIRE(prover && width && !prepared, "commit_prepare needs a prover with the instance set, once per proof");
         // randomness in the reference's order: b :583, beta :612, gamma :667, delta :673, phi :687
         TRY(draw_ring_array(b));
@@ -809,18 +882,22 @@ struct vmn_pos : ProofBase {
         TRY(draw_ring_element(delta));
         phi.resize(width);
         for (auto& ph : phi) TRY(draw_ring_element(ph));
-        std::vector<Bytes> prods;
+        std::vector<Bytes> prods, pkpow;
+        HostJobs jobs;
+        jobs.start([&] { return gexp(g, gamma, Cp_); });                          // :667-679
+        jobs.start([&] { return gexp(g, delta, Dp_); });
+        pk_powers(jobs, pkey, phi, pkpow);                                        // :687-690
         TRY(expprod_multi(wp, epsilon, eps_bits, prods));                         // :690
         Round rd(*this);
         rd.products(prods);
         TRY(rd.run());
-        TRY(gexp(g, gamma, Cp_));                                                 // :667-679
-        TRY(gexp(g, delta, Dp_));
-        TRY(pk_side(pkey, phi, prods, Fp_));                                      // :687-690
+        TRY(jobs.join());
+        TRY(pk_finish(pkpow, prods, Fp_));
         prepared = true;
         return VMN_OK;
     }
     int commit(vmn_msg** out) {
+        VMN_TRACE("pos:commit");
         REQUIRE(out && prover && e.p && width, "commit needs a prover with instance and batching vector set");
         if (!prepared) TRY(commit_prepare());
         TRY(permuted_batch_vector(e, piinv, ipe));                                // :552-554
@@ -840,6 +917,7 @@ struct vmn_pos : ProofBase {
         return VMN_OK;
     }
     int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
+        VMN_TRACE("pos:reply");
         REQUIRE(out && prover && ipe.p && s.size() == width, "reply needs commit() and the re-encryption exponents");
         TRY(set_challenge(vb, vbytes));
         Bytes ab(G.xb), cb(G.xb), fb(G.xb);
@@ -878,6 +956,7 @@ struct vmn_pos : ProofBase {
         return local_garray(u_, u_cut, &u, "u");
     }
     int compute_af() {
+        VMN_TRACE("pos:compute_af");
         REQUIRE(u && e.p && width, "computeAF needs u, the instance and the batching vector");
         std::vector<const vmn_garray*> xs{u};
         xs.insert(xs.end(), w.begin(), w.end());
@@ -891,6 +970,7 @@ struct vmn_pos : ProofBase {
         return VMN_OK;
     }
     int set_commitment(const vmn_msg* m) {
+        VMN_TRACE("pos:set_commitment");
         const vmn_msg::Item *iB = item_of(m, 0, VMN_ITEM_GARRAY), *iAp = item_of(m, 1, VMN_ITEM_ELEMENTS),
                             *iBp = item_of(m, 2, VMN_ITEM_GARRAY), *iCp = item_of(m, 3, VMN_ITEM_ELEMENTS),
                             *iDp = item_of(m, 4, VMN_ITEM_ELEMENTS), *iFp = item_of(m, 5, VMN_ITEM_ELEMENTS);
@@ -915,6 +995,7 @@ struct vmn_pos : ProofBase {
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, int* verdict, int* five) {
+        VMN_TRACE("pos:verify");
         REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
                             *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
@@ -925,16 +1006,25 @@ struct vmn_pos : ProofBase {
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
         std::vector<Num> k_F;
         for (auto& bts : split(*ikF)) k_F.push_back(G.ring_from(bts.data()));
-        // scalars that come back from the GPU first (each blocks on the stream) ...
-        Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb);
+        // the exponentiations of single elements whose operands are here already run beside everything below
+        Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), C, D, t_h0, lhsA, lhsC, lhsD, gkA, gkC, gkD, rhs, Blast, prev;
+        std::vector<Bytes> kE_prods, pkpow, lhsF(2 * width), rF;
+        Num eprod;
+        HostJobs jobs;                                                            // (after everything its jobs touch)
+        jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });              // (A) :1016-1021
+        jobs.start([&] { return gexp(g, k_A, gkA); });
+        jobs.start([&] { return gexp(g, k_C, gkC); });                            // (C) :1045-1048
+        jobs.start([&] { return gexp(g, k_D, gkD); });                            // (D) :1051-1054
+        pk_powers(jobs, pkey, k_F, pkpow);                                        // (F) :1057-1063
+        for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsF] { return G.el_expmul(F[c], v_be, cFp[c], lhsF[c]); });
+        // scalars that come back from the GPU (each blocks on the stream) ...
         TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
         TRY(vmn_garray_prod(h, hprod.data()));
         TRY(last_local(cB, mylast));
         TRY(vmn_rarray_prod(e, eprod_b.data()));                                  // :1014
-        Num eprod = G.ring_from(eprod_b.data());
+        eprod = G.ring_from(eprod_b.data());
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
-        std::vector<Bytes> kE_prods;
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
         TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));                       // :1021, :1063 — one sort of k_E
@@ -947,33 +1037,28 @@ struct vmn_pos : ProofBase {
         rd.ring_product(eprod);
         rd.collect(mylast, lasts);
         TRY(rd.run());
-        Bytes Blast, prev;
         pick_B(lasts, h0, Blast, prev);
+        // ... the exponentiations that needed them ...
+        TRY(G.el_div(uprod, hprod, C));
+        jobs.start([&] { return G.el_expmul(C, v_be, cCp, lhsC); });
+        jobs.start([&] {
+            TRY(G.el_exp(h0, eprod, t_h0));
+            TRY(G.el_div(Blast, t_h0, D));
+            return G.el_expmul(D, v_be, cDp, lhsD);
+        });
         // ... then the element-wise work of check (B) is queued ...
         GA left, right;
         TRY(bridging_sides(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // :1023-1042
-        // ... and the single-element checks run on the host while the GPU works
-        Bytes C, D, t, lhs, rhs;
-        TRY(G.el_div(uprod, hprod, C));
-        TRY(G.el_exp(h0, eprod, t));
-        TRY(G.el_div(Blast, t, D));
-        TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :1016-1021
-        TRY(gexp(g, k_A, t));
-        TRY(G.el_mul(t, kE_prods[0], rhs));
-        const int vA = lhs == rhs;
-        TRY(G.el_expmul(C, v_be, cCp, lhs));                                      // (C) :1045-1048
-        TRY(gexp(g, k_C, rhs));
-        const int vC = lhs == rhs;
-        TRY(G.el_expmul(D, v_be, cDp, lhs));                                      // (D) :1051-1054
-        TRY(gexp(g, k_D, rhs));
-        const int vD = lhs == rhs;
-        std::vector<Bytes> prods(kE_prods.begin() + 1, kE_prods.end()), rF;
-        TRY(pk_side(pkey, k_F, prods, rF));                                       // (F) :1057-1063
+        // ... and the single-element checks are compared while the GPU works
+        TRY(jobs.join());
+        TRY(G.el_mul(gkA, kE_prods[0], rhs));
+        const int vA = lhsA == rhs;
+        const int vC = lhsC == gkC;
+        const int vD = lhsD == gkD;
+        std::vector<Bytes> prods(kE_prods.begin() + 1, kE_prods.end());
+        TRY(pk_finish(pkpow, prods, rF));
         int vF = 1;
-        for (size_t c = 0; c < 2 * width; ++c) {
-            TRY(G.el_expmul(F[c], v_be, cFp[c], lhs));
-            vF = vF && lhs == rF[c];
-        }
+        for (size_t c = 0; c < 2 * width; ++c) vF = vF && lhsF[c] == rF[c];
         int vB = 0;
         TRY(vmn_garray_equals(left, right, &vB));
         Round rv(*this);
@@ -1041,14 +1126,16 @@ struct vmn_posc : ProofBase {
         TRY(draw_ring_element(gamma));
         TRY(draw_ring_element(delta));
         Bytes hp(G.eb), ga;
+        HostJobs jobs;                                 // the three host exponentiations run beside the multi-exponentiation
+        jobs.start([&] { return gexp(g, alpha, ga); });
+        jobs.start([&] { return gexp(g, gamma, Cp_); });
+        jobs.start([&] { return gexp(g, delta, Dp_); });
         TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
         Round rd(*this);
         rd.product(hp);
         TRY(rd.run());
-        TRY(gexp(g, alpha, ga));
+        TRY(jobs.join());
         TRY(G.el_mul(ga, hp, Ap_));
-        TRY(gexp(g, gamma, Cp_));
-        TRY(gexp(g, delta, Dp_));
         prepared = true;
         return VMN_OK;
     }
@@ -1123,13 +1210,18 @@ struct vmn_posc : ProofBase {
         REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
         *verdict = 0;
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
-        Bytes A(G.eb), uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), hk(G.eb);
+        Bytes A(G.eb), uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), hk(G.eb), Blast, prev, t_h0, lhsA, lhsC, lhsD, gkA, gkC, gkD, rhs, C, D;
+        Num eprod;
+        HostJobs jobs;                                                            // (after everything its jobs touch)
+        jobs.start([&] { return gexp(g, k_A, gkA); });                            // beside the GPU calls below
+        jobs.start([&] { return gexp(g, k_C, gkC); });
+        jobs.start([&] { return gexp(g, k_D, gkD); });
         TRY(vmn_garray_expprod(u, e, e_bits, A.data()));                          // :660
         TRY(vmn_garray_prod(u, uprod.data()));
         TRY(vmn_garray_prod(h, hprod.data()));
         TRY(last_local(cB, mylast));
         TRY(vmn_rarray_prod(e, eprod_b.data()));
-        Num eprod = G.ring_from(eprod_b.data());
+        eprod = G.ring_from(eprod_b.data());
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
         TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, hk.data()));
@@ -1142,24 +1234,22 @@ struct vmn_posc : ProofBase {
         rd.ring_product(eprod);
         rd.collect(mylast, lasts);
         TRY(rd.run());
-        Bytes Blast, prev;
         pick_B(lasts, h0, Blast, prev);
-        Bytes t, lhs, rhs, C, D;
-        TRY(G.el_expmul(A, v_be, cAp, lhs));                                      // (A) :676-682
-        TRY(gexp(g, k_A, t));
-        TRY(G.el_mul(t, hk, rhs));
-        if (lhs != rhs) return VMN_OK;                                            // short-circuit :682 (the same on every rank)
+        TRY(G.el_div(uprod, hprod, C));
+        jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });              // (A) :676-682
+        jobs.start([&] { return G.el_expmul(C, v_be, cCp, lhsC); });              // (C) :718-723
+        jobs.start([&] {                                                          // (D) :724-727
+            TRY(G.el_exp(h0, eprod, t_h0));
+            TRY(G.el_div(Blast, t_h0, D));
+            return G.el_expmul(D, v_be, cDp, lhsD);
+        });
+        TRY(jobs.join());
+        TRY(G.el_mul(gkA, hk, rhs));
+        if (lhsA != rhs) return VMN_OK;                                           // short-circuit :682 (the same on every rank)
         GA left, right;
         TRY(bridging_sides(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // (B) :685-715
-        TRY(G.el_div(uprod, hprod, C));
-        TRY(G.el_exp(h0, eprod, t));
-        TRY(G.el_div(Blast, t, D));
-        TRY(G.el_expmul(C, v_be, cCp, lhs));                                      // (C) :718-723
-        TRY(gexp(g, k_C, rhs));
-        const int vC = lhs == rhs;
-        TRY(G.el_expmul(D, v_be, cDp, lhs));                                      // (D) :724-727
-        TRY(gexp(g, k_D, rhs));
-        const int vD = lhs == rhs;
+        const int vC = lhsC == gkC;
+        const int vD = lhsD == gkD;
         int vB = 0;
         TRY(vmn_garray_equals(left, right, &vB));
         Round rv(*this);
@@ -1236,16 +1326,19 @@ struct vmn_ccpos : ProofBase {
         for (auto& bt : beta) TRY(draw_ring_element(bt));
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
-        std::vector<Bytes> eps_prods;
+        std::vector<Bytes> eps_prods, pkpow;
+        Bytes ga;
+        HostJobs jobs;                                 // g^alpha and pk^(-beta) run beside the multi-exponentiation
+        jobs.start([&] { return gexp(g, alpha, ga); });
+        pk_powers(jobs, pkey, beta, pkpow);
         TRY(expprod_multi(xs, epsilon, eps_bits, eps_prods));                     // :377, :391 — one sort of epsilon
         Round rd(*this);
         rd.products(eps_prods);
         TRY(rd.run());
-        Bytes ga;
-        TRY(gexp(g, alpha, ga));
+        TRY(jobs.join());
         TRY(G.el_mul(ga, eps_prods[0], Ap_));
         std::vector<Bytes> prods(eps_prods.begin() + 1, eps_prods.end());
-        TRY(pk_side(pkey, beta, prods, Bp_));
+        TRY(pk_finish(pkpow, prods, Bp_));
         prepared = true;
         return VMN_OK;
     }
@@ -1343,28 +1436,30 @@ struct vmn_ccpos : ProofBase {
         Num k_A = G.ring_from(ikA->bytes.data());
         std::vector<Num> k_B;
         for (auto& bts : split(*ikB)) k_B.push_back(G.ring_from(bts.data()));
-        Bytes t, lhs, rhs;
+        Bytes t, lhs, rhs, lhsA, gkA, Ap_rho, g_term;
+        std::vector<Bytes> pkpow, rB, lhsB(2 * width), kE_prods, prods;
+        Num rho;
+        HostJobs jobs;                                                            // (after everything its jobs touch)
+        pk_powers(jobs, pkey, k_B, pkpow);                                        // beside the multi-exponentiation below
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
         if (!raised) {                                                            // :554-570
+            jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });
+            jobs.start([&] { return gexp(g, k_A, gkA); });
+            for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsB] { return G.el_expmul(B[c], v_be, cBp[c], lhsB[c]); });
             std::vector<const vmn_garray*> xs{h};
             xs.insert(xs.end(), wp.begin(), wp.end());
-            std::vector<Bytes> kE_prods;
             TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));
             Round rd(*this);
             rd.products(kE_prods);
             TRY(rd.run());
-            TRY(G.el_expmul(A, v_be, cAp, lhs));
-            TRY(gexp(g, k_A, t));
-            TRY(G.el_mul(t, kE_prods[0], rhs));
-            if (lhs != rhs) return VMN_OK;
-            std::vector<Bytes> prods(kE_prods.begin() + 1, kE_prods.end()), rB;
-            TRY(pk_side(pkey, k_B, prods, rB));
+            TRY(jobs.join());
+            TRY(G.el_mul(gkA, kE_prods[0], rhs));
+            if (lhsA != rhs) return VMN_OK;
+            prods.assign(kE_prods.begin() + 1, kE_prods.end());
+            TRY(pk_finish(pkpow, prods, rB));
             int ok = 1;
-            for (size_t c = 0; c < 2 * width; ++c) {
-                TRY(G.el_expmul(B[c], v_be, cBp[c], lhs));
-                ok = ok && lhs == rB[c];
-            }
+            for (size_t c = 0; c < 2 * width; ++c) ok = ok && lhsB[c] == rB[c];
             *verdict = ok;
             return VMN_OK;
         }
@@ -1372,6 +1467,9 @@ struct vmn_ccpos : ProofBase {
         GA rh_own;
         const vmn_garray* rh = nullptr;
         REQUIRE(rho_bytes > 0, "empty raised exponent");
+        rho = G.reduce(rho_be, rho_bytes);
+        jobs.start([&] { return gexp(g, G.Zq.mul(k_A, rho), g_term); });
+        jobs.start([&] { return G.el_exp(cAp, rho_be, rho_bytes, Ap_rho); });
         TRY(local_garray(raisedh, rh_own, &rh, "raised generators"));
         std::vector<GA> tmp(2 * width);
         std::vector<const vmn_garray*> xs;
@@ -1379,22 +1477,24 @@ struct vmn_ccpos : ProofBase {
             TRY(vmn_garray_mul(wp[c], rh, tmp[c].out()));
             xs.push_back(tmp[c]);
         }
-        std::vector<Bytes> prods, rB;
         TRY(expprod_multi(xs, ikE->ra, kE_bits, prods));
         Round rd(*this);
         rd.products(prods);
         TRY(rd.run());
-        Num rho = G.reduce(rho_be, rho_bytes);
-        Bytes Ap_rho, g_term;
-        TRY(G.el_exp(cAp, rho_be, rho_bytes, Ap_rho));
-        TRY(gexp(g, G.Zq.mul(k_A, rho), g_term));
-        TRY(pk_side(pkey, k_B, prods, rB));
+        TRY(jobs.join());
+        for (size_t c = 0; c < 2 * width; ++c) {                                  // AB_c^v (B'_c A'^rho): one job per component
+            jobs.start([this, c, &lhsB, &Ap_rho] {
+                Bytes bt;
+                TRY(G.el_mul(cBp[c], Ap_rho, bt));
+                return G.el_expmul(AB[c], v_be, bt, lhsB[c]);
+            });
+        }
+        TRY(pk_finish(pkpow, prods, rB));
+        TRY(jobs.join());
         int ok = 1;
         for (size_t c = 0; c < 2 * width; ++c) {
-            TRY(G.el_mul(cBp[c], Ap_rho, t));
-            TRY(G.el_expmul(AB[c], v_be, t, lhs));
             TRY(G.el_mul(rB[c], g_term, rhs));
-            ok = ok && lhs == rhs;
+            ok = ok && lhsB[c] == rhs;
         }
         *verdict = ok;
         return VMN_OK;
