@@ -25,11 +25,15 @@ constexpr int BLOCK = 256;   // threads per workgroup: 4 waves, one per SIMD
 
 // "Wide" geometries for SMALL arrays (fewer elements than the chip has lanes at one element per lane): the same
 // element rows -- same R, same words in memory -- are worked on by four lanes, so that a chain of dependent products is
-// ~4 times shorter and four times as many waves are in flight.  S_ = 76 is the wide form of S = 74 (2048-bit moduli):
-// four shares of 19 columns = 76 columns, the two above the 74 limbs are zero; a product still takes ROWS = 74
-// reduction rows, so R = 2^(28*74) as in Cfg<74, 1>.  The shares are PACKED in memory (share h = words 19h .. 19h+18
-// of the 76-word row, the two padding words of the one-lane layout being the two zero columns).
-__host__ __device__ constexpr int rows_for(int S, int LPE) { return (S == 76 && LPE == 4) ? 74 : S; }
+// ~2.5 times shorter and four times as many waves are in flight.
+//   Cfg<76, 4>   the wide form of Cfg<74, 1> (2048-bit moduli): four shares of 19 columns = 76 columns, the two above the 74
+//                limbs are zero; a product still takes ROWS = 74 reduction rows, so R = 2^(28*74).
+//   Cfg<112, 4>  the wide form of Cfg<110, 2> (3072-bit moduli): four shares of 28 columns, ROWS = 110.
+// A wide geometry reads and writes the rows of its BASE geometry: limb g of the element is word
+// (g / BASE_L) * BASE_LW + g % BASE_L of the row (BASE_L limbs per share of the base layout, BASE_LW words apart), the
+// columns g >= ROWS exist in registers only.
+__host__ __device__ constexpr int rows_for(int S, int LPE) { return (S == 76 && LPE == 4) ? 74 : (S == 112 && LPE == 4) ? 110 : S; }
+__host__ __device__ constexpr int base_lpe_for(int S, int LPE) { return (S == 76 && LPE == 4) ? 1 : (S == 112 && LPE == 4) ? 2 : LPE; }
 
 template <int S_, int LPE_>
 struct Cfg {
@@ -37,13 +41,17 @@ struct Cfg {
     static constexpr int LPE = LPE_;                    // lanes per element
     static constexpr int L = S_ / LPE_;                 // limbs per lane
     static constexpr int ROWS = rows_for(S_, LPE_);     // reduction rows of a product: R = 2^(28 ROWS)
-    static constexpr bool PACKED = ROWS != S_;          // wide geometry on the rows of the one-lane layout
-    static constexpr int LW = PACKED ? L : stride_for_limbs(L);      // words of one lane's share in memory
-    static constexpr int W = PACKED ? stride_for_limbs(ROWS) : LPE_ * LW;   // words per element in memory
+    static constexpr int BASE_LPE = base_lpe_for(S_, LPE_);
+    static constexpr bool WIDE = BASE_LPE != LPE_;      // works on the rows of another geometry's layout
+    static constexpr int BASE_L = ROWS / BASE_LPE;      // limbs per share of the memory layout
+    static constexpr int BASE_LW = stride_for_limbs(BASE_L);
+    static constexpr int LW = WIDE ? 0 : BASE_LW;       // words of one lane's share in memory (own layout only)
+    static constexpr int W = BASE_LPE * BASE_LW;        // words per element in memory
     static constexpr int EPB = BLOCK / LPE_;            // elements per workgroup
     static constexpr int MINW = 2;                      // waves per SIMD the kernels are built for
-    static_assert(S_ % LPE_ == 0, "limbs must split evenly over the lanes of an element");
-    static_assert(!PACKED || W == S_, "a packed geometry covers the whole row");
+    static_assert(S_ % LPE_ == 0 && ROWS % BASE_LPE == 0, "limbs must split evenly over the lanes of an element");
+    // word of limb g (< ROWS) in the row
+    static __host__ __device__ constexpr int word_of(int g) { return (g / BASE_L) * BASE_LW + g % BASE_L; }
 };
 
 // What a lane needs to know about its place: element slot in the workgroup, which half it holds, its
@@ -86,10 +94,12 @@ __device__ __forceinline__ u32 or_all(u32 x) {
 // ---------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void load_elem(u32 (&a)[C::L], const u32* __restrict__ p, const Lane<C>& ln) {
-    if constexpr (C::PACKED) {                          // shares of L words, not 16-byte aligned: dword loads
-        const u32* q = p + ln.half * C::L;
+    if constexpr (C::WIDE) {                            // shares cut across the base layout: dword loads by limb index
 #pragma unroll
-        for (int j = 0; j < C::L; ++j) a[j] = q[j];
+        for (int j = 0; j < C::L; ++j) {
+            const int g = ln.half * C::L + j;
+            a[j] = g < C::ROWS ? p[C::word_of(g)] : 0u;
+        }
         return;
     }
     const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
@@ -104,10 +114,16 @@ __device__ __forceinline__ void load_elem(u32 (&a)[C::L], const u32* __restrict_
 }
 template <class C>
 __device__ __forceinline__ void store_elem(u32* __restrict__ p, const u32 (&a)[C::L], const Lane<C>& ln) {
-    if constexpr (C::PACKED) {                          // (the columns above the limbs are zero: value < 2N < 2^(28 ROWS))
-        u32* q = p + ln.half * C::L;
+    if constexpr (C::WIDE) {                            // (the columns above the limbs are zero: value < 2N < 2^(28 ROWS))
 #pragma unroll
-        for (int j = 0; j < C::L; ++j) q[j] = a[j];
+        for (int j = 0; j < C::L; ++j) {
+            const int g = ln.half * C::L + j;
+            if (g < C::ROWS) p[C::word_of(g)] = a[j];
+        }
+        if (ln.half < C::BASE_LPE) {                    // the padding words of the base layout stay zero
+#pragma unroll
+            for (int k = C::BASE_L; k < C::BASE_LW; ++k) p[ln.half * C::BASE_LW + k] = 0u;
+        }
         return;
     }
     uint4* q = reinterpret_cast<uint4*>(p + ln.half * C::LW);
@@ -125,10 +141,12 @@ __device__ __forceinline__ void store_elem(u32* __restrict__ p, const u32 (&a)[C
 template <class C>
 __device__ __forceinline__ void load_elem_to_lds(const Lane<C>& ln, const u32* __restrict__ p) {
     u32* dst = ln.bl + ln.half * C::L * C::EPB;
-    if constexpr (C::PACKED) {
-        const u32* q = p + ln.half * C::L;
+    if constexpr (C::WIDE) {
 #pragma unroll
-        for (int j = 0; j < C::L; ++j) dst[j * C::EPB] = q[j];
+        for (int j = 0; j < C::L; ++j) {
+            const int g = ln.half * C::L + j;
+            dst[j * C::EPB] = g < C::ROWS ? p[C::word_of(g)] : 0u;
+        }
         return;
     }
     const uint4* q = reinterpret_cast<const uint4*>(p + ln.half * C::LW);
@@ -159,13 +177,27 @@ template <class C>
 __device__ __forceinline__ void const_to_lds(const Lane<C>& ln, const u32* __restrict__ c) {
     u32* dst = ln.bl + ln.half * C::L * C::EPB;
 #pragma unroll
-    for (int j = 0; j < C::L; ++j) dst[j * C::EPB] = c[ln.half * C::LW + j];
+    for (int j = 0; j < C::L; ++j) {
+        if constexpr (C::WIDE) {
+            const int g = ln.half * C::L + j;
+            dst[j * C::EPB] = g < C::ROWS ? c[C::word_of(g)] : 0u;
+        } else {
+            dst[j * C::EPB] = c[ln.half * C::LW + j];
+        }
+    }
 }
 // this lane's share of a constant in modulus layout.  LPE = 1: uniform address => scalar loads into SGPRs.
 template <class C>
 __device__ __forceinline__ void load_modulus(u32 (&n)[C::L], const u32* __restrict__ nmod, const Lane<C>& ln) {
 #pragma unroll
-    for (int j = 0; j < C::L; ++j) n[j] = C::LPE == 1 ? nmod[j] : nmod[ln.half * C::LW + j];
+    for (int j = 0; j < C::L; ++j) {
+        if constexpr (C::WIDE) {
+            const int g = ln.half * C::L + j;
+            n[j] = g < C::ROWS ? nmod[C::word_of(g)] : 0u;
+        } else {
+            n[j] = C::LPE == 1 ? nmod[j] : nmod[ln.half * C::LW + j];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -50,9 +50,9 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // (modulus bits) -> (S limbs, NW words).  One template instantiation per supported size.
 // X(limbs, packed words, lanes per element).  3072-bit moduli (110 limbs) run two lanes per element, 4096-bit
 // moduli (148 limbs: R = 2^4144) four.
-// X(76, 64, 4) is the WIDE geometry of 2048-bit moduli (modp_kernels.h, struct Cfg): the rows of X(74, 64, 1) worked on by
-// four lanes each; launches over few elements are routed there (geom() below).
-#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(110, 96, 2) X(148, 128, 4)
+// X(76, 64, 4) and X(112, 96, 4) are the WIDE geometries of 2048- and 3072-bit moduli (modp_kernels.h, struct Cfg): the rows
+// of X(74, 64, 1) resp. X(110, 96, 2) worked on by four lanes each; launches over few elements are routed there (geom() below).
+#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(110, 96, 2) X(112, 96, 4) X(148, 128, 4)
 // elliptic curves: X(field limbs, packed words)
 // (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
 #define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
@@ -598,10 +598,12 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
         hostbig::to_be(m.n_words, nbe.data(), nbe.size());
         m.hm64 = new num64::Mod(num64::from_be(nbe.data(), nbe.size(), ((size_t)NW * 4 + 7) / 8));
     }
-    if (S == 74 && LPE == 1) {             // the wide geometry of the same rows (Cfg<76, 4>: 74 rows, four packed shares of 19 columns)
-        static_assert(Cfg<76, 4>::W == Cfg<74, 1>::W && Cfg<76, 4>::ROWS == 74, "the wide geometry reads the one-lane rows");
+    // the wide geometry of the same rows: Cfg<76, 4> (74 rows, four shares of 19 columns) / Cfg<112, 4> (110 rows, 4 x 28)
+    static_assert(Cfg<76, 4>::W == Cfg<74, 1>::W && Cfg<76, 4>::ROWS == 74, "the wide geometry reads the one-lane rows");
+    static_assert(Cfg<112, 4>::W == Cfg<110, 2>::W && Cfg<112, 4>::ROWS == 110, "the wide geometry reads the two-lane rows");
+    if ((S == 74 && LPE == 1) || (S == 110 && LPE == 2)) {
         m.wide = new vmn_modulus(m);
-        m.wide->S = 76;
+        m.wide->S = S == 74 ? 76 : 112;
         m.wide->LPE = 4;
         m.wide->wide = nullptr;
     }
