@@ -81,8 +81,31 @@ __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 
     P[S - 1] = 0;
     f_norm<S>(r, P);
 }
+// r = a^2 / R (mod p): row i multiplies only the limbs j >= i, the later ones by 2 a[i] -- each cross product a[i] a[j] is
+// formed once, doubled, in row min(i, j) (an earlier row than in f_mul, the same column; a column is complete when it is
+// reduced, in row i + j >= max(i, j)).  S (S + 1) / 2 + S^2 multiply-adds instead of 2 S^2.  Column bound: S doubled
+// products < 2^59 (the top limb of a lazy value may reach 2^30) + S reductions < 2^56: far below 2^64 for S <= 15.
 template <int S>
-__device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) { f_mul<S>(r, a, a, E); }
+__device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
+    u64 P[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const u32 ai = a[i], ai2 = a[i] << 1;
+#pragma unroll
+        for (int j = i; j < S; ++j) {                                  // columns below i keep their running sums
+            const u32 mult = j == i ? ai : ai2;
+            if (i == 0 || j == S - 1) P[j] = (u64)a[j] * mult;         // a fresh column (the top one is vacated by every shift)
+            else P[j] = (u64)a[j] * mult + P[j];
+        }
+        u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
+        u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
+#pragma unroll
+        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
+        P[0] += c;
+    }
+    P[S - 1] = 0;
+    f_norm<S>(r, P);
+}
 
 template <int S>
 __device__ __forceinline__ void f_add(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S]) {
@@ -141,14 +164,31 @@ __device__ __forceinline__ void f_canon(u32 (&r)[S], const u32 (&a)[S], const EC
 #pragma unroll
     for (int j = 0; j < S; ++j) r[j] = borrow == 0 ? d[j] : t[j];
 }
+// a = 0 mod p ?  Only the reduction half of a product (a * 1 / R): S^2 multiply-adds.  The result is = a / R mod p and
+// lies in [0, p] (a / R < 1 for every lazy value), so a = 0 mod p exactly when it is 0 or p.
 template <int S>
 __device__ __forceinline__ bool f_is_zero(const u32 (&a)[S], const ECDev& E) {
-    u32 t[S];
-    f_canon<S>(t, a, E);
-    u32 nz = 0;
+    u64 P[S];
 #pragma unroll
-    for (int j = 0; j < S; ++j) nz |= t[j];
-    return nz == 0;
+    for (int j = 0; j < S; ++j) P[j] = a[j];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
+        u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
+#pragma unroll
+        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
+        P[S - 1] = 0;
+        P[0] += c;
+    }
+    u32 t[S];
+    f_norm<S>(t, P);
+    u32 nz = 0, np = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        nz |= t[j];
+        np |= t[j] ^ E.p[j];
+    }
+    return nz == 0 || np == 0;
 }
 // r = a^(p-2): Fermat inversion, left-to-right binary (uniform exponent: no divergence).  Export only.
 template <int S>
@@ -206,6 +246,14 @@ __device__ __forceinline__ void pt_load(Pt<S>& P, const u32* __restrict__ row) {
     f_load<S>(P.X, row);
     f_load<S>(P.Y, row + FW);
     f_load<S>(P.Z, row + 2 * FW);
+    P.inf = row[3 * FW - 1];
+}
+// a NORMALISED row as the second operand of pt_madd: X, Y and the flag -- Z (= one) is not read
+template <int S>
+__device__ __forceinline__ void pt_load_normalised(Pt<S>& P, const u32* __restrict__ row) {
+    constexpr int FW = stride_for_limbs(S);
+    f_load<S>(P.X, row);
+    f_load<S>(P.Y, row + FW);
     P.inf = row[3 * FW - 1];
 }
 template <int S>
@@ -308,6 +356,60 @@ __device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q,
         } else if (Q.inf) {
             G = P;
         } else if (f_is_zero<S>(rr, E)) {
+            pt_dbl<S>(G, P, E);                        // P == Q
+        } else {
+            pt_set_inf<S>(G, E);                       // P == -Q
+        }
+    }
+    R = G;
+}
+
+// madd-2007-bl: P (Jacobian) + Q with Q NORMALISED (Z = 1, or the infinity flag): 7M + 4S instead of 11M + 5S.  The rows of
+// a normalised array keep the three-coordinate layout (Z = the Montgomery one), so every other kernel reads them as they
+// are.  Bounds (multiples of p): X1, Y1, Z1 < 66 as they leave an addition or a doubling, so the differences with them as
+// subtrahend use the 256p form (< 258); the largest product is r * (V - X3) < 516 * 258 p^2, far below R p = 2^24 p^2.
+template <int S>
+__device__ __forceinline__ void pt_madd(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q, const ECDev& E) {
+    u32 Z1Z1[S], U2[S], S2[S], H[S], HH[S], I[S], J[S], r[S], V[S], t1[S], t2[S];
+    f_sqr<S>(Z1Z1, P.Z, E);
+    f_mul<S>(U2, Q.X, Z1Z1, E);
+    f_mul<S>(t1, P.Z, Z1Z1, E);
+    f_mul<S>(S2, Q.Y, t1, E);
+    f_sub<S, true>(H, U2, P.X, E);
+    f_sub<S, true>(t1, S2, P.Y, E);                    // S2 - Y1
+    bool hz = f_is_zero<S>(H, E);
+    bool special = P.inf || Q.inf || hz;
+    Pt<S> G;
+    {
+        f_sqr<S>(HH, H, E);
+        f_small<S, 4>(I, HH);
+        f_mul<S>(J, H, I, E);
+        f_add<S>(r, t1, t1);
+        f_mul<S>(V, P.X, I, E);
+        f_sqr<S>(t2, r, E);
+        u32 t3[S];
+        f_add<S>(t3, V, V);
+        f_add<S>(t3, t3, J);
+        f_sub<S>(G.X, t2, t3, E);                      // r^2 - J - 2V
+        f_sub<S, true>(t2, V, G.X, E);
+        f_mul<S>(t3, r, t2, E);
+        f_mul<S>(t2, P.Y, J, E);
+        f_add<S>(t2, t2, t2);
+        f_sub<S>(G.Y, t3, t2, E);                      // r (V - X3) - 2 Y1 J
+        f_add<S>(t2, P.Z, H);
+        f_sqr<S>(t3, t2, E);
+        f_add<S>(t2, Z1Z1, HH);
+        f_sub<S>(G.Z, t3, t2, E);                      // (Z1 + H)^2 - Z1Z1 - HH
+        G.inf = 0;
+    }
+    if (special) {                                     // rare: wave-divergent
+        if (P.inf) {
+            G = Q;
+#pragma unroll
+            for (int j = 0; j < S; ++j) G.Z[j] = Q.inf ? 0u : E.one[j];       // (Q.Z is not loaded: it is one by contract)
+        } else if (Q.inf) {
+            G = P;
+        } else if (f_is_zero<S>(t1, E)) {
             pt_dbl<S>(G, P, E);                        // P == Q
         } else {
             pt_set_inf<S>(G, E);                       // P == -Q
@@ -594,13 +696,120 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_fixed_exp(u32* __re
 #pragma unroll 1
     for (int k = 1; k < nwin; ++k) {
         d = exp_digit(ep, ewords, k * w, w);
-        pt_load<S>(B, T + (((size_t)k << w) + d) * ROW);
-        pt_add<S>(A, A, B, E);
+        pt_load_normalised<S>(B, T + (((size_t)k << w) + d) * ROW);
+        pt_madd<S>(A, A, B, E);                        // the table is normalised when it is built
     }
     pt_store<S>(out + el * ROW, A);
 }
 
-// K3 product-tree level (see k_bucket_level)
+// Normalisation of an array (Z := 1) so that additions INTO running sums can be mixed (pt_madd).  All Z's are inverted
+// together by Montgomery's trick applied level by level: a lane multiplies a chunk of K values up (keeping the running
+// products), the chunk products are inverted by the same procedure one level higher, and on the way down a lane turns
+// the inverse of its chunk's product into the inverses of its K values.  Only the few values of the top level cost a
+// Fermat power (~380 products each); a point costs 1 + 2 products for its inverse, 4 to apply it (zi^2, zi^3, X zi^2,
+// Y zi^3) and 3 / K + 3 / K^2 ... for the upper levels.  Points at infinity take part with Z = 1 and stay flagged.
+// Field arrays (pref, tot, inv) are FW words per value.
+template <int S>
+__device__ __forceinline__ void f_store(u32* __restrict__ p, const u32 (&a)[S]) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) p[j] = a[j];
+}
+template <int S>
+__device__ __forceinline__ void z_of_row(u32 (&z)[S], const u32* __restrict__ row, const ECDev& E) {
+    constexpr int FW = ECfg<S>::FW;
+    if (row[ECfg<S>::ROW - 1]) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) z[j] = E.one[j];
+    } else {
+        f_load<S>(z, row + 2 * FW);
+    }
+}
+// up: pref[i] = the product of the values of i's chunk before i, tot[c] = the product of chunk c.  ROWS: v[i] is the Z of point row i.
+template <int S, bool ROWS>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_up(u32* __restrict__ pref, u32* __restrict__ tot, const u32* __restrict__ v,
+                                                                  size_t n, size_t K, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW, FW = ECfg<S>::FW;
+    // chunk c = the values c, c + nl, c + 2 nl ... (nl lanes): neighbouring lanes touch neighbouring rows
+    const size_t nl = (n + K - 1) / K;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= nl) return;
+    u32 acc[S], z[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = E.one[j];
+    for (size_t i = c; i < n; i += nl) {
+        f_store<S>(pref + i * FW, acc);
+        if constexpr (ROWS) z_of_row<S>(z, v + i * ROW, E);
+        else f_load<S>(z, v + i * FW);
+        f_mul<S>(acc, acc, z, E);
+    }
+    f_store<S>(tot + c * FW, acc);
+}
+// top: inv[i] = 1 / v[i] by Fermat
+template <int S>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_top(u32* __restrict__ inv, const u32* __restrict__ v, size_t n, ECDev E) {
+    constexpr int FW = ECfg<S>::FW;
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 a[S], r[S];
+    f_load<S>(a, v + i * FW);
+    f_inv<S>(r, a, E);
+    f_store<S>(inv + i * FW, r);
+}
+// down: inv[i] = 1 / v[i] from invtot[c] = 1 / (the product of chunk c)
+template <int S>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_down(u32* __restrict__ inv, const u32* __restrict__ invtot, const u32* __restrict__ pref,
+                                                                    const u32* __restrict__ v, size_t n, size_t K, ECDev E) {
+    constexpr int FW = ECfg<S>::FW;
+    const size_t nl = (n + K - 1) / K;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= nl) return;
+    u32 run[S], pr[S], z[S], zi[S];
+    f_load<S>(run, invtot + c * FW);
+    const size_t cnt = (n - c + nl - 1) / nl;          // values of this chunk
+    for (size_t k = cnt; k-- > 0;) {
+        const size_t i = c + k * nl;
+        f_load<S>(pr, pref + i * FW);
+        f_mul<S>(zi, run, pr, E);
+        f_load<S>(z, v + i * FW);
+        f_mul<S>(run, run, z, E);
+        f_store<S>(inv + i * FW, zi);
+    }
+}
+// the lowest level, fused with the use of the inverses: out[i] = (X zi^2, Y zi^3, 1)
+template <int S>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32* __restrict__ out, const u32* __restrict__ in,
+                                                                            const u32* __restrict__ invtot, const u32* __restrict__ pref,
+                                                                            size_t n, size_t K, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW, FW = ECfg<S>::FW;
+    const size_t nl = (n + K - 1) / K;
+    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= nl) return;
+    u32 run[S];
+    f_load<S>(run, invtot + c * FW);
+    const size_t cnt = (n - c + nl - 1) / nl;          // points of this chunk
+    for (size_t k = cnt; k-- > 0;) {
+        const size_t i = c + k * nl;
+        u32 zi[S], zi2[S], zi3[S], pr[S];
+        f_load<S>(pr, pref + i * FW);
+        f_mul<S>(zi, run, pr, E);                      // 1 / Z_i
+        Pt<S> P;
+        pt_load<S>(P, in + i * ROW);
+        if (P.inf) {
+            pt_set_inf<S>(P, E);                       // (took part with Z = 1: the running inverse is unchanged)
+        } else {
+            f_mul<S>(run, run, P.Z, E);
+            f_sqr<S>(zi2, zi, E);
+            f_mul<S>(zi3, zi2, zi, E);
+            f_mul<S>(P.X, P.X, zi2, E);
+            f_mul<S>(P.Y, P.Y, zi3, E);
+#pragma unroll
+            for (int j = 0; j < S; ++j) P.Z[j] = E.one[j];
+        }
+        pt_store<S>(out + i * ROW, P);
+    }
+}
+
+// K3 product-tree level (see k_bucket_level).  FIRST: `in` is a NORMALISED array (k_ec_normalize), read through `sorted`.
 template <int S, bool FIRST>
 __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* __restrict__ out, const u32* __restrict__ in,
                                                            const u32* __restrict__ sorted, const u32* __restrict__ off_in,
@@ -623,8 +832,13 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* _
     Pt<S> A, B;
     pt_load<S>(A, row(start));
     for (u32 k = start + 1; k < end; ++k) {
-        pt_load<S>(B, row(k));
-        pt_add<S>(A, A, B, E);
+        if constexpr (FIRST) {                         // the first level adds rows of the (normalised) input array
+            pt_load_normalised<S>(B, row(k));
+            pt_madd<S>(A, A, B, E);
+        } else {
+            pt_load<S>(B, row(k));
+            pt_add<S>(A, A, B, E);
+        }
     }
     pt_store<S>(out + t * ROW, A);
 }

@@ -142,7 +142,9 @@ static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double
     ctx->next_mads = products * 2 * Rw * S + squarings * sq;
     return 0;                                   // (an int so that a launch inside a macro can be written  note_work(..) ? 0 : launch(..))
 }
-static const double EC_ADD = 16, EC_DBL = 8;
+// in field products of 2 S^2 multiply-adds: a product 1, a squaring ~0.775 (symmetric), a zero test 0.5 (reduction only)
+// add = 11M + 5S + zero test, mixed add = 7M + 4S + zero test, doubling = 3M + 5S, normalising one point ~7 + inversion / K
+static const double EC_ADD = 15.4, EC_MADD = 10.6, EC_DBL = 6.9, EC_NORM = 7.0, EC_INV = 380;
 
 static unsigned light_grid(vmn_ctx* ctx, size_t work_items) {
     size_t blocks = (work_items + BLOCK - 1) / BLOCK;
@@ -2457,6 +2459,7 @@ static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
 }
 
 // Table for (base, window) cached in the group; built on the GPU from the host squaring chain.
+static int ec_normalize(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* const* ins, size_t k, size_t n, uint32_t* out);
 static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out, int reuse_hint = 1) {
     vmn_ctx* ctx = LANE(g->ctx);
     const vmn_modulus& m = g->P;
@@ -2526,6 +2529,15 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
 #undef X
         }
         free_one(ctx, m, d_base);
+        if (rc == VMN_OK) {                              // Z := 1 in every entry: k_ec_fixed_exp adds them with the mixed addition
+            DevTmp flat(ctx);
+            const size_t entries = (size_t)nwin << w;
+            rc = flat.alloc(entries * Wd * sizeof(uint32_t));
+            const uint32_t* whole[1] = {ft.d_tab};
+            if (rc == VMN_OK) rc = ec_normalize(ctx, m, whole, 1, entries, flat.as<uint32_t>());
+            if (rc == VMN_OK && hipMemcpyAsync(ft.d_tab, flat.p, entries * Wd * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                rc = VMN_ERR_DEVICE;
+        }
         if (rc != VMN_OK) {
             if (ft.d_tab) (void)hipFree(ft.d_tab);
             return rc;
@@ -2623,7 +2635,7 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
         if (m.ec) {
 #define X(S_, NW_)                                                                                                   \
     if (m.ec->S == S_)                                                                                               \
-        rc = note_work(ctx, m, EC_ADD * (double)n * (ft->nwin - 1)) ? 0 : launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+        rc = note_work(ctx, m, EC_MADD * (double)n * (ft->nwin - 1)) ? 0 : launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                           ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, ecdev(m.ec));
             VMN_FOR_CURVES(X)
 #undef X
@@ -2642,6 +2654,59 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
     }
     *out = r;
     return VMN_OK;
+}
+
+// out (k x n rows) = the points of the k arrays with Z = 1: arrays whose rows are then ADDED INTO running sums with the mixed
+// addition.  Level-by-level Montgomery trick (ec_kernels.h): chunks of K = 8 per lane; the lowest level runs per array, the
+// chunk products of all k arrays are inverted together (the one Fermat chain at the top, ~0.2 ms of latency, is paid once
+// per call, not once per array).  Field scratch: pref of level 0 (k n), per upper level its values, their inverses, pref.
+static int ec_normalize(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* const* ins, size_t k, size_t n, uint32_t* out) {
+    if (n == 0 || k == 0) return VMN_OK;
+    const size_t FWd = (size_t)stride_for_limbs(m.ec->S), Wd = (size_t)m.W, K = 8, TOP = 2048;
+    const size_t n1 = (n + K - 1) / K;                       // chunks (= level-1 values) per array
+    std::vector<size_t> sizes{k * n, k * n1};                // values per level (level 0: the Z's of the rows, k arrays of n)
+    while (sizes.back() > TOP) sizes.push_back((sizes.back() + K - 1) / K);
+    const size_t L = sizes.size();
+    size_t words = 0;
+    std::vector<size_t> off_pref(L), off_val(L), off_inv(L);
+    for (size_t l = 0; l < L; ++l) {
+        off_pref[l] = words;
+        words += (l + 1 < L ? sizes[l] : 0) * FWd;           // pref of level l (not for the top)
+        off_val[l] = words;
+        words += (l > 0 ? sizes[l] : 0) * FWd;               // values of level l
+        off_inv[l] = words;
+        words += (l > 0 ? sizes[l] : 0) * FWd;               // their inverses
+    }
+    DevTmp buf(ctx);
+    VMN_TRY(buf.alloc(words * sizeof(uint32_t)));
+    uint32_t* B = buf.as<uint32_t>();
+    double products = 7.0 * (double)(k * n) + EC_INV * (double)sizes[L - 1];
+    for (size_t l = 1; l + 1 < L; ++l) products += 3.0 * (double)sizes[l];
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                                   \
+    if (m.ec->S == S_) {                                                                                                             \
+        note_work(ctx, m, products);                                                                                                 \
+        rc = VMN_OK;                                                                                                                 \
+        for (size_t a = 0; a < k && rc == VMN_OK; ++a)                                                                               \
+            rc = launch_light(ctx, "normalize", k_finv_up<S_, true>, grid_for(n1), B + off_pref[0] + a * n * FWd,                    \
+                              B + off_val[1] + a * n1 * FWd, ins[a], n, K, ecdev(m.ec));                                             \
+        for (size_t l = 1; l + 1 < L && rc == VMN_OK; ++l)                                                                           \
+            rc = launch_light(ctx, "normalize", k_finv_up<S_, false>, grid_for(sizes[l + 1]), B + off_pref[l], B + off_val[l + 1],   \
+                              (const uint32_t*)(B + off_val[l]), sizes[l], K, ecdev(m.ec));                                          \
+        if (rc == VMN_OK)                                                                                                            \
+            rc = launch_light(ctx, "normalize", k_finv_top<S_>, grid_for(sizes[L - 1]), B + off_inv[L - 1],                          \
+                              (const uint32_t*)(B + off_val[L - 1]), sizes[L - 1], ecdev(m.ec));                                     \
+        for (size_t l = L - 2; l >= 1 && rc == VMN_OK; --l)                                                                          \
+            rc = launch_light(ctx, "normalize", k_finv_down<S_>, grid_for(sizes[l + 1]), B + off_inv[l], (const uint32_t*)(B + off_inv[l + 1]), \
+                              (const uint32_t*)(B + off_pref[l]), (const uint32_t*)(B + off_val[l]), sizes[l], K, ecdev(m.ec));      \
+        for (size_t a = 0; a < k && rc == VMN_OK; ++a)                                                                               \
+            rc = launch_light(ctx, "normalize", k_ec_normalize_down<S_>, grid_for(n1), out + a * n * Wd, ins[a],                     \
+                              (const uint32_t*)(B + off_inv[1] + a * n1 * FWd), (const uint32_t*)(B + off_pref[0] + a * n * FWd), n, \
+                              K, ecdev(m.ec));                                                                                       \
+    }
+    VMN_FOR_CURVES(X)
+#undef X
+    return rc;
 }
 
 // ---- K3 multi-exponentiation -----------------------------------------------------------------------
@@ -2729,8 +2794,13 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
     // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item
     std::vector<std::pair<uint32_t, uint32_t>> level_cache;      // (total items, max per bucket) per level, from the first array
+    DevTmp normalised(ctx);                              // curves: the k arrays with Z = 1, so that the first level's additions are mixed
+    if (m.ec) {
+        VMN_TRY(normalised.alloc(k * n * Wd * sizeof(uint32_t)));
+        VMN_TRY(ec_normalize(ctx, m, xs, k, n, normalised.as<uint32_t>()));
+    }
     for (size_t arr = 0; arr < k; ++arr) {
-    const uint32_t* x = xs[arr];
+    const uint32_t* x = m.ec ? normalised.as<uint32_t>() + arr * n * Wd : xs[arr];
     const uint32_t* cnt_in = counts;
     const uint32_t* off_in = off0;
     uint32_t* cnt_out = cntA;
@@ -2762,7 +2832,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
             rc = VMN_ERR_ARG;
 #define X(S_, NW_)                                                                                                     \
     if (m.ec->S == S_) {                                                                                               \
-        rc = note_work(ctx, m, EC_ADD * level_products) ? 0 : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, grid_for(total_out), items_out, items_in, \
+        rc = note_work(ctx, m, (first ? EC_MADD : EC_ADD) * level_products) ? 0 : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, grid_for(total_out), items_out, items_in, \
                                   (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out,    \
                                   nbuckets, total_out, F, ecdev(m.ec))                                                 \
                    : launch_light(ctx, "expprod", k_ec_bucket_level<S_, false>, grid_for(total_out), items_out,        \
