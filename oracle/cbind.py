@@ -55,6 +55,12 @@ class Oracle:
         self.lib.orc_exp_fixed(out, base, e, C.c_size_t(n), C.c_size_t(self.nb), C.c_size_t(eb), self.p_be)
         return out.raw[: n * self.nb]
 
+    def exp_fixed_table_bytes(self, base: bytes, e: bytes, n: int, eb: int, ebits: int, w: int) -> bytes:
+        out = C.create_string_buffer(max(1, n * self.nb))
+        self.lib.orc_exp_fixed_table(out, base, e, C.c_size_t(n), C.c_size_t(self.nb), C.c_size_t(eb), C.c_int(ebits), C.c_int(w),
+                                     self.p_be)
+        return out.raw[: n * self.nb]
+
     def mul_bytes(self, x: bytes, y: bytes, n: int) -> bytes:
         out = C.create_string_buffer(max(1, n * self.nb))
         self.lib.orc_mul(out, x, y, C.c_size_t(n), C.c_size_t(self.nb), self.p_be)
@@ -80,6 +86,15 @@ class Oracle:
 
     def exp_fixed(self, base: int, es) -> List[int]:
         return self.dec(self.exp_fixed_bytes(base.to_bytes(self.nb, "big"), self.enc(es), len(es), self.nb))
+
+    def exp_fixed_table(self, base: int, es, w: int = 0) -> List[int]:
+        """Fixed-base exponentiation through a precomputed table (orc_exp_fixed_table); w = 0 picks the window that
+        minimises table build + use for this array size."""
+        ebits = max(1, self.q.bit_length())
+        if not w:
+            n = max(1, len(es))
+            w = min(range(1, 13), key=lambda c: ((1 << c) + n) * ((ebits + c - 1) // c))
+        return self.dec(self.exp_fixed_table_bytes(base.to_bytes(self.nb, "big"), self.enc(es), len(es), self.nb, ebits, w))
 
     def exp_prod(self, xs, es, ebits: int = 0, pippenger_c: int = 0) -> int:
         eb = (ebits + 7) // 8 if ebits else self.nb
@@ -135,8 +150,9 @@ class GmpAdapter:
     with GMP underneath, i.e. what VCR + VMGJ bottoms out in, minus VCR's fixed-base tables (every exponentiation
     is an ``mpz_powm``)."""
 
-    def __init__(self, orc: Oracle, pippenger_c: int = 8):
+    def __init__(self, orc: Oracle, pippenger_c: int = 8, fixed_tables: bool = False):
         self.o, self.p, self.q, self.one, self.c = orc, orc.p, orc.q, 1, pippenger_c
+        self.fixed_tables = fixed_tables        # fixed-base exponentiations through precomputed tables (VCR / GMPMEE's fpowm)
 
     def mul(self, a, b):
         return a * b % self.p
@@ -148,7 +164,7 @@ class GmpAdapter:
         return pow(a, -1, self.p)
 
     def exp_fixed(self, base, es):
-        return self.o.exp_fixed(base, es)
+        return self.o.exp_fixed_table(base, es) if self.fixed_tables else self.o.exp_fixed(base, es)
 
     def exp_array(self, xs, es):
         return self.o.exp_array(xs, es)

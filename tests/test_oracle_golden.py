@@ -92,3 +92,15 @@ def test_oracle_edge_cases(oracle_for):
     assert orc.exp_prod([], []) == 1
     assert orc.exp_array([p - 1, 1, 5], [q, 0, 0]) == [pow(p - 1, q, p), 1, 1]
     assert orc.rec_lin([], []) == []
+
+
+def test_table_driven_fixed_base_power_equals_mpz_powm(oracle_for):
+    """orc_exp_fixed_table (bench.py's cpu_baseline of the mix + prove leg) against orc_exp_fixed, every window size."""
+    from oracle import pyref
+    p, q, g = pyref.modp_group(2048)
+    orc = oracle_for(p, q)
+    es = pyref.stream_ints(b"fixed-table", 40, q) + [0, 1, 2, q - 1, (1 << 2046) + 1]
+    want = orc.exp_fixed(g, es)
+    for w in (0, 1, 4, 7, 8, 12):
+        assert orc.exp_fixed_table(g, es, w) == want, w
+    assert orc.exp_fixed_table(g, []) == []
