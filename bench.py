@@ -937,7 +937,7 @@ def main() -> None:
             result["value"] = None                         # a wrong result has no throughput
         if "mix_prove" in result and "error" not in result["mix_prove"] and not distributed:
             try:
-                result["mix_prove"]["cpu_baseline"] = cpu_mix_prove(p, q, g, 8000, cores)
+                result["mix_prove"]["cpu_baseline"] = cpu_mix_prove(p, q, g, 30000, cores)
             except Exception as exc:                   # pragma: no cover
                 result["mix_prove"]["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
