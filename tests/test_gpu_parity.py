@@ -368,11 +368,11 @@ def test_worst_case_column_magnitudes(bits, vmn, gpu_ctx):
     assert X.prod() == pyref.prod(vals, N)
 
 
-@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072])
+@pytest.mark.parametrize("bits", [512, 1024, 2048, 3072, 4096])
 def test_subgroup_membership_by_jacobi_symbol(bits, groups):
-    """K10: x is in the order-q subgroup of a safe-prime group iff (x / p) = 1.  The Jacobi kernel (one element per
-    lane, also at 3072 bits where the arithmetic kernels use two) against Python on residues, non-residues and special values, one element
-    at a time and inside large arrays."""
+    """K10: x is in the order-q subgroup of a safe-prime group iff (x / p) = 1.  The Jacobi kernels (one element per
+    lane up to 2048 bits, the element's own two / four lanes at 3072 / 4096 bits) against Python on residues, non-residues
+    and special values, one element at a time and inside large arrays."""
     G, grp, _ = groups[bits]
     p, q, g = grp["p"], grp["q"], grp["g"]
     rnd = pyref.stream_ints(b"jacobi%d" % bits, 40, p)

@@ -82,6 +82,17 @@ __device__ __forceinline__ u32 from_top(u32 x) {
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
     else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);                        // [3,3,3,3]
 }
+// the value of lane h+1 of the element (the last lane receives its own: mask with nottopmask); lane 0's value on all lanes
+template <int LPE>
+__device__ __forceinline__ u32 from_above(u32 x) {
+    if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
+    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF9, 0xf, 0xf, true);                        // [1,2,3,3]
+}
+template <int LPE>
+__device__ __forceinline__ u32 from_lane0(u32 x) {
+    if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true);     // [0,0,2,2]
+    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);                        // [0,0,0,0]
+}
 template <int LPE>
 __device__ __forceinline__ u32 or_all(u32 x) {
     x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);                               // [1,0,3,2]
@@ -1117,8 +1128,8 @@ __global__ void __launch_bounds__(BLOCK) k_set_segment_heads(uint4* __restrict__
 template <class C>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_jacobi_member(const u32* __restrict__ x, size_t n, const u32* __restrict__ nmod, u32* __restrict__ flags) {
-    // ONE lane holds the whole element here, also when the arithmetic kernels split it over two lanes (the row is
-    // then two shares of L limbs, LW words apart): a and m in registers (2 S <= 220 VGPRs), updated in place.
+    // ONE lane holds the whole element: a and m in registers (2 S <= 148 VGPRs), updated in place.  (The loads below also
+    // read the two-share layout of Cfg<110, 2>; 3072-bit moduli use k_jacobi_member_lanes since that proved three times faster.)
     static_assert(C::LPE <= 2, "the element must fit one lane");
     constexpr int S = C::S, L = C::L, LW = C::LW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1197,6 +1208,76 @@ k_jacobi_member(const u32* __restrict__ x, size_t n, const u32* __restrict__ nmo
     for (int j = 1; j < S; ++j) rest |= m[j];
     bool member = !zero_in && rest == 0 && t == 0;
     if (live && !member) atomicOr(flags, 1u);
+}
+
+// The same test with the element spread over LPE lanes (4096-bit moduli: a and m do not fit one lane's registers).  The
+// lanes of an element run the binary algorithm in lockstep: every decision is taken from lane 0's low limbs (broadcast),
+// the right shifts pull the next lane's low limb in (DPP), comparison and subtraction are the element-wide borrow chains
+// of canonicalize() (sub_full: LPE sweeps).  ~1200 instructions per step, at most 2 * bits(p) steps: a tenth of x^q.
+template <class C>
+__global__ void __launch_bounds__(BLOCK, 2)
+k_jacobi_member_lanes(const u32* __restrict__ x, size_t n, const u32* __restrict__ nmod, u32* __restrict__ flags) {
+    static_assert(C::LPE > 1 && !C::WIDE, "one lane per element uses k_jacobi_member");
+    constexpr int L = C::L, LPE = C::LPE;
+    Lane<C> ln(nullptr);
+    size_t el = (size_t)blockIdx.x * C::EPB + ln.eslot;
+    bool live = el < n;
+    size_t ec = live ? el : n - 1;
+    u32 a[L], m[L], d[L];
+    load_elem<C>(a, x + ec * C::W, ln);
+    load_modulus<C>(m, nmod, ln);
+    u32 t = 0;
+    auto any = [&](const u32 (&v)[L]) {
+        u32 nz = 0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) nz |= v[j];
+        return or_all<LPE>(nz);
+    };
+    u32 nz = any(a);
+    const bool zero_in = nz == 0;
+    // invariant: m odd, 0 <= a < m at loop entry (a < p on input)
+    while (nz != 0) {
+        const u32 low = from_lane0<LPE>(a[0]);
+        const u32 up = from_above<LPE>(a[0]) & ln.nottopmask;       // the limb above this lane's share (0 above the element)
+        if (low == 0) {                          // a whole zero limb: shift by one limb (28 bits: even count, no flip)
+#pragma unroll
+            for (int j = 0; j + 1 < L; ++j) a[j] = a[j + 1];
+            a[L - 1] = up;
+            continue;
+        }
+        const int k = __builtin_ctz(low);
+        if (k) {
+            const u32 m8 = from_lane0<LPE>(m[0]) & 7u;
+            if ((k & 1) && (m8 == 3u || m8 == 5u)) t ^= 1u;
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const u32 hi = j + 1 < L ? a[j + 1] : up;
+                a[j] = ((a[j] >> k) | (hi << (LIMB_BITS - k))) & LIMB_MASK;
+            }
+        }
+        // a odd now: a - m over the whole element; borrow = -1 when a < m
+        if (sub_full<C>(d, a, m, ln) == 0) {     // a >= m: a := a - m (even; the symbol is unchanged)
+#pragma unroll
+            for (int j = 0; j < L; ++j) a[j] = d[j];
+        } else {                                 // a < m: swap by reciprocity, (a, m) := (m - a, a)
+            const u32 a0 = from_lane0<LPE>(a[0]), m0 = from_lane0<LPE>(m[0]);
+            if ((a0 & 3u) == 3u && (m0 & 3u) == 3u) t ^= 1u;
+            sub_full<C>(d, m, a, ln);
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                m[j] = a[j];
+                a[j] = d[j];
+            }
+        }
+        nz = any(a);
+    }
+    // a = 0: the symbol is (-1)^t when m = 1 (coprime), 0 otherwise
+    u32 rest = m[0] ^ (ln.half == 0 ? 1u : 0u);
+#pragma unroll
+    for (int j = 1; j < L; ++j) rest |= m[j];
+    rest = or_all<LPE>(rest);
+    const bool member = !zero_in && rest == 0 && t == 0;
+    if (live && ln.half == 0 && !member) atomicOr(flags, 1u);
 }
 
 }  // namespace vmn

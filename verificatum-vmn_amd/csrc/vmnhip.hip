@@ -2972,8 +2972,10 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
     if (g->P.ec) return VMN_OK;      // prime-order curve: every point that passed the import's curve check is a member
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
-    // safe-prime group held one element per lane: the Jacobi symbol decides (a tenth of the work of x^q = 1)
-    if (m.LPE <= 2 && !getenv("VMN_MEMBER_BY_POWER")) {
+    // safe-prime group: the Jacobi symbol decides (a tenth of the work of x^q = 1) -- one element per lane up to 2048 bits,
+    // the element's own two / four lanes at 3072 / 4096 bits (one lane holding all 110 limbs of a and m runs at a third
+    // of the speed: 220 live registers)
+    if (!getenv("VMN_MEMBER_BY_POWER")) {
         Big twoq = g->Q.n_words;
         hostbig::dbl_mod(twoq, m.n_words);
         Big pm1 = m.n_words;
@@ -2982,8 +2984,10 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
             VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
             int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                   \
-    if constexpr (LPE_ <= 2) {                                                                                             \
+    if constexpr (LPE_ == 1) {                                                                                             \
         if (m.S == S_) rc = launch_light(ctx, "member", k_jacobi_member<Cfg<S_, LPE_>>, grid_for(x->n), (const uint32_t*)x->d, x->n, (const uint32_t*)m.d_n, ctx->flags); \
+    } else if constexpr (!Cfg<S_, LPE_>::WIDE) {                                                                           \
+        if (m.S == S_) rc = launch_light(ctx, "member", k_jacobi_member_lanes<Cfg<S_, LPE_>>, egrid(m, x->n), (const uint32_t*)x->d, x->n, (const uint32_t*)m.d_n, ctx->flags); \
     }
             VMN_FOR_SIZES(X)
 #undef X
