@@ -90,6 +90,9 @@ int vmn_ctx_num_cus(vmn_ctx* ctx);
  * that each chain of dependent products is ~2.5 times shorter.  Default 40960 (the measured crossover; env
  * VMN_WIDE_MAX overrides it); 0 = never, SIZE_MAX = always.  A tuning knob: results never depend on it. */
 int vmn_ctx_set_small_array_threshold(vmn_ctx* ctx, size_t items);
+/* The same one step further: launches over at most `items` elements of a 2048-bit modulus spread every element over
+ * EIGHT lanes (default 6144 elements, env VMN_WIDE8_MAX; 0 = never).  Takes precedence over the threshold above. */
+int vmn_ctx_set_tiny_array_threshold(vmn_ctx* ctx, size_t items);
 /* Memory accounting (operations / leak hunting): bytes and blocks of freed arrays cached for reuse, bytes of live
  * allocations handed out and not yet freed (arrays + temporaries), and a group's cached fixed-base tables. */
 int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes);

@@ -1,6 +1,6 @@
 """GPU suite: the two execution geometries of 2048- and 3072-bit moduli -- the base one (Cfg<74, 1> / Cfg<110, 2>) and the
-WIDE one for small arrays (Cfg<76, 4> / Cfg<112, 4>: the same rows, four lanes per element,
-vmn_ctx_set_small_array_threshold) -- must give the same bits.  The parity cases of the other modules run here once with every launch forced into each geometry (by default the
+WIDE ones for small arrays (Cfg<76, 4> / Cfg<112, 4>: the same rows, four lanes per element,
+vmn_ctx_set_small_array_threshold; Cfg<80, 8>: eight lanes, vmn_ctx_set_tiny_array_threshold) -- must give the same bits.  The parity cases of the other modules run here once with every launch forced into each geometry (by default the
 choice depends on the size of the array, so a suite of small cases would only ever see the wide one)."""
 import os
 
@@ -16,13 +16,26 @@ from oracle import pyref
 pytestmark = pytest.mark.gpu
 
 DEFAULT = int(os.environ.get("VMN_WIDE_MAX", 40960))
+DEFAULT8 = int(os.environ.get("VMN_WIDE8_MAX", 6144))
+FORCE = {"base": (0, 0), "wide": (2 ** 63, 0), "wide8": (2 ** 63, 2 ** 63)}     # (small, tiny) thresholds; wide8 exists at 2048 bits only
 
 
-@pytest.fixture(params=["base", "wide"])
-def forced_geometry(request, gpu_ctx):
-    gpu_ctx.set_small_array_threshold(0 if request.param == "base" else 2 ** 63)
-    yield request.param
+def force(gpu_ctx, name):
+    small, tiny = FORCE[name]
+    gpu_ctx.set_small_array_threshold(small)
+    gpu_ctx.set_tiny_array_threshold(tiny)
+
+
+def restore(gpu_ctx):
     gpu_ctx.set_small_array_threshold(DEFAULT)
+    gpu_ctx.set_tiny_array_threshold(DEFAULT8)
+
+
+@pytest.fixture(params=["base", "wide", "wide8"])
+def forced_geometry(request, gpu_ctx):
+    force(gpu_ctx, request.param)
+    yield request.param
+    restore(gpu_ctx)
 
 
 @pytest.mark.parametrize("bits", [2048, 3072])
@@ -67,8 +80,8 @@ def test_geometries_agree_across_the_threshold(bits, vmn, gpu_ctx, groups):
     es = pyref.stream_ints(b"geom/e", n, q)
     fs = pyref.stream_ints(b"geom/f", n, 1 << 300)
     out = {}
-    for name, thr in (("base", 0), ("wide", 2 ** 63)):
-        gpu_ctx.set_small_array_threshold(thr)
+    for name in ("base", "wide") + (("wide8",) if bits == 2048 else ()):
+        force(gpu_ctx, name)
         try:
             E, F = G.ringArray(es), G.ringArray(fs)
             X = G.exp(g, E)
@@ -76,6 +89,6 @@ def test_geometries_agree_across_the_threshold(bits, vmn, gpu_ctx, groups):
             x, d = E.recLin(F)
             out[name] = (X.toInts(), Y.toInts(), X.expProd(F), x.toInts(), d, F.prods().toInts(), X.prod())
         finally:
-            gpu_ctx.set_small_array_threshold(DEFAULT)
-    assert out["base"] == out["wide"]
+            restore(gpu_ctx)
+    assert out["base"] == out["wide"] and out.get("wide8", out["base"]) == out["base"]
     assert out["wide"][0][:64] == [pow(g, e, p) for e in es[:64]]

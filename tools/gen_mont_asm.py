@@ -167,8 +167,11 @@ def _row_pair(L: int, first: bool, lanes: int = 2, j0: int = 0, blk: int = 0):
     NT = f"%{3 * L + 5}"                  # NOTTOP mask: 0xffffffff on all lanes but the last (pair: the even lane)
     B2 = f"%{3 * L + 6}"                  # 2*b (squaring rows only)
     sqr = blk > 0
+    # lanes = 8 (the widest geometry, small arrays of 2048-bit elements): the element is half a DPP row of 16 lanes.  m comes
+    # from lane 0 in two steps (quad broadcast, then the upper quad copies the lower one: row_shr:4 into banks 1 and 3), c from
+    # the lane above by row_shl:1 (the last lane of an element reads its neighbour's lane 0: masked by NOTTOP as before).
     bcast = "[0,0,2,2]" if lanes == 2 else "[0,0,0,0]"
-    from_above = "[1,1,3,3]" if lanes == 2 else "[1,2,3,3]"
+    from_above = "quad_perm:[1,1,3,3]" if lanes == 2 else "quad_perm:[1,2,3,3]" if lanes == 4 else "row_shl:1"
     C = f"%{L + 1}"
     MASK = "0xfffffff"
     out = []
@@ -192,6 +195,9 @@ def _row_pair(L: int, first: bool, lanes: int = 2, j0: int = 0, blk: int = 0):
     ab(4)
     out.append("s_nop 1")
     out.append(f"v_mov_b32_dpp {M}, {M} quad_perm:{bcast} row_mask:0xf bank_mask:0xf")
+    if lanes == 8:
+        out.append("s_nop 1")
+        out.append(f"v_mov_b32_dpp {M}, {M} row_shr:4 row_mask:0xf bank_mask:0xa")
     ab(5)
     ab(6)
     out.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
@@ -203,8 +209,8 @@ def _row_pair(L: int, first: bool, lanes: int = 2, j0: int = 0, blk: int = 0):
             pass
     # column L-1 was consumed by the last pass-2 multiply-add; now refill it from c
     out.append("s_nop 1")
-    out.append(f"v_mov_b32_dpp v{PAIR_PT}, v{PAIR_C} quad_perm:{from_above} row_mask:0xf bank_mask:0xf")
-    out.append(f"v_mov_b32_dpp v{PAIR_PT + 1}, v{PAIR_C + 1} quad_perm:{from_above} row_mask:0xf bank_mask:0xf")
+    out.append(f"v_mov_b32_dpp v{PAIR_PT}, v{PAIR_C} {from_above} row_mask:0xf bank_mask:0xf")
+    out.append(f"v_mov_b32_dpp v{PAIR_PT + 1}, v{PAIR_C + 1} {from_above} row_mask:0xf bank_mask:0xf")
     out.append(f"v_lshrrev_b64 {C}, 28, {C}")
     out.append(f"v_and_b32 v{PAIR_PT}, {NT}, v{PAIR_PT}")
     out.append(f"v_and_b32 v{PAIR_PT + 1}, {NT}, v{PAIR_PT + 1}")
@@ -301,7 +307,7 @@ def gen_pair(S: int, lanes: int = 2) -> str:
     return "\n".join(parts)
 
 
-def render(sizes, pair_sizes=(), quad_sizes=()) -> str:
+def render(sizes, pair_sizes=(), quad_sizes=(), octo_sizes=()) -> str:
     parts = ["// GENERATED by tools/gen_mont_asm.py " + " ".join(map(str, sizes)) + " -- do not edit.",
              "// One Montgomery row as a single asm statement: 2*S v_mad_u64_u32 + 5 VALU, see the generator."]
     for S in sizes:
@@ -314,6 +320,10 @@ def render(sizes, pair_sizes=(), quad_sizes=()) -> str:
         parts.append(f"// four lanes per element, S = {S} limbs ({S // 4} per lane)")
         parts.append(gen_pair(S, 4))
         parts.append(gen_pair_sqr(S, 4))
+    for S in octo_sizes:
+        parts.append(f"// eight lanes per element, S = {S} columns ({S // 8} per lane)")
+        parts.append(gen_pair(S, 8))
+        parts.append(gen_pair_sqr(S, 8))
     return "\n".join(parts) + "\n"
 
 
@@ -321,8 +331,9 @@ def main():
     args = sys.argv[1:]
     pair = [int(x[1:]) for x in args if x.startswith("p")]
     quad = [int(x[1:]) for x in args if x.startswith("q")]
+    octo = [int(x[1:]) for x in args if x.startswith("o")]
     sizes = [int(x) for x in args if x[0].isdigit()] or [74]
-    sys.stdout.write(render(sizes, pair, quad))
+    sys.stdout.write(render(sizes, pair, quad, octo))
 
 
 if __name__ == "__main__":

@@ -140,6 +140,11 @@ class Context:
         (``vmn_ctx_set_small_array_threshold``); 0 = never.  A tuning knob: results never depend on it."""
         _check(lib().vmn_ctx_set_small_array_threshold(self._h, C.c_size_t(min(int(items), 2 ** 64 - 1))))
 
+    def set_tiny_array_threshold(self, items: int) -> None:
+        """Launches over at most ``items`` elements of a 2048-bit modulus use eight lanes per element
+        (``vmn_ctx_set_tiny_array_threshold``); 0 = never.  Takes precedence over ``set_small_array_threshold``."""
+        _check(lib().vmn_ctx_set_tiny_array_threshold(self._h, C.c_size_t(min(int(items), 2 ** 64 - 1))))
+
     def helper_mark(self) -> None:
         """Protocol thread: what is queued up to here is what the helper may rely on (``vmn_ctx_helper_mark``)."""
         _check(lib().vmn_ctx_helper_mark(self._h))

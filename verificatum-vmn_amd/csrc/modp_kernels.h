@@ -32,8 +32,13 @@ constexpr int BLOCK = 256;   // threads per workgroup: 4 waves, one per SIMD
 // A wide geometry reads and writes the rows of its BASE geometry: limb g of the element is word
 // (g / BASE_L) * BASE_LW + g % BASE_L of the row (BASE_L limbs per share of the base layout, BASE_LW words apart), the
 // columns g >= ROWS exist in registers only.
-__host__ __device__ constexpr int rows_for(int S, int LPE) { return (S == 76 && LPE == 4) ? 74 : (S == 112 && LPE == 4) ? 110 : S; }
-__host__ __device__ constexpr int base_lpe_for(int S, int LPE) { return (S == 76 && LPE == 4) ? 1 : (S == 112 && LPE == 4) ? 2 : LPE; }
+//   Cfg<80, 8>   the widest form of Cfg<74, 1>, for the smallest arrays: eight shares of 10 columns, ROWS = 74.
+__host__ __device__ constexpr int rows_for(int S, int LPE) {
+    return ((S == 76 && LPE == 4) || (S == 80 && LPE == 8)) ? 74 : (S == 112 && LPE == 4) ? 110 : S;
+}
+__host__ __device__ constexpr int base_lpe_for(int S, int LPE) {
+    return ((S == 76 && LPE == 4) || (S == 80 && LPE == 8)) ? 1 : (S == 112 && LPE == 4) ? 2 : LPE;
+}
 
 template <int S_, int LPE_>
 struct Cfg {
@@ -72,31 +77,45 @@ struct Lane {
     }
 };
 
-// Cross-lane moves inside an element (DPP quad_perm; elements are aligned groups of 2 or 4 lanes).
-// from_below: the value of lane h-1 (lane 0 gets its own: mask with ~lowmask); from_top: the last lane's value on all
-// lanes; or_all: OR over the element's lanes, on all lanes.
+// Cross-lane moves inside an element (DPP; elements are aligned groups of 2, 4 or 8 lanes: quad_perm within a quad, row
+// shifts with bank masks for the two quads of an 8-lane element -- bank k of a DPP row = its lanes 4k .. 4k+3).
+// from_below: the value of lane h-1 (lane 0 gets its own / a neighbour's: mask with ~lowmask); from_top: the last lane's
+// value on all lanes; or_all: OR over the element's lanes, on all lanes.
 template <int LPE>
 __device__ __forceinline__ u32 from_below(u32 x) { return lane_below<LPE>(x); }
+// lower quads <- upper quads (row_shl:4 into banks 0, 2) resp. upper <- lower (row_shr:4 into banks 1, 3); other lanes keep old
+__device__ __forceinline__ u32 quad_from_upper(u32 old, u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)old, (int)x, 0x104, 0xf, 0x5, false); }
+__device__ __forceinline__ u32 quad_from_lower(u32 old, u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)old, (int)x, 0x114, 0xf, 0xA, false); }
 template <int LPE>
 __device__ __forceinline__ u32 from_top(u32 x) {
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
-    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);                        // [3,3,3,3]
+    else {
+        u32 t = (u32)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);                        // [3,3,3,3]
+        if constexpr (LPE == 8) t = quad_from_upper(t, t);
+        return t;
+    }
 }
-// the value of lane h+1 of the element (the last lane receives its own: mask with nottopmask); lane 0's value on all lanes
+// the value of lane h+1 of the element (the last lane receives its own / a neighbour's: mask with nottopmask); lane 0's value on all lanes
 template <int LPE>
 __device__ __forceinline__ u32 from_above(u32 x) {
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
-    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF9, 0xf, 0xf, true);                        // [1,2,3,3]
+    else if constexpr (LPE == 4) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF9, 0xf, 0xf, true);   // [1,2,3,3]
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);                 // row_shl:1
 }
 template <int LPE>
 __device__ __forceinline__ u32 from_lane0(u32 x) {
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true);     // [0,0,2,2]
-    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);                        // [0,0,0,0]
+    else {
+        u32 t = (u32)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);                        // [0,0,0,0]
+        if constexpr (LPE == 8) t = quad_from_lower(t, t);
+        return t;
+    }
 }
 template <int LPE>
 __device__ __forceinline__ u32 or_all(u32 x) {
     x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);                               // [1,0,3,2]
-    if constexpr (LPE == 4) x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);       // [2,3,0,1]
+    if constexpr (LPE >= 4) x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);       // [2,3,0,1]
+    if constexpr (LPE == 8) x |= quad_from_upper(0u, x) | quad_from_lower(0u, x);
     return x;
 }
 

@@ -108,11 +108,14 @@ __device__ __forceinline__ void mont_sqr_columns(u64 (&T)[S], const u32 (&a)[S],
 }
 
 // Value of the same register on the lane below within the element (lane h-1; lane 0 receives its own value: mask it).
+// (eight lanes per element = half a DPP row of 16 lanes: row_shr:1; lane 0 of an element then reads its neighbour's last
+// lane or zero -- masked by the caller like the quad forms.)
 template <int LPE>
 __device__ __forceinline__ u32 lane_below(u32 x) {
-    static_assert(LPE == 2 || LPE == 4, "lanes per element");
+    static_assert(LPE == 2 || LPE == 4 || LPE == 8, "lanes per element");
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true);     // quad_perm [0,0,2,2]
-    else return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x90, 0xf, 0xf, true);                        // quad_perm [0,0,1,2]
+    else if constexpr (LPE == 4) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x90, 0xf, 0xf, true);   // quad_perm [0,0,1,2]
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);                 // row_shr:1
 }
 
 // Multi-lane product: each lane holds L of the S = LPE*L columns; b_lds streams all S limbs of the multiplier

@@ -52,7 +52,8 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // moduli (148 limbs: R = 2^4144) four.
 // X(76, 64, 4) and X(112, 96, 4) are the WIDE geometries of 2048- and 3072-bit moduli (modp_kernels.h, struct Cfg): the rows
 // of X(74, 64, 1) resp. X(110, 96, 2) worked on by four lanes each; launches over few elements are routed there (geom() below).
-#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(110, 96, 2) X(112, 96, 4) X(148, 128, 4)
+// X(80, 64, 8): the widest geometry of 2048-bit moduli (eight lanes per element) for the smallest arrays.
+#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(80, 64, 8) X(110, 96, 2) X(112, 96, 4) X(148, 128, 4)
 // elliptic curves: X(field limbs, packed words)
 // (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
 #define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
@@ -85,8 +86,20 @@ static size_t default_wide_max() {
     }();
     return v;
 }
+// Below ctx->wide8_max elements (default 6144, env VMN_WIDE8_MAX; 2048-bit moduli only) eight lanes share an element: a
+// row is 2 x 10 multiply-adds + 22 other instructions instead of 2 x 19 + 16, so a chain is another ~1.2 times shorter --
+// as long as every wave still has a SIMD to itself (8 lanes x 8192 elements = 1024 waves); measured crossover ~6000
+// elements (tools/sweep_wide8.sh).  The always-wide launches (scans) take this form up to the four-lane threshold.
+static size_t default_wide8_max() {
+    static const size_t v = [] {
+        const char* env = getenv("VMN_WIDE8_MAX");
+        return env ? (size_t)strtoull(env, nullptr, 10) : (size_t)6144;
+    }();
+    return v;
+}
 static const vmn_modulus& geom(const vmn_ctx* ctx, const vmn_modulus& m, size_t items, bool always = false) {
     const vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
+    if (m.wide8 && root->wide8_max != 0 && (items <= root->wide8_max || (always && items <= root->wide_max))) return *m.wide8;
     if (!m.wide || root->wide_max == 0) return m;
     return (always || items <= root->wide_max) ? *m.wide : m;
 }
@@ -328,6 +341,7 @@ extern "C" int vmn_ctx_create(int device, vmn_ctx** out) {
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->wide_max = default_wide_max();
+    ctx->wide8_max = default_wide8_max();
     VMN_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     VMN_HIP(hipMalloc(&ctx->flags, 64 * sizeof(uint32_t)));
@@ -449,6 +463,13 @@ extern "C" int vmn_ctx_set_small_array_threshold(vmn_ctx* ctx, size_t items) {
     root->wide_max = items;
     return VMN_OK;
 }
+extern "C" int vmn_ctx_set_tiny_array_threshold(vmn_ctx* ctx, size_t items) {
+    ARG_CHECK(ctx, "null ctx");
+    vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
+    std::lock_guard<std::recursive_mutex> guard__(root->mu);
+    root->wide8_max = items;
+    return VMN_OK;
+}
 extern "C" int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* pool_blocks, size_t* live_bytes) {
     ARG_CHECK(ctx, "null ctx");
     size_t blocks = 0, pbytes = 0, live = 0;       // an array may be freed on another lane than it came from: only the sums mean something
@@ -550,7 +571,8 @@ static int upload_words(vmn_ctx* ctx, uint32_t** dst, const std::vector<uint32_t
 }
 
 static void modulus_destroy(vmn_modulus& m) {
-    delete m.wide;                         // a view: plain data, owns nothing
+    delete m.wide;                         // views: plain data, own nothing
+    delete m.wide8;
     if (m.d_n) (void)hipFree(m.d_n);
     if (m.d_rr) (void)hipFree(m.d_rr);
     if (m.d_one) (void)hipFree(m.d_one);
@@ -603,11 +625,20 @@ static int modulus_init(vmn_ctx* ctx, vmn_modulus& m, const uint8_t* be, size_t 
     // the wide geometry of the same rows: Cfg<76, 4> (74 rows, four shares of 19 columns) / Cfg<112, 4> (110 rows, 4 x 28)
     static_assert(Cfg<76, 4>::W == Cfg<74, 1>::W && Cfg<76, 4>::ROWS == 74, "the wide geometry reads the one-lane rows");
     static_assert(Cfg<112, 4>::W == Cfg<110, 2>::W && Cfg<112, 4>::ROWS == 110, "the wide geometry reads the two-lane rows");
+    static_assert(Cfg<80, 8>::W == Cfg<74, 1>::W && Cfg<80, 8>::ROWS == 74, "the widest geometry reads the one-lane rows");
     if ((S == 74 && LPE == 1) || (S == 110 && LPE == 2)) {
         m.wide = new vmn_modulus(m);
         m.wide->S = S == 74 ? 76 : 112;
         m.wide->LPE = 4;
         m.wide->wide = nullptr;
+        m.wide->wide8 = nullptr;
+    }
+    if (S == 74 && LPE == 1) {
+        m.wide8 = new vmn_modulus(m);
+        m.wide8->S = 80;
+        m.wide8->LPE = 8;
+        m.wide8->wide = nullptr;
+        m.wide8->wide8 = nullptr;
     }
     return VMN_OK;
 }

@@ -70,6 +70,7 @@ struct vmn_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     size_t wide_max = 0;                  // main lane: launches over at most this many elements use the wide geometry (vmnhip.hip: geom())
+    size_t wide8_max = 0;                 //   ... and over at most this many the widest one (eight lanes per 2048-bit element)
     // grow-only scratch (window tables, temporaries)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -114,6 +115,7 @@ struct vmn_modulus {
     int rows = 0;              // reduction rows of a product: R = 2^(28 rows); = S except in a wide geometry
     vmn_modulus* wide = nullptr;     // the wide geometry of the same rows (2048-bit moduli: 4 lanes per element), a view:
                                      // it shares every pointer of this object and owns nothing
+    vmn_modulus* wide8 = nullptr;    // the same with eight lanes per element (2048-bit moduli)
     int W = 0;                 // words per element row in device memory
     const vmn_curve* ec = nullptr;   // non-null: the "elements" are curve points (rows of 3 field elements)
     int nbits = 0;
