@@ -3,7 +3,7 @@
 (profiles/r02_bench_v<k>.json = one `python bench.py` line, profiles/r02_pmc_kernels.json = tools/summarize_pmc.py),
 between the markers <!-- r02-tables-begin --> and <!-- r02-tables-end -->.
 
-usage: tools/design_tables.py [profiles/r02_bench_v1.json]"""
+usage: tools/design_tables.py [profiles/r02_bench_v2.json]"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_v1.json")
+    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_v2.json")
     r = json.load(open(bench))
     pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
     mp, cc, ec = r["mix_prove"], r["mix_ccpos_3072"], r["mix_ec_p256"]
@@ -40,8 +40,8 @@ def main():
 | **mix + prove**, 2048 bits, width 1: re-encrypt + PoS prove + verify (GPU arithmetic, tape pre-generated) | {mp['total_ms']:.0f} ms = **{mp['ciphertexts_per_s']:.3e} ciphertexts/s** | executed {mp['roofline']['executed_T_mads']:.1f} T multiply-adds: frac **{mp['roofline']['frac']:.2f}** of the wall clock, {mp['roofline']['frac_kernel_time']:.2f} of the kernel time (fixed {fam(mp, 'fixed')}; modpow {fam(mp, 'modpow')}; expprod {fam(mp, 'expprod')}) |
 | the same END TO END (prover randomness on the device, Fiat-Shamir hashing, byte trees published and parsed, verifier as another party) | prove {e2e['prove_ms']:.0f} ms + verify {e2e['verify_ms']:.0f} ms = {e2e['total_ms']:.0f} ms = **{e2e['ciphertexts_per_s']:.2e} ciphertexts/s** ({e2e['ciphertexts_per_s_parties_in_parallel']:.2e} with prover and verifier on their own machines) | {e2e['hashed_bytes_per_party'] / 1e9:.2f} GB hashed per party (SHA-256, one host core, ~2.2 GB/s): the hash, not the GPU, is the critical path (see below) |
 | **configs[2]**: 3072 bits, CCPoS path | offline (commitment + PoSC) {cc['offline_ms']:.0f} ms, online (re-encrypt + CCPoS prove + verify) {cc['online_ms']:.0f} ms = **{cc['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac **{cc['roofline']['frac']:.2f}** wall / {cc['roofline']['frac_kernel_time']:.2f} kernel time (fixed {fam(cc, 'fixed')}; modpow {fam(cc, 'modpow')}; expprod {fam(cc, 'expprod')}) |
-| **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}): generic Montgomery on a Solinas prime, ~1000 launches |
-| CPU beside it (GMP `mpz_powm`, {r['cpu_baseline']['cores']} cores of the box) | {r['cpu_baseline']['value']:.0f} modexp/s (96 000-element sample, bit-exact vs the GPU); mix + prove {mp['cpu_baseline']['value']:.0f} ciphertexts/s | |
+| **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}; normalisation {fam(ec, 'normalize')}): 61 % of the issued instructions are multiply-adds, ~1000 launches (§5, curves) |
+| CPU beside it (GMP, {r['cpu_baseline']['cores']} cores of the box) | {r['cpu_baseline']['value']:.0f} modexp/s (`mpz_powm`, 96 000-element sample, bit-exact vs the GPU); mix + prove {mp['cpu_baseline']['value']:.0f} ciphertexts/s ({mp['cpu_baseline']['sample'].split(':')[0]}; fixed-base tables, Pippenger) | |
 
 PMC passes (`tools/profile_pmc.sh` -> `tools/summarize_pmc.py` -> `profiles/r02_pmc_kernels.json`; separate `--pmc` passes
 for FETCH_SIZE, WRITE_SIZE and the SQ counters; 262 144 elements / ciphertexts; per-kernel durations of the same runs:
@@ -58,7 +58,7 @@ for FETCH_SIZE, WRITE_SIZE and the SQ counters; 262 144 elements / ciphertexts; 
 {pkrow('k_bucket_level<vmn::Cfg<74, 1>, true>')}
 {pkrow('k_ec_bucket_level<10, true>')}
 {pkrow('k_ec_fixed_exp<10>')}
-{pkrow('k_scan_apply<vmn::Cfg<74, 1>>')}
+{pkrow('k_scan_apply<vmn::Cfg<112, 4>>')}
 
 The headline kernel executes {hk['valu_instr_per_unit'] / 1e6:.2f} M VALU instructions per element (canonical 16.42 M MACs = {16.422432e6 / hk['valu_instr_per_unit']:.2f} of them) at
 {hk['issued_Tlaneinstr_per_s']:.1f} T lane-instr/s.
