@@ -53,8 +53,13 @@ def test_worst_case_columns(bits, forced_geometry, vmn, gpu_ctx):
     tp.test_worst_case_column_magnitudes(bits, vmn, gpu_ctx)
 
 
-def test_config2_3072bit_ccpos_flow(forced_geometry, vmn, gpu_ctx, mods):
-    tcf.test_config2_3072bit_precompute_shrink_ccpos("native", vmn, gpu_ctx, mods)
+def test_config2_3072bit_ccpos_flow_in_the_base_geometry(vmn, gpu_ctx, mods):
+    """(tests/test_gpu_configs.py runs this flow with the default thresholds, i.e. wide at its size.)"""
+    force(gpu_ctx, "base")
+    try:
+        tcf.test_config2_3072bit_precompute_shrink_ccpos("native", vmn, gpu_ctx, mods)
+    finally:
+        restore(gpu_ctx)
 
 
 @pytest.mark.parametrize("bits", [2048, 3072])
@@ -66,8 +71,14 @@ def test_membership_and_bytetrees(bits, forced_geometry, groups):
     assert G.toElementArrayFromByteTree(X.toByteTree()).toInts() == xs
 
 
-def test_pos_transcript_2048(forced_geometry, vmn, gpu_ctx, mods):
-    tpr.test_pos_transcript_matches_oracle(2048, 130, 1, (256, 256, 100), vmn, gpu_ctx, mods, mods["native"])
+@pytest.mark.parametrize("name", ["base", "wide"])
+def test_pos_transcript_2048(name, vmn, gpu_ctx, mods):
+    """(tests/test_gpu_proofs.py runs the transcripts with the default thresholds, i.e. eight lanes per element at their size.)"""
+    force(gpu_ctx, name)
+    try:
+        tpr.test_pos_transcript_matches_oracle(2048, 70, 1, (256, 256, 100), vmn, gpu_ctx, mods, mods["native"])
+    finally:
+        restore(gpu_ctx)
 
 
 @pytest.mark.parametrize("bits", [2048, 3072])
