@@ -102,6 +102,21 @@ def test_multi_exponentiation_and_movement(ecg):
     es = [12345] * 64
     assert G.toElementArray(xs).expProd(G.ringArray(es)) == c.mul(64 * 12345, c.g)
     assert G.toElementArray([]).expProd(G.ringArray([])) is None
+    # the first bucket level adds NORMALISED rows with the mixed addition: opposite points and the identity inside one
+    # bucket, inputs that arrive with Z != 1 (results of earlier operations), an all-identity array
+    base = pts(c, 900, 12)
+    xs = base + [c.neg(p) for p in base] + [None, None, c.g, c.g, c.neg(c.g)]
+    es = [777] * 24 + [5, 777, 777, 777, 777]
+    assert G.toElementArray(xs).expProd(G.ringArray(es)) == c.exp_prod(xs, es)
+    J = G.toElementArray(base).exp(G.ringArray([3 + k for k in range(12)])).mul(G.toElementArray(base))      # Jacobian rows
+    js = [c.mul(4 + k, p) for k, p in enumerate(base)]
+    assert J.toInts() == js
+    es = [rnd.randrange(c.n) for _ in range(12)]
+    assert J.expProd(G.ringArray(es)) == c.exp_prod(js, es)
+    assert G.toElementArray([None] * 9).expProd(G.ringArray(list(range(9)))) is None
+    # fixed-base table (normalised entries, identity rows for zero digits): exponents with zero windows
+    es = [0, 1, 1 << 16, (1 << 200) + 1, c.n - 1, 1 << 255 if (1 << 255) < c.n else 1 << 200]
+    assert G.exp(base[0], G.ringArray(es)).toInts() == [c.mul(e, base[0]) for e in es]
 
 
 def test_scalar_field_arrays(ecg):
