@@ -145,6 +145,20 @@ class ReplaySource:
         return self._next("int_array")
 
 
+class ReplayWithDeviceArrays(ReplaySource):
+    """The same tape for the permutation and the O(1) scalars; the N-sized draws of the prover (r, s, b, beta, epsilon) are
+    expanded ON THE DEVICE from 32-byte seeds (vmn_random_source.array_seed, csrc/vmnproofs.cpp: random_ring_array) -- the
+    product's own path for PoSBasicTW.java:446, 473, 583, 612 and ShufflerElGamalSession.java:408-409: no N-sized
+    array crosses PCIe inside the timed region."""
+
+    def __init__(self, src, plan):
+        super().__init__(src, plan)
+        self._seeds = src
+
+    def array_seed(self):
+        return self._seeds.array_seed()
+
+
 def fiat_shamir_seed(grp, arrays, prefix: bytes = b"bench"):
     """The hashing the reference does on the host around a proof (reported as its own line, never part
     of ciphertexts/s): seed = RO(prefix || bytetree(g, h, u, pk, w, w')) as in PoSTW.java:118-130 -- the byte trees of
@@ -216,14 +230,22 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
     phases = {}
     best = None
     bulk = rnd
+    device_draws = drivers == "native"          # the C++ drivers expand the prover's N-sized draws on the device
     for _ in range(steps):
         EB = NE + NV + NR
-        rnd = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, s
-                                  ("ring_array", n), ("ring_element",), ("int_array", n, EB),   # r, alpha, epsilon
-                                  ("int_array", 1, 256),                                        # seed of the batching vector
-                                  ("ring_array", n), ("ring_array", n),                         # b, beta
-                                  ("ring_element",), ("ring_element",), ("ring_element",),      # gamma, delta, phi
-                                  ("int_array", 1, NV)])                                        # v (challenge)
+        if device_draws:
+            rnd = ReplayWithDeviceArrays(bulk, [("permutation", n),                             # pi   (s: on the device)
+                                                ("ring_element",),                              # alpha (r, epsilon: on the device)
+                                                ("int_array", 1, 256),                          # seed of the batching vector
+                                                ("ring_element",), ("ring_element",), ("ring_element",),   # gamma, delta, phi (b, beta: device)
+                                                ("int_array", 1, NV)])                          # v (challenge)
+        else:
+            rnd = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, s
+                                      ("ring_array", n), ("ring_element",), ("int_array", n, EB),   # r, alpha, epsilon
+                                      ("int_array", 1, 256),                                        # seed of the batching vector
+                                      ("ring_array", n), ("ring_array", n),                         # b, beta
+                                      ("ring_element",), ("ring_element",), ("ring_element",),      # gamma, delta, phi
+                                      ("int_array", 1, NV)])                                        # v (challenge)
         ctx.timing_reset()
         ctx.timing_enable(True)
         gc.collect()        # release the previous pass's arrays into the pool before the clock starts
@@ -231,7 +253,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
         t0 = time.perf_counter()
         # --- A0: re-encryption + permutation
         pi = rnd.permutation(n)
-        S = [grp.ringArray(rnd.ring_array(n))]
+        S = [hv.random_ring_array_native(grp, rnd, n, NR)] if device_draws else [grp.ringArray(rnd.ring_array(n))]
         prover = hv.PoSBasicTW(grp, NV, NE, NR, rand=rnd)
         WP = do_reencrypt(hv, mx, grp, pkey, W, S, pi)
         sync()
@@ -451,13 +473,22 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     W = [grp.exp(g, T), M.mul(YT)]
     for a in (T, M, YT):
         a.free()
-    tape = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, commitment exponents r
-                               ("int_array", 1, 256),                                        # seed of the PoSC batching vector
-                               ("ring_array", n), ("ring_element",), ("int_array", n, EB), ("ring_array", n),   # b, alpha, eps, beta
-                               ("ring_element",), ("ring_element",), ("int_array", 1, NV),                        # gamma, delta, v
-                               ("ring_array", n),                                            # s
-                               ("int_array", 1, 256), ("ring_element",), ("int_array", n, EB), ("ring_element",), # e seed, alpha, eps, beta
-                               ("int_array", 1, NV)])
+    device_draws = drivers == "native"          # the C++ drivers expand the provers' N-sized draws on the device (see mix_prove)
+    if device_draws:
+        tape = ReplayWithDeviceArrays(bulk, [("permutation", n), ("ring_array", n),          # pi, commitment exponents r (offline input)
+                                             ("int_array", 1, 256),                          # seed of the PoSC batching vector
+                                             ("ring_element",),                              # alpha (b, eps, beta: on the device)
+                                             ("ring_element",), ("ring_element",), ("int_array", 1, NV),     # gamma, delta, v
+                                             ("int_array", 1, 256), ("ring_element",), ("ring_element",),   # e seed, alpha, beta (s, eps: device)
+                                             ("int_array", 1, NV)])
+    else:
+        tape = ReplaySource(bulk, [("permutation", n), ("ring_array", n),                       # pi, commitment exponents r
+                                   ("int_array", 1, 256),                                        # seed of the PoSC batching vector
+                                   ("ring_array", n), ("ring_element",), ("int_array", n, EB), ("ring_array", n),   # b, alpha, eps, beta
+                                   ("ring_element",), ("ring_element",), ("int_array", 1, NV),                        # gamma, delta, v
+                                   ("ring_array", n),                                            # s
+                                   ("int_array", 1, 256), ("ring_element",), ("int_array", n, EB), ("ring_element",), # e seed, alpha, eps, beta
+                                   ("int_array", 1, NV)])
     ctx.timing_reset()
     ctx.timing_enable(True)
     gc.collect()            # release the previous pass's arrays into the pool before the clock starts
@@ -483,7 +514,7 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     sync()
     t1 = time.perf_counter()
     # ---- online
-    S = [grp.ringArray(tape.ring_array(n))]
+    S = [hv.random_ring_array_native(grp, tape, n, NR)] if device_draws else [grp.ringArray(tape.ring_array(n))]
     WP = do_reencrypt(hv, mx, grp, pkey, W, S, pi)
     sync()
     t2 = time.perf_counter()
@@ -548,9 +579,15 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
         YT.free()
     for t in Ts:
         t.free()
-    plan = [("permutation", n), ("ring_array", n)] + [("ring_array", n)] * width + \
-           [("int_array", 1, 256), ("ring_element",), ("int_array", n, EB)] + [("ring_element",)] * width + [("int_array", 1, NV)]
-    tape = ReplaySource(bulk, plan)
+    device_draws = drivers == "native"          # the C++ drivers expand the prover's N-sized draws on the device (see mix_prove)
+    if device_draws:
+        plan = [("permutation", n), ("ring_array", n), ("int_array", 1, 256), ("ring_element",)] + [("ring_element",)] * width + \
+               [("int_array", 1, NV)]
+        tape = ReplayWithDeviceArrays(bulk, plan)
+    else:
+        plan = [("permutation", n), ("ring_array", n)] + [("ring_array", n)] * width + \
+               [("int_array", 1, 256), ("ring_element",), ("int_array", n, EB)] + [("ring_element",)] * width + [("int_array", 1, NV)]
+        tape = ReplaySource(bulk, plan)
     ctx.timing_reset()
     ctx.timing_enable(True)
     gc.collect()            # release the previous pass's arrays into the pool before the clock starts
@@ -560,7 +597,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
     U, R = do_permutation_commitment(hv, mx, grp, g, H, tape.ring_array(n), pi)
     sync()
     t1 = time.perf_counter()
-    S = [grp.ringArray(tape.ring_array(n)) for _ in range(width)]
+    S = [hv.random_ring_array_native(grp, tape, n, NR) if device_draws else grp.ringArray(tape.ring_array(n)) for _ in range(width)]
     WP = do_reencrypt(hv, mx, grp, pkey, W, S, pi)
     sync()
     t2 = time.perf_counter()

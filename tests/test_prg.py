@@ -110,6 +110,9 @@ def test_random_vector_over_a_curve_order(vmn, gpu_ctx):
     seed = pyref_prg.random_oracle(b"curve", 256)
     assert G.ringArrayFromPRG(seed, 200, 128).toInts() == pyref_prg.random_integers(seed, 200, 128)
     assert G.ringArrayFromPRG(seed, 200, 256).toInts() == [x % G.q for x in pyref_prg.random_integers(seed, 200, 256)]
+    # wider than twice the order (the 612-bit epsilon of a proof, bits(q) + rbitlen random bits, three and four parts)
+    for bits in (356, 612, 700, 1025):
+        assert G.ringArrayFromPRG(seed, 77, bits).toInts() == [x % G.q for x in pyref_prg.random_integers(seed, 77, bits)], bits
 
 
 @pytest.mark.gpu

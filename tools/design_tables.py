@@ -37,7 +37,7 @@ def main():
 | leg | result | roofline (bound: integer VALU, peak 39.3 T multiply-adds/s) |
 |---|---|---|
 | **headline**, configs[1]: 10^6 x 2048-bit modPow, 2047-bit exponents | **{r['value']:.3e} modexp/s**, {r['ms_per_step']:.1f} ms per step, kernel {rf['avg_kernel_ms']:.1f} ms (HIP events) | achieved {rf['achieved']:.2f} TMAC/s canonical (16 422 432 per modexp, SURVEY.md §8d) = **{rf['frac']:.3f}**; issued {issued} T lane-instr/s of the {rf['peak_measured']:.1f} T/s the hardware sustains for `v_mad_u64_u32` at two waves per SIMD; HBM traffic {traffic} per launch (PMC) against 0.77 GB algorithmic: the per-lane window tables, 2 % of the HBM roof |
-| **mix + prove**, 2048 bits, width 1: re-encrypt + PoS prove + verify (GPU arithmetic, tape pre-generated) | {mp['total_ms']:.0f} ms = **{mp['ciphertexts_per_s']:.3e} ciphertexts/s** | executed {mp['roofline']['executed_T_mads']:.1f} T multiply-adds: frac **{mp['roofline']['frac']:.2f}** of the wall clock, {mp['roofline']['frac_kernel_time']:.2f} of the kernel time (fixed {fam(mp, 'fixed')}; modpow {fam(mp, 'modpow')}; expprod {fam(mp, 'expprod')}) |
+| **mix + prove**, 2048 bits, width 1: re-encrypt + PoS prove + verify (GPU arithmetic; the N-sized random arrays expanded on the device, scalars and the permutation from a tape) | {mp['total_ms']:.0f} ms = **{mp['ciphertexts_per_s']:.3e} ciphertexts/s** | executed {mp['roofline']['executed_T_mads']:.1f} T multiply-adds: frac **{mp['roofline']['frac']:.2f}** of the wall clock, {mp['roofline']['frac_kernel_time']:.2f} of the kernel time (fixed {fam(mp, 'fixed')}; modpow {fam(mp, 'modpow')}; expprod {fam(mp, 'expprod')}) |
 | the same END TO END (prover randomness on the device, Fiat-Shamir hashing, byte trees published and parsed, verifier as another party) | prove {e2e['prove_ms']:.0f} ms + verify {e2e['verify_ms']:.0f} ms = {e2e['total_ms']:.0f} ms = **{e2e['ciphertexts_per_s']:.2e} ciphertexts/s** ({e2e['ciphertexts_per_s_parties_in_parallel']:.2e} with prover and verifier on their own machines) | {e2e['hashed_bytes_per_party'] / 1e9:.2f} GB hashed per party (SHA-256, one host core, ~2.2 GB/s): the hash, not the GPU, is the critical path (see below) |
 | **configs[2]**: 3072 bits, CCPoS path | offline (commitment + PoSC) {cc['offline_ms']:.0f} ms, online (re-encrypt + CCPoS prove + verify) {cc['online_ms']:.0f} ms = **{cc['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac **{cc['roofline']['frac']:.2f}** wall / {cc['roofline']['frac_kernel_time']:.2f} kernel time (fixed {fam(cc, 'fixed')}; modpow {fam(cc, 'modpow')}; expprod {fam(cc, 'expprod')}) |
 | **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}; normalisation {fam(ec, 'normalize')}): 61 % of the issued instructions are multiply-adds, ~1000 launches (§5, curves) |

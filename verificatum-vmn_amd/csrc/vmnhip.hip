@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <future>
 #include <memory>
+#include <system_error>
 #include <utility>
 
 #include "ec_kernels.h"
@@ -2189,39 +2190,45 @@ static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, si
     if (n == 0) return VMN_OK;
     const size_t Wd = elem_words(m);
     const size_t vb = ((size_t)vbits + 7) / 8, mb = ((size_t)m.nbits + 7) / 8;
-    const size_t pb = std::min(vb, mb);
-    if (vb - pb > mb || 8 * (vb - pb) + 8 > (size_t)m.nbits) {
-        set_error("PRG values of %d bits are too wide for a %d-bit modulus", vbits, m.nbits);
-        return VMN_ERR_UNSUPPORTED;
-    }
     DevTmp rows(ctx);
-    // low part: < 2^(8 pb) <= R, reduced by the import when it can reach the modulus
-    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, vb - pb, pb, pb, rows));
-    const int mode_lo = (vb > pb || vbits >= m.nbits) ? 2 : 0;
-    if (vb == pb) return import_dev(ctx, m, pb, rows.as<uint8_t>(), mode_lo, n, d_out, nullptr);
-    DevTmp lo(ctx), hi(ctx), cdev(ctx);
-    VMN_TRY(lo.alloc(n * Wd * sizeof(uint32_t)));
-    VMN_TRY(hi.alloc(n * Wd * sizeof(uint32_t)));
-    VMN_TRY(import_dev(ctx, m, pb, rows.as<uint8_t>(), 2, n, lo.as<uint32_t>(), nullptr));
-    const size_t hb = vb - pb;                                  // high part: < 2^(8 hb) < m
-    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, hb, hb, rows));
-    VMN_TRY(import_dev(ctx, m, hb, rows.as<uint8_t>(), 0, n, hi.as<uint32_t>(), nullptr));
-    Big c(m.NW, 0);                                             // c = 2^(8 pb) mod m as one element
+    if (vb <= mb) {
+        // one part: < 2^(8 vb) <= 2^(8 mb) <= R, reduced by the import when it can reach the modulus
+        VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, vb, vb, rows));
+        return import_dev(ctx, m, vb, rows.as<uint8_t>(), vbits >= m.nbits ? 2 : 0, n, d_out, nullptr);
+    }
+    // wider than the modulus (bits(q) + rbitlen random bits for a ring element; the 612-bit epsilon of a proof over a
+    // 256-bit curve order): parts of mb bytes from the most significant end, each reduced by its import (< 2^(8 mb) <= R),
+    // combined by Horner with c = 2^(8 mb) mod m:  value = (..(top c + part_1) c + ..) c + part_last  mod m
+    const size_t nparts = (vb + mb - 1) / mb, top_len = vb - (nparts - 1) * mb;
+    DevTmp acc(ctx), part(ctx), cdev(ctx);
+    VMN_TRY(acc.alloc(n * Wd * sizeof(uint32_t)));
+    VMN_TRY(part.alloc(n * Wd * sizeof(uint32_t)));
+    Big c(m.NW, 0);
     c[0] = 1;
-    for (size_t k = 0; k < 8 * pb; ++k) hostbig::dbl_mod(c, m.n_words);
+    for (size_t k = 0; k < 8 * mb; ++k) hostbig::dbl_mod(c, m.n_words);
     std::vector<uint8_t> cbe(mb);
     hostbig::to_be(c, cbe.data(), mb);
     VMN_TRY(cdev.alloc(Wd * sizeof(uint32_t)));
     int ok = 1;
     VMN_TRY(import_be(ctx, m, mb, cbe.data(), 1, cdev.as<uint32_t>(), &ok));
-    int rc = VMN_ERR_ARG;                                       // out = hi * c + lo   (ring op 2 with this modulus)
+    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, top_len, top_len, rows));
+    VMN_TRY(import_dev(ctx, m, top_len, rows.as<uint8_t>(), 2, n, acc.as<uint32_t>(), nullptr));
+    uint32_t* cur = acc.as<uint32_t>();
+    for (size_t pidx = 1; pidx < nparts; ++pidx) {
+        VMN_TRY(prg_rows(ctx, w, n, vb, vbits, top_len + (pidx - 1) * mb, mb, mb, rows));
+        VMN_TRY(import_dev(ctx, m, mb, rows.as<uint8_t>(), 2, n, part.as<uint32_t>(), nullptr));
+        uint32_t* dst = pidx + 1 == nparts ? d_out : cur;          // element-wise: a lane reads its operands before it writes
+        int rc = VMN_ERR_ARG;                                       // dst = cur * c + part   (ring op 2 with this modulus)
 #define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_)                                                                                                            \
-        rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), d_out, (const uint32_t*)hi.as<uint32_t>(), \
-                    (const uint32_t*)lo.as<uint32_t>(), (const uint32_t*)cdev.as<uint32_t>(), 2, n, m.d_n, m.n0inv);
-    VMN_DISPATCH(n, X)
+        rc = launch(ctx, "ring", k_ring_elementwise<Cfg<S_, LPE_>>, egrid(m, n), lds_bytes(m), dst, (const uint32_t*)cur,          \
+                    (const uint32_t*)part.as<uint32_t>(), (const uint32_t*)cdev.as<uint32_t>(), 2, n, m.d_n, m.n0inv);
+        VMN_DISPATCH(n, X)
 #undef X
-    return rc;
+        VMN_TRY(rc);
+        cur = dst;
+    }
+    return VMN_OK;
 }
 
 extern "C" int vmn_prg_bytes(const uint8_t* seed, size_t seedlen, uint8_t* out, size_t nbytes) {
@@ -2942,7 +2949,13 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         num64::to_be(hm.from_m(acc), out_be + arr * ebytes_out, g->nbytes);
     };
     std::vector<std::future<void>> others;                 // one chain per array: the arrays beyond the first on threads of their own
-    for (size_t arr = 1; arr < k; ++arr) others.emplace_back(std::async(std::launch::async, horner, arr));
+    for (size_t arr = 1; arr < k; ++arr) {
+        try {
+            others.emplace_back(std::async(std::launch::async, horner, arr));
+        } catch (const std::system_error&) {             // no thread to be had: this chain runs here
+            horner(arr);
+        }
+    }
     horner(0);
     for (auto& f : others) f.get();
     return VMN_OK;

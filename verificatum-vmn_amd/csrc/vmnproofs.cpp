@@ -19,6 +19,7 @@
 #include <future>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "hostcurve.h"
@@ -129,7 +130,12 @@ struct HostJobs {
             pending.emplace_back(std::async(std::launch::deferred, [rc] { return rc; }));
             return;
         }
-        pending.emplace_back(std::async(std::launch::async, std::forward<F>(f)));
+        try {
+            pending.emplace_back(std::async(std::launch::async, f));
+        } catch (const std::system_error&) {        // no thread to be had: the job runs here and now
+            int rc = f();
+            pending.emplace_back(std::async(std::launch::deferred, [rc] { return rc; }));
+        }
     }
     int join() {
         VMN_TRACE("host:jobs_join");
