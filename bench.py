@@ -948,8 +948,19 @@ def main() -> None:
         result["mix_ec_p256"]["passes_reencrypt_ms"] = [round(r["reencrypt_ms"], 1) for r in runs]
         result["mix_ec_p256"]["passes_kernel_ms"] = [r["kernel_ms_by_family"] for r in runs]
 
+    def leg_small():
+        # BASELINE.json configs[0]'s size (the reference's demo: 10^4 ciphertexts, 2048 bits, width 1): below ~4 x 10^4
+        # elements every launch runs in a wide geometry; the proof is bound by per-lane chain latency
+        ctx.timing_reset()
+        sm = mix_prove(entry, vmn, ctx, grp, 10000, 777, barrier, steps=3, drivers=args.drivers)
+        sm.pop("fiat_shamir_host_ms", None)
+        sm["workload"] = "re-encrypt + PoS prove + verify at the reference's demo size (BASELINE.json configs[0]: 10^4 ciphertexts, 2048 bits, width 1)"
+        result["mix_prove_n10000"] = sm
+
     if args.mix_n > 0:
         guarded("mix_prove", leg_mix_prove)
+    if args.mix_n >= 10000 and not distributed:
+        guarded("mix_prove_n10000", leg_small)
     if args.ccpos_n > 0 and not distributed:
         guarded("mix_ccpos_3072", leg_ccpos)
     if args.ec_n > 0 and not distributed:
