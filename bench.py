@@ -67,7 +67,7 @@ def source_fingerprint() -> str:
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "verificatum-vmn_amd", "csrc")
-    for name in ("mont28.h", "modp_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
+    for name in ("mont28.h", "modp_kernels.h", "light_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -19,7 +19,7 @@ HEADLINE = "k_modpow<vmn::Cfg<74, 1>"
 def fingerprint():
     h = hashlib.sha256()
     base = os.path.join(ROOT, "verificatum-vmn_amd", "csrc")
-    for name in ("mont28.h", "modp_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
+    for name in ("mont28.h", "modp_kernels.h", "light_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
         h.update(open(os.path.join(base, name), "rb").read())
     return h.hexdigest()[:16]
 

@@ -565,26 +565,6 @@ k_to_words(u32* __restrict__ out, const u32* __restrict__ in, size_t n, const u3
     emit_words<C, NW>(r, ln, [&](int k, u32 w) { if (live) dst[k] = w; });
 }
 
-// out[0] = max over the n integers (nw packed little-endian words each) of their bit length.  One thread per
-// integer; serves the verifier, which must use every bit of an exponent array it was sent (a reply's k_E) and
-// still wants the short path when the entries are as short as an honest prover's.
-__global__ void __launch_bounds__(BLOCK) k_words_maxbits(const u32* __restrict__ w, size_t n, int nw, u32* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    u32 bits = 0;
-    if (i < n) {
-        const u32* p = w + i * (size_t)nw;
-        for (int k = nw - 1; k >= 0; --k) {
-            u32 v = p[k];
-            if (v) {
-                bits = 32u * (u32)k + (32u - (u32)__builtin_clz(v));
-                break;
-            }
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (u32)__shfl_xor((int)bits, o));
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(out, bits);
-}
-
 // ---------------------------------------------------------------------------------------------
 // K4: out[i] = x[i] * y[i]        (ystride = 0: every x[i] times the single element y)
 // ---------------------------------------------------------------------------------------------
@@ -683,37 +663,6 @@ k_modpow(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict
 // second part: fixed-base tables (K2), multi-exponentiation (K3), reductions (K5), comparison
 // (K6), data movement (K7) and the ring kernels over Z_q (K8).
 // =============================================================================================
-
-// ---------------------------------------------------------------------------------------------
-// K6: flags[0] |= 1 if x != y anywhere.  One thread per 16-byte chunk (HBM-bound, coalesced).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_compare(const uint4* __restrict__ x, const uint4* __restrict__ y,
-                                                   size_t nchunks, u32* __restrict__ flags) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool diff = false;
-    for (; i < nchunks; i += (size_t)gridDim.x * BLOCK) {
-        uint4 a = x[i], b = y[i];
-        diff |= (a.x != b.x) | (a.y != b.y) | (a.z != b.z) | (a.w != b.w);
-    }
-    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K7: out[i] = in[idx[i]]  (idx[i] == 0xffffffff: out[i] = fill).  One thread per 16-byte chunk of
-// a row: rows are contiguous W-word records, so a gather moves whole aligned rows.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_gather(uint4* __restrict__ out, const uint4* __restrict__ in,
-                                                  const u32* __restrict__ idx, const uint4* __restrict__ fill,
-                                                  size_t n_out, int chunks_per_row) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = n_out * (size_t)chunks_per_row;
-    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t row = t / chunks_per_row;
-        int c = (int)(t % chunks_per_row);
-        u32 src = idx[row];
-        out[t] = src == 0xffffffffu ? fill[c] : in[(size_t)src * chunks_per_row + c];
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // K5 and friends: strided reduction.  out[seg][j] = OP_k x[seg][j + k*L], k = 0 .. ceil(len/L)-1,
@@ -891,30 +840,6 @@ k_scan_apply(u32* __restrict__ out, const u32* __restrict__ e, const u32* __rest
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K2 fixed base.  Table T[k][d] = base^(d * 2^(w*k)), k < nwin, d < 2^w, rows of W words at
-// (k*2^w + d)*W.  The host supplies sq[j] = base^(2^j) (the sequential squaring chain); level l
-// fills d in (2^l, 2^(l+1)):  T[k][d] = T[k][d - 2^l] * T[k][2^l].
-// ---------------------------------------------------------------------------------------------
-// one thread per (k, l) plus the d = 0 rows; plain row copies (W words, constants are in row layout)
-__global__ void __launch_bounds__(BLOCK) k_fixed_seed(u32* __restrict__ T, const u32* __restrict__ sq, int w, int nwin,
-                                                      const u32* __restrict__ one_row, int W) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = (size_t)nwin * (w + 1);
-    if (t >= total) return;
-    int k = (int)(t / (w + 1)), l = (int)(t % (w + 1));
-    u32* dst;
-    const u32* src;
-    if (l == w) {                          // d = 0: the Montgomery one
-        dst = T + ((size_t)k << w) * W;
-        src = one_row;
-    } else {
-        dst = T + (((size_t)k << w) + ((size_t)1 << l)) * W;
-        src = sq + ((size_t)k * w + l) * W;
-    }
-    for (int j = 0; j < W; ++j) dst[j] = src[j];
-}
-
 template <class C>
 __global__ void __launch_bounds__(BLOCK, C::MINW)
 k_fixed_level(u32* __restrict__ T, int w, int nwin, int l, const u32* __restrict__ nmod, u32 n0inv) {
@@ -968,112 +893,6 @@ k_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin, c
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K3 multi-exponentiation (Pippenger): counting sort of (window, digit), then a product tree per bucket.
-// ---------------------------------------------------------------------------------------------
-// counts[win][d] += 1 for every element; one thread per (element, window).
-__global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts, const u32* __restrict__ e, int ewords,
-                                                       size_t n, int c, int nwin) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = n * (size_t)nwin;
-    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t i = t % n;
-        int w = (int)(t / n);
-        u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
-        atomicAdd(&counts[((size_t)w << c) + d], 1u);
-    }
-}
-
-// ---- generic exclusive scan of a u32 array (three tiny kernels; n up to a few million) ----------
-constexpr int SCAN_ITEMS = 16;                         // items per thread
-__global__ void __launch_bounds__(BLOCK) k_u32_blocksum(u32* __restrict__ bsum, const u32* __restrict__ in, size_t n) {
-    __shared__ u32 part[BLOCK];
-    size_t base = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * SCAN_ITEMS;
-    u32 s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) s += base + k < n ? in[base + k] : 0u;
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = BLOCK / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) bsum[blockIdx.x] = part[0];
-}
-__global__ void k_u32_scan_top(u32* __restrict__ bsum, size_t nblocks, u32* __restrict__ total) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        u32 run = 0;
-        for (size_t i = 0; i < nblocks; ++i) {
-            u32 v = bsum[i];
-            bsum[i] = run;
-            run += v;
-        }
-        *total = run;
-    }
-}
-// out[i] = exclusive prefix; out2 (optional) receives a copy (the scatter cursors); out[n] = total
-__global__ void __launch_bounds__(BLOCK) k_u32_scan_apply(u32* __restrict__ out, u32* __restrict__ out2,
-                                                          const u32* __restrict__ in, const u32* __restrict__ bsum, size_t n) {
-    __shared__ u32 part[BLOCK];
-    size_t base = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * SCAN_ITEMS;
-    u32 v[SCAN_ITEMS];
-    u32 s = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = base + k < n ? in[base + k] : 0u;
-        s += v[k];
-    }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 run = bsum[blockIdx.x];
-        for (int i = 0; i < BLOCK; ++i) {
-            u32 t = part[i];
-            part[i] = run;
-            run += t;
-        }
-    }
-    __syncthreads();
-    u32 run = part[threadIdx.x];
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) {
-            out[base + k] = run;
-            if (out2) out2[base + k] = run;
-        }
-        run += v[k];
-        if (base + k + 1 == n) out[n] = run;
-    }
-}
-
-// sorted[cursor[bucket]++] = element index; one thread per (element, window); bucket = w*2^c + digit
-__global__ void __launch_bounds__(BLOCK) k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ cursor,
-                                                          const u32* __restrict__ e, int ewords, size_t n, int c, int nwin) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = n * (size_t)nwin;
-    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t i = t % n;
-        int w = (int)(t / n);
-        u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
-        u32 pos = atomicAdd(&cursor[((size_t)w << c) + d], 1u);
-        sorted[pos] = (u32)i;
-    }
-}
-// digit 0 contributes nothing: drop those buckets' items
-__global__ void __launch_bounds__(BLOCK) k_bucket_drop_zero(u32* __restrict__ counts, int c, int nwin) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t < (size_t)nwin) counts[t << c] = 0;
-}
-// cnt_out[b] = ceil(cnt_in[b] / F); maxcnt = max over b
-__global__ void __launch_bounds__(BLOCK) k_task_counts(u32* __restrict__ cnt_out, const u32* __restrict__ cnt_in,
-                                                       size_t nbuckets, u32 F, u32* __restrict__ maxcnt) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    u32 v = 0;
-    if (t < nbuckets) {
-        v = (cnt_in[t] + F - 1) / F;
-        cnt_out[t] = v;
-    }
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o));
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(maxcnt, v);
-}
-
 // One level of the per-bucket product tree.  Bucket b owns cnt_in[b] items at off_in[b]; output item
 // (b, j) = product of its input items [jF, (j+1)F) and lands at off_out[b] + j.  One lane (pair) per output
 // item, so a bucket of any size is spread over ceil(size/F) lanes: no lane ever walks a long bucket
@@ -1112,27 +931,6 @@ k_bucket_level(u32* __restrict__ out, const u32* __restrict__ in, const u32* __r
     }
     canonicalize<C>(acc, nn, ln);
     if (live) store_elem<C>(out + t * W, acc, ln);
-}
-// B[b] = the bucket's single remaining item, or one if it is empty (row copies, 16-byte chunks)
-__global__ void __launch_bounds__(BLOCK) k_bucket_finalize(uint4* __restrict__ B, const uint4* __restrict__ items,
-                                                           const u32* __restrict__ off_in, const u32* __restrict__ cnt_in,
-                                                           size_t nbuckets, const uint4* __restrict__ one_row, int cpr) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = nbuckets * cpr;
-    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t b = t / cpr;
-        int ch = (int)(t % cpr);
-        B[t] = cnt_in[b] ? items[(size_t)off_in[b] * cpr + ch] : one_row[ch];
-    }
-}
-// overwrite element 0 of every segment with `one` (the d = 0 slot of the suffix products)
-__global__ void __launch_bounds__(BLOCK) k_set_segment_heads(uint4* __restrict__ a, size_t seglen, size_t nseg,
-                                                             const uint4* __restrict__ one_row, int cpr) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= nseg * cpr) return;
-    size_t s = t / cpr;
-    int ch = (int)(t % cpr);
-    a[s * seglen * cpr + ch] = one_row[ch];
 }
 
 // ---------------------------------------------------------------------------------------------

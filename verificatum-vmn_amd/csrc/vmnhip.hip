@@ -13,10 +13,19 @@
 
 #include "ec_kernels.h"
 #include "modp_kernels.h"
+#include "modp_instances.h"
+#include "light_kernels.h"
 #include "vmnhip_internal.h"
 #include "sha256.h"
 #include "sha512.h"
 #include "hostnum64.h"
+
+// the Cfg-templated kernels are compiled in the instantiation units csrc/inst_*.hip (modp_instances.h); here they are declared
+VMN_UNIT_SMALL(extern template)
+VMN_UNIT_2048(extern template)
+VMN_UNIT_2048_WIDE(extern template)
+VMN_UNIT_3072(extern template)
+VMN_UNIT_4096(extern template)
 
 using namespace vmn;
 using vmn::hostbig::Big;
