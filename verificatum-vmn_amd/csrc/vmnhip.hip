@@ -2822,10 +2822,15 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     uint32_t* bsum = offB + (nbuckets + 1);
     uint32_t* misc = bsum + scan_blocks;             // [0] = total, [1] = max count
     VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
-    VMN_TRY(buckets.alloc(2 * nbuckets * Wd * sizeof(uint32_t)));
+    // The bucket aggregation (suffix scan + reduction over nwin x 2^c rows per array) is a handful of short launches: it
+    // runs once for a GROUP of arrays (all k when their buckets fit 16 GB), not once per array -- over curves, where a
+    // multi-exponentiation has 7 arrays and few buckets, that is a quarter of the kernel time of a proof.
+    const size_t bucket_bytes = nbuckets * Wd * sizeof(uint32_t);
+    const size_t G = std::max<size_t>(1, std::min<size_t>(k, ((size_t)16 << 30) / (2 * bucket_bytes)));
+    VMN_TRY(buckets.alloc(2 * G * bucket_bytes));
     VMN_TRY(wres.alloc(k * (size_t)nwin * Wd * sizeof(uint32_t)));      // window results of all k arrays
-    uint32_t* B = buckets.as<uint32_t>();
-    uint32_t* Ssuf = B + nbuckets * Wd;
+    uint32_t* Ball = buckets.as<uint32_t>();
+    uint32_t* Ssuf = Ball + G * nbuckets * Wd;
     auto scan_u32 = [&](uint32_t* out, uint32_t* out2, const uint32_t* in) -> int {
         VMN_TRY(launch_light(ctx, "expprod_sort", k_u32_blocksum, (unsigned)scan_blocks, bsum, in, nbuckets));
         hipLaunchKernelGGL(k_u32_scan_top, dim3(1), dim3(64), 0, ctx->stream, bsum, scan_blocks, misc);
@@ -2919,14 +2924,18 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         cnt_out = (cnt_out == cntA) ? cntB : cntA;
         off_out = (off_out == offA) ? offB : offA;
     }
+    uint32_t* B = Ball + (arr % G) * nbuckets * Wd;
     VMN_TRY(launch_light(ctx, "expprod_agg", k_bucket_finalize, light_grid(ctx, nbuckets * (Wd / 4)),
                          reinterpret_cast<uint4*>(B), reinterpret_cast<const uint4*>(items_in), off_in, cnt_in,
                          nbuckets, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
-    // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce
-    VMN_TRY(scan_affine(ctx, m, B, nullptr, (size_t)nwin * nb, nb, 1, Ssuf));
-    VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for((size_t)nwin * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
-                         nb, (size_t)nwin, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
-    VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, nwin, true, wres.as<uint32_t>() + arr * (size_t)nwin * Wd));
+    if (arr % G == G - 1 || arr + 1 == k) {
+        // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce -- for the group
+        const size_t gsz = arr % G + 1, first_arr = arr + 1 - gsz, segs = gsz * (size_t)nwin;
+        VMN_TRY(scan_affine(ctx, m, Ball, nullptr, segs * nb, nb, 1, Ssuf));
+        VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for(segs * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
+                             nb, segs, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
+        VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, segs, true, wres.as<uint32_t>() + first_arr * (size_t)nwin * Wd));
+    }
     }
     // Horner over the windows, once for all k arrays: the chain of c * nwin doublings / squarings is sequential
     // (one lane per array on the GPU for curves; on the host for modular groups), so it is done for the k arrays
