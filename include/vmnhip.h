@@ -101,7 +101,9 @@ size_t vmn_group_table_bytes(const vmn_group* grp);
 /* ---- groups -------------------------------------------------------------------------------
  * ModPGroup(p, q, g): ref: P/elgamal/ProtocolElGamal.java:738-800 (group shapes), the marshalled
  * example at demo/mixnet/benchmarks/bench_config:43.  p, q, g are big-endian, nbytes each.
- * Supported modulus sizes: 512, 1024, 2048, 3072, 4096 bits (nbytes*8 rounded up to those). */
+ * Supported modulus sizes: 512, 1024, 2048, 3072, 4096 bits, and -- for completeness, untuned (the reference offers safe
+ * primes up to 15 424 bits and benchmarks with a 15 492-bit group) -- 8192 and 16384 bits (a modulus runs in the smallest
+ * size that holds it). */
 int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const uint8_t* q_be, const uint8_t* g_be,
                           size_t nbytes, vmn_group** out);
 /* ECqPGroup over a named NIST curve ("P-256", "P-384"; a = -3).  ref: the default group of the

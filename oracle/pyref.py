@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 #     p = 2^n - 2^(n-64) - 1 + 2^64 * (floor(2^(n-130) * pi) + c).
 # 4 = 2^2 generates the order-q subgroup.  BASELINE.json's configs name the 2048-bit ("group 14")
 # and 3072-bit ("group 15") moduli.
-_RFC_MODP_C = {768: 149686, 1024: 129093, 1536: 741804, 2048: 124476, 3072: 1690314, 4096: 240904}
+_RFC_MODP_C = {768: 149686, 1024: 129093, 1536: 741804, 2048: 124476, 3072: 1690314, 4096: 240904, 6144: 929484, 8192: 4743158}
 
 RFC3526_14_HEX = (
     "FFFFFFFFFFFFFFFFC90FDAA22168C234C4C6628B80DC1CD129024E088A67CC74020BBEA63B139B22514A08798E3404DD"
@@ -46,7 +46,7 @@ def _pi_scaled(bits: int) -> int:
 
 
 def rfc_modp_prime(bits: int) -> int:
-    """The RFC 2409 / RFC 3526 safe prime of the given size (768 ... 4096)."""
+    """The RFC 2409 / RFC 3526 safe prime of the given size (768 ... 8192)."""
     c = _RFC_MODP_C[bits]
     return (1 << bits) - (1 << (bits - 64)) - 1 + (1 << 64) * ((_pi_scaled(bits - 130)) + c)
 

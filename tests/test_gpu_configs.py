@@ -172,6 +172,18 @@ def test_config0_size_10000_ciphertexts_2048bit(vmn, gpu_ctx, mods, oracle_for):
     check_pos("native", mods, G, K, g, h, pkey, w, t, (256, 256, 100))
 
 
+def test_proof_of_shuffle_over_rfc3526_group_18(vmn, gpu_ctx, mods, oracle_for):
+    """Above north_star's range but inside the reference's (safe primes up to 15 424 bits): a whole PoS transcript over
+    the 8192-bit group (eight lanes per element; single elements on 128 host limbs) against the C + GMP oracle."""
+    from oracle import pyref
+    from oracle.cbind import GmpAdapter
+    p, q, g = pyref.modp_group(8192)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    K = GmpAdapter(oracle_for(p, q))
+    h, pkey, w, t = make_instance(K, g, 14, 1, b"rfc18")
+    check_pos("native", mods, G, K, g, h, pkey, w, t, (256, 256, 100))
+
+
 class WideEpsilonTape(Tape):
     """A prover whose epsilon is uniform in Z_q instead of n_e + n_v + n_r bits: its proofs are still valid (the
     verification equations hold for every epsilon), and its k_E fills the whole field."""

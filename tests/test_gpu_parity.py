@@ -390,3 +390,46 @@ def test_subgroup_membership_by_jacobi_symbol(bits, groups):
         tampered = list(members)
         tampered[pos] = tampered[pos] * nonres % p
         assert not G.toElementArray(tampered).isMember(), pos
+
+
+@pytest.mark.parametrize("bits", [6144, 8192])
+def test_rfc3526_groups_17_and_18(bits, vmn, gpu_ctx, oracle_for):
+    """Moduli above 4096 bits (eight lanes per element): the RFC 3526 groups of 6144 and 8192 bits, array operations against
+    the GMP oracle (CPython's pow takes 0.6 s per 8192-bit power), membership by the multi-lane Jacobi kernel."""
+    p, q, g = pyref.modp_group(bits)
+    orc = oracle_for(p, q)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    n = 24
+    es = pyref.stream_ints(b"rfc%d/e" % bits, n, q)
+    fs = pyref.stream_ints(b"rfc%d/f" % bits, n, 1 << 613)
+    X = G.exp(g, G.ringArray(es))
+    xs = orc.exp_fixed(g, es)
+    assert X.toInts() == xs and X.isMember()
+    assert X.exp(G.ringArray(es[::-1])).toInts() == orc.exp_array(xs, es[::-1])
+    assert X.exp(fs[0]).toInts() == orc.exp_scalar(xs, fs[0])
+    assert X.mul(G.toElementArray(xs[::-1])).toInts() == orc.mul(xs, xs[::-1])
+    assert X.expProd(G.ringArray(fs)) == orc.exp_prod(xs, fs, pippenger_c=6)
+    assert X.expProd(G.ringArray(es)) == orc.exp_prod(xs, es, pippenger_c=6)
+    assert X.prod() == orc.prod(xs)
+    E, F = G.ringArray(es), G.ringArray(fs)
+    x, d = E.recLin(F)
+    want, last = pyref.rec_lin(es, fs, q)
+    assert x.toInts() == want and d == last
+    assert F.prods().toInts() == pyref.prods(fs, q)
+    assert not G.toElementArray([xs[0], p - 1, xs[1]]).isMember()
+    assert G.toElementArrayFromByteTree(X.toByteTree()).toInts() == xs
+
+
+@pytest.mark.parametrize("bits", [8192, 16384])
+def test_worst_case_column_magnitudes_above_4096_bits(bits, vmn, gpu_ctx, oracle_for):
+    """The reliefs of the 8- and 16-lane products (every 74 rows; every two shares in a squaring): all-ones modulus and operands."""
+    N = (1 << bits) - 1
+    orc = oracle_for(N, N)
+    G = vmn.ModPGroup(gpu_ctx, N, N, 3, nbytes=bits // 8)
+    vals = [N - 1, N - 2, (1 << (bits - 1)) - 1, N >> 1, (N // 3) | 1, 1, 2, N - (1 << 28)] + [v | 1 for v in pyref.stream_ints(b"worst%d" % bits, 4, N)]
+    X = G.toElementArray(vals)
+    assert X.mul(G.toElementArray(vals[::-1])).toInts() == [a * b % N for a, b in zip(vals, vals[::-1])]
+    assert X.mul(X).toInts() == [a * a % N for a in vals]
+    es = [N - 1, N - 2, (1 << bits) - (1 << 64) - 1, 1, 0, 2, 3, (1 << (bits - 1)) + 1] + pyref.stream_ints(b"worst-e%d" % bits, 4, N)
+    assert X.exp(G.ringArray(es)).toInts() == orc.exp_array(vals, es)
+    assert G.exp(N - 1, G.ringArray(es)).toInts() == orc.exp_fixed(N - 1, es)

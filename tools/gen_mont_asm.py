@@ -170,6 +170,7 @@ def _row_pair(L: int, first: bool, lanes: int = 2, j0: int = 0, blk: int = 0):
     # lanes = 8 (the widest geometry, small arrays of 2048-bit elements): the element is half a DPP row of 16 lanes.  m comes
     # from lane 0 in two steps (quad broadcast, then the upper quad copies the lower one: row_shr:4 into banks 1 and 3), c from
     # the lane above by row_shl:1 (the last lane of an element reads its neighbour's lane 0: masked by NOTTOP as before).
+    # lanes = 16 (moduli above 8192 bits): a whole DPP row; one more broadcast step (row_shr:8 into banks 2 and 3).
     bcast = "[0,0,2,2]" if lanes == 2 else "[0,0,0,0]"
     from_above = "quad_perm:[1,1,3,3]" if lanes == 2 else "quad_perm:[1,2,3,3]" if lanes == 4 else "row_shl:1"
     C = f"%{L + 1}"
@@ -198,6 +199,11 @@ def _row_pair(L: int, first: bool, lanes: int = 2, j0: int = 0, blk: int = 0):
     if lanes == 8:
         out.append("s_nop 1")
         out.append(f"v_mov_b32_dpp {M}, {M} row_shr:4 row_mask:0xf bank_mask:0xa")
+    if lanes == 16:
+        out.append("s_nop 1")
+        out.append(f"v_mov_b32_dpp {M}, {M} row_shr:4 row_mask:0xf bank_mask:0x2")
+        out.append("s_nop 1")
+        out.append(f"v_mov_b32_dpp {M}, {M} row_shr:8 row_mask:0xf bank_mask:0xc")
     ab(5)
     ab(6)
     out.append(f"v_mad_u64_u32 {C}, vcc, {M}, {N(0)}, {P(0)}")
@@ -307,7 +313,7 @@ def gen_pair(S: int, lanes: int = 2) -> str:
     return "\n".join(parts)
 
 
-def render(sizes, pair_sizes=(), quad_sizes=(), octo_sizes=()) -> str:
+def render(sizes, pair_sizes=(), quad_sizes=(), octo_sizes=(), hexa_sizes=()) -> str:
     parts = ["// GENERATED by tools/gen_mont_asm.py " + " ".join(map(str, sizes)) + " -- do not edit.",
              "// One Montgomery row as a single asm statement: 2*S v_mad_u64_u32 + 5 VALU, see the generator."]
     for S in sizes:
@@ -324,6 +330,10 @@ def render(sizes, pair_sizes=(), quad_sizes=(), octo_sizes=()) -> str:
         parts.append(f"// eight lanes per element, S = {S} columns ({S // 8} per lane)")
         parts.append(gen_pair(S, 8))
         parts.append(gen_pair_sqr(S, 8))
+    for S in hexa_sizes:
+        parts.append(f"// sixteen lanes per element, S = {S} columns ({S // 16} per lane)")
+        parts.append(gen_pair(S, 16))
+        parts.append(gen_pair_sqr(S, 16))
     return "\n".join(parts) + "\n"
 
 
@@ -332,8 +342,9 @@ def main():
     pair = [int(x[1:]) for x in args if x.startswith("p")]
     quad = [int(x[1:]) for x in args if x.startswith("q")]
     octo = [int(x[1:]) for x in args if x.startswith("o")]
+    hexa = [int(x[1:]) for x in args if x.startswith("h")]
     sizes = [int(x) for x in args if x[0].isdigit()] or [74]
-    sys.stdout.write(render(sizes, pair, quad, octo))
+    sys.stdout.write(render(sizes, pair, quad, octo, hexa))
 
 
 if __name__ == "__main__":

@@ -56,3 +56,5 @@
 #define VMN_UNIT_2048_WIDE(KW) VMN_MODP_INSTANCES(KW, 76, 64, 4) VMN_MODP_INSTANCES(KW, 80, 64, 8)
 #define VMN_UNIT_3072(KW) VMN_MODP_INSTANCES(KW, 110, 96, 2) VMN_MODP_INSTANCES(KW, 112, 96, 4) VMN_MEMBER_INSTANCE_LANES(KW, 110, 2)
 #define VMN_UNIT_4096(KW) VMN_MODP_INSTANCES(KW, 148, 128, 4) VMN_MEMBER_INSTANCE_LANES(KW, 148, 4)
+#define VMN_UNIT_8192(KW) VMN_MODP_INSTANCES(KW, 296, 256, 8) VMN_MEMBER_INSTANCE_LANES(KW, 296, 8)
+#define VMN_UNIT_16384(KW) VMN_MODP_INSTANCES(KW, 592, 512, 16) VMN_MEMBER_INSTANCE_LANES(KW, 592, 16)

@@ -16,6 +16,9 @@
 //   LPE = 4  four lanes per element (4096-bit moduli, S = 148, L = 37: two lanes would need 4*74 = 296
 //            VGPRs).  Same scheme inside a quad of lanes (quad_perm DPP); carries / borrows cross the
 //            three lane boundaries by repeated sweeps.
+//   LPE = 8 / 16  moduli up to 8192 / 16384 bits (S = 296 / 592, L = 37): half a DPP row resp. a whole one (row shifts
+//            with bank masks); the same kernels, the columns relieved every 74 rows.  Built for completeness -- the
+//            reference offers safe primes up to 15 424 bits and benchmarks with a 15 492-bit group -- not tuned.
 #pragma once
 #include "mont28.h"
 
@@ -86,12 +89,17 @@ __device__ __forceinline__ u32 from_below(u32 x) { return lane_below<LPE>(x); }
 // lower quads <- upper quads (row_shl:4 into banks 0, 2) resp. upper <- lower (row_shr:4 into banks 1, 3); other lanes keep old
 __device__ __forceinline__ u32 quad_from_upper(u32 old, u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)old, (int)x, 0x104, 0xf, 0x5, false); }
 __device__ __forceinline__ u32 quad_from_lower(u32 old, u32 x) { return (u32)__builtin_amdgcn_update_dpp((int)old, (int)x, 0x114, 0xf, 0xA, false); }
+// (sixteen lanes per element = a whole DPP row: one more step of each kind)
 template <int LPE>
 __device__ __forceinline__ u32 from_top(u32 x) {
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
     else {
         u32 t = (u32)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);                        // [3,3,3,3]
         if constexpr (LPE == 8) t = quad_from_upper(t, t);
+        if constexpr (LPE == 16) {
+            t = (u32)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x104, 0xf, 0x4, false);           // lanes 8-11 <- 12-15 (row_shl:4, bank 2)
+            t = (u32)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x108, 0xf, 0x3, false);           // lanes 0-7 <- 8-15 (row_shl:8, banks 0, 1)
+        }
         return t;
     }
 }
@@ -100,7 +108,7 @@ template <int LPE>
 __device__ __forceinline__ u32 from_above(u32 x) {
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true);     // [1,1,3,3]
     else if constexpr (LPE == 4) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xF9, 0xf, 0xf, true);   // [1,2,3,3]
-    else return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);                 // row_shl:1
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);                 // row_shl:1 (8 or 16 lanes)
 }
 template <int LPE>
 __device__ __forceinline__ u32 from_lane0(u32 x) {
@@ -108,6 +116,10 @@ __device__ __forceinline__ u32 from_lane0(u32 x) {
     else {
         u32 t = (u32)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);                        // [0,0,0,0]
         if constexpr (LPE == 8) t = quad_from_lower(t, t);
+        if constexpr (LPE == 16) {
+            t = (u32)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x114, 0xf, 0x2, false);           // lanes 4-7 <- 0-3 (row_shr:4, bank 1)
+            t = (u32)__builtin_amdgcn_update_dpp((int)t, (int)t, 0x118, 0xf, 0xC, false);           // lanes 8-15 <- 0-7 (row_shr:8, banks 2, 3)
+        }
         return t;
     }
 }
@@ -116,6 +128,10 @@ __device__ __forceinline__ u32 or_all(u32 x) {
     x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);                               // [1,0,3,2]
     if constexpr (LPE >= 4) x |= (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);       // [2,3,0,1]
     if constexpr (LPE == 8) x |= quad_from_upper(0u, x) | quad_from_lower(0u, x);
+    if constexpr (LPE == 16) {
+        x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false);                   // row_ror:4
+        x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);                   // row_ror:8
+    }
     return x;
 }
 

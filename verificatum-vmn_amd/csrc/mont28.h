@@ -112,10 +112,10 @@ __device__ __forceinline__ void mont_sqr_columns(u64 (&T)[S], const u32 (&a)[S],
 // lane or zero -- masked by the caller like the quad forms.)
 template <int LPE>
 __device__ __forceinline__ u32 lane_below(u32 x) {
-    static_assert(LPE == 2 || LPE == 4 || LPE == 8, "lanes per element");
+    static_assert(LPE == 2 || LPE == 4 || LPE == 8 || LPE == 16, "lanes per element");
     if constexpr (LPE == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true);     // quad_perm [0,0,2,2]
     else if constexpr (LPE == 4) return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x90, 0xf, 0xf, true);   // quad_perm [0,0,1,2]
-    else return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);                 // row_shr:1
+    else return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);                 // row_shr:1 (8 or 16 lanes)
 }
 
 // Multi-lane product: each lane holds L of the S = LPE*L columns; b_lds streams all S limbs of the multiplier
@@ -139,28 +139,36 @@ __device__ __forceinline__ void relieve_columns(u64 (&T)[L], u32 lowmask, u32 no
 }
 // ROWS <= S = LPE * L is the number of reduction rows (R = 2^(28 ROWS)): the limbs of the multiplier above ROWS are zero
 // (the wide geometries of modp_kernels.h), their rows are not run.
+// A column collects two products < 2^56 per row: beyond 128 rows (S = 148 and the 8- / 16-lane geometries of the moduli
+// above 4096 bits) the columns are relieved every RELIEF_STEP = 74 rows.
+constexpr int RELIEF_STEP = 74;
 template <int L, int LPE, int ROWS = LPE * L>
 __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&a)[L], const u32* b_lds, int bstride,
                                                        const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask) {
     constexpr int S = ROWS;
-    constexpr int HALF = 2 * S > 256 ? S / 2 : S;       // rows before the relief (S: none)
-    static_assert(S <= 256 && ROWS <= LPE * L, "one relief is not enough beyond 256 limbs");
+    constexpr bool RELIEVE = 2 * S > 256;
+    static_assert(ROWS <= LPE * L, "rows beyond the columns");
     u32 bi = b_lds[0];
     u32 bn = b_lds[bstride];
     mont_lanes_row_asm_first<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
+    if constexpr (!RELIEVE) {
 #pragma unroll 2
-    for (int i = 2; i <= HALF; ++i) {
-        bi = bn;
-        bn = b_lds[(i < S ? i : 0) * bstride];
-        mont_lanes_row_asm_next<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
-    }
-    if constexpr (HALF < S) {
-        relieve_columns<L, LPE>(T, lowmask, nottopmask);
-#pragma unroll 2
-        for (int i = HALF + 1; i <= S; ++i) {
+        for (int i = 2; i <= S; ++i) {
             bi = bn;
             bn = b_lds[(i < S ? i : 0) * bstride];
             mont_lanes_row_asm_next<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
+        }
+    } else {
+#pragma unroll 1
+        for (int base = 1; base < S; base += RELIEF_STEP) {             // rows base+1 .. min(base + STEP, S), then a relief
+            const int end = base + RELIEF_STEP < S ? base + RELIEF_STEP : S;
+#pragma unroll 2
+            for (int i = base + 1; i <= end; ++i) {
+                bi = bn;
+                bn = b_lds[(i < S ? i : 0) * bstride];
+                mont_lanes_row_asm_next<L, LPE>(T, a, bi, n, n0inv, lowmask, nottopmask);
+            }
+            if (end < S) relieve_columns<L, LPE>(T, lowmask, nottopmask);
         }
     }
 }
@@ -187,14 +195,14 @@ template <int L, int LPE, int ROWS = LPE * L>
 __device__ __forceinline__ void mont_sqr_columns_lanes(u64 (&T)[L], const u32 (&a)[L], const u32* a_lds, int bstride,
                                                        const u32 (&n)[L], u32 n0inv, u32 lowmask, u32 nottopmask) {
     constexpr int LAST = ROWS - (LPE - 1) * L;          // rows of the last share
-    static_assert(ROWS <= 256 && LAST >= 1 && LAST <= L, "one relief is not enough beyond 256 limbs");
+    static_assert(LAST >= 1 && LAST <= L && (2 * ROWS <= 256 || 2 * L <= 85), "two shares of doubled products between reliefs must fit 64 bits");
     u32 b0 = a_lds[0];
     u32 bn = a_lds[bstride];
     mont_lanes_sqr_row_asm_first<L, LPE>(T, a, b0, b0 << 1, n, n0inv, lowmask, nottopmask);
 #pragma unroll 1
     for (int u = 0; u < LPE - (LAST < L ? 1 : 0); ++u) {
-        if constexpr (2 * ROWS > 256) {
-            if (u == LPE / 2) relieve_columns<L, LPE>(T, lowmask, nottopmask);      // half way, as in the general product
+        if constexpr (2 * ROWS > 256) {                 // doubled products: at most 85 rows between reliefs = two shares of L <= 42
+            if (u > 0 && u % 2 == 0) relieve_columns<L, LPE>(T, lowmask, nottopmask);
         }
         mont_sqr_lanes_share<L, LPE, ROWS, L, 0>(T, a, a_lds, bstride, n, n0inv, lowmask, nottopmask, bn, u * L, u == 0 ? 1 : 0);
     }

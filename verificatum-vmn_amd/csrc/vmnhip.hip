@@ -26,6 +26,8 @@ VMN_UNIT_2048(extern template)
 VMN_UNIT_2048_WIDE(extern template)
 VMN_UNIT_3072(extern template)
 VMN_UNIT_4096(extern template)
+VMN_UNIT_8192(extern template)
+VMN_UNIT_16384(extern template)
 
 using namespace vmn;
 using vmn::hostbig::Big;
@@ -63,14 +65,17 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 // X(76, 64, 4) and X(112, 96, 4) are the WIDE geometries of 2048- and 3072-bit moduli (modp_kernels.h, struct Cfg): the rows
 // of X(74, 64, 1) resp. X(110, 96, 2) worked on by four lanes each; launches over few elements are routed there (geom() below).
 // X(80, 64, 8): the widest geometry of 2048-bit moduli (eight lanes per element) for the smallest arrays.
-#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(80, 64, 8) X(110, 96, 2) X(112, 96, 4) X(148, 128, 4)
+// X(296, 256, 8), X(592, 512, 16): moduli up to 8192 / 16384 bits (the reference offers safe primes up to 15 424 bits,
+// demo/mixnet/.conf:189-195, and benchmarks with a 15 492-bit group, benchmarks/bench_config:43): eight / sixteen lanes per
+// element, the same kernels; built for completeness, outside north_star's 2048-4096 range and not tuned.
+#define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(80, 64, 8) X(110, 96, 2) X(112, 96, 4) X(148, 128, 4) X(296, 256, 8) X(592, 512, 16)
 // elliptic curves: X(field limbs, packed words)
 // (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
 #define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
 
 static bool size_for_bits(int nbits, int* S, int* NW, int* LPE) {
     const int sizes[][4] = {{256, 10, 8, 1}, {384, 14, 12, 1}, {512, 19, 16, 1}, {1024, 37, 32, 1}, {2048, 74, 64, 1},
-                            {3072, 110, 96, 2}, {4096, 148, 128, 4}};
+                            {3072, 110, 96, 2}, {4096, 148, 128, 4}, {8192, 296, 256, 8}, {16384, 592, 512, 16}};
     for (auto& s : sizes) {
         if (nbits <= s[0]) {
             *S = s[1];
@@ -661,7 +666,7 @@ extern "C" int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const ui
     int nbits = hostbig::bit_length(pw);
     int S, NW, LPE;
     if (!size_for_bits(nbits, &S, &NW, &LPE)) {
-        set_error("vmn_modp_group_create: %d-bit modulus not supported (max 4096)", nbits);
+        set_error("vmn_modp_group_create: %d-bit modulus not supported (max 16384)", nbits);
         return VMN_ERR_UNSUPPORTED;
     }
     std::unique_ptr<vmn_group> g(new vmn_group());
