@@ -418,6 +418,7 @@ def mix_prove_e2e(entry, vmn, ctx, grp, n: int, seed: int, sync):
     th.start()
     ver.computeAF()                                                 # beside the challenge hash (PoSTW.java:231-233)
     ver.setCommitment(com_in)
+    ver.verifyPrepare(rep_in)                                       # the reply side of verify(): needs no challenge (vmn_pos_verify_prepare)
     th.join()
     ver.setChallenge(box["v"])
     ok = ver.verify(rep_in)

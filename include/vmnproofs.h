@@ -163,6 +163,12 @@ int vmn_pos_reply(vmn_pos* p, const uint8_t* v_be, size_t vbytes, vmn_msg** repl
 int vmn_pos_compute_af(vmn_pos* p);                               /* :407-410 */
 int vmn_pos_set_commitment(vmn_pos* p, const vmn_msg* commitment);/* :780-823 (parsed form) */
 int vmn_pos_set_challenge(vmn_pos* p, const uint8_t* v_be, size_t vbytes);            /* :840-847 */
+/* The part of verify() that needs the reply but not the challenge -- the right side of check (B), the multi-exponentiations
+ * with k_E, g^{k_A}, g^{k_C}, g^{k_D}, pk^{-k_F}: four fifths of the verifier's work -- so that it can run while the
+ * challenge is still being derived (the verifier hashes the whole commitment for it; the reply is published long
+ * before).  Needs computeAF and setCommitment.  Optional: verify() does this part itself when it was not called for the
+ * same reply. */
+int vmn_pos_verify_prepare(vmn_pos* p, const vmn_msg* reply);
 /* :1000-1066; all five checks are evaluated; verdicts5 (may be NULL) = A, B, C, D, F */
 int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts5);
 

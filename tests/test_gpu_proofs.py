@@ -366,3 +366,47 @@ def test_interactive_independent_generators(vmn, gpu_ctx, mods, hv):
     assert all(over.verify(l, v) for l in range(1, thr + 1)) and over.verify_combined(v)
     ver.setReply(2, (over.k_a[2] + 1) % q)
     assert not ver.verify(2) and not ver.verify() and ver.verify(1)
+
+
+def test_verify_prepare_is_the_reply_side_of_verify(vmn, gpu_ctx, mods):
+    """vmn_pos_verify_prepare: the part of verify() that needs no challenge, run ahead (while the challenge is hashed);
+    the verdicts are those of verify() alone, and a verifier prepared for one reply recomputes for another."""
+    hv = mods["native"]
+    NV, NE, NR = 256, 256, 100
+    bits, n, width = 2048, 40, 1
+    p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"prep")
+    pi, s, e, v = t.permutation(n), [t.ring_array(n)], t.int_array(n, NE), t.int_array(1, NV)[0]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H, W, S = G.toElementArray(h), [G.toElementArray(c) for c in w], [G.ringArray(c) for c in s]
+    pr = hv.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prep-prover", q))
+    pr.precompute(g, H, pi)
+    WP = hv.reencrypt_native(G, pkey, W, S, pi)
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com = pr.commit()
+    rep = pr.reply(v)
+
+    def verifier():
+        ver = hv.PoSBasicTW(G, NV, NE, NR)
+        ver.precompute(g, H)
+        ver.setPermutationCommitment(pr.u)
+        ver.setInstance(pkey, W, WP)
+        ver.setBatchVector(e)
+        ver.computeAF()
+        ver.setCommitment(com.native)
+        return ver
+    plain = verifier()
+    plain.setChallenge(v)
+    assert plain.verify(rep.native) and plain.verdicts == (True,) * 5
+    ver = verifier()
+    ver.verifyPrepare(rep.native)                      # before the challenge is known
+    ver.setChallenge(v)
+    assert ver.verify(rep.native) and ver.verdicts == (True,) * 5
+    ver.verifyPrepare(rep.native)
+    bad = dict(rep)
+    bad["k_F"] = [(x + 1) % q for x in rep["k_F"]]
+    assert not ver.verify(bad) and ver.verdicts == (True, True, True, True, False)      # another reply: recomputed, not reused
+    assert ver.verify(rep.native)
+    ver.setChallenge((v + 1) % (1 << NV))              # the prepared part does not depend on the challenge; the verdict does
+    ver.verifyPrepare(rep.native)
+    assert not ver.verify(rep.native)

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <future>
 #include <memory>
 #include <string>
@@ -296,6 +297,11 @@ struct vmn_msg {
     };
     std::vector<Item> items;
     bool ec = false;                   // group elements are curve points: an element is node(leaf(x), leaf(y)) on the wire
+    uint64_t serial = next_serial();   // distinguishes a message from an earlier one that lived at the same address
+    static uint64_t next_serial() {
+        static std::atomic<uint64_t> counter{1};
+        return counter.fetch_add(1);
+    }
     vmn_msg() {}
     explicit vmn_msg(bool ec_) : ec(ec_) {}
     ~vmn_msg() {
@@ -715,15 +721,23 @@ struct ProofBase {
     int bridging_sides(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
                        const vmn_rarray* k_E, int kE_bits, GA& left, GA& right) {
         VMN_TRACE("proof:bridging_sides");
-        GA B_exp_v, g_exp_k_B, B_shift, B_shift_exp_k_E;
+        TRY(bridging_left(B, Bp, left));
+        return bridging_right(g, prev, B, k_B, k_E, kE_bits, right);
+    }
+    // left side B_i^v B'_i: needs the challenge
+    int bridging_left(const vmn_garray* B, const vmn_garray* Bp, GA& left) {
+        GA B_exp_v;
         TRY(vmn_garray_exp_scalar(B, v_be.data(), v_be.size(), B_exp_v.out()));
-        TRY(vmn_garray_mul(B_exp_v, Bp, left.out()));
-        B_exp_v.reset();
+        return vmn_garray_mul(B_exp_v, Bp, left.out());
+    }
+    // right side g^{k_B,i} B_{i-1}^{k_E,i}: needs the reply only, not the challenge
+    int bridging_right(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_rarray* k_B, const vmn_rarray* k_E, int kE_bits,
+                       GA& right) {
+        GA g_exp_k_B, B_shift, B_shift_exp_k_E;
         TRY(vmn_group_exp_fixed(G.grp, g.data(), k_B, g_exp_k_B.out()));
         TRY(vmn_garray_shift_push(B, prev.data(), B_shift.out()));
         TRY(vmn_garray_exp_array(B_shift, k_E, kE_bits, B_shift_exp_k_E.out()));
-        TRY(vmn_garray_mul(g_exp_k_B, B_shift_exp_k_E, right.out()));
-        return VMN_OK;
+        return vmn_garray_mul(g_exp_k_B, B_shift_exp_k_E, right.out());
     }
     // the last B of the whole proof and the element in front of this shard's B, from every rank's last local B
     void pick_B(const std::vector<Bytes>& lasts, const Bytes& h0, Bytes& Blast, Bytes& prev) const {
@@ -1000,29 +1014,45 @@ struct vmn_pos : ProofBase {
         }
         return VMN_OK;
     }
-    int verify(const vmn_msg* rep, int* verdict, int* five) {
-        VMN_TRACE("pos:verify");
-        REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
+    // ---- verification in two parts.  Everything that needs the REPLY but not the CHALLENGE -- the right side of check (B)
+    // with its 613-bit per-element powers, the multi-exponentiations with k_E, the products over u, h, e, g^{k_A}, g^{k_C},
+    // g^{k_D}, pk^{-k_F}: four fifths of the verifier's GPU time -- can run while the challenge is still being derived (the
+    // verifier hashes 0.5 GB of commitment for it; the reply is on the bulletin board long before that is done).
+    // vmn_pos_verify_prepare(reply) does that part and keeps the results; verify() does it itself when it was not called.
+    struct Prepared {
+        const vmn_msg* rep = nullptr;
+        uint64_t serial = 0;
+        Bytes gkA, gkC, gkD, C, D;
+        std::vector<Bytes> kE_prods, pkpow;
+        GA right;
+        void clear() {
+            rep = nullptr;
+            serial = 0;
+            right.reset();
+            kE_prods.clear();
+            pkpow.clear();
+        }
+    } prep;
+    int verify_prepare(const vmn_msg* rep) {
+        VMN_TRACE("pos:verify_prepare");
+        REQUIRE(cB && !A.empty(), "verify_prepare needs computeAF and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
                             *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
                             *ikE = item_of(rep, 4, VMN_ITEM_RARRAY), *ikF = item_of(rep, 5, VMN_ITEM_RING);
         REQUIRE(rep && rep->items.size() == 6 && ikA && ikB && ikC && ikD && ikE && ikF, "reply is not (k_A, k_B, k_C, k_D, k_E, k_F)");
         REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikF->count == width && ikA->width == G.xb,
                 "reply items have the wrong shape");
+        prep.clear();
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
         std::vector<Num> k_F;
         for (auto& bts : split(*ikF)) k_F.push_back(G.ring_from(bts.data()));
-        // the exponentiations of single elements whose operands are here already run beside everything below
-        Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), C, D, t_h0, lhsA, lhsC, lhsD, gkA, gkC, gkD, rhs, Blast, prev;
-        std::vector<Bytes> kE_prods, pkpow, lhsF(2 * width), rF;
+        Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), t_h0, Blast, prev;
         Num eprod;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });              // (A) :1016-1021
-        jobs.start([&] { return gexp(g, k_A, gkA); });
-        jobs.start([&] { return gexp(g, k_C, gkC); });                            // (C) :1045-1048
-        jobs.start([&] { return gexp(g, k_D, gkD); });                            // (D) :1051-1054
-        pk_powers(jobs, pkey, k_F, pkpow);                                        // (F) :1057-1063
-        for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsF] { return G.el_expmul(F[c], v_be, cFp[c], lhsF[c]); });
+        jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // (A) :1016-1021
+        jobs.start([&] { return gexp(g, k_C, prep.gkC); });                       // (C) :1045-1048
+        jobs.start([&] { return gexp(g, k_D, prep.gkD); });                       // (D) :1051-1054
+        pk_powers(jobs, pkey, k_F, prep.pkpow);                                   // (F) :1057-1063
         // scalars that come back from the GPU (each blocks on the stream) ...
         TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
         TRY(vmn_garray_prod(h, hprod.data()));
@@ -1033,40 +1063,56 @@ struct vmn_pos : ProofBase {
         xs.insert(xs.end(), wp.begin(), wp.end());
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
-        TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));                       // :1021, :1063 — one sort of k_E
+        TRY(expprod_multi(xs, ikE->ra, kE_bits, prep.kE_prods));                  // :1021, :1063 — one sort of k_E
         // ... completed over the ranks in ONE exchange ...
         std::vector<Bytes> lasts;
         Round rd(*this);
         rd.product(uprod);
         rd.product(hprod);
-        rd.products(kE_prods);
+        rd.products(prep.kE_prods);
         rd.ring_product(eprod);
         rd.collect(mylast, lasts);
         TRY(rd.run());
         pick_B(lasts, h0, Blast, prev);
-        // ... the exponentiations that needed them ...
-        TRY(G.el_div(uprod, hprod, C));
-        jobs.start([&] { return G.el_expmul(C, v_be, cCp, lhsC); });
+        TRY(G.el_div(uprod, hprod, prep.C));
         jobs.start([&] {
             TRY(G.el_exp(h0, eprod, t_h0));
-            TRY(G.el_div(Blast, t_h0, D));
-            return G.el_expmul(D, v_be, cDp, lhsD);
+            return G.el_div(Blast, t_h0, prep.D);
         });
-        // ... then the element-wise work of check (B) is queued ...
-        GA left, right;
-        TRY(bridging_sides(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // :1023-1042
-        // ... and the single-element checks are compared while the GPU works
+        // ... then the reply side of check (B) is queued :1030-1033
+        TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
         TRY(jobs.join());
-        TRY(G.el_mul(gkA, kE_prods[0], rhs));
+        prep.rep = rep;
+        prep.serial = rep->serial;
+        return VMN_OK;
+    }
+    int verify(const vmn_msg* rep, int* verdict, int* five) {
+        VMN_TRACE("pos:verify");
+        REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
+        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep));
+        Bytes lhsA, lhsC, lhsD, rhs;
+        std::vector<Bytes> lhsF(2 * width), rF;
+        GA left;
+        int vB = 0;
+        {
+            HostJobs jobs;                                                        // the challenge side: four short powers
+            jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });          // (A) :1016-1021
+            jobs.start([&] { return G.el_expmul(prep.C, v_be, cCp, lhsC); });     // (C)
+            jobs.start([&] { return G.el_expmul(prep.D, v_be, cDp, lhsD); });     // (D)
+            for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsF] { return G.el_expmul(F[c], v_be, cFp[c], lhsF[c]); });
+            TRY(bridging_left(cB, cBp, left));                                    // :1028-1029
+            TRY(vmn_garray_equals(left, prep.right, &vB));
+            TRY(jobs.join());
+        }
+        TRY(G.el_mul(prep.gkA, prep.kE_prods[0], rhs));
         const int vA = lhsA == rhs;
-        const int vC = lhsC == gkC;
-        const int vD = lhsD == gkD;
-        std::vector<Bytes> prods(kE_prods.begin() + 1, kE_prods.end());
-        TRY(pk_finish(pkpow, prods, rF));
+        const int vC = lhsC == prep.gkC;
+        const int vD = lhsD == prep.gkD;
+        std::vector<Bytes> prods(prep.kE_prods.begin() + 1, prep.kE_prods.end());
+        TRY(pk_finish(prep.pkpow, prods, rF));
         int vF = 1;
         for (size_t c = 0; c < 2 * width; ++c) vF = vF && lhsF[c] == rF[c];
-        int vB = 0;
-        TRY(vmn_garray_equals(left, right, &vB));
+        prep.clear();                                                             // the reply side is used once
         Round rv(*this);
         rv.all_true(vB);
         if (sharded) TRY(rv.run());
@@ -2190,6 +2236,10 @@ int vmn_pos_set_commitment(vmn_pos* p, const vmn_msg* commitment) {
 int vmn_pos_set_challenge(vmn_pos* p, const uint8_t* v_be, size_t vbytes) {
     NONNULL(p);
     return p->set_challenge(v_be, vbytes);
+}
+int vmn_pos_verify_prepare(vmn_pos* p, const vmn_msg* reply) {
+    NONNULL(p);
+    return p->verify_prepare(reply);
 }
 int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts5) {
     NONNULL(p);

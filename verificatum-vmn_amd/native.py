@@ -397,6 +397,11 @@ class PoSBasicTW(_NativeProof):
         self._com = msg if isinstance(msg, Message) else self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
         self._call("set_commitment", self._com._h)
 
+    def verifyPrepare(self, reply) -> None:
+        """``vmn_pos_verify_prepare``: the part of verify() that needs the reply but not the challenge (a Message only:
+        verify() recognises the same object)."""
+        self._call("verify_prepare", reply._h)
+
     def verify(self, reply) -> bool:
         m = reply if isinstance(reply, Message) else self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
         verdict = C.c_int(0)
