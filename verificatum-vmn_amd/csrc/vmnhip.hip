@@ -14,6 +14,7 @@
 #include "ec_kernels.h"
 #include "modp_kernels.h"
 #include "modp_instances.h"
+#include "ec_instances.h"
 #include "light_kernels.h"
 #include "vmnhip_internal.h"
 #include "sha256.h"
@@ -28,6 +29,8 @@ VMN_UNIT_3072(extern template)
 VMN_UNIT_4096(extern template)
 VMN_UNIT_8192(extern template)
 VMN_UNIT_16384(extern template)
+VMN_UNIT_P256(extern template)
+VMN_UNIT_P384(extern template)
 
 using namespace vmn;
 using vmn::hostbig::Big;
