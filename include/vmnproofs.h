@@ -187,6 +187,7 @@ int vmn_posc_commit(vmn_posc* p, vmn_msg** commitment);           /* :363-529 */
 int vmn_posc_reply(vmn_posc* p, const uint8_t* v_be, size_t vbytes, vmn_msg** reply);  /* :607-636 */
 int vmn_posc_set_commitment(vmn_posc* p, const vmn_msg* commitment);
 int vmn_posc_set_challenge(vmn_posc* p, const uint8_t* v_be, size_t vbytes);
+int vmn_posc_verify_prepare(vmn_posc* p, const vmn_msg* reply);                      /* the reply side of verify(), see vmn_pos_verify_prepare */
 int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict);                 /* :646-727 */
 
 /* ---- CCPoSBasicW -------------------------------------------------------------------------------------------- */
@@ -209,6 +210,9 @@ int vmn_ccpos_set_challenge(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes);
 /* computeAB :493-506; raisedu = u^rho selects the single-equation form (NULL = plain) */
 int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu);
 /* verify :519-584; raisedh / rho_be = NULL for the plain form */
+/* The reply side of verify() (here: ALL its array work, the multi-exponentiations with k_E); same raisedh / rho as the
+ * verify() that follows.  See vmn_pos_verify_prepare. */
+int vmn_ccpos_verify_prepare(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes);
 int vmn_ccpos_verify(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be,
                      size_t rho_bytes, int* verdict);
 

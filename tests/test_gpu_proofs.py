@@ -410,3 +410,47 @@ def test_verify_prepare_is_the_reply_side_of_verify(vmn, gpu_ctx, mods):
     ver.setChallenge((v + 1) % (1 << NV))              # the prepared part does not depend on the challenge; the verdict does
     ver.verifyPrepare(rep.native)
     assert not ver.verify(rep.native)
+
+
+@pytest.mark.parametrize("raised", [False, True])
+def test_verify_prepare_of_posc_and_ccpos(raised, vmn, gpu_ctx, mods):
+    """vmn_posc_verify_prepare / vmn_ccpos_verify_prepare: the same verdicts as verify() alone, honest and tampered."""
+    hv, mx = mods["native"], mods["mixnet"]
+    NV, NE, NR = 256, 256, 100
+    bits, n, width = 2048, 30, 2
+    p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"prep2")
+    pi, r, s = t.permutation(n), t.ring_array(n), [t.ring_array(n) for _ in range(width)]
+    e, v = t.int_array(n, NE), t.int_array(1, NV)[0]
+    rho = t.int_array(1, mx.RAISED_BITLENGTH)[0]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H, W, S, R = G.toElementArray(h), [G.toElementArray(c) for c in w], [G.ringArray(c) for c in s], G.ringArray(r)
+    U = G.toElementArray(P.permutation_commitment(g, h, r, pi, p))
+    WP = hv.reencrypt_native(G, pkey, W, S, pi)
+    # PoSC
+    pr = hv.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"prep2-posc", q))
+    pr.setInstance(g, H, U, R, pi)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    for tamper in (False, True):
+        ver = hv.PoSCBasicTW(G, NV, NE, NR)
+        ver.setInstance(g, H, U)
+        ver.setBatchVector(e)
+        ver.setCommitment(com.native)
+        ver.verifyPrepare(rep.native)
+        ver.setChallenge(v if not tamper else v ^ 1)
+        assert ver.verify(rep.native) is (not tamper)
+    # CCPoS, plain or raised
+    cp = hv.CCPoSBasicW(G, NV, NE, NR, rand=Tape(b"prep2-ccpos", q))
+    cp.setInstance(g, H, U, pkey, W, WP, R, pi, S)
+    cp.setBatchVector(e)
+    com2, rep2 = cp.commit(), cp.reply(v)
+    RU, RH = (U.exp(rho), H.exp(rho)) if raised else (None, None)
+    for tamper in (False, True):
+        cv = hv.CCPoSBasicW(G, NV, NE, NR)
+        cv.setInstance(g, H, U, pkey, W, WP)
+        cv.setBatchVector(e)
+        cv.setCommitment(com2.native)
+        cv.computeAB(RU)
+        cv.verifyPrepare(rep2.native, RH, rho if raised else None)
+        cv.setChallenge(v if not tamper else v ^ 1)
+        assert cv.verify(rep2.native, RH, rho if raised else None) is (not tamper)

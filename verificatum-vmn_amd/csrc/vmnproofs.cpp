@@ -1253,22 +1253,36 @@ struct vmn_posc : ProofBase {
         }
         return VMN_OK;
     }
-    int verify(const vmn_msg* rep, int* verdict) {
-        REQUIRE(verdict && cB && e.p && !v_be.empty(), "verify needs the batching vector, setCommitment and setChallenge");
+    // verification in two parts, as in vmn_pos: verify_prepare(reply) = everything that needs no challenge
+    struct Prepared {
+        const vmn_msg* rep = nullptr;
+        uint64_t serial = 0;
+        Bytes gkA, gkC, gkD, A, C, D, hk;
+        GA right;
+        void clear() {
+            rep = nullptr;
+            serial = 0;
+            right.reset();
+        }
+    } prep;
+    int verify_prepare(const vmn_msg* rep) {
+        REQUIRE(cB && e.p, "verify_prepare needs the batching vector and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
                             *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
                             *ikE = item_of(rep, 4, VMN_ITEM_RARRAY);
         REQUIRE(rep && rep->items.size() == 5 && ikA && ikB && ikC && ikD && ikE, "reply is not (k_A, k_B, k_C, k_D, k_E)");
         REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
-        *verdict = 0;
+        prep.clear();
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
-        Bytes A(G.eb), uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), hk(G.eb), Blast, prev, t_h0, lhsA, lhsC, lhsD, gkA, gkC, gkD, rhs, C, D;
+        Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), Blast, prev, t_h0;
+        prep.A.assign(G.eb, 0);
+        prep.hk.assign(G.eb, 0);
         Num eprod;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        jobs.start([&] { return gexp(g, k_A, gkA); });                            // beside the GPU calls below
-        jobs.start([&] { return gexp(g, k_C, gkC); });
-        jobs.start([&] { return gexp(g, k_D, gkD); });
-        TRY(vmn_garray_expprod(u, e, e_bits, A.data()));                          // :660
+        jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // beside the GPU calls below
+        jobs.start([&] { return gexp(g, k_C, prep.gkC); });
+        jobs.start([&] { return gexp(g, k_D, prep.gkD); });
+        TRY(vmn_garray_expprod(u, e, e_bits, prep.A.data()));                     // :660
         TRY(vmn_garray_prod(u, uprod.data()));
         TRY(vmn_garray_prod(h, hprod.data()));
         TRY(last_local(cB, mylast));
@@ -1276,38 +1290,54 @@ struct vmn_posc : ProofBase {
         eprod = G.ring_from(eprod_b.data());
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
-        TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, hk.data()));
+        TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, prep.hk.data()));
         std::vector<Bytes> lasts;
         Round rd(*this);
-        rd.product(A);
+        rd.product(prep.A);
         rd.product(uprod);
         rd.product(hprod);
-        rd.product(hk);
+        rd.product(prep.hk);
         rd.ring_product(eprod);
         rd.collect(mylast, lasts);
         TRY(rd.run());
         pick_B(lasts, h0, Blast, prev);
-        TRY(G.el_div(uprod, hprod, C));
-        jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });              // (A) :676-682
-        jobs.start([&] { return G.el_expmul(C, v_be, cCp, lhsC); });              // (C) :718-723
-        jobs.start([&] {                                                          // (D) :724-727
+        TRY(G.el_div(uprod, hprod, prep.C));
+        jobs.start([&] {
             TRY(G.el_exp(h0, eprod, t_h0));
-            TRY(G.el_div(Blast, t_h0, D));
-            return G.el_expmul(D, v_be, cDp, lhsD);
+            return G.el_div(Blast, t_h0, prep.D);
         });
+        TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));  // the reply side of (B) :685-715
         TRY(jobs.join());
-        TRY(G.el_mul(gkA, hk, rhs));
-        if (lhsA != rhs) return VMN_OK;                                           // short-circuit :682 (the same on every rank)
-        GA left, right;
-        TRY(bridging_sides(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, left, right));   // (B) :685-715
-        const int vC = lhsC == gkC;
-        const int vD = lhsD == gkD;
+        prep.rep = rep;
+        prep.serial = rep->serial;
+        return VMN_OK;
+    }
+    int verify(const vmn_msg* rep, int* verdict) {
+        REQUIRE(verdict && cB && e.p && !v_be.empty(), "verify needs the batching vector, setCommitment and setChallenge");
+        *verdict = 0;
+        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep));
+        Bytes lhsA, lhsC, lhsD, rhs;
         int vB = 0;
-        TRY(vmn_garray_equals(left, right, &vB));
+        bool a_ok = false;
+        {
+            HostJobs jobs;
+            jobs.start([&] { return G.el_expmul(prep.A, v_be, cAp, lhsA); });     // (A) :676-682
+            jobs.start([&] { return G.el_expmul(prep.C, v_be, cCp, lhsC); });     // (C) :718-723
+            jobs.start([&] { return G.el_expmul(prep.D, v_be, cDp, lhsD); });     // (D) :724-727
+            GA left;
+            TRY(bridging_left(cB, cBp, left));
+            TRY(vmn_garray_equals(left, prep.right, &vB));
+            TRY(jobs.join());
+        }
+        TRY(G.el_mul(prep.gkA, prep.hk, rhs));
+        a_ok = lhsA == rhs;                                                       // short-circuit :682: nothing after (A) counts when it fails
+        const int vC = lhsC == prep.gkC;
+        const int vD = lhsD == prep.gkD;
+        prep.clear();
         Round rv(*this);
         rv.all_true(vB);
         if (sharded) TRY(rv.run());
-        *verdict = vB && vC && vD;
+        *verdict = a_ok && vB && vC && vD;
         return VMN_OK;
     }
 };
@@ -1477,77 +1507,109 @@ struct vmn_ccpos : ProofBase {
         have_ab = true;
         return VMN_OK;
     }
-    int verify(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes, int* verdict) {
-        REQUIRE(verdict && have_commitment && have_ab && !v_be.empty(), "verify needs computeAB, setCommitment and setChallenge");
+    // verification in two parts, as in vmn_pos: verify_prepare(reply, raisedh, rho) = everything that needs no challenge --
+    // here ALL the GPU work of verify(): the multi-exponentiations with k_E
+    struct Prepared {
+        const vmn_msg* rep = nullptr;
+        uint64_t serial = 0;
+        Bytes gkA, Ap_rho, g_term;
+        std::vector<Bytes> pkpow, kE_prods, prods;
+        void clear() {
+            rep = nullptr;
+            serial = 0;
+        }
+    } prep;
+    int verify_prepare(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes) {
+        REQUIRE(have_commitment && have_ab, "verify_prepare needs computeAB and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RING),
                             *ikE = item_of(rep, 2, VMN_ITEM_RARRAY);
         REQUIRE(rep && rep->items.size() == 3 && ikA && ikB && ikE, "reply is not (k_A, k_B, k_E)");
         REQUIRE(ikB->count == width && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
         REQUIRE(raised == (raisedh != nullptr) && raised == (rho_be != nullptr), "raised / plain form must match computeAB");
-        *verdict = 0;
+        prep.clear();
         Num k_A = G.ring_from(ikA->bytes.data());
         std::vector<Num> k_B;
         for (auto& bts : split(*ikB)) k_B.push_back(G.ring_from(bts.data()));
-        Bytes t, lhs, rhs, lhsA, gkA, Ap_rho, g_term;
-        std::vector<Bytes> pkpow, rB, lhsB(2 * width), kE_prods, prods;
         Num rho;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        pk_powers(jobs, pkey, k_B, pkpow);                                        // beside the multi-exponentiation below
+        pk_powers(jobs, pkey, k_B, prep.pkpow);                                   // beside the multi-exponentiation below
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
         if (!raised) {                                                            // :554-570
-            jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });
-            jobs.start([&] { return gexp(g, k_A, gkA); });
-            for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsB] { return G.el_expmul(B[c], v_be, cBp[c], lhsB[c]); });
+            jobs.start([&] { return gexp(g, k_A, prep.gkA); });
             std::vector<const vmn_garray*> xs{h};
             xs.insert(xs.end(), wp.begin(), wp.end());
-            TRY(expprod_multi(xs, ikE->ra, kE_bits, kE_prods));
+            TRY(expprod_multi(xs, ikE->ra, kE_bits, prep.kE_prods));
             Round rd(*this);
-            rd.products(kE_prods);
+            rd.products(prep.kE_prods);
             TRY(rd.run());
-            TRY(jobs.join());
-            TRY(G.el_mul(gkA, kE_prods[0], rhs));
-            if (lhsA != rhs) return VMN_OK;
-            prods.assign(kE_prods.begin() + 1, kE_prods.end());
-            TRY(pk_finish(pkpow, prods, rB));
-            int ok = 1;
+        } else {                                                                  // raised, single-equation form :571-580
+            GA rh_own;
+            const vmn_garray* rh = nullptr;
+            REQUIRE(rho_bytes > 0, "empty raised exponent");
+            rho = G.reduce(rho_be, rho_bytes);
+            jobs.start([&] { return gexp(g, G.Zq.mul(k_A, rho), prep.g_term); });
+            jobs.start([&] { return G.el_exp(cAp, rho_be, rho_bytes, prep.Ap_rho); });
+            TRY(local_garray(raisedh, rh_own, &rh, "raised generators"));
+            std::vector<GA> tmp(2 * width);
+            std::vector<const vmn_garray*> xs;
+            for (size_t c = 0; c < 2 * width; ++c) {
+                TRY(vmn_garray_mul(wp[c], rh, tmp[c].out()));
+                xs.push_back(tmp[c]);
+            }
+            TRY(expprod_multi(xs, ikE->ra, kE_bits, prep.prods));
+            Round rd(*this);
+            rd.products(prep.prods);
+            TRY(rd.run());
+        }
+        TRY(jobs.join());
+        prep.rep = rep;
+        prep.serial = rep->serial;
+        return VMN_OK;
+    }
+    int verify(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes, int* verdict) {
+        REQUIRE(verdict && have_commitment && have_ab && !v_be.empty(), "verify needs computeAB, setCommitment and setChallenge");
+        *verdict = 0;
+        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep, raisedh, rho_be, rho_bytes));
+        REQUIRE(raised == (raisedh != nullptr) && raised == (rho_be != nullptr), "raised / plain form must match computeAB");
+        Bytes rhs, lhsA;
+        std::vector<Bytes> rB, lhsB(2 * width);
+        if (!raised) {                                                            // A^v A' = g^{k_A} prod h^{k_E}; B^v B' = pk^{-k_B} prod w'^{k_E}
+            {
+                HostJobs jobs;
+                jobs.start([&] { return G.el_expmul(A, v_be, cAp, lhsA); });
+                for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsB] { return G.el_expmul(B[c], v_be, cBp[c], lhsB[c]); });
+                TRY(jobs.join());
+            }
+            TRY(G.el_mul(prep.gkA, prep.kE_prods[0], rhs));
+            const bool a_ok = lhsA == rhs;
+            std::vector<Bytes> prods(prep.kE_prods.begin() + 1, prep.kE_prods.end());
+            TRY(pk_finish(prep.pkpow, prods, rB));
+            int ok = a_ok ? 1 : 0;                                                // :562 returns at the first failing check
             for (size_t c = 0; c < 2 * width; ++c) ok = ok && lhsB[c] == rB[c];
+            prep.clear();
             *verdict = ok;
             return VMN_OK;
         }
-        // raised, single-equation form :571-580:  AB^v (B' A'^rho) = pk^{-k_B} prod (w'_i h_i^rho)^{k_E,i} g^{k_A rho}
-        GA rh_own;
-        const vmn_garray* rh = nullptr;
-        REQUIRE(rho_bytes > 0, "empty raised exponent");
-        rho = G.reduce(rho_be, rho_bytes);
-        jobs.start([&] { return gexp(g, G.Zq.mul(k_A, rho), g_term); });
-        jobs.start([&] { return G.el_exp(cAp, rho_be, rho_bytes, Ap_rho); });
-        TRY(local_garray(raisedh, rh_own, &rh, "raised generators"));
-        std::vector<GA> tmp(2 * width);
-        std::vector<const vmn_garray*> xs;
-        for (size_t c = 0; c < 2 * width; ++c) {
-            TRY(vmn_garray_mul(wp[c], rh, tmp[c].out()));
-            xs.push_back(tmp[c]);
+        // raised:  AB^v (B' A'^rho) = pk^{-k_B} prod (w'_i h_i^rho)^{k_E,i} g^{k_A rho}
+        {
+            HostJobs jobs;
+            for (size_t c = 0; c < 2 * width; ++c) {                              // AB_c^v (B'_c A'^rho): one job per component
+                jobs.start([this, c, &lhsB] {
+                    Bytes bt;
+                    TRY(G.el_mul(cBp[c], prep.Ap_rho, bt));
+                    return G.el_expmul(AB[c], v_be, bt, lhsB[c]);
+                });
+            }
+            TRY(pk_finish(prep.pkpow, prep.prods, rB));
+            TRY(jobs.join());
         }
-        TRY(expprod_multi(xs, ikE->ra, kE_bits, prods));
-        Round rd(*this);
-        rd.products(prods);
-        TRY(rd.run());
-        TRY(jobs.join());
-        for (size_t c = 0; c < 2 * width; ++c) {                                  // AB_c^v (B'_c A'^rho): one job per component
-            jobs.start([this, c, &lhsB, &Ap_rho] {
-                Bytes bt;
-                TRY(G.el_mul(cBp[c], Ap_rho, bt));
-                return G.el_expmul(AB[c], v_be, bt, lhsB[c]);
-            });
-        }
-        TRY(pk_finish(pkpow, prods, rB));
-        TRY(jobs.join());
         int ok = 1;
         for (size_t c = 0; c < 2 * width; ++c) {
-            TRY(G.el_mul(rB[c], g_term, rhs));
+            TRY(G.el_mul(rB[c], prep.g_term, rhs));
             ok = ok && lhsB[c] == rhs;
         }
+        prep.clear();
         *verdict = ok;
         return VMN_OK;
     }
@@ -2276,6 +2338,10 @@ int vmn_posc_set_challenge(vmn_posc* p, const uint8_t* v_be, size_t vbytes) {
     NONNULL(p);
     return p->set_challenge(v_be, vbytes);
 }
+int vmn_posc_verify_prepare(vmn_posc* p, const vmn_msg* reply) {
+    NONNULL(p);
+    return p->verify_prepare(reply);
+}
 int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict) {
     NONNULL(p);
     return p->verify(reply, verdict);
@@ -2315,6 +2381,10 @@ int vmn_ccpos_set_challenge(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes) {
 int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu) {
     NONNULL(p);
     return p->compute_ab(raisedu);
+}
+int vmn_ccpos_verify_prepare(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes) {
+    NONNULL(p);
+    return p->verify_prepare(reply, raisedh, rho_be, rho_bytes);
 }
 int vmn_ccpos_verify(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes,
                      int* verdict) {

@@ -441,6 +441,10 @@ class PoSCBasicTW(_NativeProof):
         self._com = msg if isinstance(msg, Message) else self._as_msg(msg, self._com_keys, self._com_scalar, self._com_kinds)
         self._call("set_commitment", self._com._h)
 
+    def verifyPrepare(self, reply) -> None:
+        """``vmn_posc_verify_prepare``: the part of verify() that needs the reply but not the challenge."""
+        self._call("verify_prepare", reply._h)
+
     def verify(self, reply) -> bool:
         m = reply if isinstance(reply, Message) else self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
         verdict = C.c_int(0)
@@ -474,6 +478,14 @@ class CCPoSBasicW(_NativeProof):
 
     def computeAB(self, raisedu=None):
         self._call("compute_ab", raisedu._h if raisedu is not None else None)
+
+    def verifyPrepare(self, reply, raisedh=None, raisedExponent: Optional[int] = None) -> None:
+        """``vmn_ccpos_verify_prepare``: the reply side of verify() -- all its array work; same arguments as the verify() that follows."""
+        if raisedExponent is None:
+            self._call("verify_prepare", reply._h, None, None, C.c_size_t(0))
+        else:
+            rho = _be(raisedExponent)
+            self._call("verify_prepare", reply._h, raisedh._h, rho, C.c_size_t(len(rho)))
 
     def verify(self, reply, raisedh=None, raisedExponent: Optional[int] = None) -> bool:
         m = reply if isinstance(reply, Message) else self._as_msg(reply, self._rep_keys, self._rep_scalar, self._rep_kinds)
