@@ -328,11 +328,15 @@ struct DevTmp {
     void* p = nullptr;
     size_t bytes = 0;
     explicit DevTmp(vmn_ctx* c) : ctx(c) {}
-    int alloc(size_t nbytes) {
+    int alloc(size_t nbytes) {          // a second alloc() on the same object hands the first block back (stream-ordered reuse)
+        if (p) pool_free(ctx, p, bytes);
+        p = nullptr;
         bytes = nbytes ? nbytes : 16;
         return pool_alloc(ctx, bytes, &p);
     }
     ~DevTmp() { pool_free(ctx, p, bytes); }
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
     template <typename T>
     T* as() { return reinterpret_cast<T*>(p); }
 };
