@@ -6,6 +6,20 @@
 
 namespace vmn {
 
+// t = row * per + c, per a small count of 16-byte chunks per row.  A 64-bit division costs ~100 instructions, more than the
+// 16-byte copy it addresses: the 32-bit form is used whenever the index fits (it always does up to 2^32 chunks = 64 GB).
+__device__ __forceinline__ void split_chunk(size_t t, int per, size_t& row, int& c) {
+    if (t <= 0xffffffffull) {
+        const u32 tt = (u32)t, pp = (u32)per;
+        const u32 r = tt / pp;
+        row = r;
+        c = (int)(tt - r * pp);
+    } else {
+        row = t / (size_t)per;
+        c = (int)(t % (size_t)per);
+    }
+}
+
 // ---- generic exclusive scan of a u32 array (three tiny kernels; n up to a few million) ----------
 constexpr int SCAN_ITEMS = 16;                         // items per thread
 
@@ -53,8 +67,9 @@ __global__ void __launch_bounds__(BLOCK) k_gather(uint4* __restrict__ out, const
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t total = n_out * (size_t)chunks_per_row;
     for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t row = t / chunks_per_row;
-        int c = (int)(t % chunks_per_row);
+        size_t row;
+        int c;
+        split_chunk(t, chunks_per_row, row, c);
         u32 src = idx[row];
         out[t] = src == 0xffffffffu ? fill[c] : in[(size_t)src * chunks_per_row + c];
     }
@@ -88,15 +103,16 @@ __global__ void __launch_bounds__(BLOCK) k_fixed_seed(u32* __restrict__ T, const
 // K3 multi-exponentiation (Pippenger): counting sort of (window, digit), then a product tree per bucket.
 // ---------------------------------------------------------------------------------------------
 // counts[win][d] += 1 for every element; one thread per (element, window).
+// (grid = gx blocks per window: the window of a block is blockIdx.x / gx -- one scalar division per block instead of two
+// 64-bit divisions per item, which were most of this kernel's instructions)
 __global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts, const u32* __restrict__ e, int ewords,
-                                                       size_t n, int c, int nwin) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = n * (size_t)nwin;
-    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t i = t % n;
-        int w = (int)(t / n);
-        u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
-        atomicAdd(&counts[((size_t)w << c) + d], 1u);
+                                                       size_t n, int c, int nwin, u32 gx) {
+    const u32 w = blockIdx.x / gx, bx = blockIdx.x % gx;
+    if ((int)w >= nwin) return;
+    u32* __restrict__ cw = counts + ((size_t)w << c);
+    for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
+        u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
+        atomicAdd(&cw[d], 1u);
     }
 }
 
@@ -161,14 +177,13 @@ __global__ void __launch_bounds__(BLOCK) k_u32_scan_apply(u32* __restrict__ out,
 
 // sorted[cursor[bucket]++] = element index; one thread per (element, window); bucket = w*2^c + digit
 __global__ void __launch_bounds__(BLOCK) k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ cursor,
-                                                          const u32* __restrict__ e, int ewords, size_t n, int c, int nwin) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    size_t total = n * (size_t)nwin;
-    for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t i = t % n;
-        int w = (int)(t / n);
-        u32 d = exp_digit(e + i * ewords, ewords, w * c, c);
-        u32 pos = atomicAdd(&cursor[((size_t)w << c) + d], 1u);
+                                                          const u32* __restrict__ e, int ewords, size_t n, int c, int nwin, u32 gx) {
+    const u32 w = blockIdx.x / gx, bx = blockIdx.x % gx;
+    if ((int)w >= nwin) return;
+    u32* __restrict__ cw = cursor + ((size_t)w << c);
+    for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
+        u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
+        u32 pos = atomicAdd(&cw[d], 1u);
         sorted[pos] = (u32)i;
     }
 }
@@ -199,8 +214,9 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_finalize(uint4* __restrict__ B
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t total = nbuckets * cpr;
     for (; t < total; t += (size_t)gridDim.x * BLOCK) {
-        size_t b = t / cpr;
-        int ch = (int)(t % cpr);
+        size_t b;
+        int ch;
+        split_chunk(t, cpr, b, ch);
         B[t] = cnt_in[b] ? items[(size_t)off_in[b] * cpr + ch] : one_row[ch];
     }
 }
@@ -210,8 +226,9 @@ __global__ void __launch_bounds__(BLOCK) k_set_segment_heads(uint4* __restrict__
                                                              const uint4* __restrict__ one_row, int cpr) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= nseg * cpr) return;
-    size_t s = t / cpr;
-    int ch = (int)(t % cpr);
+    size_t s;
+    int ch;
+    split_chunk(t, cpr, s, ch);
     a[s * seglen * cpr + ch] = one_row[ch];
 }
 

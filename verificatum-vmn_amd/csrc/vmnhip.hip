@@ -2821,17 +2821,20 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     const size_t nbuckets = (size_t)nwin * nb;
     const uint32_t F = 8;                              // fan-in of the per-bucket product tree
     DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx);
-    // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | cntA[nb] | cntB[nb] | offA[nb+1] | offB[nb+1] | bsum | misc
+    // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | per tree level l < LV: cnt_l[nb], off_l[nb+1] | bsum | misc.
+    // The shape of the product trees depends on the exponents only, so the per-level counts and offsets are computed
+    // for the FIRST array and kept: the other arrays of a multi-array call reuse them (four short launches per level and
+    // array less -- a tenth of a proof over curves).
+    const int LV = 12;                               // fan-in 8: 8^12 items per bucket
     const size_t scan_blocks = (nbuckets + (size_t)BLOCK * SCAN_ITEMS - 1) / ((size_t)BLOCK * SCAN_ITEMS);
-    VMN_TRY(meta.alloc((7 * (nbuckets + 1) + scan_blocks + 16) * sizeof(uint32_t)));
+    VMN_TRY(meta.alloc(((3 + 2 * LV) * (nbuckets + 1) + scan_blocks + 16) * sizeof(uint32_t)));
     uint32_t* counts = meta.as<uint32_t>();
     uint32_t* cursor = counts + (nbuckets + 1);
     uint32_t* off0 = cursor + (nbuckets + 1);
-    uint32_t* cntA = off0 + (nbuckets + 1);
-    uint32_t* cntB = cntA + (nbuckets + 1);
-    uint32_t* offA = cntB + (nbuckets + 1);
-    uint32_t* offB = offA + (nbuckets + 1);
-    uint32_t* bsum = offB + (nbuckets + 1);
+    uint32_t* levels0 = off0 + (nbuckets + 1);
+    auto cnt_of = [&](int level) { return levels0 + (size_t)(2 * level) * (nbuckets + 1); };
+    auto off_of = [&](int level) { return levels0 + (size_t)(2 * level + 1) * (nbuckets + 1); };
+    uint32_t* bsum = levels0 + (size_t)(2 * LV) * (nbuckets + 1);
     uint32_t* misc = bsum + scan_blocks;             // [0] = total, [1] = max count
     VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
     // The bucket aggregation (suffix scan + reduction over nwin x 2^c rows per array) is a handful of short launches: it
@@ -2851,10 +2854,11 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     };
     // counting sort of (window, digit)
     VMN_HIP(hipMemsetAsync(counts, 0, nbuckets * sizeof(uint32_t), ctx->stream));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, light_grid(ctx, n * nwin), counts, e_words, ewords, n, c, nwin));
+    const unsigned gx = std::max<unsigned>(1, std::min<unsigned>((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)(ctx->num_cus * 8 / std::max(nwin, 1) + 1)));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx));
     VMN_TRY(scan_u32(off0, cursor, counts));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, light_grid(ctx, n * nwin), sorted.as<uint32_t>(), cursor,
-                         e_words, ewords, n, c, nwin));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
+                         e_words, ewords, n, c, nwin, gx));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
     // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item
     std::vector<std::pair<uint32_t, uint32_t>> level_cache;      // (total items, max per bucket) per level, from the first array
@@ -2867,8 +2871,6 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     const uint32_t* x = m.ec ? normalised.as<uint32_t>() + arr * n * Wd : xs[arr];
     const uint32_t* cnt_in = counts;
     const uint32_t* off_in = off0;
-    uint32_t* cnt_out = cntA;
-    uint32_t* off_out = offA;
     const uint32_t* items_in = x;
     bool first = true;
     size_t cap = (size_t)nwin * n / F + nbuckets + 1;        // items of level 1 (later levels are smaller)
@@ -2876,15 +2878,17 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     uint32_t* items_out = itemsA.as<uint32_t>();
     uint32_t* items_other = itemsB.p ? itemsB.as<uint32_t>() : nullptr;
     int rc = VMN_ERR_ARG;
-    for (int level = 0; level < 64; ++level) {
-        VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
-        VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_out, cnt_in, nbuckets, F, misc + 1));
-        VMN_TRY(scan_u32(off_out, (uint32_t*)nullptr, cnt_out));
+    for (int level = 0; level < LV; ++level) {
+        uint32_t* cnt_out = cnt_of(level);
+        uint32_t* off_out = off_of(level);
         uint32_t hm2[2];
-        if ((size_t)level < level_cache.size()) {            // same exponents => same tree shape: no readback
+        if ((size_t)level < level_cache.size()) {            // same exponents => same tree shape: counts, offsets and totals are there
             hm2[0] = level_cache[level].first;
             hm2[1] = level_cache[level].second;
         } else {
+            VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
+            VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_out, cnt_in, nbuckets, F, misc + 1));
+            VMN_TRY(scan_u32(off_out, (uint32_t*)nullptr, cnt_out));
             VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             VMN_HIP(hipStreamSynchronize(ctx->stream));
             level_cache.emplace_back(hm2[0], hm2[1]);
@@ -2933,8 +2937,10 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
             items_other = itemsB.as<uint32_t>();
         }
         std::swap(items_out, items_other);
-        cnt_out = (cnt_out == cntA) ? cntB : cntA;
-        off_out = (off_out == offA) ? offB : offA;
+        if (level + 1 == LV) {
+            set_error("multi-exponentiation: a bucket holds more than 8^%d items", LV);
+            return VMN_ERR_UNSUPPORTED;
+        }
     }
     uint32_t* B = Ball + (arr % G) * nbuckets * Wd;
     VMN_TRY(launch_light(ctx, "expprod_agg", k_bucket_finalize, light_grid(ctx, nbuckets * (Wd / 4)),
