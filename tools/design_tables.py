@@ -11,8 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
-    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_v2.json")
+def render(bench):
+    """The generated block as text (tests/test_docs_consistency.py compares it with what DESIGN.md holds)."""
     r = json.load(open(bench))
     pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
     mp, cc, ec = r["mix_prove"], r["mix_ccpos_3072"], r["mix_ec_p256"]
@@ -71,12 +71,20 @@ End-to-end timeline at N = 10^6 (prover): seed-independent GPU work done at {e2e
 {e2e['prover_phases_ms']['seed_known']:.0f} ms (hash thread busy {e2e['instance_hash_thread_busy_ms'][0]:.0f} ms: fully overlapped, hash-bound), commitment published at {e2e['prover_phases_ms']['commitment_published']:.0f} ms, challenge
 at {e2e['prover_phases_ms']['challenge_known']:.0f} ms, reply at {e2e['prover_phases_ms']['reply_published']:.0f} ms; verifier: seed at {e2e['verifier_phases_ms']['seed_known']:.0f} ms, computeAF beside the challenge hash, verdict at
 {e2e['verifier_phases_ms']['verified']:.0f} ms.  GPU kernels are {e2e['gpu_kernel_ms']:.0f} ms of the {e2e['total_ms']:.0f} ms."""
+    return text
+
+
+BEGIN, END = "<!-- r02-tables-begin -->", "<!-- r02-tables-end -->"
+
+
+def main():
+    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_v2.json")
+    text = render(bench)
     path = os.path.join(ROOT, "DESIGN.md")
     s = open(path).read()
-    b, e = "<!-- r02-tables-begin -->", "<!-- r02-tables-end -->"
-    i, j = s.index(b) + len(b), s.index(e)
+    i, j = s.index(BEGIN) + len(BEGIN), s.index(END)
     open(path, "w").write(s[:i] + "\n" + text + "\n" + s[j:])
-    print("DESIGN.md §6 tables regenerated from", rel)
+    print("DESIGN.md §6 tables regenerated from", os.path.relpath(bench, ROOT))
 
 
 if __name__ == "__main__":
