@@ -169,6 +169,7 @@ def main():
     if mirror:
         backend = backend[: -len("-mirror")]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("VMN_COMBINED_MIN", "1")     # the sharded verifiers take check (B) in its combined form (with the carried-in B) too
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     device = None

@@ -440,3 +440,24 @@ def test_worst_case_column_magnitudes_above_4096_bits(bits, vmn, gpu_ctx, oracle
     es = [N - 1, N - 2, (1 << bits) - (1 << 64) - 1, 1, 0, 2, 3, (1 << (bits - 1)) + 1] + pyref.stream_ints(b"worst-e%d" % bits, 4, N)
     assert X.exp(G.ringArray(es)).toInts() == orc.exp_array(vals, es)
     assert G.exp(N - 1, G.ringArray(es)).toInts() == orc.exp_fixed(N - 1, es)
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_simultaneous_power_and_array_inverse(bits, groups, oracle_for):
+    """vmn_garray_exp2 (x^e y^f with shared squarings) and vmn_garray_inv against the oracle: exponent pairs of unequal and
+    equal length, zero digits and windows, e = 0, a shared exponent longer than the per-element ones."""
+    G, grp, _ = groups[bits]
+    p, q = grp["p"], grp["q"]
+    orc = oracle_for(p, q)
+    n = 70
+    xs, fs = _inputs(b"exp2-%d" % bits, n, p, q)
+    ys = [pow(x, 3, p) for x in xs[::-1]]
+    X, Y = G.toElementArray(xs), G.toElementArray(ys)
+    inv = X.inv().toInts()
+    assert inv == [pow(x, -1, p) for x in xs]
+    for e, fbits in ((pyref.stream_ints(b"exp2/e", 1, 1 << 256)[0], 613), (0, 613), (1, 1), ((1 << 255) + 1, 40), (q - 1, q.bit_length())):
+        f = [v % (1 << fbits) for v in fs]
+        f[0], f[1] = 0, (1 << (fbits - 1)) if fbits > 1 else 1
+        got = X.exp2(e, Y, G.ringArray(f), fbits).toInts()
+        want = orc.mul(orc.exp_scalar(xs, e), orc.exp_array(ys, f))
+        assert got == want, (e.bit_length(), fbits)

@@ -454,3 +454,65 @@ def test_verify_prepare_of_posc_and_ccpos(raised, vmn, gpu_ctx, mods):
         cv.verifyPrepare(rep2.native, RH, rho if raised else None)
         cv.setChallenge(v if not tamper else v ^ 1)
         assert cv.verify(rep2.native, RH, rho if raised else None) is (not tamper)
+
+
+def test_check_b_as_one_simultaneous_power_gives_the_same_verdicts(vmn, gpu_ctx, mods, monkeypatch):
+    """Large arrays verify check (B) in the form (B_i^v (B_{i-1}^{-1})^{k_E,i}) B'_i = g^{k_B,i} (vmn_garray_exp2 +
+    vmn_garray_inv); here at a small size (VMN_COMBINED_MIN=1) beside the separate form: honest and tampered replies and
+    commitments, PoS and PoSC, and a commitment with the residue 0 in B (no inverse: the separate form takes over)."""
+    hv = mods["native"]
+    NV, NE, NR = 256, 256, 100
+    bits, n, width = 2048, 45, 1
+    p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"comb")
+    pi, r, s = t.permutation(n), t.ring_array(n), [t.ring_array(n)]
+    e, v = t.int_array(n, NE), t.int_array(1, NV)[0]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H, W, S, R = G.toElementArray(h), [G.toElementArray(c) for c in w], [G.ringArray(c) for c in s], G.ringArray(r)
+    pr = hv.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"comb-prover", q))
+    pr.precompute(g, H, pi)
+    WP = hv.reencrypt_native(G, pkey, W, S, pi)
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    U = G.toElementArray(P.permutation_commitment(g, h, r, pi, p))
+    pc = hv.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"comb-posc", q))
+    pc.setInstance(g, H, U, R, pi)
+    pc.setBatchVector(e)
+    com_c, rep_c = pc.commit(), pc.reply(v)
+
+    def tampered(msg, key, pos, delta, mod):
+        out = dict(msg)
+        vals = msg[key].toInts()
+        vals[pos] = (vals[pos] + delta) % mod if delta else 0
+        out[key] = G.ringArray(vals) if mod == q else G.toElementArray(vals, checked=False)
+        return out
+    cases = [(com, rep), (com, tampered(rep, "k_B", 7, 1, q)), (com, tampered(rep, "k_E", n - 1, 1, q)),
+             (tampered(com, "B", 3, 1, p), rep), (tampered(com, "Bp", 0, 5, p), rep),
+             (tampered(com, "B", 11, 0, p), rep), (tampered(com, "B", n - 1, 0, p), rep)]       # the last two: a zero in B
+    verdicts = {}
+    for mode in ("separate", "combined"):
+        monkeypatch.setenv("VMN_COMBINED_MIN", "1" if mode == "combined" else "1000000000")
+        out = []
+        for c, rp in cases:
+            ver = hv.PoSBasicTW(G, NV, NE, NR)
+            ver.precompute(g, H)
+            ver.setPermutationCommitment(pr.u)
+            ver.setInstance(pkey, W, WP)
+            ver.setBatchVector(e)
+            ver.computeAF()
+            ver.setCommitment(c)
+            ver.setChallenge(v)
+            ok = ver.verify(rp)
+            out.append((ok, ver.verdicts))
+        for c, rp in [(com_c, rep_c), (com_c, tampered(rep_c, "k_B", 2, 1, q)), (tampered(com_c, "B", 5, 0, p), rep_c)]:
+            ver = hv.PoSCBasicTW(G, NV, NE, NR)
+            ver.setInstance(g, H, U)
+            ver.setBatchVector(e)
+            ver.setCommitment(c)
+            ver.setChallenge(v)
+            out.append((ver.verify(rp), None))
+        verdicts[mode] = out
+    assert verdicts["separate"] == verdicts["combined"]
+    assert verdicts["combined"][0] == (True, (True,) * 5) and verdicts["combined"][1] == (False, (True, False, True, True, True))
+    assert [ok for ok, _ in verdicts["combined"][2:7]] == [False] * 5
+    assert [ok for ok, _ in verdicts["combined"][7:]] == [True, False, False]

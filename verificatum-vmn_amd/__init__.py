@@ -510,6 +510,14 @@ class PGroupElementArray(_ArrayBase):
     def _new(self, h) -> "PGroupElementArray":
         return PGroupElementArray(self.group, h)
 
+    def exp2(self, e: int, y: "PGroupElementArray", f: "PRingElementArray", fbits: int = 0) -> "PGroupElementArray":
+        """``vmn_garray_exp2``: self[i]^e * y[i]^f[i] as one simultaneous power (modular groups)."""
+        h = C.c_void_p()
+        e = int(e)
+        nb = max(1, (e.bit_length() + 7) // 8)
+        _check(lib().vmn_garray_exp2(self._h, int_to_be(e, nb), C.c_size_t(nb), y._h, f._h, C.c_int(fbits), C.byref(h)))
+        return self._new(h)
+
     # K1a / K1b
     def exp(self, e, ebits: int = 0) -> "PGroupElementArray":
         """``X.exp(PRingElementArray)`` (per-element exponents) or ``X.exp(int)`` (shared exponent)."""

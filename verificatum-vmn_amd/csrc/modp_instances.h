@@ -19,6 +19,9 @@
                                                       vmn::u32);                                                                         \
     KW __global__ void vmn::k_modpow<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, int, size_t,     \
                                                          const vmn::u32*, vmn::u32, const vmn::u32*, vmn::u32*);                         \
+    KW __global__ void vmn::k_modpow2<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, const vmn::u32*,  \
+                                                          const vmn::u32*, int, size_t, int, int, size_t, const vmn::u32*, vmn::u32,      \
+                                                          const vmn::u32*, vmn::u32*);                                                  \
     KW __global__ void vmn::k_reduce_strided<vmn::Cfg<S_, LPE_>, true>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t,               \
                                                                        const vmn::u32*, vmn::u32);                                       \
     KW __global__ void vmn::k_reduce_strided<vmn::Cfg<S_, LPE_>, false>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t,              \

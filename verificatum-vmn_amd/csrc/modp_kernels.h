@@ -675,6 +675,81 @@ k_modpow(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Simultaneous power of two bases (Straus): out[i] = x[i]^e1 * y[i]^e2 with the squarings shared -- max(ebits1, ebits2)
+// squarings instead of their sum.  Either exponent may be shared (stride 0) or per element.  Per-lane tables of both bases
+// in scratch (2 * 2^w rows).  Used by the verifiers' check (B) in the form B_i^v (B_{i-1}^{-1})^{k_E,i}.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_modpow2(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e1, int ewords1, size_t estride1, int ebits1,
+          const u32* __restrict__ y, const u32* __restrict__ e2, int ewords2, size_t estride2, int ebits2, int wbits, size_t n,
+          const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ one_m, u32* __restrict__ tab) {
+    constexpr int W = C::W;
+    extern __shared__ u32 lds[];
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const size_t ntiles = (n + C::EPB - 1) / C::EPB;
+    const int tsize = 1 << wbits;
+    u32* tab1 = tab + ((size_t)blockIdx.x * C::EPB + ln.eslot) * (size_t)(2 * tsize) * W;
+    u32* tab2 = tab1 + (size_t)tsize * W;
+    const int nwin1 = (ebits1 + wbits - 1) / wbits, nwin2 = (ebits2 + wbits - 1) / wbits;
+    const int nwin = nwin1 > nwin2 ? nwin1 : nwin2;
+
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        size_t el = t * C::EPB + ln.eslot;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        const u32* ep1 = e1 + ec * estride1;
+        const u32* ep2 = e2 + ec * estride2;
+        u32 a[C::L];
+        // tables: tab[0] = 1, tab[1] = base, tab[k] = tab[k-1] * base
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            u32* tb = which ? tab2 : tab1;
+            {
+                u32 o[C::L];
+                load_modulus<C>(o, one_m, ln);
+                store_elem<C>(tb, o, ln);
+            }
+            load_elem<C>(a, (which ? y : x) + ec * W, ln);
+            store_elem<C>(tb + W, a, ln);
+            regs_to_lds<C>(ln, a);
+#pragma unroll 1
+            for (int k = 2; k < tsize; ++k) {
+                u32 r[C::L];
+                mont_mul<C>(r, a, ln, nn, n0inv);          // base * tab[k-1]
+                store_elem<C>(tb + (size_t)k * W, r, ln);
+                regs_to_lds<C>(ln, r);
+            }
+        }
+        load_modulus<C>(a, one_m, ln);
+#pragma unroll 1
+        for (int wi = nwin - 1; wi >= 0; --wi) {
+            if (wi != nwin - 1) {
+#pragma unroll 1
+                for (int s = 0; s < wbits; ++s) {
+                    regs_to_lds<C>(ln, a);
+                    mont_sqr<C>(a, a, ln, nn, n0inv);
+                }
+            }
+            if (wi < nwin1) {                              // (uniform over the launch: window counts, not digits, decide)
+                u32 d = exp_digit(ep1, ewords1, wi * wbits, wbits);
+                load_elem_to_lds<C>(ln, tab1 + (size_t)d * W);
+                mont_mul<C>(a, a, ln, nn, n0inv);
+            }
+            if (wi < nwin2) {
+                u32 d = exp_digit(ep2, ewords2, wi * wbits, wbits);
+                load_elem_to_lds<C>(ln, tab2 + (size_t)d * W);
+                mont_mul<C>(a, a, ln, nn, n0inv);
+            }
+        }
+        canonicalize<C>(a, nn, ln);
+        if (live) store_elem<C>(out + el * W, a, ln);
+    }
+}
+
 // =============================================================================================
 // second part: fixed-base tables (K2), multi-exponentiation (K3), reductions (K5), comparison
 // (K6), data movement (K7) and the ring kernels over Z_q (K8).

@@ -1398,6 +1398,65 @@ extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, s
     return VMN_OK;
 }
 
+// out[i] = x[i]^e * y[i]^f[i]: one simultaneous power (k_modpow2), the squarings shared between the two exponents.
+// The verifiers' check (B): B_i^v (B_{i-1}^{-1})^{k_E,i}.  Modular groups only.
+extern "C" int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, const vmn_garray* y, const vmn_rarray* f,
+                               int fbits, vmn_garray** out) {
+    ARG_CHECK(x && e_be && ebytes > 0 && y && f && out, "null argument");
+    ARG_CHECK(x->grp == y->grp && x->grp == f->grp && x->n == y->n && x->n == f->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = LANE(g->ctx);
+    VMN_ENTER(ctx);
+    if (g->P.ec) {
+        set_error("vmn_garray_exp2: modular groups only");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    if (fbits <= 0 || fbits > g->Q.nbits) fbits = g->Q.nbits;
+    const size_t n = x->n;
+    int ewords = (int)((ebytes + 3) / 4);
+    Big e = hostbig::from_be(e_be, ebytes, ewords);
+    const int ebits = std::max(1, hostbig::bit_length(e));
+    ewords = (ebits + 31) / 32;
+    vmn_garray* r = nullptr;
+    VMN_TRY(new_garray(g, n, &r));
+    if (n == 0) {
+        *out = r;
+        return VMN_OK;
+    }
+    DevTmp ew(ctx), fw(ctx);
+    int rc = ew.alloc(ewords * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = h2d(ctx, ew.p, e.data(), ewords * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = fw.alloc(n * (size_t)g->Q.NW * sizeof(uint32_t));
+    if (rc == VMN_OK) rc = to_words(ctx, g->Q, f->d, n, fw.as<uint32_t>());
+    if (rc == VMN_OK) {
+        const vmn_modulus& m = geom(ctx, g->P, n);
+        const int wbits = std::min(pick_window(std::max(ebits, fbits)), 5);       // two tables per lane
+        const unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+        const unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
+        const size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * ((size_t)2 << wbits) * elem_words(m) * sizeof(uint32_t);
+        rc = ensure_scratch(ctx, tab_bytes);
+        if (rc == VMN_OK) {
+            const int nw1 = (ebits + wbits - 1) / wbits, nw2 = (fbits + wbits - 1) / wbits;
+            note_work(ctx, m, (double)n * (nw1 + nw2 + 2 * ((1 << wbits) - 2)), (double)n * (std::max(nw1, nw2) - 1) * wbits);
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                                       \
+    if (m.S == S_)                                                                                                             \
+        rc = launch(ctx, "modpow", k_modpow2<Cfg<S_, LPE_>>, grid, lds_bytes(m), r->d, (const uint32_t*)x->d,                      \
+                    (const uint32_t*)ew.as<uint32_t>(), ewords, (size_t)0, ebits, (const uint32_t*)y->d,                         \
+                    (const uint32_t*)fw.as<uint32_t>(), g->Q.NW, (size_t)g->Q.NW, fbits, wbits, n, m.d_n, m.n0inv, m.d_one,    \
+                    reinterpret_cast<uint32_t*>(ctx->scratch));
+            VMN_FOR_SIZES(X)
+#undef X
+        }
+    }
+    if (rc != VMN_OK) {
+        vmn_garray_free(r);
+        return rc;
+    }
+    *out = r;
+    return VMN_OK;
+}
+
 // ================================================================================================
 // second part: K2 fixed base, K3 multi-exponentiation, K5 reductions, K6 compare, K7 movement,
 // K8 ring operations
@@ -1961,12 +2020,9 @@ extern "C" int vmn_garray_inv(const vmn_garray* x, vmn_garray** out) {
                 set_error("vmn_garray_inv: an element is not invertible");
                 rc = VMN_ERR_FORMAT;
             } else {
-                Big e = m.n_words;                    // p - 2
-                Big two(m.NW, 0);
-                two[0] = 2;
-                hostbig::sub_in(e, two);
-                Big ti = hm.from_mont(hm.pow_m(hm.to_mont(t), e));
-                hostbig::to_be(ti, tbe.data(), g->nbytes);
+                (void)hm;
+                const num64::Mod& h64 = *m.hm64;              // binary Euclid (0.15 ms at 2048 bits; a Fermat power takes 16)
+                num64::to_be(h64.inv(num64::from_be(tbe.data(), g->nbytes, h64.nl)), tbe.data(), g->nbytes);
                 uint32_t* d_t = nullptr;
                 rc = import_one(ctx, m, g->nbytes, tbe.data(), &d_t);
                 if (rc == VMN_OK) {

@@ -13,6 +13,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -724,6 +725,33 @@ struct ProofBase {
         TRY(bridging_left(B, Bp, left));
         return bridging_right(g, prev, B, k_B, k_E, kE_bits, right);
     }
+    // Check (B) as ONE simultaneous power (modular groups): B_i^v B'_i = g^{k_B,i} B_{i-1}^{k_E,i}  <=>  (B_i^v (B_{i-1}^{-1})^{k_E,i}) B'_i = g^{k_B,i}
+    // for invertible B_{i-1}; the squarings of the 256-bit and the 613-bit exponent are shared (vmn_garray_exp2) and the
+    // inverses of the whole array cost a few products per element (vmn_garray_inv).  *done = 0 when some B is not invertible
+    // (the residue 0 -- no group element): the caller then evaluates the two sides separately, as the reference does.
+    int bridging_combined(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
+                          const vmn_rarray* k_E, int kE_bits, GA& left, GA& right, int* done) {
+        *done = 0;
+        // (small arrays are latency-bound: the inversion's scans and its host round trip cost more than the squarings they
+        // save; VMN_COMBINED_MIN moves the threshold -- the tests run the combined form at their sizes with it)
+        const char* env = getenv("VMN_COMBINED_MIN");
+        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)32768;
+        if (G.ec || N < min_n) return VMN_OK;
+        Bytes prev_inv;
+        TRY(G.el_inv(prev, prev_inv));
+        bool prev_zero = true;
+        for (uint8_t c : prev_inv) prev_zero = prev_zero && c == 0;
+        if (prev_zero) return VMN_OK;
+        GA Binv, Bs, L;
+        if (vmn_garray_inv(B, Binv.out()) != VMN_OK) return VMN_OK;               // an element without inverse: the separate form
+        TRY(vmn_garray_shift_push(Binv, prev_inv.data(), Bs.out()));
+        Binv.reset();
+        TRY(vmn_garray_exp2(B, v_be.data(), v_be.size(), Bs, k_E, kE_bits, L.out()));
+        TRY(vmn_garray_mul(L, Bp, left.out()));
+        TRY(vmn_group_exp_fixed(G.grp, g.data(), k_B, right.out()));
+        *done = 1;
+        return VMN_OK;
+    }
     // left side B_i^v B'_i: needs the challenge
     int bridging_left(const vmn_garray* B, const vmn_garray* Bp, GA& left) {
         GA B_exp_v;
@@ -1025,15 +1053,19 @@ struct vmn_pos : ProofBase {
         Bytes gkA, gkC, gkD, C, D;
         std::vector<Bytes> kE_prods, pkpow;
         GA right;
+        bool deferred = false;             // the reply side of check (B) was left to verify() (which then uses the combined form)
+        Bytes prev;
+        int kE_bits = 0;
         void clear() {
             rep = nullptr;
             serial = 0;
             right.reset();
             kE_prods.clear();
             pkpow.clear();
+            deferred = false;
         }
     } prep;
-    int verify_prepare(const vmn_msg* rep) {
+    int verify_prepare(const vmn_msg* rep, bool defer_bridge = false) {
         VMN_TRACE("pos:verify_prepare");
         REQUIRE(cB && !A.empty(), "verify_prepare needs computeAF and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
@@ -1079,8 +1111,11 @@ struct vmn_pos : ProofBase {
             TRY(G.el_exp(h0, eprod, t_h0));
             return G.el_div(Blast, t_h0, prep.D);
         });
-        // ... then the reply side of check (B) is queued :1030-1033
-        TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
+        // ... then the reply side of check (B) is queued :1030-1033 -- unless verify() follows at once and takes the combined form
+        prep.deferred = defer_bridge && !G.ec;
+        prep.prev = prev;
+        prep.kE_bits = kE_bits;
+        if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
@@ -1089,7 +1124,7 @@ struct vmn_pos : ProofBase {
     int verify(const vmn_msg* rep, int* verdict, int* five) {
         VMN_TRACE("pos:verify");
         REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
-        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep));
+        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep, true));
         Bytes lhsA, lhsC, lhsD, rhs;
         std::vector<Bytes> lhsF(2 * width), rF;
         GA left;
@@ -1100,7 +1135,13 @@ struct vmn_pos : ProofBase {
             jobs.start([&] { return G.el_expmul(prep.C, v_be, cCp, lhsC); });     // (C)
             jobs.start([&] { return G.el_expmul(prep.D, v_be, cDp, lhsD); });     // (D)
             for (size_t c = 0; c < 2 * width; ++c) jobs.start([this, c, &lhsF] { return G.el_expmul(F[c], v_be, cFp[c], lhsF[c]); });
-            TRY(bridging_left(cB, cBp, left));                                    // :1028-1029
+            int combined = 0;
+            if (prep.deferred) {                                                  // (B) :1023-1042, both sides now
+                const vmn_msg::Item *ikB = item_of(rep, 1, VMN_ITEM_RARRAY), *ikE = item_of(rep, 4, VMN_ITEM_RARRAY);
+                TRY(bridging_combined(g, prep.prev, cB, cBp, ikB->ra, ikE->ra, prep.kE_bits, left, prep.right, &combined));
+                if (!combined) TRY(bridging_right(g, prep.prev, cB, ikB->ra, ikE->ra, prep.kE_bits, prep.right));
+            }
+            if (!combined) TRY(bridging_left(cB, cBp, left));                     // :1028-1029
             TRY(vmn_garray_equals(left, prep.right, &vB));
             TRY(jobs.join());
         }
@@ -1259,13 +1300,17 @@ struct vmn_posc : ProofBase {
         uint64_t serial = 0;
         Bytes gkA, gkC, gkD, A, C, D, hk;
         GA right;
+        bool deferred = false;             // see vmn_pos
+        Bytes prev;
+        int kE_bits = 0;
         void clear() {
             rep = nullptr;
             serial = 0;
             right.reset();
+            deferred = false;
         }
     } prep;
-    int verify_prepare(const vmn_msg* rep) {
+    int verify_prepare(const vmn_msg* rep, bool defer_bridge = false) {
         REQUIRE(cB && e.p, "verify_prepare needs the batching vector and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
                             *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
@@ -1306,7 +1351,10 @@ struct vmn_posc : ProofBase {
             TRY(G.el_exp(h0, eprod, t_h0));
             return G.el_div(Blast, t_h0, prep.D);
         });
-        TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));  // the reply side of (B) :685-715
+        prep.deferred = defer_bridge && !G.ec;
+        prep.prev = prev;
+        prep.kE_bits = kE_bits;
+        if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));  // the reply side of (B) :685-715
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
@@ -1315,7 +1363,7 @@ struct vmn_posc : ProofBase {
     int verify(const vmn_msg* rep, int* verdict) {
         REQUIRE(verdict && cB && e.p && !v_be.empty(), "verify needs the batching vector, setCommitment and setChallenge");
         *verdict = 0;
-        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep));
+        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep, true));
         Bytes lhsA, lhsC, lhsD, rhs;
         int vB = 0;
         bool a_ok = false;
@@ -1325,7 +1373,13 @@ struct vmn_posc : ProofBase {
             jobs.start([&] { return G.el_expmul(prep.C, v_be, cCp, lhsC); });     // (C) :718-723
             jobs.start([&] { return G.el_expmul(prep.D, v_be, cDp, lhsD); });     // (D) :724-727
             GA left;
-            TRY(bridging_left(cB, cBp, left));
+            int combined = 0;
+            if (prep.deferred) {                                                  // (B) :685-715, both sides now
+                const vmn_msg::Item *ikB = item_of(rep, 1, VMN_ITEM_RARRAY), *ikE = item_of(rep, 4, VMN_ITEM_RARRAY);
+                TRY(bridging_combined(g, prep.prev, cB, cBp, ikB->ra, ikE->ra, prep.kE_bits, left, prep.right, &combined));
+                if (!combined) TRY(bridging_right(g, prep.prev, cB, ikB->ra, ikE->ra, prep.kE_bits, prep.right));
+            }
+            if (!combined) TRY(bridging_left(cB, cBp, left));
             TRY(vmn_garray_equals(left, prep.right, &vB));
             TRY(jobs.join());
         }
