@@ -729,14 +729,17 @@ struct ProofBase {
     // for invertible B_{i-1}; the squarings of the 256-bit and the 613-bit exponent are shared (vmn_garray_exp2) and the
     // inverses of the whole array cost a few products per element (vmn_garray_inv).  *done = 0 when some B is not invertible
     // (the residue 0 -- no group element): the caller then evaluates the two sides separately, as the reference does.
+    // (small arrays are latency-bound: the inversion's scans and its host round trip cost more than the squarings they
+    // save; VMN_COMBINED_MIN moves the threshold -- the tests run the combined form at their sizes with it)
+    bool combined_form_pays() const {
+        const char* env = getenv("VMN_COMBINED_MIN");
+        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)32768;
+        return !G.ec && N >= min_n;
+    }
     int bridging_combined(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
                           const vmn_rarray* k_E, int kE_bits, GA& left, GA& right, int* done) {
         *done = 0;
-        // (small arrays are latency-bound: the inversion's scans and its host round trip cost more than the squarings they
-        // save; VMN_COMBINED_MIN moves the threshold -- the tests run the combined form at their sizes with it)
-        const char* env = getenv("VMN_COMBINED_MIN");
-        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)32768;
-        if (G.ec || N < min_n) return VMN_OK;
+        if (!combined_form_pays()) return VMN_OK;
         Bytes prev_inv;
         TRY(G.el_inv(prev, prev_inv));
         bool prev_zero = true;
@@ -1112,7 +1115,7 @@ struct vmn_pos : ProofBase {
             return G.el_div(Blast, t_h0, prep.D);
         });
         // ... then the reply side of check (B) is queued :1030-1033 -- unless verify() follows at once and takes the combined form
-        prep.deferred = defer_bridge && !G.ec;
+        prep.deferred = defer_bridge && combined_form_pays();
         prep.prev = prev;
         prep.kE_bits = kE_bits;
         if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
@@ -1351,7 +1354,7 @@ struct vmn_posc : ProofBase {
             TRY(G.el_exp(h0, eprod, t_h0));
             return G.el_div(Blast, t_h0, prep.D);
         });
-        prep.deferred = defer_bridge && !G.ec;
+        prep.deferred = defer_bridge && combined_form_pays();
         prep.prev = prev;
         prep.kE_bits = kE_bits;
         if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));  // the reply side of (B) :685-715
