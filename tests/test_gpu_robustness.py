@@ -1,0 +1,227 @@
+"""GPU suite: behaviour at the edges of the proof-level ABI that a transcript comparison does not reach -- a cached
+reply side never survives a change of the verifier's inputs, ring scalars of a reply must be field elements
+(PoSBasicTW.java:985-989: pRing.toElement), a block freed by the other lane's thread returns to the lane that owns it."""
+import threading
+
+import pytest
+
+from oracle import pyref_proofs as P
+from tape import Tape
+from test_gpu_proofs import make_instance, mods  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+NV, NE, NR = 100, 100, 50
+
+
+def _pos_case(vmn, gpu_ctx, nat, n=24, seed=b"robust"):
+    p, q, g, h, pkey, w, t = make_instance(512, n, 1, seed)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H, W = G.toElementArray(h), [G.toElementArray(c) for c in w]
+    pi, s, e, v = t.permutation(n), [t.ring_array(n)], t.int_array(n, NE), t.int_array(1, NV)[0]
+    S = [G.ringArray(s[0])]
+    pr = nat.PoSBasicTW(G, NV, NE, NR, rand=Tape(seed + b"-prover", q))
+    pr.precompute(g, H, pi)
+    WP = nat.reencrypt_native(G, pkey, W, S, pi)
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+
+    def verifier(commitment=com):
+        ver = nat.PoSBasicTW(G, NV, NE, NR)
+        ver.precompute(g, H)
+        ver.setPermutationCommitment(pr.u)
+        ver.setInstance(pkey, W, WP)
+        ver.setBatchVector(e)
+        ver.computeAF()
+        ver.setCommitment(commitment)
+        return ver
+    return dict(G=G, p=p, q=q, g=g, H=H, W=W, WP=WP, pkey=pkey, e=e, v=v, com=com, rep=rep, verifier=verifier, pr=pr, keep=(S, pr))
+
+
+def test_a_prepared_reply_side_does_not_survive_new_inputs(vmn, gpu_ctx, mods):
+    """verify_prepare(reply) caches D = B_last / h0^prod(e), the right side of check (B) and the k_E products; a new
+    commitment / batching vector / instance after it must not be combined with them."""
+    nat = mods["native"]
+    c = _pos_case(vmn, gpu_ctx, nat)
+    G, q, p, com, rep, v = c["G"], c["q"], c["p"], c["com"], c["rep"], c["v"]
+    bad_com = dict(com)
+    b = com["B"].toInts()
+    b[-1] = b[-1] * c["g"] % p                                   # another last B: D changes, check (B) fails at the last position
+    bad_com["B"] = G.toElementArray(b)
+    # prepared with the honest commitment, then the commitment is replaced: the verdict is the one of the new commitment
+    ver = c["verifier"]()
+    ver.verifyPrepare(rep.native)
+    ver.setCommitment(bad_com)
+    ver.setChallenge(v)
+    assert not ver.verify(rep.native) and ver.verdicts == (True, False, True, False, True)
+    # ... and the other way round
+    ver = c["verifier"](bad_com)
+    ver.verifyPrepare(rep.native)
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep.native)
+    # a new batching vector after the preparation: A, F and prod(e) are recomputed for it
+    ver = c["verifier"]()
+    ver.verifyPrepare(rep.native)
+    e2 = list(c["e"])
+    e2[0] ^= 1
+    ver.setBatchVector(e2)
+    ver.computeAF()
+    ver.setChallenge(v)
+    assert not ver.verify(rep.native)
+
+
+def test_ccpos_prepared_state_is_bound_to_the_raised_arguments(vmn, gpu_ctx, mods):
+    """vmn_ccpos_verify(reply, raisedh, rho) after vmn_ccpos_verify_prepare with OTHER raised generators must not
+    silently use the prepared ones."""
+    hv, mx = mods["native"], mods["mixnet"]
+    n, width = 20, 1
+    p, q, g, h, pkey, w, t = make_instance(512, n, width, b"robust-cc")
+    pi, r, s = t.permutation(n), t.ring_array(n), [t.ring_array(n)]
+    e, v = t.int_array(n, NE), t.int_array(1, NV)[0]
+    rho = t.int_array(1, mx.RAISED_BITLENGTH)[0]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    H, W, S, R = G.toElementArray(h), [G.toElementArray(c) for c in w], [G.ringArray(c) for c in s], G.ringArray(r)
+    U = G.toElementArray(P.permutation_commitment(g, h, r, pi, p))
+    WP = hv.reencrypt_native(G, pkey, W, S, pi)
+    cp = hv.CCPoSBasicW(G, NV, NE, NR, rand=Tape(b"robust-ccpos", q))
+    cp.setInstance(g, H, U, pkey, W, WP, R, pi, S)
+    cp.setBatchVector(e)
+    com, rep = cp.commit(), cp.reply(v)
+    RU, RH = U.exp(rho), H.exp(rho)
+    wrong_RH = H.exp(rho + 1)
+    cv = hv.CCPoSBasicW(G, NV, NE, NR)
+    cv.setInstance(g, H, U, pkey, W, WP)
+    cv.setBatchVector(e)
+    cv.setCommitment(com.native)
+    cv.computeAB(RU)
+    cv.setChallenge(v)
+    cv.verifyPrepare(rep.native, RH, rho)
+    assert not cv.verify(rep.native, wrong_RH, rho)             # other generators than the prepared ones: recomputed, rejected
+    cv.verifyPrepare(rep.native, wrong_RH, rho)
+    assert cv.verify(rep.native, RH, rho)
+    cv.verifyPrepare(rep.native, RH, rho)
+    assert not cv.verify(rep.native, RH, rho + 1)
+
+
+def test_reply_scalars_must_be_below_q(vmn, gpu_ctx, mods):
+    """k_A + q is the same exponent but not the same field element: the reference's parser (pRing.toElement) refuses it,
+    so this verifier must too -- through the byte-tree reader and for a message assembled by hand."""
+    nat = mods["native"]
+    c = _pos_case(vmn, gpu_ctx, nat, seed=b"robust-q")
+    G, q, rep, v, n = c["G"], c["q"], c["rep"], c["v"], 24
+    assert rep["k_A"] + q < 1 << (8 * G.exp_bytes)
+    ver = c["verifier"]()
+    ver.setChallenge(v)
+    assert ver.verify(rep)
+    for key in ("k_A", "k_C", "k_D"):
+        bad = dict(rep)
+        bad[key] = rep[key] + q
+        assert not ver.verify(bad) and ver.verdicts == (False,) * 5, key
+    bad = dict(rep)
+    bad["k_F"] = [rep["k_F"][0] + q]
+    assert not ver.verify(bad)
+    assert ver.verify(rep)
+    # the wire: a reply whose k_A leaf holds k_A + q is not a reply
+    bt = bytearray(rep.native.toByteTree())
+    ka = rep["k_A"].to_bytes(G.exp_bytes, "big")
+    at = bytes(bt).index(ka)
+    bt[at:at + G.exp_bytes] = (rep["k_A"] + q).to_bytes(G.exp_bytes, "big")
+    assert ver.readReply(bytes(bt), n, 1) is None
+    assert ver.readReply(rep.native.toByteTree(), n, 1) is not None
+    # PoSC and CCPoS share the rule
+    hv = nat
+    p, g = c["p"], c["g"]
+    t = Tape(b"robust-q2", q)
+    h = c["H"].toInts()
+    pi, r, e = t.permutation(n), t.ring_array(n), t.int_array(n, NE)
+    U = G.toElementArray(P.permutation_commitment(g, h, r, pi, p))
+    pc = hv.PoSCBasicTW(G, NV, NE, NR, rand=Tape(b"robust-posc", q))
+    pc.setInstance(g, c["H"], U, G.ringArray(r), pi)
+    pc.setBatchVector(e)
+    com_c, rep_c = pc.commit(), pc.reply(v)
+    vc = hv.PoSCBasicTW(G, NV, NE, NR)
+    vc.setInstance(g, c["H"], U)
+    vc.setBatchVector(e)
+    vc.setCommitment(com_c)
+    vc.setChallenge(v)
+    assert vc.verify(rep_c)
+    bad = dict(rep_c)
+    bad["k_D"] = rep_c["k_D"] + q
+    assert not vc.verify(bad)
+
+
+def test_decryption_reply_above_q_is_a_false_verdict(vmn, gpu_ctx, mods):
+    """DistrElGamalSessionBasic.setReply (:606-613): a reply that is not a field element becomes 0 and the party's verdict
+    false -- it is not reduced."""
+    nat = mods["native"]
+    n, k, thr = 12, 3, 2
+    p, q, g, h, pkey, w, t = make_instance(512, n, 1, b"robust-dec")
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    U = G.toElementArray(w[0])
+    x = t.ring_element()
+    y = pow(g, x, p)
+    e, v = t.int_array(n, NE), t.int_array(1, NV)[0]
+    F = nat.decryptionFactors(U, x, q, k)
+    pr = nat.DistrElGamalSessionBasic(G, 1, k, thr, NE, rand=Tape(b"robust-dec-p", q))
+    ys, fs = [None, y] + [y] * (k - 1), [None, F] + [None] * (k - 1)
+    pr.setInstance(U, ys, fs)
+    pr.setBatchVector(e)
+    pr.batchInput()
+    yp, Bp = pr.commit(x)
+    kx = pr.reply(v)
+    ver = nat.DistrElGamalSessionBasic(G, 2, k, thr, NE)
+    ver.setInstance(U, ys, fs)
+    ver.setBatchVector(e)
+    ver.batchInput()
+    ver.setCommitment(1, yp, Bp)
+    ver.batch(1)
+    ver.setReply(1, kx)
+    assert ver.verify(1, v)
+    ver.setReply(1, kx + q)
+    assert not ver.verify(1, v)
+    ver.setReply(1, kx)
+    assert ver.verify(1, v)
+
+
+def test_an_array_freed_by_the_helper_returns_to_the_lane_that_owns_it(vmn, gpu_ctx):
+    """vmn_garray_free on the helper thread used to put a main-lane block into the HELPER's pool while
+    the main stream still had kernels queued on it; the helper's next allocation of that size then overwrote it on the
+    other stream.  Now the block goes back to its own lane (ordered behind the freeing thread's queued work)."""
+    from oracle import pyref
+    p, q, g = pyref.modp_group(2048)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    n = 4096
+    xs = [pow(g, k + 2, p) for k in range(n)]
+    es = pyref.stream_ints(b"lane/e", n, q)
+    X, E = G.toElementArray(xs), G.ringArray(es)
+    live0 = gpu_ctx.memory_stats()["live_bytes"]
+    gpu_ctx.helper_mark()
+    errors = []
+    junk = [p - 1 - k for k in range(n)]
+
+    def helper_thread(victim):
+        try:
+            with gpu_ctx.helper():
+                victim.free()                                   # the last reference dropped on the helper thread
+                for _ in range(4):                              # same size class: would have been handed the block back
+                    J = G.toElementArray(junk, checked=False)
+                    J.free()
+        except Exception as exc:      # pragma: no cover
+            errors.append(exc)
+
+    outs = []
+    for rnd in range(3):
+        Xc = X.copyOfRange(0, n)
+        out = Xc.exp(E)                                         # queued on the main stream, reads Xc for ~ms
+        th = threading.Thread(target=helper_thread, args=(Xc,))
+        th.start()
+        th.join()
+        outs.append(out)
+    assert not errors
+    want = [pow(x, e, p) for x, e in zip(xs[:64], es[:64])]
+    for out in outs:
+        got = out.toInts()
+        assert got[:64] == want and got == outs[0].toInts()
+        out.free()
+    assert gpu_ctx.memory_stats()["live_bytes"] == live0        # the accounting of neither lane went negative / leaked

@@ -1192,7 +1192,8 @@ static int new_garray(vmn_group* grp, size_t n, vmn_garray** out) {
     a->grp = grp;
     a->n = n;
     a->bytes = elems_bytes(grp->P, n);
-    VMN_TRY(alloc_elems(LANE(grp->ctx), grp->P, n, &a->d));
+    a->lane = LANE(grp->ctx);
+    VMN_TRY(alloc_elems(a->lane, grp->P, n, &a->d));
     *out = a.release();
     return VMN_OK;
 }
@@ -1201,21 +1202,39 @@ static int new_rarray(vmn_group* grp, size_t n, vmn_rarray** out) {
     a->grp = grp;
     a->n = n;
     a->bytes = elems_bytes(grp->Q, n);
-    VMN_TRY(alloc_elems(LANE(grp->ctx), grp->Q, n, &a->d));
+    a->lane = LANE(grp->ctx);
+    VMN_TRY(alloc_elems(a->lane, grp->Q, n, &a->d));
     *out = a.release();
     return VMN_OK;
 }
 
+// A block goes back to the pool of the lane it was allocated on -- the pool's one guarantee is "reuse is ordered on that
+// lane's stream".  When another lane's thread frees it (the helper dropping the last reference to a main-lane array, or
+// the other way round), whatever that thread has queued on ITS stream may still touch the block: the owner's stream is
+// made to wait for it (an event, no host blocking) before the block can be handed out again.  Work queued on a third
+// party's behalf is the caller's to order: an array must outlive the calls that use it, as with any library.
+static void free_to_owner(vmn_ctx* owner, vmn_ctx* caller, void* d, size_t bytes) {
+    if (!owner) owner = caller;
+    if (caller != owner && d) {
+        hipEvent_t ev = nullptr;
+        bool ordered = false;
+        if (hipSetDevice(caller->device) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+            ordered = hipEventRecord(ev, caller->stream) == hipSuccess && hipStreamWaitEvent(owner->stream, ev, 0) == hipSuccess;
+            (void)hipEventDestroy(ev);                 // released by the runtime once the wait has been satisfied
+        }
+        if (!ordered) (void)hipStreamSynchronize(caller->stream);
+    }
+    std::lock_guard<std::recursive_mutex> guard__(owner->mu);
+    pool_free(owner, d, bytes);
+}
 extern "C" void vmn_garray_free(vmn_garray* a) {
     if (!a) return;
-    std::lock_guard<std::recursive_mutex> guard__(LANE(a->grp->ctx)->mu);
-    pool_free(LANE(a->grp->ctx), a->d, a->bytes);
+    free_to_owner(a->lane, LANE(a->grp->ctx), a->d, a->bytes);
     delete a;
 }
 extern "C" void vmn_rarray_free(vmn_rarray* a) {
     if (!a) return;
-    std::lock_guard<std::recursive_mutex> guard__(LANE(a->grp->ctx)->mu);
-    pool_free(LANE(a->grp->ctx), a->d, a->bytes);
+    free_to_owner(a->lane, LANE(a->grp->ctx), a->d, a->bytes);
     delete a;
 }
 extern "C" size_t vmn_garray_size(const vmn_garray* a) { return a ? a->n : 0; }

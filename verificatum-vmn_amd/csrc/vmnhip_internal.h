@@ -159,6 +159,7 @@ struct vmn_garray {
     uint32_t* d = nullptr;     // n * W words, M28 form mod p
     size_t n = 0;
     size_t bytes = 0;          // allocation size (pool key)
+    vmn_ctx* lane = nullptr;   // the lane (stream + pool) the block was allocated on: it returns there, whoever frees it
 };
 
 struct vmn_rarray {
@@ -166,4 +167,5 @@ struct vmn_rarray {
     uint32_t* d = nullptr;     // n * W words, M28 form mod q
     size_t n = 0;
     size_t bytes = 0;
+    vmn_ctx* lane = nullptr;   // see vmn_garray
 };

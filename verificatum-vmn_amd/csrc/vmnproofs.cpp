@@ -421,6 +421,20 @@ struct ProofBase {
     vmn_comm comm{};
     size_t Ntot = 0, lo = 0, hi = 0;
     RA e_full_own;                     // the whole batching vector (sharded provers permute it)
+    // Every setter that changes an input of a verification (instance, commitment, batching vector, A / F) bumps the epoch;
+    // a cached reply side (Prepared, below) is only used by the verify() of the epoch it was prepared in -- a verdict is
+    // never computed from mixed inputs.  (The challenge is not part of the reply side.)
+    uint64_t epoch = 1;
+    void touch() { ++epoch; }
+    // The ring scalars of a reply must be field elements: the reference parses them with pRing.toElement, which rejects
+    // a value >= q (PoSBasicTW.java:985-989), so k_A + q makes ITS verifier answer false -- and this one too, whether the
+    // reply came through vmn_msg_from_bytetree (which refuses it) or was assembled with vmn_msg_push_ring.
+    bool ring_items_in_range(std::initializer_list<const vmn_msg::Item*> its) const {
+        for (const vmn_msg::Item* it : its)
+            for (size_t k = 0; it && k < it->count; ++k)
+                if (vmn::num64::cmp(G.ring_from(it->bytes.data() + k * it->width), G.Zq.n) >= 0) return false;
+        return true;
+    }
 
     int init(vmn_group* grp, int vb, int ebl, int rb, const vmn_random_source* r) {
         TRY(G.init(grp));
@@ -523,6 +537,7 @@ struct ProofBase {
     }
     // the batching vector: this rank's shard in e; sharded objects keep the whole vector as well (e' = permute(e, pi^-1))
     int keep_batch_vector(RA& all, RA& e) {
+        touch();
         if (!sharded) {
             e.reset();
             e.p = all.release();
@@ -554,6 +569,14 @@ struct ProofBase {
     // host for ModPGroup
     int gexp(const Bytes& base, const Num& e, Bytes& out) const { return G.el_exp(base, e, out); }
 
+    template <typename P>
+    int mark_malformed(P& prep, const vmn_msg* rep) const {
+        prep.malformed = true;
+        prep.rep = rep;
+        prep.serial = rep->serial;
+        prep.epoch = epoch;
+        return VMN_OK;
+    }
     // ---- exchanges between the ranks: every rank contributes `mine` (same length everywhere) -----------------------
     int exchange(const Bytes& mine, std::vector<Bytes>& all) {
         all.clear();
@@ -868,6 +891,7 @@ struct vmn_pos : ProofBase {
     std::vector<Bytes> cFp;
 
     int precompute(const uint8_t* g_be, const vmn_garray* h_, const uint32_t* pi_) {
+        touch();
         VMN_TRACE("pos:precompute");
         REQUIRE(g_be && h_, "null argument");
         REQUIRE(vmn_garray_size(h_) > 0, "empty generator array");
@@ -906,6 +930,7 @@ struct vmn_pos : ProofBase {
     }
     int set_instance(const uint8_t* pkey_be, size_t width_, const vmn_garray* const* w_, const vmn_garray* const* wp_,
                      const vmn_rarray* const* s_) {
+        touch();
         REQUIRE(pkey_be && width_ > 0 && Ntot > 0, "null argument or precompute not called");
         width = width_;
         TRY(local_components(w_, 2 * width, w_own, w, "w"));
@@ -1003,10 +1028,12 @@ struct vmn_pos : ProofBase {
     }
     GA u_cut;
     int set_permutation_commitment(const vmn_garray* u_) {
+        touch();
         REQUIRE(u_, "null argument");
         return local_garray(u_, u_cut, &u, "u");
     }
     int compute_af() {
+        touch();
         VMN_TRACE("pos:compute_af");
         REQUIRE(u && e.p && width, "computeAF needs u, the instance and the batching vector");
         std::vector<const vmn_garray*> xs{u};
@@ -1021,6 +1048,7 @@ struct vmn_pos : ProofBase {
         return VMN_OK;
     }
     int set_commitment(const vmn_msg* m) {
+        touch();
         VMN_TRACE("pos:set_commitment");
         const vmn_msg::Item *iB = item_of(m, 0, VMN_ITEM_GARRAY), *iAp = item_of(m, 1, VMN_ITEM_ELEMENTS),
                             *iBp = item_of(m, 2, VMN_ITEM_GARRAY), *iCp = item_of(m, 3, VMN_ITEM_ELEMENTS),
@@ -1052,7 +1080,8 @@ struct vmn_pos : ProofBase {
     // vmn_pos_verify_prepare(reply) does that part and keeps the results; verify() does it itself when it was not called.
     struct Prepared {
         const vmn_msg* rep = nullptr;
-        uint64_t serial = 0;
+        uint64_t serial = 0, epoch = 0;
+        bool malformed = false;             // a ring scalar of the reply is >= q: the verdict is false, nothing else was computed
         Bytes gkA, gkC, gkD, C, D;
         std::vector<Bytes> kE_prods, pkpow;
         GA right;
@@ -1062,6 +1091,7 @@ struct vmn_pos : ProofBase {
         void clear() {
             rep = nullptr;
             serial = 0;
+            malformed = false;
             right.reset();
             kE_prods.clear();
             pkpow.clear();
@@ -1078,6 +1108,7 @@ struct vmn_pos : ProofBase {
         REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikF->count == width && ikA->width == G.xb,
                 "reply items have the wrong shape");
         prep.clear();
+        if (!ring_items_in_range({ikA, ikC, ikD, ikF})) return mark_malformed(prep, rep);
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
         std::vector<Num> k_F;
         for (auto& bts : split(*ikF)) k_F.push_back(G.ring_from(bts.data()));
@@ -1122,12 +1153,19 @@ struct vmn_pos : ProofBase {
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
+        prep.epoch = epoch;
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, int* verdict, int* five) {
         VMN_TRACE("pos:verify");
         REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
-        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep, true));
+        if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch) TRY(verify_prepare(rep, true));
+        if (prep.malformed) {                                                     // a ring scalar >= q: not a reply (:985-989)
+            prep.clear();
+            if (five) five[0] = five[1] = five[2] = five[3] = five[4] = 0;
+            *verdict = 0;
+            return VMN_OK;
+        }
         Bytes lhsA, lhsC, lhsD, rhs;
         std::vector<Bytes> lhsF(2 * width), rF;
         GA left;
@@ -1191,6 +1229,7 @@ struct vmn_posc : ProofBase {
 
     // h: the whole array; u / r: whole arrays or this rank's shards (a prover's pi is always the whole permutation)
     int set_instance(const uint8_t* g_be, const vmn_garray* h_, const vmn_garray* u_, const vmn_rarray* r_, const uint32_t* pi_) {
+        touch();
         REQUIRE(g_be && h_ && u_, "null argument");
         set_total(vmn_garray_size(h_));
         REQUIRE(Ntot > 0, "h / u empty");
@@ -1278,6 +1317,7 @@ struct vmn_posc : ProofBase {
         return VMN_OK;
     }
     int set_commitment(const vmn_msg* m) {
+        touch();
         const vmn_msg::Item *iB = item_of(m, 0, VMN_ITEM_GARRAY), *iAp = item_of(m, 1, VMN_ITEM_ELEMENTS),
                             *iBp = item_of(m, 2, VMN_ITEM_GARRAY), *iCp = item_of(m, 3, VMN_ITEM_ELEMENTS),
                             *iDp = item_of(m, 4, VMN_ITEM_ELEMENTS);
@@ -1300,7 +1340,8 @@ struct vmn_posc : ProofBase {
     // verification in two parts, as in vmn_pos: verify_prepare(reply) = everything that needs no challenge
     struct Prepared {
         const vmn_msg* rep = nullptr;
-        uint64_t serial = 0;
+        uint64_t serial = 0, epoch = 0;
+        bool malformed = false;             // a ring scalar of the reply is >= q: the verdict is false, nothing else was computed
         Bytes gkA, gkC, gkD, A, C, D, hk;
         GA right;
         bool deferred = false;             // see vmn_pos
@@ -1309,6 +1350,7 @@ struct vmn_posc : ProofBase {
         void clear() {
             rep = nullptr;
             serial = 0;
+            malformed = false;
             right.reset();
             deferred = false;
         }
@@ -1321,6 +1363,7 @@ struct vmn_posc : ProofBase {
         REQUIRE(rep && rep->items.size() == 5 && ikA && ikB && ikC && ikD && ikE, "reply is not (k_A, k_B, k_C, k_D, k_E)");
         REQUIRE(vmn_rarray_size(ikB->ra) == N && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
         prep.clear();
+        if (!ring_items_in_range({ikA, ikC, ikD})) return mark_malformed(prep, rep);
         Num k_A = G.ring_from(ikA->bytes.data()), k_C = G.ring_from(ikC->bytes.data()), k_D = G.ring_from(ikD->bytes.data());
         Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), Blast, prev, t_h0;
         prep.A.assign(G.eb, 0);
@@ -1361,12 +1404,18 @@ struct vmn_posc : ProofBase {
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
+        prep.epoch = epoch;
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, int* verdict) {
         REQUIRE(verdict && cB && e.p && !v_be.empty(), "verify needs the batching vector, setCommitment and setChallenge");
         *verdict = 0;
-        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep, true));
+        if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch) TRY(verify_prepare(rep, true));
+        if (prep.malformed) {                                                     // a ring scalar >= q: not a reply
+            prep.clear();
+            *verdict = 0;
+            return VMN_OK;
+        }
         Bytes lhsA, lhsC, lhsD, rhs;
         int vB = 0;
         bool a_ok = false;
@@ -1429,6 +1478,7 @@ struct vmn_ccpos : ProofBase {
     int set_instance(const uint8_t* g_be, const vmn_garray* h_, const vmn_garray* u_, const uint8_t* pkey_be, size_t width_,
                      const vmn_garray* const* w_, const vmn_garray* const* wp_, const vmn_rarray* r_, const uint32_t* pi_,
                      const vmn_rarray* const* s_) {
+        touch();
         REQUIRE(g_be && h_ && u_ && pkey_be && width_ > 0, "null argument");
         set_total(vmn_garray_size(h_));
         REQUIRE(Ntot > 0, "h / u empty");
@@ -1519,6 +1569,7 @@ struct vmn_ccpos : ProofBase {
         return VMN_OK;
     }
     int set_commitment(const vmn_msg* m) {
+        touch();
         const vmn_msg::Item *iAp = item_of(m, 0, VMN_ITEM_ELEMENTS), *iBp = item_of(m, 1, VMN_ITEM_ELEMENTS);
         REQUIRE(m && m->items.size() == 2 && iAp && iBp && iAp->count == 1 && iBp->count == 2 * width && iAp->width == G.eb &&
                     iBp->width == G.eb, "commitment is not (A', B')");
@@ -1534,6 +1585,7 @@ struct vmn_ccpos : ProofBase {
     }
     GA ru_own;
     int compute_ab(const vmn_garray* raisedu) {
+        touch();
         REQUIRE(u && e.p && width, "computeAB needs the instance and the batching vector");
         raised = raisedu != nullptr;
         if (!raised) {
@@ -1568,12 +1620,21 @@ struct vmn_ccpos : ProofBase {
     // here ALL the GPU work of verify(): the multi-exponentiations with k_E
     struct Prepared {
         const vmn_msg* rep = nullptr;
-        uint64_t serial = 0;
+        uint64_t serial = 0, epoch = 0;
+        bool malformed = false;             // a ring scalar of the reply is >= q: the verdict is false, nothing else was computed
         Bytes gkA, Ap_rho, g_term;
         std::vector<Bytes> pkpow, kE_prods, prods;
+        const vmn_garray* raisedh = nullptr;       // what the raised form was prepared with: verify() must be handed the same
+        Bytes rho;
         void clear() {
             rep = nullptr;
             serial = 0;
+            malformed = false;
+            raisedh = nullptr;
+            rho.clear();
+        }
+        bool same_raised(const vmn_garray* rh, const uint8_t* rho_be, size_t rho_bytes) const {
+            return raisedh == rh && rho.size() == (rho_be ? rho_bytes : 0) && (rho.empty() || memcmp(rho.data(), rho_be, rho.size()) == 0);
         }
     } prep;
     int verify_prepare(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes) {
@@ -1584,6 +1645,7 @@ struct vmn_ccpos : ProofBase {
         REQUIRE(ikB->count == width && vmn_rarray_size(ikE->ra) == N && ikA->width == G.xb, "reply items have the wrong shape");
         REQUIRE(raised == (raisedh != nullptr) && raised == (rho_be != nullptr), "raised / plain form must match computeAB");
         prep.clear();
+        if (!ring_items_in_range({ikA, ikB})) return mark_malformed(prep, rep);
         Num k_A = G.ring_from(ikA->bytes.data());
         std::vector<Num> k_B;
         for (auto& bts : split(*ikB)) k_B.push_back(G.ring_from(bts.data()));
@@ -1622,13 +1684,21 @@ struct vmn_ccpos : ProofBase {
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
+        prep.epoch = epoch;
+        prep.raisedh = raisedh;
+        if (rho_be) prep.rho.assign(rho_be, rho_be + rho_bytes);
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes, int* verdict) {
         REQUIRE(verdict && have_commitment && have_ab && !v_be.empty(), "verify needs computeAB, setCommitment and setChallenge");
         *verdict = 0;
-        if (!rep || prep.rep != rep || prep.serial != rep->serial) TRY(verify_prepare(rep, raisedh, rho_be, rho_bytes));
+        if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch || !prep.same_raised(raisedh, rho_be, rho_bytes))
+            TRY(verify_prepare(rep, raisedh, rho_be, rho_bytes));
         REQUIRE(raised == (raisedh != nullptr) && raised == (rho_be != nullptr), "raised / plain form must match computeAB");
+        if (prep.malformed) {                                                     // a ring scalar >= q: not a reply
+            prep.clear();
+            return VMN_OK;                                                        // (*verdict = 0 above)
+        }
         Bytes rhs, lhsA;
         std::vector<Bytes> rB, lhsB(2 * width);
         if (!raised) {                                                            // A^v A' = g^{k_A} prod h^{k_E}; B^v B' = pk^{-k_B} prod w'^{k_E}
@@ -1817,6 +1887,10 @@ struct vmn_decproof {
     int verify(int l, const uint8_t* v_be, size_t vbytes, int* verdict) {
         TRY(party(l));
         REQUIRE(verdict && v_be && vbytes && !A.empty() && !B[l].empty() && !yp[l].empty() && have_kx[l], "verify needs batch(l), the commitment and the reply of l");
+        if (have_kx[l] == 2) {                                                   // malformed reply: verdicts[l] = false (:719-721)
+            *verdict = 0;
+            return VMN_OK;
+        }
         Num v = G.reduce(v_be, vbytes);
         Bytes yinv, t, lhs, rhs;
         TRY(G.el_inv(y[l], yinv));
@@ -2160,6 +2234,12 @@ int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const i
             }
         }
         if (!good) return VMN_OK;
+        if (it.kind == VMN_ITEM_RING) {                // pRing.toElement rejects a value >= q (PoSBasicTW.java:985-989)
+            Bytes qb(xb);
+            TRY(vmn_group_get_order(grp, qb.data()));
+            for (size_t k = 0; k < it.count; ++k)
+                if (memcmp(it.bytes.data() + k * xb, qb.data(), xb) >= 0) return VMN_OK;
+        }
         m->items.push_back(std::move(it));
     }
     if (rd.p != rd.end) return VMN_OK;
@@ -2572,8 +2652,12 @@ int vmn_decproof_set_reply(vmn_decproof* p, int l, const uint8_t* kx_be) {
     NONNULL(p);
     TRY(p->party(l));
     if (!kx_be) return fail(VMN_ERR_ARG, "vmn_decproof_set_reply: null argument");
-    p->k_x[l] = p->G.reduce(kx_be, p->G.xb);
+    p->k_x[l] = p->G.ring_from(kx_be);
     p->have_kx[l] = 1;
+    if (vmn::num64::cmp(p->k_x[l], p->G.Zq.n) >= 0) {          // pRing.toElement fails: k_x = 0, verdict false (:606-613)
+        p->k_x[l] = Num(p->G.ql, 0);
+        p->have_kx[l] = 2;
+    }
     return VMN_OK;
 }
 int vmn_decproof_batch(vmn_decproof* p, int l) {

@@ -230,7 +230,9 @@ class Message:
                 buf = group.enc_els(part[1])
                 _check(plib().vmn_msg_push_elements(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.elem_bytes)))
             else:
-                buf = b"".join(int_to_be(x % group.q, group.exp_bytes) for x in part[1])
+                # a value that fits the wire width travels as it is (a reply may hold k + q: the verifier must say no)
+                lim = 1 << (8 * group.exp_bytes)
+                buf = b"".join(int_to_be(x if 0 <= x < lim else x % group.q, group.exp_bytes) for x in part[1])
                 _check(plib().vmn_msg_push_ring(h, buf, C.c_size_t(len(part[1])), C.c_size_t(group.exp_bytes)))
         return m
 
@@ -667,8 +669,11 @@ class DistrElGamalSessionBasic:
         self._call("set_commitment", C.c_int(l), self.G.enc_el(yp), self.G.enc_el(Bp))
 
     def setReply(self, l: int, k_x: int):
+        # a value that fits the wire width is handed over as it is: one >= q is not a field element and costs the party
+        # its verdict (DistrElGamalSessionBasic.java:606-613), it is not reduced
+        raw = k_x if 0 <= k_x < 1 << (8 * self.G.exp_bytes) else k_x % self.q
         self.k_x[l] = k_x % self.q
-        self._call("set_reply", C.c_int(l), int_to_be(k_x % self.q, self.G.exp_bytes))
+        self._call("set_reply", C.c_int(l), int_to_be(raw, self.G.exp_bytes))
 
     def batch(self, l: int):
         self._call("batch", C.c_int(l))
