@@ -632,75 +632,198 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
             "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
-def mix_prove_sharded(entry, vmn, ctx, grp, n_per_gpu: int, seed: int, sync, dist, device):
-    """The same workload sharded over the ranks: N = n_per_gpu x world ciphertexts (at most BASELINE.json configs[3]'s
-    4 194 304), ONE proof through the sharded C++ drivers (vmn_pos_set_comm, include/vmnproofs.h): every
-    position-indexed array is split by position; the public inputs h, w and the prover's N-sized random arrays -- expanded
-    on every GPU from the same 32-byte seeds -- are held whole, so the permuted arrays are local gathers; the only
-    collectives are all-gathers of a few hundred bytes (partial products, partial sums, scan carries, verdict bits;
-    RCCL over xGMI) -- one per phase."""
-    par, mx, nat = load_sub(entry, "parallel"), load_sub(entry, "mixnet"), load_sub(entry, "native")
-    comm = par.Comm(dist, device)
+def _synthetic_instance(grp, mx, seed: int, n: int, width: int = 1):
+    """Public instance of a sharded leg, the same on every rank and made on the device (untimed setup): h = g^a,
+    key y = g^x, honest ciphertexts w = (g^t, g^m y^t) per column -- exponent arrays expanded from 32-byte seeds."""
+    q, g = grp.q, grp.g
+    pub = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)
+    y = grp.k_exp(g, pub.ring_element())
+    pkey = [g] * width + [y] * width
+    rnd_arr = lambda: grp.ringArrayFromPRG(pub.array_seed(), n, q.bit_length() - 1)
+    A = rnd_arr()
+    H = grp.exp(g, A)
+    A.free()
+    W = [None] * (2 * width)
+    for c in range(width):
+        T, Mx = rnd_arr(), rnd_arr()
+        M, YT = grp.exp(g, Mx), grp.exp(y, T)
+        W[c] = grp.exp(g, T)
+        W[width + c] = M.mul(YT)
+        for a in (T, Mx, M, YT):
+            a.free()
+    return pub, y, pkey, H, W
+
+
+def _collective_record(dist, comm, ncomm):
+    return {"backend": comm.backend_used or (dist.get_backend() if dist.is_initialized() else None), "world": comm.world,
+            "fell_back": comm.fell_back, "all_gathers_per_proof_leg": ncomm.exchanges, "bytes_sent_per_rank": ncomm.bytes_sent}
+
+
+def mix_prove_sharded(entry, vmn, ctx, grp, n: int, seed: int, sync, comm):
+    """ONE proof of a shuffle of n ciphertexts sharded over the ranks through the C++ drivers (vmn_pos_set_comm,
+    include/vmnproofs.h): every position-indexed array is split by position; the public inputs h and w are whole on
+    every GPU (the permuted arrays are local gathers, no element crosses a link); the prover's N-sized random arrays, the
+    re-encryption exponents and the batching vector are 32-byte seeds of which a rank expands only its own positions and
+    the rows it reads through the permutation (O(n / world) per rank); the only collectives are all-gathers of a few
+    hundred bytes (partial products, partial sums, scan carries, verdict bits; RCCL over xGMI) -- one per phase."""
+    mx, nat = load_sub(entry, "mixnet"), load_sub(entry, "native")
     ncomm = nat.NativeComm(comm)
     NV = NE = 256
     NR = 100
-    n = min(n_per_gpu * comm.world, 4_194_304)
     lo, hi = nat.shard_bounds_native(n, comm.world, comm.rank)
-    p, q, g = grp.p, grp.q, grp.g
-    pub = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)             # same seed on every rank: replicated public instance
-    y = pow(g, pub.ring_element(), p)
-    pkey = [g, y]
-    for base in pkey:                      # session setup (tables sized for this rank's shard)
+    pub, y, pkey, H, W = _synthetic_instance(grp, mx, seed, n)
+    g = grp.g
+    for base in (g, y):                    # session setup (tables sized for this rank's shard)
         grp.precomputeFixed(base, max(1, hi - lo), 16)
-    H = grp.exp(g, grp.ringArray(pub.ring_array(n)))
-    T = grp.ringArray(pub.ring_array(n))
-    M = grp.exp(g, grp.ringArray(pub.ring_array(n)))
-    YT = grp.exp(y, T)
-    W = [grp.exp(g, T), M.mul(YT)]
-    for a in (T, M, YT):
+    best = None
+    for _ in range(2):
+        ncomm.exchanges = ncomm.bytes_sent = 0
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        gc.collect()            # release the previous pass's arrays into the pool before the clock starts
+        sync()
+        t0 = time.perf_counter()
+        pi = pub.permutation(n)                                                # the same on every rank
+        prover = nat.PoSBasicTW(grp, NV, NE, NR, rand=pub)
+        prover.setComm(ncomm)
+        prover.precompute(g, H, pi)
+        WP, S = nat.reencrypt_shard_seeded_native(grp, pkey, W, pub, NR, pi, lo, hi)   # this rank's shards of w' and s
+        sync()
+        t1 = time.perf_counter()
+        prover.setInstance(pkey, W, WP, S)
+        e_seed = pub.array_seed()
+        prover.setBatchVectorSeed(e_seed)
+        com = prover.commit()
+        v = int.from_bytes(pub.int_array(1, NV), "big")
+        rep = prover.reply(v)
+        sync()
+        t2 = time.perf_counter()
+        ver = nat.PoSBasicTW(grp, NV, NE, NR)
+        ver.setComm(ncomm)
+        ver.precompute(g, H)
+        ver.setPermutationCommitment(prover.u)
+        ver.setInstance(pkey, W, WP)
+        ver.setBatchVectorSeed(e_seed)
+        ver.computeAF()
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        ok = ver.verify(rep)
+        sync()
+        t3 = time.perf_counter()
+        ctx.timing_enable(False)
+        fam = ctx.timing_report()
+        cur = {"kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
+               "precompute_and_reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
+               "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "n": n, "ciphertexts_per_rank": hi - lo,
+               "collective": _collective_record(comm.dist, comm, ncomm),
+               "roofline_rank0": leg_roofline(fam, (t3 - t0) * 1e3)}
+        com = rep = None
+        for a in WP + S:
+            a.free()
+        ver.free()
+        prover.free()
+        if best is None or cur["total_ms"] < best["total_ms"]:
+            best = cur
+    for a in [H] + W:
         a.free()
-    ctx.timing_reset()
-    ctx.timing_enable(True)
-    gc.collect()            # release the previous pass's arrays into the pool before the clock starts
-    sync()
-    t0 = time.perf_counter()
-    pi = pub.permutation(n)                                                # the same on every rank
-    S = [nat.random_ring_array_native(grp, pub, n, NR)]                    # whole array on every rank, from one 32-byte seed
-    prover = nat.PoSBasicTW(grp, NV, NE, NR, rand=pub)
-    prover.setComm(ncomm)
-    prover.precompute(g, H, pi)
-    WP = nat.reencrypt_shard_native(grp, pkey, W, S, pi, lo, hi)           # this rank's shard of w'
-    sync()
-    t1 = time.perf_counter()
-    prover.setInstance(pkey, W, WP, S)
-    e_seed = pub.array_seed()
-    prover.setBatchVectorSeed(e_seed)
-    com = prover.commit()
-    v = int.from_bytes(pub.int_array(1, NV), "big")
-    rep = prover.reply(v)
-    sync()
-    t2 = time.perf_counter()
-    ver = nat.PoSBasicTW(grp, NV, NE, NR)
-    ver.setComm(ncomm)
-    ver.precompute(g, H)
-    ver.setPermutationCommitment(prover.u)
-    ver.setInstance(pkey, W, WP)
-    ver.setBatchVectorSeed(e_seed)
-    ver.computeAF()
-    ver.setCommitment(com)
-    ver.setChallenge(v)
-    ok = ver.verify(rep)
-    sync()
-    t3 = time.perf_counter()
-    ctx.timing_enable(False)
-    fam = ctx.timing_report()
-    return {"kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
-            "precompute_and_reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
-            "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "n": n, "ciphertexts_per_rank": hi - lo,
-            "collective": {"backend": dist.get_backend() if dist.is_initialized() else None, "world": comm.world,
-                           "all_gathers_per_proof": ncomm.exchanges, "bytes_sent_per_rank": ncomm.bytes_sent},
-            "ciphertexts_per_s": n / (t3 - t0),
-            "canonical_TMACs_survey_8d": 3280 * 8256 * n / (t3 - t0) / 1e12, "roofline": leg_roofline(fam, (t3 - t0) * 1e3)}
+    best["total_ms"] = comm.max_over_ranks(best["total_ms"])
+    best["accepted"] = comm.all_true(best["accepted"])
+    best["ciphertexts_per_s"] = n / (best["total_ms"] / 1e3)
+    return best
+
+
+def mix_ccpos_sharded(entry, vmn, ctx, grp, label: str, n: int, seed: int, sync, comm, width: int, with_posc: bool):
+    """The commitment-consistent path sharded over the ranks (BASELINE.json configs[4]: P-256, width 3, on 8 GPUs;
+    configs[2]'s 3072-bit group the same way): offline = this rank's shard of the permutation commitment (+ a sharded
+    PoSC prove + verify when with_posc), online = this rank's shard of the re-encryption + CCPoS prove + verify through
+    vmn_ccpos_set_comm (hvzk/CCPoSBasicW.java:344-396, 462-506, 519-584).  Exponent arrays are seeds (see mix_prove_sharded)."""
+    mx, nat = load_sub(entry, "mixnet"), load_sub(entry, "native")
+    ncomm = nat.NativeComm(comm)
+    NV = NE = 256
+    NR = 100
+    lo, hi = nat.shard_bounds_native(n, comm.world, comm.rank)
+    pub, y, pkey, H, W = _synthetic_instance(grp, mx, seed, n, width)
+    g = grp.g
+    for base in (g, y):
+        grp.precomputeFixed(base, max(1, hi - lo), 16)
+    best = None
+    for _ in range(2):
+        ncomm.exchanges = ncomm.bytes_sent = 0
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        gc.collect()
+        sync()
+        t0 = time.perf_counter()
+        pi = pub.permutation(n)
+        U, R = nat.permutation_commitment_shard_seeded_native(grp, g, H, pub, NR, pi, lo, hi)
+        ok_posc = True
+        if with_posc:
+            e1 = pub.array_seed()
+            pr = nat.PoSCBasicTW(grp, NV, NE, NR, rand=pub)
+            pr.setComm(ncomm)
+            pr.setInstance(g, H, U, R, pi)
+            pr.setBatchVectorSeed(e1)
+            com = pr.commit()
+            v1 = int.from_bytes(pub.int_array(1, NV), "big")
+            rep = pr.reply(v1)
+            pv = nat.PoSCBasicTW(grp, NV, NE, NR)
+            pv.setComm(ncomm)
+            pv.setInstance(g, H, U)
+            pv.setBatchVectorSeed(e1)
+            pv.setCommitment(com)
+            pv.setChallenge(v1)
+            ok_posc = pv.verify(rep)
+            com = rep = None
+            pv.free()
+            pr.free()
+        sync()
+        t1 = time.perf_counter()
+        WP, S = nat.reencrypt_shard_seeded_native(grp, pkey, W, pub, NR, pi, lo, hi)
+        sync()
+        t2 = time.perf_counter()
+        e2 = pub.array_seed()
+        cp = nat.CCPoSBasicW(grp, NV, NE, NR, rand=pub)
+        cp.setComm(ncomm)
+        cp.setInstance(g, H, U, pkey, W, WP, R, pi, S)
+        cp.setBatchVectorSeed(e2)
+        com2 = cp.commit()
+        v2 = int.from_bytes(pub.int_array(1, NV), "big")
+        rep2 = cp.reply(v2)
+        sync()
+        t3 = time.perf_counter()
+        cv = nat.CCPoSBasicW(grp, NV, NE, NR)
+        cv.setComm(ncomm)
+        cv.setInstance(g, H, U, pkey, W, WP)
+        cv.setBatchVectorSeed(e2)
+        cv.setCommitment(com2)
+        cv.setChallenge(v2)
+        cv.computeAB()
+        ok = cv.verify(rep2)
+        sync()
+        t4 = time.perf_counter()
+        ctx.timing_enable(False)
+        fam = ctx.timing_report()
+        cur = {"workload": label, "n": n, "ciphertexts_per_rank": hi - lo, "accepted": bool(ok and ok_posc),
+               "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3, "ccpos_prove_ms": (t3 - t2) * 1e3,
+               "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": (t4 - t1) * 1e3, "total_ms": (t4 - t0) * 1e3,
+               "collective": _collective_record(comm.dist, comm, ncomm),
+               "roofline_rank0": leg_roofline(fam, (t4 - t0) * 1e3),
+               "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+        com2 = rep2 = None
+        for a in WP + S + [U, R]:
+            a.free()
+        cv.free()
+        cp.free()
+        if best is None or cur["online_ms"] < best["online_ms"]:
+            best = cur
+    for a in [H] + W:
+        a.free()
+    best["online_ms"] = comm.max_over_ranks(best["online_ms"])
+    best["total_ms"] = comm.max_over_ranks(best["total_ms"])
+    best["accepted"] = comm.all_true(best["accepted"])
+    best["ciphertexts_per_s_online"] = n / (best["online_ms"] / 1e3)
+    best["ciphertexts_per_s_total"] = n / (best["total_ms"] / 1e3)
+    return best
 
 
 def cpu_mix_prove(p, q, g, n: int, cores: int):
@@ -745,6 +868,56 @@ def cpu_mix_prove(p, q, g, n: int, cores: int):
                       "fixed-base tables (window sized for the array, rebuilt per call), Pippenger, OpenMP static chunks"}
 
 
+def gpu_runtime_loaded() -> bool:
+    """True when this process has already mapped the HIP runtime or a profiler's preloaded library (rocprofv3 initialises
+    the GPU before the program starts): such a process must not spawn compilers or launchers on this pool."""
+    try:
+        with open("/proc/self/maps") as f:
+            maps = f.read()
+    except OSError:
+        return False
+    return "libamdhip64" in maps or "librocprofiler" in maps
+
+
+def ensure_built(entry) -> None:
+    """The three libraries, built here only when missing AND nothing in this process has touched the GPU (the round-end
+    driver and tools/*.sh build beforehand; under rocprofv3 a missing library is an error, not a reason to run hipcc)."""
+    need = [entry.LIB, entry.PROOFS_LIB, os.path.join(ROOT, "oracle", "libvmnoracle.so")]
+    missing = [p for p in need if not os.path.exists(p)]
+    if not missing:
+        return
+    if gpu_runtime_loaded():
+        print("bench.py: " + ", ".join(os.path.relpath(m, ROOT) for m in missing) + " missing and the GPU runtime is already loaded in this "
+              "process: run `python3 __graft_entry__.py` first", file=sys.stderr)
+        sys.exit(2)
+    entry.build()
+
+
+def self_launch(args) -> int:
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks as a CHILD process group (one process per GPU,
+    `python -m torch.distributed.run`, rendezvous on 127.0.0.1) before anything in this process touches the GPU, relay
+    its output (rank 0 prints the JSON line) and return its exit code.  With fewer visible GPUs than ranks the run is a
+    rehearsal: the ranks share the GPUs and gloo carries the collectives (RCCL needs one GPU per rank) -- the line says so."""
+    import socket
+    import subprocess
+    import __graft_entry__ as entry
+    ensure_built(entry)
+    import torch
+    have = torch.cuda.device_count()              # counts devices without initialising one (this image)
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if have < args.gpus and "VMN_BENCH_BACKEND" not in env:
+        print(f"bench.py: {have} GPU(s) visible for {args.gpus} ranks -- rehearsal: ranks share GPUs, collectives over gloo", file=sys.stderr)
+        env["VMN_BENCH_BACKEND"] = "gloo"
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -761,13 +934,19 @@ def main() -> None:
     ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=1_000_000,
                     help="ciphertexts of the 3072-bit CCPoS leg (BASELINE configs[2]; 0 = skip; single GPU only)")
     ap.add_argument("--no-e2e", dest="no_e2e", action="store_true", help="skip the end-to-end pass of the mix + prove leg (profiling runs)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = --elements / --mix-elements PER GPU (BASELINE configs[1] on every GPU), strong = in TOTAL "
+                         "(north_star's 1M-ciphertext shuffle split over the GPUs); the mix legs always report both")
     args = ap.parse_args()
+
+    # `python3 bench.py --gpus N` typed without a launcher starts its own ranks (as a child, before any GPU call)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     # Build (only if a prebuilt library is missing) BEFORE anything touches the GPU: a process that has
     # initialised the GPU must not exec children on this pool, and under rocprofv3 it already has.
     import __graft_entry__ as entry
-    if not (os.path.exists(entry.LIB) and os.path.exists(entry.PROOFS_LIB) and os.path.exists(os.path.join(ROOT, "oracle", "libvmnoracle.so"))):
-        entry.build()
+    ensure_built(entry)
     vmn = entry.load_package()
 
     import torch
@@ -776,28 +955,50 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run", file=sys.stderr)
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     distributed = world > 1
+    if os.environ.get("VMN_BENCH_LAUNCH_ONLY"):       # launcher self-test (tests/test_bench_contract.py): no GPU is touched
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": world, "scaling": args.scaling, "steps": args.steps}))
+        sys.exit(0)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
         sys.exit(2)
     # Rehearsal on a one-GPU box: VMN_BENCH_BACKEND=gloo lets several ranks share GPU 0 (RCCL needs one GPU per rank).
     backend = os.environ.get("VMN_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    n_devices = torch.cuda.device_count()
+    if distributed and backend == "nccl" and n_devices < world:
+        backend = "gloo"                          # RCCL needs one GPU per rank: this is a rehearsal on shared GPUs
+    dev_index = local_rank % n_devices
     torch.cuda.set_device(dev_index)
+    gloo_group = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(minutes=5)     # a rank that dies inside a leg must not hold the others for RCCL's default 10 min
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
+            try:
+                gloo_group = dist.new_group(backend="gloo")      # safety net of parallel.Comm (never used unless RCCL raises)
+            except Exception as exc:      # pragma: no cover
+                print(f"bench.py: no gloo fallback group ({exc})", file=sys.stderr)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
     red_device = "cuda" if backend == "nccl" else "cpu"
+    comm = load_sub(entry, "parallel").Comm(dist if distributed else None, torch.device("cuda", dev_index) if (distributed and backend == "nccl") else None,
+                                            fallback=gloo_group)
 
     p, q, g = load_sub(entry, "stdgroups").modp_group(2048)      # RFC 3526 group 14
     nbytes = 256
-    n = args.n
+    # weak: --elements per GPU; strong: --elements in total, this rank's contiguous share of them
+    if distributed and args.scaling == "strong":
+        base, rem = divmod(args.n, world)
+        n = base + (1 if rank < rem else 0)
+    else:
+        n = args.n
+    n_all = args.n if (distributed and args.scaling == "strong") else args.n * world
     ctx = vmn.Context(dev_index)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -837,7 +1038,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total = n * world * args.steps
+    total = n_all * args.steps
     value = total / elapsed
     avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
     achieved = MAC_2048_2047 * n / avg_kernel_s / 1e12
@@ -877,15 +1078,18 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if distributed else "weak",
         "vs_baseline": None,
         "dtype": "u32 limbs (28-bit radix), u64 accumulate",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: batched modPow, RFC 3526 group 14 (2048-bit safe prime), "
                                "random bases, random 2047-bit exponents, device-resident in/out",
-                   "elements_per_gpu": n, "parallelism": f"shard{world}" if world > 1 else "single",
-                   "world_size": world, "collective_backend": (backend if distributed else None),
-                   "note": "element-wise op: contiguous shards, no data-path collective (weak scaling)"},
+                   "elements_per_gpu": n, "elements_total": n_all, "parallelism": f"shard{world}" if world > 1 else "single",
+                   "world_size": world, "ranks_seen": (dist.get_world_size() if distributed else 1),
+                   "collective_backend": (backend if distributed else None),
+                   "gpus_visible": n_devices, "rehearsal_ranks_share_gpus": bool(distributed and n_devices < world),
+                   "scaling": args.scaling if distributed else "weak",
+                   "note": "element-wise op: contiguous shards, no data-path collective; the mix legs below exchange scalars only"},
         "roofline": {"bound": "valu-int", "kernel": "k_modpow<74>", "achieved": achieved, "peak": PEAK_TMACS,
                      "unit": "TMAC/s (32x32->64-bit multiply-accumulate)", "frac": achieved / PEAK_TMACS,
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
@@ -913,12 +1117,27 @@ def main() -> None:
         E.free()
         ctx.timing_reset()
         if distributed:
-            mp = mix_prove_sharded(entry, vmn, ctx, grp, args.mix_n, 777, barrier, dist,
-                                   torch.device("cuda", dev_index) if backend == "nccl" else None)
-            t = torch.tensor([mp["total_ms"]], dtype=torch.float64, device=red_device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mp["total_ms"] = float(t.item())
-            mp["ciphertexts_per_s"] = mp["n"] / (mp["total_ms"] / 1e3)
+            # One proof sharded over the ranks, in both scaling forms: weak = mix_n ciphertexts PER GPU, strong = mix_n in
+            # TOTAL (north_star: "near-linear 1/2/4/8-GPU scaling on a 1M-ciphertext shuffle"); --scaling picks the one the
+            # object's top level reports.  BASELINE configs[3] (4 194 304 ciphertexts on the node) is added when it is
+            # neither of the two.
+            sizes = {"weak": args.mix_n * world, "strong": args.mix_n}
+            first = args.scaling
+            mp = mix_prove_sharded(entry, vmn, ctx, grp, sizes[first], 777, barrier, comm)
+            mp["scaling"] = first
+            other = "strong" if first == "weak" else "weak"
+            extra = {other: sizes[other]}
+            if 4_194_304 not in sizes.values() and args.mix_n >= 100_000:
+                extra["configs3_4Mi"] = 4_194_304
+            for name, size in extra.items():
+                try:
+                    sub = mix_prove_sharded(entry, vmn, ctx, grp, size, 778, barrier, comm)
+                    sub.pop("roofline_rank0", None)
+                    mp[name] = sub
+                except Exception as exc:               # pragma: no cover - reported in the line
+                    import traceback
+                    traceback.print_exc(file=sys.stderr)
+                    mp[name] = {"error": f"{type(exc).__name__}: {exc}"}
         else:
             mp = mix_prove(entry, vmn, ctx, grp, args.mix_n, 777 + rank, barrier, steps=2, drivers=args.drivers)
         if not distributed and not args.no_e2e:
@@ -926,14 +1145,43 @@ def main() -> None:
                 runs = [mix_prove_e2e(entry, vmn, ctx, grp, args.mix_n, 4321 + k, barrier) for k in range(2)]
                 mp["end_to_end"] = min(runs, key=lambda r: r["total_ms"])
                 mp["end_to_end"]["passes_total_ms"] = [round(r["total_ms"], 1) for r in runs]
+                mp["end_to_end"]["mean_total_ms"] = sum(r["total_ms"] for r in runs) / len(runs)
+                mp["end_to_end"]["ciphertexts_per_s_mean_of_passes"] = args.mix_n / (mp["end_to_end"]["mean_total_ms"] / 1e3)
             except Exception as exc:                   # pragma: no cover - reported in the line
                 import traceback
                 traceback.print_exc(file=sys.stderr)
                 mp["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
         mp["workload"] = ("re-encrypt + PoS (Terelius-Wikstrom) prove + verify, ModPGroup 2048-bit, width 1, "
-                          "n_e = n_v = 256, n_r = 100; N = mix_n x n_gpus ciphertexts, ONE proof sharded by position "
-                          "(all-gather of partial products / scan carries only)")
+                          "n_e = n_v = 256, n_r = 100" + ("; ONE proof sharded by position over the ranks (all-gather of partial "
+                                                           "products / scan carries only)" if distributed else ""))
         result["mix_prove"] = mp
+
+    def leg_ccpos_sharded():
+        ctx.timing_reset()
+        p3, q3, g3 = load_sub(entry, "stdgroups").modp_group(3072)
+        grp3 = vmn.ModPGroup(ctx, p3, q3, g3, nbytes=384)
+        size = args.ccpos_n * world if args.scaling == "weak" else args.ccpos_n
+        r = mix_ccpos_sharded(entry, vmn, ctx, grp3, "BASELINE.json configs[2] sharded over the ranks: ModPGroup 3072-bit, width 1; offline = "
+                              "permutation commitment + PoSC prove+verify, online = re-encrypt + CCPoS prove+verify", size, 4242, barrier, comm, 1, True)
+        r["scaling"] = args.scaling
+        result["mix_ccpos_3072"] = r
+
+    def leg_ec_sharded():
+        ctx.timing_reset()
+        grpc = vmn.ECqPGroup(ctx, "P-256")
+        # BASELINE configs[4] is 1M ciphertexts of width 3 on the 8 GPUs of the node (= the strong form); weak = 1M per GPU
+        sizes = {"weak": args.ec_n * world, "strong": args.ec_n}
+        label = "BASELINE.json configs[4]: ECqPGroup P-256, width 3, sharded over the ranks; offline = permutation commitment, online = re-encrypt + CCPoS prove+verify"
+        r = mix_ccpos_sharded(entry, vmn, ctx, grpc, label, sizes[args.scaling], 555, barrier, comm, 3, False)
+        r["scaling"] = args.scaling
+        other = "strong" if args.scaling == "weak" else "weak"
+        try:
+            sub = mix_ccpos_sharded(entry, vmn, ctx, grpc, label, sizes[other], 556, barrier, comm, 3, False)
+            sub.pop("roofline_rank0", None)
+            r[other] = sub
+        except Exception as exc:                       # pragma: no cover - reported in the line
+            r[other] = {"error": f"{type(exc).__name__}: {exc}"}
+        result["mix_ec_p256"] = r
 
     def leg_ccpos():
         ctx.timing_reset()
@@ -962,10 +1210,10 @@ def main() -> None:
         guarded("mix_prove", leg_mix_prove)
     if args.mix_n >= 10000 and not distributed:
         guarded("mix_prove_n10000", leg_small)
-    if args.ccpos_n > 0 and not distributed:
-        guarded("mix_ccpos_3072", leg_ccpos)
-    if args.ec_n > 0 and not distributed:
-        guarded("mix_ec_p256", leg_ec)
+    if args.ccpos_n > 0:
+        guarded("mix_ccpos_3072", leg_ccpos_sharded if distributed else leg_ccpos)
+    if args.ec_n > 0:
+        guarded("mix_ec_p256", leg_ec_sharded if distributed else leg_ec)
 
     if rank == 0 and not args.no_cpu:
         from oracle.cbind import Oracle

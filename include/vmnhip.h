@@ -268,6 +268,14 @@ int vmn_random_oracle_hash(int hash_bits, const uint8_t* data, size_t len, int n
  * as field elements.  ref: P/hvzk/PoSBasicTW.java:533-538, PoSCBasicTW.java:350-355, CCPoSBasicW.java:330-335.
  * Value i = the i-th ceil(bits/8) bytes of the stream, leading bits cleared; reduced mod q when it can reach q. */
 int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out);
+/* Parts of the same array without the rest (the stream is counter mode): values [first, first + n), resp. the values
+ * idx[0 .. n-1] (host indices) -- equal to copy_range / gather of vmn_rarray_from_prg(.., N, ..).  A rank of a sharded
+ * proof generates its own positions of r, s, b, beta, epsilon, e and the rows e_{pi^-1(i)}, r_{pi(i)}, s_{pi^-1(i)} it
+ * reads through the permutation, instead of all N values on every GPU (the reference has no counterpart:
+ * P/hvzk/PoSBasicTW.java:446, 473, 552-554 run on one machine). */
+int vmn_rarray_from_prg_range(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t first, size_t n, int bits, vmn_rarray** out);
+int vmn_rarray_from_prg_gather(vmn_group* grp, const uint8_t* seed, size_t seedlen, const uint32_t* idx, size_t n, int bits,
+                               vmn_rarray** out);
 /* Independent generators: pGroup.randomElementArray(n, prg, rbitlen) of a safe-prime ModPGroup, generated on the
  * device.  ref: P/distr/IndependentGeneratorsRO.java:117-130 (seed = RO(globalPrefix || bytetree(sid))).
  * t_i = the i-th ceil((bits(p) + rbitlen)/8) bytes, leading bits cleared; h_i = t_i^((p-1)/q) = t_i^2 mod p.

@@ -113,8 +113,10 @@ int vmn_msg_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, const i
  *   u, w, w', r, s, raised  the whole array or this rank's shard -- told apart by their size;
  *   pi                      the whole permutation table;
  *   messages                scalars are identical on every rank, array items are this rank's shard.
- * The batching vector and the prover's N-sized random arrays are generated in full on every rank (a PRG pass), so
- * permuted reads are local gathers and no element crosses a link; the exchanges are fixed-size all-gathers of scalars:
+ * h and w are read through the permutation as local gathers, so no element crosses a link.  The batching vector (from its
+ * seed) and the prover's N-sized random arrays (vmn_random_source.array_seed) are counter-mode PRG streams: a rank
+ * generates only its own positions and the rows it reads through the permutation (vmn_rarray_from_prg_range / _gather),
+ * O(N / world) work per rank; handed over as host rows they are kept whole.  The exchanges are fixed-size all-gathers of scalars:
  * partial products of expProd / prod, partial sums, scan carries, each shard's last B, verdict bits -- at most one per
  * phase and a few hundred bytes per rank ("all-reduce" of north_star: modular multiplication is not a reduction operator
  * of RCCL, so it is all-gather + local multiplication).
@@ -132,6 +134,15 @@ int vmn_shuffle_reencrypt_shard(vmn_group* grp, const uint8_t* pkey_be, size_t w
                                 const vmn_rarray* const* s_full, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** wp_out);
 int vmn_permutation_commitment_shard(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_rarray* r_full,
                                      const uint32_t* pi, size_t lo, size_t hi, vmn_garray** u_out);
+/* The same for exponents that are PRG draws: rs->array_seed is asked for one seed per column (the order vmn_rarray_random
+ * would ask in), and the rank generates just the rows it reads -- s_{pi^-1(i)} resp. r_{pi(i)} for i in [lo, hi) -- and its
+ * own positions s[lo, hi) resp. r[lo, hi), returned for the proof object (s_out: `width` arrays).  Without array_seed the
+ * source's host rows are used (whole arrays).  ref: ShufflerElGamalSession.java:400-409, PermutationCommitment.java:189-215. */
+int vmn_shuffle_reencrypt_shard_seeded(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w_full,
+                                       const vmn_random_source* rs, int rbitlen, const uint32_t* pi, size_t lo, size_t hi,
+                                       vmn_garray** wp_out, vmn_rarray** s_out);
+int vmn_permutation_commitment_shard_seeded(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_random_source* rs,
+                                            int rbitlen, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** u_out, vmn_rarray** r_out);
 
 /* ---- PoSBasicTW --------------------------------------------------------------------------------------------- */
 typedef struct vmn_pos vmn_pos;

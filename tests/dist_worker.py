@@ -3,7 +3,9 @@ checks the gathered transcript against the single-process oracle.  Backend "fake
 the CPU (gloo) under the Python mirror of the sharded drivers; backend "hip..." = the real library on this rank's GPU
 under the sharded C++ drivers (vmn_*_set_comm), or -- with "-mirror" -- under the Python mirror.
 
-argv: backend bits n width out_path [flow]      flow = pos (default) | ccpos | posc"""
+argv: backend bits n width out_path [flow]      flow = pos (default) | ccpos | posc | pos-seeded | ccpos-seeded
+("-seeded": the prover's N-sized draws, the shuffler's exponents and the batching vector are 32-byte seeds -- each rank
+generates only the rows it reads, vmn_rarray_from_prg_range / _gather -- against the oracle run on the expanded arrays)"""
 import importlib.util
 import json
 import os
@@ -19,7 +21,7 @@ import torch.distributed as dist
 import __graft_entry__ as entry
 from conftest import load_golden
 from oracle import pyref, pyref_proofs as P
-from tape import Tape
+from tape import SeedTape, Tape
 
 
 def load_parallel():
@@ -162,6 +164,93 @@ def flow_ccpos_or_posc(flow, native, par, nat, comm, dist, rank, world, G, K, g,
     gather_and_check(dist, rank, world, mine, expect, out_path)
 
 
+def flow_seeded(flow, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, q, n, width, bits3, out_path):
+    """PoS or CCPoS through the sharded C++ drivers with every N-sized random array a PRG draw: what bench.py's
+    multi-GPU legs run.  The oracle expands the same seeds in full (SeedTape(expanding=True))."""
+    from oracle import pyref_prg
+    NV, NE, NR = bits3
+    ncomm = nat.NativeComm(comm)
+    lo, hi = par.shard_bounds(n, world, rank)
+    H, W = G.toElementArray(h), [G.toElementArray(c) for c in w]
+    ints = lambda a: a.toInts() if hasattr(a, "toInts") else a
+    small = Tape(b"seeded-small", q)
+    pi, v = small.permutation(n), small.int_array(1, NV)[0]
+    e_seed = pyref_prg.random_oracle(b"seeded-e", 256)
+    e = pyref_prg.random_integers(e_seed, n, NE)
+    shuffler_o = SeedTape(b"shuffler", q, NR, expanding=True)
+    if flow == "pos-seeded":
+        s = [shuffler_o.ring_array(n) for _ in range(width)]
+        o = P.GPoS(K, NV, NE, NR, rand=SeedTape(b"prover", q, NR, expanding=True))
+        o.precompute(g, h, pi)
+        wp_o = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+        o.setInstance(pkey, w, wp_o, s)
+        o.setBatchVector(e)
+        com_o, rep_o = o.commit(), o.reply(v)
+        pr = nat.PoSBasicTW(G, NV, NE, NR, rand=SeedTape(b"prover", q, NR))
+        pr.setComm(ncomm)
+        pr.precompute(g, H, pi)
+        WP, S = nat.reencrypt_shard_seeded_native(G, pkey, W, SeedTape(b"shuffler", q, NR), NR, pi, lo, hi)
+        pr.setInstance(pkey, W, WP, S)
+        pr.setBatchVectorSeed(e_seed)
+        com, rep = pr.commit(), pr.reply(v)
+        ver = nat.PoSBasicTW(G, NV, NE, NR)
+        ver.setComm(ncomm)
+        ver.precompute(g, H)
+        ver.setPermutationCommitment(pr.u)
+        ver.setInstance(pkey, W, WP)
+        ver.setBatchVectorSeed(e_seed)
+        ver.computeAF()
+        ver.setCommitment(com)
+        ver.setChallenge(v)
+        ok = ver.verify(rep)
+        arrays = {"u": ints(pr.u), "B": ints(com["B"]), "Bp": ints(com["Bp"]), "k_B": ints(rep["k_B"]), "k_E": ints(rep["k_E"])}
+        expect = {"arrays": {"u": o.u, "B": com_o["B"], "Bp": com_o["Bp"], "k_B": rep_o["k_B"], "k_E": rep_o["k_E"]},
+                  "scalars": [com_o["Ap"], com_o["Cp"], com_o["Dp"], com_o["Fp"], rep_o["k_A"], rep_o["k_C"], rep_o["k_D"], rep_o["k_F"]],
+                  "flags": {"ok": True}}
+        for c in range(2 * width):
+            arrays["wp%d" % c] = ints(WP[c])
+            expect["arrays"]["wp%d" % c] = wp_o[c]
+        for c in range(width):
+            arrays["s%d" % c] = ints(S[c])
+            expect["arrays"]["s%d" % c] = s[c]
+        mine = {"arrays": arrays, "scalars": [com["Ap"], com["Cp"], com["Dp"], com["Fp"], rep["k_A"], rep["k_C"], rep["k_D"], rep["k_F"]],
+                "flags": {"ok": ok}, "exchanges": ncomm.exchanges}
+        gather_and_check(dist, rank, world, mine, expect, out_path)
+    # ccpos-seeded: permutation commitment and re-encryption from seeds, then the commitment-consistent proof
+    r = shuffler_o.ring_array(n)
+    s = [shuffler_o.ring_array(n) for _ in range(width)]
+    u = P.g_permutation_commitment(K, g, h, r, pi)
+    wp = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi)
+    oc = P.GCCPoS(K, NV, NE, NR, rand=SeedTape(b"prover", q, NR, expanding=True))
+    oc.setInstance(g, h, u, pkey, w, wp, r, pi, s)
+    oc.setBatchVector(e)
+    com_o, rep_o = oc.commit(), oc.reply(v)
+    shuffler = SeedTape(b"shuffler", q, NR)
+    U, R = nat.permutation_commitment_shard_seeded_native(G, g, H, shuffler, NR, pi, lo, hi)
+    WP, S = nat.reencrypt_shard_seeded_native(G, pkey, W, shuffler, NR, pi, lo, hi)
+    pr = nat.CCPoSBasicW(G, NV, NE, NR, rand=SeedTape(b"prover", q, NR))
+    pr.setComm(ncomm)
+    pr.setInstance(g, H, U, pkey, W, WP, R, pi, S)
+    pr.setBatchVectorSeed(e_seed)
+    com, rep = pr.commit(), pr.reply(v)
+    ver = nat.CCPoSBasicW(G, NV, NE, NR)
+    ver.setComm(ncomm)
+    ver.setInstance(g, H, U, pkey, W, WP)
+    ver.setBatchVectorSeed(e_seed)
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    ver.computeAB()
+    ok = ver.verify(rep)
+    arrays = {"u": ints(U), "r": ints(R), "k_E": ints(rep["k_E"])}
+    expect = {"arrays": {"u": u, "r": r, "k_E": rep_o["k_E"]}, "scalars": [com_o["Ap"], com_o["Bp"], rep_o["k_A"], rep_o["k_B"]],
+              "flags": {"ok": True}}
+    for c in range(2 * width):
+        arrays["wp%d" % c] = ints(WP[c])
+        expect["arrays"]["wp%d" % c] = wp[c]
+    mine = {"arrays": arrays, "scalars": [com["Ap"], com["Bp"], rep["k_A"], rep["k_B"]], "flags": {"ok": ok}, "exchanges": ncomm.exchanges}
+    gather_and_check(dist, rank, world, mine, expect, out_path)
+
+
 def main():
     backend, bits, n, width, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     flow = sys.argv[6] if len(sys.argv) > 6 else "pos"
@@ -218,6 +307,9 @@ def main():
     else:
         from fake_backend import FakeGroup
         G = FakeGroup(p, q, g)
+    if flow.endswith("-seeded"):
+        assert native, "seeded flows run the C++ drivers"
+        flow_seeded(flow, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, q, n, width, (NV, NE, NR), out_path)
     if flow != "pos":
         t2 = Tape(b"dist-%s%d" % (flow.encode(), bits), q)
         flow_ccpos_or_posc(flow, native, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, t2, q, n, width, (NV, NE, NR), out_path)

@@ -105,6 +105,19 @@ def test_sharded_cxx_drivers_two_ranks_one_gpu(flow, backend, bits, n, width, tm
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flow,backend,bits,n,width,world", [("pos-seeded", "hip-gloo", 2048, 131, 1, 2), ("pos-seeded", "hip-gloo", 512, 5, 2, 3),
+                                                             ("ccpos-seeded", "hip-gloo-ec", 256, 50, 3, 2),
+                                                             ("ccpos-seeded", "hip-gloo", 2048, 64, 1, 3)])
+def test_sharded_cxx_drivers_generate_only_their_rows_of_the_prg_arrays(flow, backend, bits, n, width, world, tmp_path):
+    """The form bench.py's multi-GPU legs run: r, s, b, beta, epsilon and the batching vector are 32-byte seeds, and a rank
+    expands just its positions and the rows it reads through the permutation (struct Draw, csrc/vmnproofs.cpp;
+    vmn_shuffle_reencrypt_shard_seeded, vmn_permutation_commitment_shard_seeded).  Transcript, u, w', r, s shards == the
+    oracle run on the fully expanded arrays."""
+    res = run_world(world, backend, bits, n, width, tmp_path, timeout=900, flow=flow)
+    assert res["pass"], res["why"]
+
+
+@pytest.mark.gpu
 def test_sharded_cxx_drivers_three_ranks_ragged_and_empty(tmp_path):
     res = run_world(3, "hip-gloo", 512, 2, 1, tmp_path, timeout=900, flow="pos")      # one rank owns nothing
     assert res["pass"], res["why"]

@@ -86,6 +86,32 @@ def test_device_random_vector_and_generators(bits, vmn, gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_parts_of_a_prg_array_without_the_rest(vmn, gpu_ctx):
+    """vmn_rarray_from_prg_range / _gather (what a rank of a sharded proof generates: its positions and the rows it reads
+    through the permutation) against slices of the Python PRG integers, over a ModP order and a curve order, for values
+    narrower than, as wide as and wider than the order (one part, reduced, several parts)."""
+    import random
+    grp, _ = load_golden(2048)
+    groups = [vmn.ModPGroup(gpu_ctx, grp["p"], grp["q"], grp["g"]), vmn.ECqPGroup(gpu_ctx, "P-256")]
+    for G in groups:
+        q = G.q
+        for hashname, seedlen in (("sha256", 32), ("sha512", 64)):
+            seed = pyref_prg.random_oracle(b"parts", 8 * seedlen, hashname)
+            for bits in (37, 256, q.bit_length(), q.bit_length() + 100, 612):
+                n = 500
+                vb = (bits + 7) // 8
+                stream = pyref_prg.prg_bytes(seed, n * vb, hashname)
+                want = [(int.from_bytes(stream[i * vb:(i + 1) * vb], "big") & ((1 << bits) - 1)) % q for i in range(n)]
+                assert G.ringArrayFromPRG(seed, n, bits).toInts() == want
+                for first, cnt in ((0, 1), (0, n), (123, 77), (n - 1, 1), (499, 0), (64, 256)):
+                    assert G.ringArrayFromPRGRange(seed, first, cnt, bits).toInts() == want[first:first + cnt], (bits, first, cnt)
+                rng = random.Random(bits)
+                idx = [rng.randrange(n) for _ in range(300)] + [0, n - 1, 7, 7]
+                assert G.ringArrayFromPRGGather(seed, idx, bits).toInts() == [want[i] for i in idx], bits
+                assert G.ringArrayFromPRGGather(seed, [], bits).toInts() == []
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hashname,seedlen", [("sha384", 48), ("sha512", 64)])
 def test_device_generators_with_sha384_and_sha512_seeds(hashname, seedlen, vmn, gpu_ctx):
     grp, _ = load_golden(2048)

@@ -353,6 +353,21 @@ class ModPGroup:
         _check(lib().vmn_rarray_from_prg(self._h, bytes(seed), C.c_size_t(len(seed)), C.c_size_t(n), C.c_int(bits), C.byref(h)))
         return PRingElementArray(self, h)
 
+    def ringArrayFromPRGRange(self, seed: bytes, first: int, n: int, bits: int) -> "PRingElementArray":
+        """Values [first, first + n) of ``ringArrayFromPRG`` without the rest (``vmn_rarray_from_prg_range``)."""
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_from_prg_range(self._h, bytes(seed), C.c_size_t(len(seed)), C.c_size_t(first), C.c_size_t(n),
+                                               C.c_int(bits), C.byref(h)))
+        return PRingElementArray(self, h)
+
+    def ringArrayFromPRGGather(self, seed: bytes, idx, bits: int) -> "PRingElementArray":
+        """The values ``idx`` of ``ringArrayFromPRG`` (``vmn_rarray_from_prg_gather``): a permuted read of a PRG array."""
+        arr, _keep = _u32_array(idx)
+        h = C.c_void_p()
+        _check(lib().vmn_rarray_from_prg_gather(self._h, bytes(seed), C.c_size_t(len(seed)), arr, C.c_size_t(len(idx)), C.c_int(bits),
+                                                C.byref(h)))
+        return PRingElementArray(self, h)
+
     def elementArrayFromPRG(self, seed: bytes, n: int, rbitlen: int) -> "PGroupElementArray":
         """``pGroup.randomElementArray(n, prg, rbitlen)``: independent generators derived on the GPU
         (IndependentGeneratorsRO.java:117-130; safe-prime ModPGroup)."""

@@ -2089,23 +2089,26 @@ __host__ __device__ inline void prg_block_bytes(uint8_t (&dg)[HASH / 8], const u
         for (int b = 0; b < HASH / 8; ++b) dg[b] = (uint8_t)(d[b >> 3] >> (56 - 8 * (b & 7)));
     }
 }
-// Row i = bytes [part_off, part_off + part_len) of the i-th val_bytes-byte value of the PRG stream (value i =
-// stream bytes [i*val_bytes, (i+1)*val_bytes), first byte masked with top_mask), right-aligned in row_bytes bytes.
+// Row i = bytes [part_off, part_off + part_len) of value number vi of the PRG stream (value vi = stream bytes
+// [vi*val_bytes, (vi+1)*val_bytes), first byte masked with top_mask), right-aligned in row_bytes bytes; vi = first + i,
+// or idx[i] when an index table is given -- the stream is counter mode, so a shard of the positions (or the rows a
+// permutation selects) is generated without the rest (the sharded proofs: DESIGN.md §7).
 // One lane per row; a lane hashes the digest-sized blocks its value overlaps (<= val_bytes / digest + 2 compressions).
 template <int HASH>
 __global__ void __launch_bounds__(256) k_prg_rows(uint8_t* __restrict__ out, size_t row_bytes, size_t val_bytes, uint32_t top_mask,
                                                   size_t part_off, size_t part_len, const uint32_t* __restrict__ seed_words,
-                                                  size_t n) {
+                                                  size_t n, size_t first, const uint32_t* __restrict__ idx) {
     constexpr int DB = HASH / 8;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const size_t vi = idx ? (size_t)idx[i] : first + i;
     uint32_t seed[HASH / 32];
 #pragma unroll
     for (int k = 0; k < HASH / 32; ++k) seed[k] = seed_words[k];
     uint8_t* row = out + i * row_bytes;
     const size_t pad = row_bytes - part_len;
     for (size_t k = 0; k < pad; ++k) row[k] = 0;
-    const size_t v0 = i * val_bytes;                       // stream offset of the value
+    const size_t v0 = vi * val_bytes;                      // stream offset of the value
     const size_t lo = v0 + part_off, hi = lo + part_len;   // stream range wanted
     for (size_t blk = lo / DB; blk * DB < hi; ++blk) {
         uint8_t dg[DB];
@@ -2240,8 +2243,13 @@ static int prg_seed_words(const uint8_t* seed, size_t seedlen, PrgSeed& ps) {
     return VMN_OK;
 }
 // device rows of one part of the PRG values (see k_prg_rows)
+// The values wanted of a PRG stream: n consecutive ones from `first`, or the ones a device index table names.
+struct PrgSel {
+    size_t first = 0;
+    const uint32_t* d_idx = nullptr;
+};
 static int prg_rows(vmn_ctx* ctx, const PrgSeed& ps, size_t n, size_t val_bytes, int val_bits, size_t part_off, size_t part_len,
-                    size_t row_bytes, DevTmp& rows) {
+                    size_t row_bytes, DevTmp& rows, const PrgSel& sel = PrgSel()) {
     DevTmp dseed(ctx);
     VMN_TRY(dseed.alloc(64));
     VMN_TRY(h2d(ctx, dseed.p, ps.w, 64));
@@ -2249,12 +2257,12 @@ static int prg_rows(vmn_ctx* ctx, const PrgSeed& ps, size_t n, size_t val_bytes,
     uint32_t top_mask = val_bits % 8 ? (1u << (val_bits % 8)) - 1 : 0xffu;
     if (ps.hash == 256)
         return launch_light(ctx, "prg", k_prg_rows<256>, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
-                            (const uint32_t*)dseed.as<uint32_t>(), n);
+                            (const uint32_t*)dseed.as<uint32_t>(), n, sel.first, sel.d_idx);
     if (ps.hash == 384)
         return launch_light(ctx, "prg", k_prg_rows<384>, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
-                            (const uint32_t*)dseed.as<uint32_t>(), n);
+                            (const uint32_t*)dseed.as<uint32_t>(), n, sel.first, sel.d_idx);
     return launch_light(ctx, "prg", k_prg_rows<512>, grid_for(n), rows.as<uint8_t>(), row_bytes, val_bytes, top_mask, part_off, part_len,
-                        (const uint32_t*)dseed.as<uint32_t>(), n);
+                        (const uint32_t*)dseed.as<uint32_t>(), n, sel.first, sel.d_idx);
 }
 // rows already on the device -> residues (mode: see k_import_be)
 static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* d_rows, int mode, size_t n, uint32_t* d_out,
@@ -2282,14 +2290,15 @@ static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const u
 // fit the modulus' bytes are imported directly (reduced by the import when they can reach m); wider ones -- bits(m) +
 // rbitlen bits: the statistically-close-to-uniform sampling of randomElementArray -- are split as hi * 2^(8 pb) + lo
 // with pb = the modulus' byte length, and recombined with one multiply-add mod m.
-static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, size_t n, int vbits, uint32_t* d_out) {
+static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, size_t n, int vbits, uint32_t* d_out,
+                        const PrgSel& sel = PrgSel()) {
     if (n == 0) return VMN_OK;
     const size_t Wd = elem_words(m);
     const size_t vb = ((size_t)vbits + 7) / 8, mb = ((size_t)m.nbits + 7) / 8;
     DevTmp rows(ctx);
     if (vb <= mb) {
         // one part: < 2^(8 vb) <= 2^(8 mb) <= R, reduced by the import when it can reach the modulus
-        VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, vb, vb, rows));
+        VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, vb, vb, rows, sel));
         return import_dev(ctx, m, vb, rows.as<uint8_t>(), vbits >= m.nbits ? 2 : 0, n, d_out, nullptr);
     }
     // wider than the modulus (bits(q) + rbitlen random bits for a ring element; the 612-bit epsilon of a proof over a
@@ -2307,11 +2316,11 @@ static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, si
     VMN_TRY(cdev.alloc(Wd * sizeof(uint32_t)));
     int ok = 1;
     VMN_TRY(import_be(ctx, m, mb, cbe.data(), 1, cdev.as<uint32_t>(), &ok));
-    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, top_len, top_len, rows));
+    VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, top_len, top_len, rows, sel));
     VMN_TRY(import_dev(ctx, m, top_len, rows.as<uint8_t>(), 2, n, acc.as<uint32_t>(), nullptr));
     uint32_t* cur = acc.as<uint32_t>();
     for (size_t pidx = 1; pidx < nparts; ++pidx) {
-        VMN_TRY(prg_rows(ctx, w, n, vb, vbits, top_len + (pidx - 1) * mb, mb, mb, rows));
+        VMN_TRY(prg_rows(ctx, w, n, vb, vbits, top_len + (pidx - 1) * mb, mb, mb, rows, sel));
         VMN_TRY(import_dev(ctx, m, mb, rows.as<uint8_t>(), 2, n, part.as<uint32_t>(), nullptr));
         uint32_t* dst = pidx + 1 == nparts ? d_out : cur;          // element-wise: a lane reads its operands before it writes
         int rc = VMN_ERR_ARG;                                       // dst = cur * c + part   (ring op 2 with this modulus)
@@ -2377,22 +2386,53 @@ extern "C" int vmn_random_oracle(const uint8_t* data, size_t len, int nout_bits,
     return vmn_random_oracle_hash(256, data, len, nout_bits, out);
 }
 
-extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out) {
-    ARG_CHECK(grp && out && bits > 0, "bad argument");
+// values [first, first + n) of the stream, or (idx != null) the values idx[0 .. n-1]
+static int rarray_from_prg_sel(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t first, const uint32_t* idx, size_t n, int bits,
+                               vmn_rarray** out) {
     vmn_ctx* ctx = LANE(grp->ctx);
-    VMN_ENTER(ctx);
     PrgSeed w;
     VMN_TRY(prg_seed_words(seed, seedlen, w));
+    const size_t vb = ((size_t)bits + 7) / 8;
+    if (n && !idx && (first + n) > (((size_t)1 << 32) * (size_t)w.digest_bytes()) / vb) {
+        set_error("PRG stream position beyond the 32-bit block counter of PRGHeuristic");
+        return VMN_ERR_ARG;
+    }
     vmn_rarray* a = nullptr;
     VMN_TRY(new_rarray(grp, n, &a));
+    PrgSel sel;
+    sel.first = first;
+    DevTmp didx(ctx);
+    int rc = VMN_OK;
+    if (idx && n) {
+        rc = didx.alloc(n * sizeof(uint32_t));
+        if (rc == VMN_OK) rc = h2d(ctx, didx.p, idx, n * sizeof(uint32_t));
+        sel.d_idx = didx.as<uint32_t>();
+    }
     // integers that may reach the order act as field elements: reduced mod q (also when wider than q)
-    int rc = prg_residues(ctx, grp->Q, w, n, bits, a->d);
+    if (rc == VMN_OK) rc = prg_residues(ctx, grp->Q, w, n, bits, a->d, sel);
     if (rc != VMN_OK) {
         vmn_rarray_free(a);
         return rc;
     }
     *out = a;
     return VMN_OK;
+}
+extern "C" int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t n, int bits, vmn_rarray** out) {
+    ARG_CHECK(grp && out && bits > 0, "bad argument");
+    VMN_ENTER(LANE(grp->ctx));
+    return rarray_from_prg_sel(grp, seed, seedlen, 0, nullptr, n, bits, out);
+}
+extern "C" int vmn_rarray_from_prg_range(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t first, size_t n, int bits,
+                                         vmn_rarray** out) {
+    ARG_CHECK(grp && out && bits > 0, "bad argument");
+    VMN_ENTER(LANE(grp->ctx));
+    return rarray_from_prg_sel(grp, seed, seedlen, first, nullptr, n, bits, out);
+}
+extern "C" int vmn_rarray_from_prg_gather(vmn_group* grp, const uint8_t* seed, size_t seedlen, const uint32_t* idx, size_t n, int bits,
+                                          vmn_rarray** out) {
+    ARG_CHECK(grp && out && bits > 0 && (idx || n == 0), "bad argument");
+    VMN_ENTER(LANE(grp->ctx));
+    return rarray_from_prg_sel(grp, seed, seedlen, 0, idx, n, bits, out);
 }
 
 // Random curve points from a PRG seed (see k_ec_random_points): candidates in batches, kept rows compacted in order.

@@ -399,14 +399,75 @@ int random_integer_array(vmn_group* grp, const vmn_random_source& rs, size_t n, 
     return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
 }
 
+// An N-sized draw of a SHARDED prover.  With a seed source (vmn_random_source.array_seed) the draw IS its 32-byte seed:
+// a rank generates the positions it holds and the rows it reads through the permutation (vmn_rarray_from_prg_range /
+// _gather: the stream is counter mode), never all N values.  With host rows the whole array is kept, as before.
+struct Draw {
+    bool seeded = false;
+    uint8_t seed[32] = {0};
+    int bits = 0;
+    RA all;
+    // the values idx[0 .. n-1] of the draw
+    int rows(vmn_group* grp, const uint32_t* idx, size_t n, RA& out) const {
+        if (seeded) return vmn_rarray_from_prg_gather(grp, seed, 32, idx, n, bits, out.out());
+        return vmn_rarray_gather(all, idx, n, out.out());
+    }
+    int range(vmn_group* grp, size_t lo, size_t hi, RA& out) const {
+        if (seeded) return vmn_rarray_from_prg_range(grp, seed, 32, lo, hi - lo, bits, out.out());
+        return vmn_rarray_copy_range(all, lo, hi, out.out());
+    }
+};
+// ring elements (ring = true: bits(q) + rbitlen random bits reduced mod q) or integers of `bits` bits, n of them
+int make_draw(vmn_group* grp, const vmn_random_source& rs, size_t n, bool ring, int bits, Draw& d) {
+    d.bits = bits;
+    if (rs.array_seed && n > 1) {
+        if (rs.array_seed(rs.user, d.seed) != 0) return fail(VMN_ERR_ARG, "random source failed");
+        d.seeded = true;
+        return VMN_OK;
+    }
+    d.seeded = false;
+    const uint8_t* rows = nullptr;
+    const bool got = ring ? (rs.ring_elements && rs.ring_elements(rs.user, n, &rows) == 0)
+                          : (rs.integers && rs.integers(rs.user, n, bits, &rows) == 0);
+    if (!got || (!rows && n)) return fail(VMN_ERR_ARG, "random source failed");
+    int ok = 1;
+    TRY(vmn_rarray_from_be(grp, rows, n, d.all.out(), &ok));
+    return ok ? VMN_OK : fail(VMN_ERR_FORMAT, "random source returned a value >= q");
+}
+
+// u_i = h_{idx(i)} g^{rsel_i}: the rows of a permutation commitment (PermutationCommitment.java:200-215) for n positions
+int permutation_commitment_rows(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_rarray* rsel,
+                                const uint32_t* idx, size_t n, vmn_garray** u_out) {
+    GA hsel, gr;
+    TRY(vmn_group_exp_fixed(grp, g_be, rsel, gr.out()));
+    TRY(vmn_garray_gather(h_full, idx, n, hsel.out()));
+    return vmn_garray_mul(hsel, gr, u_out);
+}
+// w'_i = w_{idx(i)} pk^{ssel_i} for n positions and the 2 width components (ShufflerElGamalSession.java:273-278, 407)
+int reencrypt_rows(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w_full, const vmn_rarray* const* ssel,
+                   const uint32_t* idx, size_t n, vmn_garray** wp_out) {
+    const size_t eb = vmn_group_elem_bytes(grp);
+    std::vector<GA> res(2 * width);
+    for (size_t c = 0; c < 2 * width; ++c) {
+        GA factors, wsel;
+        TRY(vmn_group_exp_fixed(grp, pkey_be + c * eb, ssel[c % width], factors.out()));
+        TRY(vmn_garray_gather(w_full[c], idx, n, wsel.out()));
+        TRY(vmn_garray_mul(wsel, factors, res[c].out()));
+    }
+    for (size_t c = 0; c < 2 * width; ++c) wp_out[c] = res[c].release();
+    return VMN_OK;
+}
+
 // ---- what the three proofs share -----------------------------------------------------------------------------
 // Sharding (include/vmnproofs.h vmn_comm): with a communicator set, every rank runs the SAME call sequence
 // with random sources that return the SAME values; position-indexed arrays live as contiguous shards [lo, hi) of the N
-// positions.  Public inputs that are read through the permutation (h for u = permute(h g^r, pi), the batching vector for
-// e' = permute(e, pi^-1)) and the N-sized random arrays are held in full on every rank -- generating them is a PRG
-// pass, cheap beside the exponentiations -- so the permuted arrays are local gathers and no element ever crosses a
-// link.  What crosses: one fixed-size all-gather per group of scalars -- partial products of expProd / prod, partial
-// sums of the inner products, the carries of the two scans, each shard's last B, verdict bits.
+// positions.  The public inputs that are read through the permutation (h for u = permute(h g^r, pi), w for w') are held in
+// full on every rank, so the permuted arrays are local gathers and no element ever crosses a link.  The batching vector
+// and the N-sized random arrays are NOT: they are PRG streams in counter mode, and a rank generates exactly the values
+// it reads -- its own positions [lo, hi) and the rows e_{pi^-1(i)}, r_{pi(i)} (struct Draw) -- so the work per rank is
+// O(N / world) (arrays handed over as host rows are still kept whole).  What crosses: one fixed-size all-gather per
+// group of scalars -- partial products of expProd / prod, partial sums of the inner products, the carries of the two
+// scans, each shard's last B, verdict bits.
 struct ProofBase {
     HostGroup G;
     int vbitlen, ebitlen, rbitlen;
@@ -420,7 +481,8 @@ struct ProofBase {
     bool sharded = false;
     vmn_comm comm{};
     size_t Ntot = 0, lo = 0, hi = 0;
-    RA e_full_own;                     // the whole batching vector (sharded provers permute it)
+    RA e_full_own;                     // the whole batching vector when it was handed over as host rows (sharded provers permute it)
+    Bytes e_seed;                      // ... or its PRG seed: the permuted rows are generated, not gathered
     // Every setter that changes an input of a verification (instance, commitment, batching vector, A / F) bumps the epoch;
     // a cached reply side (Prepared, below) is only used by the verify() of the epoch it was prepared in -- a verdict is
     // never computed from mixed inputs.  (The challenge is not part of the reply side.)
@@ -501,25 +563,23 @@ struct ProofBase {
         return fail(VMN_ERR_ARG, "%s: %zu elements, expected this rank's %zu or all %zu", what, n, N, Ntot);
     }
     int need_rs() const { return has_rs ? VMN_OK : fail(VMN_ERR_ARG, "this proof object was created without a random source (verifier)"); }
-    // N-sized draws: the whole array on every rank (same source values everywhere), of which `out` is this rank's shard;
-    // `full` (may be null) keeps the whole array for draws that are read through the permutation.
-    int draw_ring_array(RA& out, RA* full = nullptr) {
+    // N-sized draws: `out` is this rank's shard; `full` (may be null) remembers the draw for reads through the permutation.
+    int draw_ring_array(RA& out, Draw* full = nullptr) {
         VMN_TRACE("proof:draw_ring_array");
         TRY(need_rs());
         if (!sharded) return random_ring_array(G.grp, rs, Ntot, G.qbits, rbitlen, out);
-        RA all;
-        TRY(random_ring_array(G.grp, rs, Ntot, G.qbits, rbitlen, all));
-        TRY(vmn_rarray_copy_range(all, lo, hi, out.out()));
-        if (full) full->p = all.release();
-        return VMN_OK;
+        Draw local;
+        Draw& d = full ? *full : local;
+        TRY(make_draw(G.grp, rs, Ntot, true, G.qbits + rbitlen, d));
+        return d.range(G.grp, lo, hi, out);
     }
     int draw_integers(int bits, RA& out) {
         VMN_TRACE("proof:draw_integers");
         TRY(need_rs());
         if (!sharded) return random_integer_array(G.grp, rs, Ntot, bits, out);
-        RA all;
-        TRY(random_integer_array(G.grp, rs, Ntot, bits, all));
-        return vmn_rarray_copy_range(all, lo, hi, out.out());
+        Draw d;
+        TRY(make_draw(G.grp, rs, Ntot, false, bits, d));
+        return d.range(G.grp, lo, hi, out);
     }
     int draw_ring_element(Num& out) {
         TRY(need_rs());
@@ -550,6 +610,13 @@ struct ProofBase {
     }
     int batch_vector_seed(const uint8_t* seed, size_t seedlen, RA& e) {
         if (!Ntot) return fail(VMN_ERR_ARG, "batching vector before the instance (size unknown)");
+        if (sharded) {                                   // this rank's positions only; e' is generated row by row (below)
+            touch();
+            e_full_own.reset();
+            e_seed.assign(seed, seed + seedlen);
+            e.reset();
+            return vmn_rarray_from_prg_range(G.grp, seed, seedlen, lo, N, ebitlen, e.out());
+        }
         RA all;
         TRY(vmn_rarray_from_prg(G.grp, seed, seedlen, Ntot, ebitlen, all.out()));
         return keep_batch_vector(all, e);
@@ -557,12 +624,14 @@ struct ProofBase {
     int batch_vector(const uint8_t* e_be, RA& e) {
         RA all;
         TRY(import_batch_vector(G.grp, e_be, Ntot, ebitlen, all));
+        e_seed.clear();
         return keep_batch_vector(all, e);
     }
     // e' = permute(e, pi^-1), this rank's positions
     int permuted_batch_vector(const RA& e, const std::vector<uint32_t>& piinv, RA& ipe) {
         VMN_TRACE("proof:permuted_batch_vector");
         if (!sharded) return vmn_rarray_permute(e, piinv.data(), ipe.out());
+        if (!e_seed.empty()) return vmn_rarray_from_prg_gather(G.grp, e_seed.data(), e_seed.size(), piinv.data() + lo, N, ebitlen, ipe.out());
         return vmn_rarray_gather(e_full_own, piinv.data() + lo, N, ipe.out());
     }
     // g^a for a ring scalar; through the cached fixed-base table when the group is a curve (one launch), on the
@@ -907,8 +976,8 @@ struct vmn_pos : ProofBase {
         pi.assign(pi_, pi_ + Ntot);
         piinv = inverse_permutation(pi_, Ntot);
         // :446-465  u_i = g^{r_pi(i)} h_pi(i)
-        RA r_full;
-        TRY(draw_ring_array(r, sharded ? &r_full : nullptr));
+        Draw r_draw;
+        TRY(draw_ring_array(r, sharded ? &r_draw : nullptr));
         TRY(draw_ring_element(alpha));
         TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
         Bytes hp(G.eb), ga;
@@ -917,7 +986,9 @@ struct vmn_pos : ProofBase {
         if (!sharded) {
             TRY(vmn_permutation_commitment(G.grp, g.data(), h_, r, pi.data(), u_own.out()));
         } else {
-            TRY(vmn_permutation_commitment_shard(G.grp, g.data(), h_, r_full, pi.data(), lo, hi, u_own.out()));
+            RA r_perm;                                           // r_{pi(i)}, i in [lo, hi)
+            TRY(r_draw.rows(G.grp, pi.data() + lo, N, r_perm));
+            TRY(permutation_commitment_rows(G.grp, g.data(), h_, r_perm, pi.data() + lo, N, u_own.out()));
         }
         u = u_own;
         // :481  A' = g^alpha prod h_i^eps_i
@@ -2291,32 +2362,70 @@ int vmn_permutation_commitment_shard(vmn_group* grp, const uint8_t* g_be, const 
     if (!grp || !g_be || !h_full || !r_full || !pi || !u_out || lo > hi || hi > vmn_garray_size(h_full) ||
         vmn_rarray_size(r_full) != vmn_garray_size(h_full))
         return fail(VMN_ERR_ARG, "vmn_permutation_commitment_shard: bad argument");
-    GA hsel, gr;
     RA rsel;
     TRY(vmn_rarray_gather(r_full, pi + lo, hi - lo, rsel.out()));
-    TRY(vmn_group_exp_fixed(grp, g_be, rsel, gr.out()));
-    TRY(vmn_garray_gather(h_full, pi + lo, hi - lo, hsel.out()));
-    return vmn_garray_mul(hsel, gr, u_out);
+    return vmnp::permutation_commitment_rows(grp, g_be, h_full, rsel, pi + lo, hi - lo, u_out);
 }
 
 // this rank's positions [lo, hi) of w' = permute(w pk^s, pi^-1), gathered out of the whole w and s
 int vmn_shuffle_reencrypt_shard(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w_full,
                                 const vmn_rarray* const* s_full, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** wp_out) {
     if (!grp || !pkey_be || !width || !w_full || !s_full || !pi || !wp_out || lo > hi) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt_shard: null argument");
-    const size_t eb = vmn_group_elem_bytes(grp);
     const size_t n = vmn_garray_size(w_full[0]);
     if (hi > n || !is_permutation(pi, n)) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt_shard: pi is not a permutation of [0, N) or the range is outside it");
     std::vector<uint32_t> inv = inverse_permutation(pi, n);
-    std::vector<GA> res(2 * width);
-    for (size_t c = 0; c < 2 * width; ++c) {
-        RA ssel;
-        GA factors, wsel;
-        TRY(vmn_rarray_gather(s_full[c % width], inv.data() + lo, hi - lo, ssel.out()));
-        TRY(vmn_group_exp_fixed(grp, pkey_be + c * eb, ssel, factors.out()));
-        TRY(vmn_garray_gather(w_full[c], inv.data() + lo, hi - lo, wsel.out()));
-        TRY(vmn_garray_mul(wsel, factors, res[c].out()));
+    std::vector<RA> ssel(width);
+    std::vector<const vmn_rarray*> sp(width);
+    for (size_t c = 0; c < width; ++c) {
+        TRY(vmn_rarray_gather(s_full[c], inv.data() + lo, hi - lo, ssel[c].out()));
+        sp[c] = ssel[c];
     }
-    for (size_t c = 0; c < 2 * width; ++c) wp_out[c] = res[c].release();
+    return vmnp::reencrypt_rows(grp, pkey_be, width, w_full, sp.data(), inv.data() + lo, hi - lo, wp_out);
+}
+
+// The same two lines for a party whose exponents are PRG draws (vmn_random_source.array_seed): the rank generates the rows
+// it needs -- s_{pi^-1(i)} resp. r_{pi(i)} for its positions, and its own positions of s resp. r (what the proof object is
+// handed afterwards) -- instead of the whole arrays.  The source is asked for the same seeds in the same order as
+// vmn_rarray_random would ask (one per column), so every rank -- and a single-GPU run on the same source -- computes
+// the same shuffle.
+int vmn_shuffle_reencrypt_shard_seeded(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w_full,
+                                       const vmn_random_source* rs, int rbitlen, const uint32_t* pi, size_t lo, size_t hi,
+                                       vmn_garray** wp_out, vmn_rarray** s_out) {
+    if (!grp || !pkey_be || !width || !w_full || !rs || !pi || !wp_out || !s_out || lo > hi || rbitlen < 0)
+        return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt_shard_seeded: bad argument");
+    const size_t n = vmn_garray_size(w_full[0]);
+    if (hi > n || !is_permutation(pi, n)) return fail(VMN_ERR_ARG, "vmn_shuffle_reencrypt_shard_seeded: pi is not a permutation of [0, N) or the range is outside it");
+    HostGroup G;
+    TRY(G.init(grp));
+    std::vector<uint32_t> inv = inverse_permutation(pi, n);
+    std::vector<RA> ssel(width), smine(width);
+    std::vector<const vmn_rarray*> sp(width);
+    for (size_t c = 0; c < width; ++c) {
+        vmnp::Draw d;
+        TRY(vmnp::make_draw(grp, *rs, n, true, G.qbits + rbitlen, d));
+        TRY(d.rows(grp, inv.data() + lo, hi - lo, ssel[c]));
+        TRY(d.range(grp, lo, hi, smine[c]));
+        sp[c] = ssel[c];
+    }
+    TRY(vmnp::reencrypt_rows(grp, pkey_be, width, w_full, sp.data(), inv.data() + lo, hi - lo, wp_out));
+    for (size_t c = 0; c < width; ++c) s_out[c] = smine[c].release();
+    return VMN_OK;
+}
+int vmn_permutation_commitment_shard_seeded(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_random_source* rs,
+                                            int rbitlen, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** u_out, vmn_rarray** r_out) {
+    if (!grp || !g_be || !h_full || !rs || !pi || !u_out || !r_out || lo > hi || hi > vmn_garray_size(h_full) || rbitlen < 0)
+        return fail(VMN_ERR_ARG, "vmn_permutation_commitment_shard_seeded: bad argument");
+    const size_t n = vmn_garray_size(h_full);
+    if (!is_permutation(pi, n)) return fail(VMN_ERR_ARG, "vmn_permutation_commitment_shard_seeded: pi is not a permutation of [0, N)");
+    HostGroup G;
+    TRY(G.init(grp));
+    vmnp::Draw d;
+    RA rsel, rmine;
+    TRY(vmnp::make_draw(grp, *rs, n, true, G.qbits + rbitlen, d));
+    TRY(d.rows(grp, pi + lo, hi - lo, rsel));
+    TRY(d.range(grp, lo, hi, rmine));
+    TRY(vmnp::permutation_commitment_rows(grp, g_be, h_full, rsel, pi + lo, hi - lo, u_out));
+    *r_out = rmine.release();
     return VMN_OK;
 }
 

@@ -529,6 +529,36 @@ def permutation_commitment_shard_native(group, g, h_full, r_full, pi, lo: int, h
     return PGroupElementArray(group, out)
 
 
+def reencrypt_shard_seeded_native(group, pkey, w_full, tape, rbitlen: int, pi, lo: int, hi: int):
+    """``vmn_shuffle_reencrypt_shard_seeded``: positions [lo, hi) of w' and of the re-encryption exponents s, the exponents
+    being PRG draws of the tape's 32-byte seeds (one per column) of which only the rows this rank reads are generated.
+    Returns (w' shard: 2 width arrays, s shard: width arrays)."""
+    width = len(pkey) // 2
+    rs = RandomSource(group, tape)
+    out = (C.c_void_p * (2 * width))()
+    s_out = (C.c_void_p * width)()
+    ptr, keep = _u32_array(pi)
+    rc = plib().vmn_shuffle_reencrypt_shard_seeded(group._h, group.enc_els(pkey), C.c_size_t(width), _ptr_array(w_full), C.byref(rs.struct),
+                                                   C.c_int(rbitlen), ptr, C.c_size_t(lo), C.c_size_t(hi), out, s_out)
+    if rc != 0 and rs.error is not None:
+        raise rs.error
+    _check(rc)
+    return ([PGroupElementArray(group, C.c_void_p(h)) for h in out], [PRingElementArray(group, C.c_void_p(h)) for h in s_out])
+
+
+def permutation_commitment_shard_seeded_native(group, g, h_full, tape, rbitlen: int, pi, lo: int, hi: int):
+    """``vmn_permutation_commitment_shard_seeded``: (u[lo, hi), r[lo, hi)) with r a PRG draw of the tape's next seed."""
+    rs = RandomSource(group, tape)
+    u, r = C.c_void_p(), C.c_void_p()
+    ptr, keep = _u32_array(pi)
+    rc = plib().vmn_permutation_commitment_shard_seeded(group._h, group.enc_el(g), h_full._h, C.byref(rs.struct), C.c_int(rbitlen), ptr,
+                                                        C.c_size_t(lo), C.c_size_t(hi), C.byref(u), C.byref(r))
+    if rc != 0 and rs.error is not None:
+        raise rs.error
+    _check(rc)
+    return PGroupElementArray(group, u), PRingElementArray(group, r)
+
+
 def permutation_commitment_native(group, g, h, r, pi):
     """``vmn_permutation_commitment``: u = permute(h * g^r, pi)."""
     out = C.c_void_p()

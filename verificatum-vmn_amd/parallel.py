@@ -35,48 +35,94 @@ def shard_bounds(n: int, world: int, rank: int):
 
 
 class Comm:
-    """Small-object exchange between the ranks of one node."""
+    """Small-object exchange between the ranks of one node.
 
-    def __init__(self, dist=None, device=None):
+    ``device`` given (the GPU box): the all-gather is RCCL's (``torch.distributed`` backend ``nccl``) on this rank's GPU.
+    The payloads are the few hundred bytes the proof drivers finish on the HOST (the Horner tails of the
+    multi-exponentiations, inner products read back): they are staged through page-locked send / receive buffers that
+    live as long as the communicator -- one async copy in, the collective, one async copy out, ONE stream
+    synchronisation; no pageable copy, no allocation per call.  ``fallback`` (a gloo process group, optional): if the RCCL
+    path raises, the communicator switches to it for good and says so (``fell_back``) -- a bench line must not be lost to
+    a transport problem, and must not hide one either.  ``device`` None: gloo on host tensors (CPU tests, rehearsals)."""
+
+    def __init__(self, dist=None, device=None, fallback=None):
         self.dist = dist if (dist is not None and dist.is_available() and dist.is_initialized()) else None
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1
         self.device = device                      # torch device for nccl; None for gloo / single process
+        self.fallback = fallback
+        self.fell_back = None                     # why the RCCL path was abandoned (None: it was not)
+        self.backend_used = None                  # set by the first exchange: "nccl", "gloo", "gloo (fallback)"
+        self._cap = 0
+        self._send_pin = self._recv_pin = self._send_dev = self._recv_dev = None
 
-    def all_gather_ints(self, values: Sequence[int], nbytes: int) -> List[List[int]]:
-        """Every rank contributes ``len(values)`` non-negative integers (< 2^(8 nbytes)); returns the
-        per-rank lists in rank order.  One fixed-size tensor all-gather (RCCL on the GPU box)."""
-        if not self.dist:
-            return [list(values)]
+    def _stage(self, nbytes: int):
         import torch
-        payload = b"".join(int(v).to_bytes(nbytes, "big") for v in values)
-        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
-        if self.device is not None:
-            t = t.to(self.device)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
-        res = []
-        for o in out:
-            raw = bytes(o.cpu().numpy().tobytes())
-            res.append([int.from_bytes(raw[i * nbytes:(i + 1) * nbytes], "big") for i in range(len(values))])
-        return res
+        if nbytes > self._cap:
+            cap = max(4096, 1 << (nbytes - 1).bit_length())
+            self._send_pin = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._recv_pin = torch.empty(cap * self.world, dtype=torch.uint8).pin_memory()
+            self._send_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self._recv_dev = torch.empty(cap * self.world, dtype=torch.uint8, device=self.device)
+            self._cap = cap
+
+    def _gather_device(self, data: bytes) -> bytes:
+        import torch
+        n = len(data)
+        self._stage(n)
+        self._send_pin[:n].copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+        self._send_dev[:n].copy_(self._send_pin[:n], non_blocking=True)
+        self.dist.all_gather_into_tensor(self._recv_dev[:n * self.world], self._send_dev[:n])
+        self._recv_pin[:n * self.world].copy_(self._recv_dev[:n * self.world], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._recv_pin[:n * self.world].numpy().tobytes()
+
+    def _gather_host(self, data: bytes, group=None) -> bytes:
+        import torch
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        out = torch.empty(self.world * len(data), dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(out, t, group=group)
+        return out.numpy().tobytes()
 
     def all_gather_bytes(self, data: bytes) -> List[bytes]:
         """Every rank contributes ``len(data)`` bytes (the same length everywhere); the per-rank blocks in rank order.
         This is the one primitive the C++ proof drivers call back for (``vmn_comm.all_gather``, include/vmnproofs.h)."""
         if not self.dist:
             return [bytes(data)]
-        import torch
-        t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-        if self.device is not None:
-            t = t.to(self.device)
-        out = torch.empty(self.world * len(data), dtype=torch.uint8, device=t.device)
-        self.dist.all_gather_into_tensor(out, t)
-        raw = out.cpu().numpy().tobytes()
-        return [raw[k * len(data):(k + 1) * len(data)] for k in range(self.world)]
+        n = len(data)
+        if n == 0:
+            return [b""] * self.world
+        if self.device is not None and self.fell_back is None:
+            try:
+                raw = self._gather_device(data)
+                self.backend_used = "nccl"
+            except Exception as exc:              # pragma: no cover - needs a broken transport
+                if self.fallback is None:
+                    raise
+                self.fell_back = f"{type(exc).__name__}: {exc}"[:300]
+                print(f"parallel.Comm: RCCL all-gather failed ({self.fell_back}); continuing over gloo", file=sys.stderr)
+                raw = self._gather_host(data, self.fallback)
+                self.backend_used = "gloo (fallback)"
+        elif self.device is not None:
+            raw = self._gather_host(data, self.fallback)
+        else:
+            raw = self._gather_host(data)
+            self.backend_used = "gloo"
+        return [raw[k * n:(k + 1) * n] for k in range(self.world)]
+
+    def all_gather_ints(self, values: Sequence[int], nbytes: int) -> List[List[int]]:
+        """Every rank contributes ``len(values)`` non-negative integers (< 2^(8 nbytes)); returns the per-rank lists in
+        rank order (one fixed-size all-gather)."""
+        parts = self.all_gather_bytes(b"".join(int(v).to_bytes(nbytes, "big") for v in values))
+        return [[int.from_bytes(raw[i * nbytes:(i + 1) * nbytes], "big") for i in range(len(values))] for raw in parts]
 
     def all_true(self, flag: bool) -> bool:
         return all(v[0] == 1 for v in self.all_gather_ints([1 if flag else 0], 1))
+
+    def max_over_ranks(self, x: float) -> float:
+        """The slowest rank's value (timings of a sharded leg)."""
+        import struct
+        return max(struct.unpack(">d", b)[0] for b in self.all_gather_bytes(struct.pack(">d", float(x))))
 
 
 def _take(arr, idx):
