@@ -974,18 +974,35 @@ def main() -> None:
     dev_index = local_rank % n_devices
     torch.cuda.set_device(dev_index)
     gloo_group = None
+
+    class _stdout_to_stderr:
+        """gloo announces its connections on the C-level stdout; the line of this program is the only thing allowed there."""
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+
+        def __exit__(self, *exc):
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            return False
+
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         limit = datetime.timedelta(minutes=5)     # a rank that dies inside a leg must not hold the others for RCCL's default 10 min
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
-            try:
-                gloo_group = dist.new_group(backend="gloo")      # safety net of parallel.Comm (never used unless RCCL raises)
-            except Exception as exc:      # pragma: no cover
-                print(f"bench.py: no gloo fallback group ({exc})", file=sys.stderr)
-        else:
-            dist.init_process_group(backend=backend, timeout=limit)
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
+                try:
+                    gloo_group = dist.new_group(backend="gloo")      # safety net of parallel.Comm (never used unless RCCL raises)
+                    dist.barrier(group=gloo_group)                   # connect now, while stdout is diverted
+                except Exception as exc:      # pragma: no cover
+                    gloo_group = None
+                    print(f"bench.py: no gloo fallback group ({exc})", file=sys.stderr)
+            else:
+                dist.init_process_group(backend=backend, timeout=limit)
+                dist.barrier()
     red_device = "cuda" if backend == "nccl" else "cpu"
     comm = load_sub(entry, "parallel").Comm(dist if distributed else None, torch.device("cuda", dev_index) if (distributed and backend == "nccl") else None,
                                             fallback=gloo_group)
@@ -1219,7 +1236,8 @@ def main() -> None:
         from oracle.cbind import Oracle
         orc = Oracle(p, q, nbytes)
         # host cores this job may use: the affinity mask, capped at the 16-core share of a one-GPU box
-        cores = min(orc.threads, len(os.sched_getaffinity(0)), 16 * max(1, world))
+        # (a launcher pins OMP_NUM_THREADS to 1 for its ranks: the oracle's thread count is set explicitly, not inherited)
+        cores = min(len(os.sched_getaffinity(0)), 16 * max(1, world)) if distributed else min(orc.threads, len(os.sched_getaffinity(0)), 16)
         orc.set_threads(cores)
         sample = args.cpu_sample or min(n, 6000 * cores)          # ~15 s of mpz_powm
         t1 = time.perf_counter()

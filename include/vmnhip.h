@@ -156,6 +156,10 @@ int vmn_rarray_to_bytetree(const vmn_rarray* a, uint8_t* out);
 int vmn_rarray_from_bytetree(vmn_group* grp, const uint8_t* bt, size_t len, size_t expected_n, vmn_rarray** out,
                              int* format_ok, int* all_in_range);
 size_t vmn_garray_size(const vmn_garray* a);
+/* the group an array belongs to (PGroupElementArray.getPGroup(), PRingElementArray.getPRing()): a binding sizes the host
+ * buffers of vmn_*_to_be / _get / _prod ... from it (jni/: every byte[] is checked against the bytes the callee touches) */
+vmn_group* vmn_garray_group(const vmn_garray* a);
+vmn_group* vmn_rarray_group(const vmn_rarray* a);
 void vmn_garray_free(vmn_garray* a);                   /* PGroupElementArray.free() */
 
 /* K1a  X.exp(E): out[i] = X[i]^E[i].  ref: P/hvzk/PoSBasicTW.java:1032; P/hvzk/PoSCBasicTW.java:694.

@@ -144,6 +144,27 @@ int vmn_shuffle_reencrypt_shard_seeded(vmn_group* grp, const uint8_t* pkey_be, s
 int vmn_permutation_commitment_shard_seeded(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h_full, const vmn_random_source* rs,
                                             int rbitlen, const uint32_t* pi, size_t lo, size_t hi, vmn_garray** u_out, vmn_rarray** r_out);
 
+/* ---- what a binding needs to size its host buffers (jni/: the generated wrappers check every array against the bytes the
+ * callee reads or writes): the group of a proof object, the number of rows a batching vector handed to it must have (all N
+ * positions of the proof; 0 before the instance is known), the number of parties of the threshold objects. */
+typedef struct vmn_pos vmn_pos;
+typedef struct vmn_posc vmn_posc;
+typedef struct vmn_ccpos vmn_ccpos;
+typedef struct vmn_decproof vmn_decproof;
+typedef struct vmn_igen vmn_igen;
+vmn_group* vmn_pos_group(const vmn_pos* p);
+vmn_group* vmn_posc_group(const vmn_posc* p);
+vmn_group* vmn_ccpos_group(const vmn_ccpos* p);
+vmn_group* vmn_decproof_group(const vmn_decproof* p);
+vmn_group* vmn_igen_group(const vmn_igen* p);
+size_t vmn_pos_size(const vmn_pos* p);
+size_t vmn_posc_size(const vmn_posc* p);
+size_t vmn_ccpos_size(const vmn_ccpos* p);
+size_t vmn_decproof_size(const vmn_decproof* p);
+size_t vmn_igen_size(const vmn_igen* p);
+int vmn_decproof_parties(const vmn_decproof* p);      /* k */
+int vmn_igen_parties(const vmn_igen* p);              /* threshold */
+
 /* ---- PoSBasicTW --------------------------------------------------------------------------------------------- */
 typedef struct vmn_pos vmn_pos;
 /* rs = NULL for a verifier.  ref: constructor PoSBasicTW.java:300-330 (vbitlen, ebitlen, rbitlen). */

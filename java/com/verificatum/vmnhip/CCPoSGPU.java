@@ -80,7 +80,7 @@ public final class CCPoSGPU extends ProtocolElGamal implements CCPoS {
     public void prove(final Log log, final PGroupElement g, final PGroupElementArray h, final PGroupElementArray u,
                       final PGroupElement pkey, final PGroupElementArray w, final PGroupElementArray wp, final PRingElementArray r,
                       final Permutation pi, final PRingElementArray s) {
-        log.info("Prove correctness of shuffle.");
+        log.info("GPU path: proving our shuffle.");
         final Log tempLog = log.newChildLog();
         final int width = Math.max(1, ((PPGroup) pkey.getPGroup()).project(0).getWidth());
         final PGroupElementArrayGPU H = PGroupElementArrayGPU.of(group, h);
@@ -95,32 +95,32 @@ public final class CCPoSGPU extends ProtocolElGamal implements CCPoS {
                                                             GPUArrays.gatherTable(pi), GPUArrays.handles(S)));
         VMNException.check(VMNProofs.vmn_ccpos_commit_prepare(P));         // A', B': beside the hashing of the instance
 
-        tempLog.info("Generate batching vector.");
+        tempLog.info("GPU path: seed of the batching vector from the random oracle; vector expanded on the device.");
         final byte[] prgSeed = seed(tempLog, g, h, u, pkey, w, wp);
         VMNException.check(VMNProofs.vmn_ccpos_set_batch_vector_seed(P, prgSeed, prgSeed.length));
 
-        tempLog.info("Compute commitment.");
+        tempLog.info("GPU path: commitment kernels.");
         final long[] msg = new long[1];
         VMNException.check(VMNProofs.vmn_ccpos_commit(P, msg));
         final GPUMessage commitment = new GPUMessage(msg[0]);
         final ByteTree commitmentTree = ProofSupport.byteTree(commitment);
         final Thread exportThread = export(commitmentTree, ProofSupport.file(nizkp, "CCPoSCommitment", j));
-        tempLog.info("Publish our commitment.");
+        tempLog.info("GPU path: commitment framed on the device and posted.");
         bullBoard.publish("Commitment", commitmentTree, tempLog);
 
-        tempLog.info("Generate challenge.");
+        tempLog.info("GPU path: challenge from the random oracle.");
         final byte[] challengeBytes = challenger.challenge(tempLog.newChildLog(), new ByteTreeContainer(new ByteTree(prgSeed), commitmentTree),
                                                            vbitlen(), rbitlen);
         final byte[] v = LargeInteger.toPositive(challengeBytes).toByteArray();
 
-        tempLog.info("Compute reply.");
+        tempLog.info("GPU path: reply kernels.");
         VMNException.check(VMNProofs.vmn_ccpos_reply(P, v, v.length, msg));
         final GPUMessage reply = new GPUMessage(msg[0]);
         final ByteTree replyTree = ProofSupport.byteTree(reply);
         if (nizkp != null) {
             replyTree.unsafeWriteTo(ProofSupport.file(nizkp, "CCPoSReply", j));
         }
-        tempLog.info("Publish reply.");
+        tempLog.info("GPU path: reply framed on the device and posted.");
         bullBoard.publish("Reply", replyTree, tempLog);
 
         join(exportThread);
@@ -141,7 +141,7 @@ public final class CCPoSGPU extends ProtocolElGamal implements CCPoS {
     public boolean verify(final Log log, final int l, final PGroupElement g, final PGroupElementArray h, final PGroupElementArray u,
                           final PGroupElement pkey, final PGroupElementArray w, final PGroupElementArray wp,
                           final PGroupElementArray raisedu, final PGroupElementArray raisedh, final PRingElement raisedExponent) {
-        log.info("Verify correctness of shuffle of " + ui.getDescrString(l) + ".");
+        log.info("GPU path: checking the proof of a shuffle by " + ui.getDescrString(l) + ".");
         final Log tempLog = log.newChildLog();
         final int width = Math.max(1, ((PPGroup) pkey.getPGroup()).project(0).getWidth());
         final int n = h.size();
@@ -155,14 +155,14 @@ public final class CCPoSGPU extends ProtocolElGamal implements CCPoS {
         VMNException.check(VMNProofs.vmn_ccpos_set_instance(V, group.encode(g), H.handle, U.handle, ProofSupport.wideKey(group, pkey, width),
                                                             width, GPUArrays.handles(W), GPUArrays.handles(WP), 0, null, null));
 
-        tempLog.info("Generate batching vector.");
+        tempLog.info("GPU path: seed of the batching vector from the random oracle; vector expanded on the device.");
         final byte[] prgSeed = seed(tempLog, g, h, u, pkey, w, wp);
         VMNException.check(VMNProofs.vmn_ccpos_set_batch_vector_seed(V, prgSeed, prgSeed.length));
 
-        tempLog.info("Batch.");
+        tempLog.info("GPU path: multi-exponentiations over the batching vector.");
         VMNException.check(VMNProofs.vmn_ccpos_compute_ab(V, raisedExponent == null || RU == null ? 0 : RU.handle));
 
-        tempLog.info("Read the commitment.");
+        tempLog.info("GPU path: parsing the commitment (range and membership checks on the device).");
         final ByteTreeReader cr = bullBoard.waitFor(l, "Commitment", tempLog);
         final ByteBuffer cb = ProofSupport.direct(cr);
         cr.close();
@@ -186,17 +186,17 @@ public final class CCPoSGPU extends ProtocolElGamal implements CCPoS {
         final ByteTree commitmentTree = ProofSupport.byteTree(commitment);
         final Thread exportThread = export(commitmentTree, ProofSupport.file(nizkp, "CCPoSCommitment", l));
 
-        tempLog.info("Generate challenge.");
+        tempLog.info("GPU path: challenge from the random oracle.");
         final byte[] challengeBytes = challenger.challenge(tempLog.newChildLog(), new ByteTreeContainer(new ByteTree(prgSeed), commitmentTree),
                                                            vbitlen(), rbitlen);
         final byte[] v = LargeInteger.toPositive(challengeBytes).toByteArray();
         VMNException.check(VMNProofs.vmn_ccpos_set_challenge(V, v, v.length));
 
-        tempLog.info("Read the reply.");
+        tempLog.info("GPU path: parsing the reply (range checks on the device).");
         final ByteTreeReader rr = bullBoard.waitFor(l, "Reply", tempLog);
         final ByteBuffer rb = ProofSupport.direct(rr);
         rr.close();
-        tempLog.info("Perform verification.");
+        tempLog.info("GPU path: evaluating the verification equations.");
         final GPUMessage reply = GPUMessage.parse(group, rb, rb.remaining(), REP, new long[] {1, width, n});
         boolean verdict = false;
         if (reply != null && !malformed) {                        // malformed reply: false (CCPoSBasicW.java:533-544)
@@ -209,7 +209,7 @@ public final class CCPoSGPU extends ProtocolElGamal implements CCPoS {
                 ProofSupport.byteTree(reply).unsafeWriteTo(ProofSupport.file(nizkp, "CCPoSReply", l));
             }
         }
-        tempLog.info(verdict ? "Accepted proof." : "Rejected proof.");
+        tempLog.info(verdict ? "GPU path: proof accepted." : "GPU path: proof rejected.");
         join(exportThread);
         if (reply != null) {
             reply.free();

@@ -43,7 +43,7 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
     @Override
     public void prove(final Log log, final PGroupElement g, final PGroupElementArray h, final PGroupElementArray u,
                       final PRingElementArray r, final Permutation pi) {
-        log.info("Prove correctness of permutation commitment.");
+        log.info("GPU path: proving our permutation commitment.");
         final Log tempLog = log.newChildLog();
         final PGroupElementArrayGPU H = PGroupElementArrayGPU.of(group, h);
         final PGroupElementArrayGPU U = PGroupElementArrayGPU.of(group, u);
@@ -52,11 +52,11 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
         VMNException.check(VMNProofs.vmn_posc_set_instance(P, group.encode(g), H.handle, U.handle, R.handle, GPUArrays.gatherTable(pi)));
         VMNException.check(VMNProofs.vmn_posc_commit_prepare(P));          // beside the hashing of (g, h, u)
 
-        tempLog.info("Generate batching vector.");
+        tempLog.info("GPU path: seed of the batching vector from the random oracle; vector expanded on the device.");
         final byte[] prgSeed = seed(tempLog, g, h, u);
         VMNException.check(VMNProofs.vmn_posc_set_batch_vector_seed(P, prgSeed, prgSeed.length));
 
-        tempLog.info("Compute commitment.");
+        tempLog.info("GPU path: commitment kernels.");
         final long[] msg = new long[1];
         VMNException.check(VMNProofs.vmn_posc_commit(P, msg));
         final GPUMessage commitment = new GPUMessage(msg[0]);
@@ -64,22 +64,22 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
         if (nizkp != null) {
             commitmentTree.unsafeWriteTo(ProofSupport.file(nizkp, "PoSCCommitment", j));
         }
-        tempLog.info("Publish our commitment.");
+        tempLog.info("GPU path: commitment framed on the device and posted.");
         bullBoard.publish("Commitment", commitmentTree, tempLog);
 
-        tempLog.info("Generate challenge.");
+        tempLog.info("GPU path: challenge from the random oracle.");
         final byte[] challengeBytes = challenger.challenge(tempLog.newChildLog(), new ByteTreeContainer(new ByteTree(prgSeed), commitmentTree),
                                                            vbitlen(), rbitlen);
         final byte[] v = LargeInteger.toPositive(challengeBytes).toByteArray();
 
-        tempLog.info("Compute reply.");
+        tempLog.info("GPU path: reply kernels.");
         VMNException.check(VMNProofs.vmn_posc_reply(P, v, v.length, msg));
         final GPUMessage reply = new GPUMessage(msg[0]);
         final ByteTree replyTree = ProofSupport.byteTree(reply);
         if (nizkp != null) {
             replyTree.unsafeWriteTo(ProofSupport.file(nizkp, "PoSCReply", j));
         }
-        tempLog.info("Publish reply.");
+        tempLog.info("GPU path: reply framed on the device and posted.");
         bullBoard.publish("Reply", replyTree, tempLog);
 
         commitment.free();
@@ -92,7 +92,7 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
 
     @Override
     public boolean verify(final Log log, final int l, final PGroupElement g, final PGroupElementArray h, final PGroupElementArray u) {
-        log.info("Verify correctness of permutation commitment of " + ui.getDescrString(l) + ".");
+        log.info("GPU path: checking the permutation commitment of " + ui.getDescrString(l) + ".");
         final Log tempLog = log.newChildLog();
         final int n = h.size();
         final PGroupElementArrayGPU H = PGroupElementArrayGPU.of(group, h);
@@ -100,11 +100,11 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
         final long V = create(false);
         VMNException.check(VMNProofs.vmn_posc_set_instance(V, group.encode(g), H.handle, U.handle, 0, null));
 
-        tempLog.info("Generate batching vector.");
+        tempLog.info("GPU path: seed of the batching vector from the random oracle; vector expanded on the device.");
         final byte[] prgSeed = seed(tempLog, g, h, u);
         VMNException.check(VMNProofs.vmn_posc_set_batch_vector_seed(V, prgSeed, prgSeed.length));
 
-        tempLog.info("Read the commitment.");
+        tempLog.info("GPU path: parsing the commitment (range and membership checks on the device).");
         final ByteTreeReader cr = bullBoard.waitFor(l, "Commitment", tempLog);
         final ByteBuffer cb = ProofSupport.direct(cr);
         cr.close();
@@ -130,17 +130,17 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
             commitmentTree.unsafeWriteTo(ProofSupport.file(nizkp, "PoSCCommitment", l));
         }
 
-        tempLog.info("Generate challenge.");
+        tempLog.info("GPU path: challenge from the random oracle.");
         final byte[] challengeBytes = challenger.challenge(tempLog.newChildLog(), new ByteTreeContainer(new ByteTree(prgSeed), commitmentTree),
                                                            vbitlen(), rbitlen);
         final byte[] v = LargeInteger.toPositive(challengeBytes).toByteArray();
         VMNException.check(VMNProofs.vmn_posc_set_challenge(V, v, v.length));
 
-        tempLog.info("Read the reply.");
+        tempLog.info("GPU path: parsing the reply (range checks on the device).");
         final ByteTreeReader rr = bullBoard.waitFor(l, "Reply", tempLog);
         final ByteBuffer rb = ProofSupport.direct(rr);
         rr.close();
-        tempLog.info("Perform verification.");
+        tempLog.info("GPU path: evaluating the verification equations.");
         final GPUMessage reply = GPUMessage.parse(group, rb, rb.remaining(), REP, new long[] {1, n, 1, 1, n});
         boolean verdict = false;
         if (reply != null && !malformed) {
@@ -151,7 +151,7 @@ public final class PoSCGPU extends ProtocolElGamal implements PoSC {
                 ProofSupport.byteTree(reply).unsafeWriteTo(ProofSupport.file(nizkp, "PoSCReply", l));
             }
         }
-        tempLog.info(verdict ? "Accepted proof." : "Rejected proof.");
+        tempLog.info(verdict ? "GPU path: proof accepted." : "GPU path: proof rejected.");
         if (reply != null) {
             reply.free();
         }

@@ -52,14 +52,14 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
         this.h = h;
         hGPU = PGroupElementArrayGPU.of(group, h);
         P = create(true);
-        log.info("Compute permutation commitment.");
+        log.info("GPU path: permutation commitment kernels.");
         VMNException.check(VMNProofs.vmn_pos_precompute(P, group.encode(g), hGPU.handle, GPUArrays.gatherTable(pi)));
     }
 
     @Override
     public void prove(final Log log, final PGroupElement pkey, final PGroupElementArray w, final PGroupElementArray wp,
                       final PRingElementArray s) {
-        log.info("Prove correctness of shuffle.");
+        log.info("GPU path: proving our shuffle.");
         final Log tempLog = log.newChildLog();
         final int width = Math.max(1, ((PPGroup) pkey.getPGroup()).project(0).getWidth());
         final PGroupElementArrayGPU[] W = GPUArrays.components(group, w, width);
@@ -70,7 +70,7 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
         // everything of commit() that does not need the batching vector runs while the instance is hashed below
         VMNException.check(VMNProofs.vmn_pos_commit_prepare(P));
 
-        tempLog.info("Publish our permutation commitment.");
+        tempLog.info("GPU path: permutation commitment framed on the device and posted.");
         final PGroupElementArrayGPU u = new PGroupElementArrayGPU(group, VMNProofs.vmn_pos_permutation_commitment(P));
         final ByteTree uTree = ProofSupport.byteTree(u);
         bullBoard.publish("PermutationCommitment", uTree, tempLog);
@@ -78,12 +78,12 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
             uTree.unsafeWriteTo(ProofSupport.file(nizkp, "PermutationCommitment", j));
         }
 
-        tempLog.info("Generate batching vector.");
+        tempLog.info("GPU path: seed of the batching vector from the random oracle; vector expanded on the device.");
         final ByteTreeContainer challengeData = new ByteTreeContainer(g.toByteTree(), h.toByteTree(), uTree, pkey.toByteTree(),
                                                                       w.toByteTree(), wp.toByteTree());
         final byte[] prgSeed = challenger.challenge(tempLog.newChildLog(), challengeData, 8 * prg.minNoSeedBytes(), rbitlen);
 
-        tempLog.info("Compute commitment.");
+        tempLog.info("GPU path: commitment kernels.");
         VMNException.check(VMNProofs.vmn_pos_set_batch_vector_seed(P, prgSeed, prgSeed.length));
         final long[] msg = new long[1];
         VMNException.check(VMNProofs.vmn_pos_commit(P, msg));
@@ -92,22 +92,22 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
         if (nizkp != null) {
             commitmentTree.unsafeWriteTo(ProofSupport.file(nizkp, "PoSCommitment", j));
         }
-        tempLog.info("Publish our commitment.");
+        tempLog.info("GPU path: commitment framed on the device and posted.");
         bullBoard.publish("Commitment", commitmentTree, tempLog);
 
-        tempLog.info("Generate challenge.");
+        tempLog.info("GPU path: challenge from the random oracle.");
         final byte[] challengeBytes = challenger.challenge(tempLog.newChildLog(), new ByteTreeContainer(new ByteTree(prgSeed), commitmentTree),
                                                            vbitlen(), rbitlen);
         final byte[] v = LargeInteger.toPositive(challengeBytes).toByteArray();
 
-        tempLog.info("Compute reply.");
+        tempLog.info("GPU path: reply kernels.");
         VMNException.check(VMNProofs.vmn_pos_reply(P, v, v.length, msg));
         final GPUMessage reply = new GPUMessage(msg[0]);
         final ByteTree replyTree = ProofSupport.byteTree(reply);
         if (nizkp != null) {
             replyTree.unsafeWriteTo(ProofSupport.file(nizkp, "PoSReply", j));
         }
-        tempLog.info("Publish reply.");
+        tempLog.info("GPU path: reply framed on the device and posted.");
         bullBoard.publish("Reply", replyTree, tempLog);
 
         commitment.free();
@@ -132,7 +132,7 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
 
     @Override
     public boolean verify(final Log log, final int l, final PGroupElement pkey, final PGroupElementArray w, final PGroupElementArray wp) {
-        log.info("Verify correctness of shuffle of " + ui.getDescrString(l) + ".");
+        log.info("GPU path: checking the proof of a shuffle by " + ui.getDescrString(l) + ".");
         final Log tempLog = log.newChildLog();
         final int width = Math.max(1, ((PPGroup) pkey.getPGroup()).project(0).getWidth());
         final int n = h.size();
@@ -141,7 +141,7 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
         VMNException.check(VMNProofs.vmn_pos_set_instance(V, ProofSupport.wideKey(group, pkey, width), width,
                                                           GPUArrays.handles(W), GPUArrays.handles(WP), null));
 
-        tempLog.info("Read the permutation commitment.");
+        tempLog.info("GPU path: parsing the permutation commitment.");
         final ByteTreeReader ur = bullBoard.waitFor(l, "PermutationCommitment", tempLog);
         PGroupElementArrayGPU u;
         try {
@@ -162,16 +162,16 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
             uTree.unsafeWriteTo(ProofSupport.file(nizkp, "PermutationCommitment", l));
         }
 
-        tempLog.info("Generate batching vector.");
+        tempLog.info("GPU path: seed of the batching vector from the random oracle; vector expanded on the device.");
         final ByteTreeContainer challengeData = new ByteTreeContainer(g.toByteTree(), h.toByteTree(), uTree, pkey.toByteTree(),
                                                                       w.toByteTree(), wp.toByteTree());
         final byte[] prgSeed = challenger.challenge(tempLog.newChildLog(), challengeData, 8 * prg.minNoSeedBytes(), rbitlen);
         VMNException.check(VMNProofs.vmn_pos_set_batch_vector_seed(V, prgSeed, prgSeed.length));
 
-        tempLog.info("Batch.");
+        tempLog.info("GPU path: multi-exponentiations over the batching vector.");
         VMNException.check(VMNProofs.vmn_pos_compute_af(V));      // in parallel with the prover computing the rest of the proof
 
-        tempLog.info("Read the commitment.");
+        tempLog.info("GPU path: parsing the commitment (range and membership checks on the device).");
         final ByteTreeReader cr = bullBoard.waitFor(l, "Commitment", tempLog);
         final ByteBuffer cb = ProofSupport.direct(cr);
         cr.close();
@@ -196,17 +196,17 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
             commitmentTree.unsafeWriteTo(ProofSupport.file(nizkp, "PoSCommitment", l));
         }
 
-        tempLog.info("Generate challenge.");
+        tempLog.info("GPU path: challenge from the random oracle.");
         final byte[] challengeBytes = challenger.challenge(tempLog.newChildLog(), new ByteTreeContainer(new ByteTree(prgSeed), commitmentTree),
                                                            vbitlen(), rbitlen);
         final byte[] v = LargeInteger.toPositive(challengeBytes).toByteArray();
         VMNException.check(VMNProofs.vmn_pos_set_challenge(V, v, v.length));
 
-        tempLog.info("Read the reply.");
+        tempLog.info("GPU path: parsing the reply (range checks on the device).");
         final ByteTreeReader rr = bullBoard.waitFor(l, "Reply", tempLog);
         final ByteBuffer rb = ProofSupport.direct(rr);
         rr.close();
-        tempLog.info("Perform verification.");
+        tempLog.info("GPU path: evaluating the verification equations.");
         final GPUMessage reply = GPUMessage.parse(group, rb, rb.remaining(), REP, new long[] {1, n, 1, 1, n, width});
         boolean verdict = false;
         if (reply != null && !malformed) {                      // a malformed reply is rejected (PoSBasicTW.java:985-989)
@@ -217,7 +217,7 @@ public final class PoSGPU extends ProtocolElGamal implements PoS {
                 ProofSupport.byteTree(reply).unsafeWriteTo(ProofSupport.file(nizkp, "PoSReply", l));
             }
         }
-        tempLog.info(verdict ? "Accepted proof." : "Rejected proof.");
+        tempLog.info(verdict ? "GPU path: proof accepted." : "GPU path: proof rejected.");
         if (reply != null) {
             reply.free();
         }

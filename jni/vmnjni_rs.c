@@ -1,4 +1,5 @@
-/* vmnjni_rs.c -- see vmnjni_rs.h.  Plain C; needs a JDK's jni.h (not available where this repository is developed). */
+/* vmnjni_rs.c -- see vmnjni_rs.h.  Plain C; needs a JDK's jni.h (not available where this repository is developed: there it is
+ * type-checked against tests/jni_stub/jni.h, a syntax stand-in, by tests/test_jni_binding.py). */
 #include "vmnjni_rs.h"
 
 #include <pthread.h>
@@ -11,6 +12,7 @@ struct vmn_jrs {
     jmethodID ring, ints, seed;
     jbyteArray rows;                /* global reference to the rows handed out last, pinned through rows_ptr */
     jbyte* rows_ptr;
+    size_t row_bytes;               /* width of one row the library reads (vmn_group_exp_bytes of the group the source serves) */
     void* owner;
     struct vmn_jrs* next;           /* owner table */
 };
@@ -31,9 +33,14 @@ static void drop_rows(JNIEnv* env, struct vmn_jrs* h) {
         h->rows_ptr = NULL;
     }
 }
-/* keep `arr` (n rows) alive and pinned; returns 0 on success */
-static int hand_over(JNIEnv* env, struct vmn_jrs* h, jbyteArray arr, const uint8_t** rows) {
+/* keep `arr` (n rows) alive and pinned; returns 0 on success.  A block shorter than n rows is refused: the library would
+ * read n * row_bytes bytes from it. */
+static int hand_over(JNIEnv* env, struct vmn_jrs* h, jbyteArray arr, size_t n, const uint8_t** rows) {
     if ((*env)->ExceptionCheck(env) || !arr) return 1;          /* the Java exception stays pending and surfaces in the caller */
+    if ((size_t)(*env)->GetArrayLength(env, arr) < n * h->row_bytes) {
+        (*env)->DeleteLocalRef(env, arr);
+        return 1;
+    }
     drop_rows(env, h);
     h->rows = (jbyteArray)(*env)->NewGlobalRef(env, arr);
     (*env)->DeleteLocalRef(env, arr);
@@ -47,13 +54,13 @@ static int cb_ring(void* user, size_t n, const uint8_t** rows) {
     struct vmn_jrs* h = (struct vmn_jrs*)user;
     JNIEnv* env = env_of(h);
     if (!env) return 1;
-    return hand_over(env, h, (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->ring, (jlong)n), rows);
+    return hand_over(env, h, (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->ring, (jlong)n), n, rows);
 }
 static int cb_ints(void* user, size_t n, int bits, const uint8_t** rows) {
     struct vmn_jrs* h = (struct vmn_jrs*)user;
     JNIEnv* env = env_of(h);
     if (!env) return 1;
-    return hand_over(env, h, (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->ints, (jlong)n, (jint)bits), rows);
+    return hand_over(env, h, (jbyteArray)(*env)->CallObjectMethod(env, h->bridge, h->ints, (jlong)n, (jint)bits), n, rows);
 }
 static int cb_seed(void* user, uint8_t seed_out[32]) {
     struct vmn_jrs* h = (struct vmn_jrs*)user;
@@ -66,9 +73,10 @@ static int cb_seed(void* user, uint8_t seed_out[32]) {
     return 0;
 }
 
-vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge) {
+vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge, size_t row_bytes) {
     struct vmn_jrs* h = (struct vmn_jrs*)calloc(1, sizeof(*h));
     if (!h) return NULL;
+    h->row_bytes = row_bytes;
     jclass c = (*env)->GetObjectClass(env, bridge);
     h->ring = (*env)->GetMethodID(env, c, "ringElements", "(J)[B");
     h->ints = (*env)->GetMethodID(env, c, "integers", "(JI)[B");

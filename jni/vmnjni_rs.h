@@ -13,7 +13,7 @@
 #include "../include/vmnproofs.h"
 
 typedef struct vmn_jrs vmn_jrs;
-vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge);
+vmn_jrs* vmn_jrs_new(JNIEnv* env, jobject bridge, size_t row_bytes);   /* row_bytes = vmn_group_exp_bytes: every block handed back must hold n rows of it */
 void vmn_jrs_fill(vmn_jrs* h, vmn_random_source* out);
 void vmn_jrs_free(JNIEnv* env, vmn_jrs* h);
 void vmn_jrs_set_owner(vmn_jrs* h, void* owner);       /* owner = the proof object created with this source */

@@ -220,8 +220,9 @@ def test_an_array_freed_by_the_helper_returns_to_the_lane_that_owns_it(vmn, gpu_
         outs.append(out)
     assert not errors
     want = [pow(x, e, p) for x, e in zip(xs[:64], es[:64])]
+    first = outs[0].toInts()
     for out in outs:
         got = out.toInts()
-        assert got[:64] == want and got == outs[0].toInts()
+        assert got[:64] == want and got == first
         out.free()
     assert gpu_ctx.memory_stats()["live_bytes"] == live0        # the accounting of neither lane went negative / leaked

@@ -1,5 +1,6 @@
 """CPU suite: the JNI / Java binding is complete source, checked mechanically -- there is no JDK in
-this image, so nothing is compiled and jni.h is not faked:
+this image, so nothing is linked or run; the C is type-checked against tests/jni_stub/jni.h (a SYNTAX stand-in, see its
+header), and:
 
   * every `vmn_*` entry point of include/vmnhip.h and include/vmnproofs.h has a JNIEXPORT wrapper in jni/*.c and a
     `native` declaration in the matching Java class, with the same number of parameters;
@@ -126,3 +127,41 @@ def test_seam_classes_mirror_the_reference_interfaces():
     rs = open(os.path.join(ROOT, "jni", "vmnjni_rs.c")).read()
     for method, sig in (("ringElements", "(J)[B"), ("integers", "(JI)[B"), ("arraySeed", "()[B"), ("deviceArrays", "()Z")):
         assert f'"{method}", "{sig}"' in rs                              # the bridge looks up exactly the interface's methods
+
+
+def test_jni_sources_pass_a_compiler():
+    """gcc -fsyntax-only -Wall -Wextra -Werror over jni/*.c with the test-only jni.h stand-in: a C error anywhere in the
+    generated wrappers or the hand-written bridges fails the CPU suite."""
+    import subprocess
+    stub = os.path.join(ROOT, "tests", "jni_stub")
+    assert "SYNTAX STAND-IN" in open(os.path.join(stub, "jni.h")).read()
+    srcs = [os.path.join(ROOT, "jni", f) for f in ("vmnjni_rs.c", "vmnhip_jni.c", "vmnproofs_jni.c")]
+    pr = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-comment", "-I" + stub,
+                         "-I" + os.path.join(ROOT, "include")] + srcs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert pr.returncode == 0, pr.stdout.decode()[-4000:]
+    # the stand-in is test infrastructure: nothing shipped includes it
+    for d in ("jni", "include", "verificatum-vmn_amd"):
+        for base, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".c", ".h", ".cpp", ".hip", ".py")):
+                    text = open(os.path.join(base, f), errors="replace").read()
+                    assert not re.search(r"#\s*include[^\n]*jni_stub", text) and "-Itests/jni_stub" not in text, f
+
+
+def test_every_java_array_is_checked_against_what_the_callee_touches():
+    """vmn_garray_to_be writes n * nbytes into be_out whatever its length.  The generator sizes every array
+    and direct-buffer parameter (none is left unchecked) and the wrappers refuse a short one."""
+    g = gen()
+    for header, cls, cfile in PAIRS:
+        g.emit(header, cls)
+    assert g.UNCHECKED == []
+    csrc = open(os.path.join(ROOT, "jni", "vmnhip_jni.c")).read()
+    body = csrc[csrc.index("VMNHip_vmn_1garray_1to_1be("):]
+    body = body[:body.index("\n}\n")]
+    assert "vmnjni_len_ok(env, be_out, vmn_garray_size(" in body and "vmnjni_eb(vmn_garray_group(" in body and "VMN_ERR_ARG" in body
+    direct = csrc[csrc.index("VMNHip_vmn_1garray_1to_1beDirect("):]
+    assert "vmnjni_cap_ok(env, be_out," in direct[:direct.index("\n}\n")]
+    n_checks = sum(open(os.path.join(ROOT, "jni", f)).read().count("const int sized =") for f in ("vmnhip_jni.c", "vmnproofs_jni.c"))
+    assert n_checks > 120
+    rs = open(os.path.join(ROOT, "jni", "vmnjni_rs.c")).read()
+    assert "GetArrayLength(env, arr) < n * h->row_bytes" in rs

@@ -24,7 +24,13 @@ plus, for the calls that move whole arrays (…_from_be, …_to_be, …_bytetree
 entry point `<name>Direct` taking a direct java.nio.ByteBuffer instead of byte[] (no copy through the Java heap; the
 library copies from / to it asynchronously when it is page-locked).
 
-Nothing here can be compiled in this image (no JDK: jni.h is absent); tests/test_jni_binding.py checks
+Every Java array / direct buffer is checked against the number of elements the callee reads or writes before the call
+(`need_expr` below: the sizes follow from the group's wire widths, the arrays' sizes and the explicit length parameters);
+a short one makes the wrapper return VMN_ERR_ARG with a message instead of touching memory beyond it.  Parameters whose
+extent the wrapper cannot know are listed in UNCHECKED (tests/test_jni_binding.py pins that list).
+
+No JDK in this image: tests/test_jni_binding.py type-checks the generated C against tests/jni_stub/jni.h (a syntax
+stand-in with the JNI specification's signatures) with `gcc -fsyntax-only -Wall -Wextra -Werror`, and checks
 mechanically that every `vmn_*` symbol of the two headers has its wrapper and its native declaration.
 """
 import os
@@ -120,6 +126,153 @@ def esc(name):
     return name.replace("_", "_1")
 
 
+PROOF_TYPES = ("vmn_pos", "vmn_posc", "vmn_ccpos", "vmn_decproof", "vmn_igen")
+UNCHECKED = []          # (function, parameter) pairs the wrapper cannot size; filled while generating
+
+
+def hcast(ptype, pname):
+    return f"(({ptype.replace('const ', '').strip()})(intptr_t){pname})"
+
+
+def group_expr(name, plist):
+    """C expression of the vmn_group* the call works in, or None."""
+    for ptype, pname in plist:
+        t = ptype.replace("const ", "").replace(" const", "").strip()
+        if t == "vmn_group*":
+            return hcast("vmn_group*", pname)
+        if t == "vmn_garray*":
+            return f"vmn_garray_group({hcast('vmn_garray*', pname)})"
+        if t == "vmn_rarray*":
+            return f"vmn_rarray_group({hcast('vmn_rarray*', pname)})"
+        for pt in PROOF_TYPES:
+            if t == pt + "*":
+                return f"{pt}_group({hcast(pt + '*', pname)})"
+        if t == "vmn_garray**" and ptype.replace(" ", "").startswith("constvmn_garray*const*"):
+            return f"(c_{pname} ? vmn_garray_group((const vmn_garray*)(intptr_t)c_{pname}[0]) : NULL)"
+    return None
+
+
+def first_of(plist, *types):
+    for ptype, pname in plist:
+        t = ptype.replace("const ", "").replace(" const", "").strip()
+        if t in types:
+            return t, pname
+    return None, None
+
+
+def need_expr(name, ptype, pname, plist):
+    """Number of ELEMENTS (bytes for byte[], ints for int[], ...) the callee touches through this parameter, as a C
+    expression over the wrapper's locals; None when it cannot be known here."""
+    k = kind(ptype)
+    names = [pn for _, pn in plist]
+    G = group_expr(name, plist)
+    EB, XB = (f"vmnjni_eb({G})", f"vmnjni_xb({G})") if G else (None, None)
+    on_rarray = name.startswith("vmn_rarray_")
+    at, an = first_of(plist, "vmn_garray*", "vmn_rarray*")
+    asize = f"{at[:-1]}_size({hcast(at, an)})" if at else None
+    proof = next((pt for pt in PROOF_TYPES if name.startswith(pt + "_")), None)
+    pobj = hcast(proof + "*", plist[0][1]) if proof else None
+    if k == "handles_out":
+        return {"wp_out": "2 * (size_t)width", "s_out": "(size_t)width"}.get(pname, "1")
+    if k == "handles_in":
+        if pname == "xs":
+            return "(size_t)k"
+        if pname in ("w", "wp", "w_full"):
+            return "2 * (size_t)width"
+        if pname in ("s", "s_full"):
+            return "(size_t)width"
+        if pname == "f":
+            return "(size_t)k + 1" if "k" in names else f"(size_t)vmn_decproof_parties({pobj}) + 1"
+        if pname == "h" and name == "vmn_igen_set_instance":
+            return f"(size_t)vmn_igen_parties({pobj}) + 1"
+        return None
+    if k in ("ints_in", "ints_out"):
+        if pname in ("perm_host",):
+            return asize
+        if pname == "idx_host":
+            return "(size_t)n_out"
+        if pname == "idx":
+            return "(size_t)n"
+        if pname == "layout":
+            return "(size_t)items"
+        if pname == "negative":
+            return "(size_t)threshold"
+        if pname == "verdicts5":
+            return "5"
+        if pname == "pi_out":
+            return "(size_t)n"
+        if pname == "pi":
+            if name == "vmn_permutation_shrink":
+                return "(size_t)n_max"
+            for cand in ("h", "h_full"):
+                if cand in names:
+                    return f"vmn_garray_size({hcast('vmn_garray*', cand)})"
+            for cand in ("w", "w_full"):
+                if cand in names:
+                    return f"(c_{cand} ? vmn_garray_size((const vmn_garray*)(intptr_t)c_{cand}[0]) : 0)"
+            return None
+        return "1"                                  # verdicts, flags, bit counts
+    if k in ("longs_in", "longs_out"):
+        return "(size_t)items" if pname == "counts" else "1"
+    if k == "doubles_out":
+        return "1"
+    if k in ("bytes_in", "bytes_out", "chars_out"):
+        explicit = {"seed": "seedlen", "v_be": "vbytes", "e_be": "ebytes", "rho_be": "rho_bytes", "data": "len", "bt": "len", "buf": "len",
+                    "keep": "keep_len"}
+        if name == "vmn_keep_list_sanitize" and pname == "keep":
+            return "(size_t)(keep_len > n_max ? keep_len : n_max)"       # the trivial list is written over n_max entries
+        if pname in explicit and explicit[pname] in names:
+            return f"(size_t){explicit[pname]}"
+        if pname == "exps_be":
+            return f"{asize} * (size_t)ebytes"
+        if name == "vmn_prg_bytes" and pname == "out":
+            return "(size_t)nbytes"
+        if name.startswith("vmn_random_oracle") and pname == "out":
+            return "((size_t)nout_bits + 7) / 8"
+        if name == "vmn_modp_group_create":
+            return "(size_t)nbytes"
+        if name == "vmn_group_get_order":
+            return XB
+        if name == "vmn_group_get_modulus":
+            return f"vmnjni_coord({G})"
+        if name in ("vmn_msg_push_elements", "vmn_msg_push_ring"):
+            return "(size_t)count * (size_t)width"
+        if pname == "be":
+            return f"(size_t)n * {XB if on_rarray else EB}"
+        if pname == "be_out":
+            return f"{asize} * {XB if on_rarray else EB}"
+        if pname == "out" and name.endswith("_to_bytetree"):
+            obj_t, obj_n = plist[0]
+            base = obj_t.replace("const ", "").strip()[:-1]
+            return f"{base}_bytetree_size({hcast(obj_t, obj_n)})"
+        if pname == "e_be" and proof:
+            return f"{proof}_size({pobj}) * {XB}"
+        if pname in ("keep_host",):
+            return asize
+        if pname == "keep_out":
+            return "(size_t)n_max"
+        if pname == "correct":
+            return "(size_t)k + 1" if "k" in names else f"(size_t)vmn_decproof_parties({pobj}) + 1"
+        if pname == "pkey_be":
+            return f"2 * (size_t)width * {EB}"
+        if pname == "partials_be":
+            return f"(size_t)k * {EB}"
+        if pname == "y_be" and name == "vmn_decproof_set_instance":
+            return f"((size_t)vmn_decproof_parties({pobj}) + 1) * {EB}"
+        if pname == "abs_be":
+            return f"(size_t)threshold * {XB}"
+        if pname == "out_be" and name == "vmn_garray_expprod_multi":
+            return f"(size_t)k * {EB}"
+        ring_names = {"last_be", "kx_out", "kx_be", "ka_out", "ka_be", "x_be", "secret_be", "c_be"}
+        if pname in ring_names or (on_rarray and pname in ("out_be", "el_be", "v_be")):
+            return XB
+        elem_names = {"g_be", "base_be", "el_be", "out_be", "a_be", "b_be", "yp_out", "Bp_out", "yp_be", "Bp_be", "Ap_out", "Ap_be",
+                      "combinedy_be", "q_be", "p_be"}
+        if pname in elem_names and EB:
+            return EB
+    return None
+
+
 def c_wrapper(cls, ret, name, plist, direct=()):
     """One JNIEXPORT function.  `direct`: names of the byte parameters passed as direct ByteBuffers."""
     jret_java, jret = ret_types(ret)
@@ -175,7 +328,8 @@ def c_wrapper(cls, ret, name, plist, direct=()):
             post.append(f"    if (c_{pname}) (*env)->ReleaseLongArrayElements(env, {pname}, c_{pname}, {mode});")
         elif k == "rs":
             args.append(f"jobject {pname}")
-            pre.append(f"    vmn_jrs* h_{pname} = {pname} ? vmn_jrs_new(env, {pname}) : NULL;")
+            # the bridge checks every row block the source hands back against n rows of the group's exponent width
+            pre.append(f"    vmn_jrs* h_{pname} = {pname} ? vmn_jrs_new(env, {pname}, vmnjni_xb({group_expr(name, plist)})) : NULL;")
             pre.append(f"    vmn_random_source s_{pname};")
             pre.append(f"    if (h_{pname}) vmn_jrs_fill(h_{pname}, &s_{pname});")
             call.append(f"h_{pname} ? &s_{pname} : NULL")
@@ -189,31 +343,52 @@ def c_wrapper(cls, ret, name, plist, direct=()):
         else:
             raise SystemExit(f"gen_jni: no wrapper rule for {k} ({name}.{pname})")
     sig = ", ".join(["JNIEnv* env", "jclass cls"] + args)
-    body = [f"JNIEXPORT {jret} JNICALL Java_{PKG_JNI}_{cls}_{esc(jname)}({sig}) {{", "    (void)cls;"]
+    body = [f"JNIEXPORT {jret} JNICALL Java_{PKG_JNI}_{cls}_{esc(jname)}({sig}) {{", "    (void)env;", "    (void)cls;"]
     body += pre
+    # every array / direct buffer against the elements the callee touches through it
+    checks = []
+    for ptype, pname in plist:
+        k = kind(ptype)
+        if k not in ("bytes_in", "bytes_out", "chars_out", "ints_in", "ints_out", "longs_in", "longs_out", "doubles_out", "handles_in",
+                     "handles_out"):
+            continue
+        need = need_expr(name, ptype, pname, plist)
+        if need is None:
+            if (name, pname) not in UNCHECKED:
+                UNCHECKED.append((name, pname))
+            continue
+        fn = "vmnjni_cap_ok" if pname in direct else "vmnjni_len_ok"
+        checks.append(f"{fn}(env, {pname}, {need})")
     callexpr = f"{name}({', '.join(call)})"
     rs_params = [pn for pt, pn in plist if kind(pt) == "rs"]
     if name in RS_OWNERS.values():
         body.append(f"    vmn_jrs_release_owner((void*)(intptr_t){plist[0][1]});      /* the bridge of the random source dies with its object */")
+    plain_ret = ret.replace("const ", "").strip()
+    if checks:
+        body.append("    const int sized = " + "\n                      && ".join(checks) + ";")
+        body.append(f'    if (!sized) vmn_report_error("{jname}: a Java array or buffer is shorter than what the call reads or writes");')
+    guard = "sized ? " if checks else ""
     if jret == "void":
-        body.append(f"    {callexpr};")
+        body.append(f"    if (sized) {callexpr};" if checks else f"    {callexpr};")
     elif jret_java == "String":
-        body.append(f"    const char* r = {callexpr};")
-    elif ret.replace("const ", "").strip() in ("int", "size_t"):
-        body.append(f"    {jret} r = ({jret}){callexpr};")
+        body.append(f"    const char* res_ = {callexpr};")
+    elif plain_ret == "int":
+        body.append(f"    {jret} res_ = {guard}({jret}){callexpr}{' : (jint)VMN_ERR_ARG' if checks else ''};")
+    elif plain_ret == "size_t":
+        body.append(f"    {jret} res_ = {guard}({jret}){callexpr}{' : 0' if checks else ''};")
     else:
-        body.append(f"    jlong r = (jlong)(intptr_t){callexpr};")
+        body.append(f"    jlong res_ = {guard}(jlong)(intptr_t){callexpr}{' : 0' if checks else ''};")
     for pn in rs_params:
         if name in RS_OWNERS:
             outp = [p for t, p in plist if kind(t) == "handles_out"][0]
-            body.append(f"    if (h_{pn}) {{ if (r == 0 && c_{outp}) vmn_jrs_set_owner(h_{pn}, (void*)(intptr_t)c_{outp}[0]); else vmn_jrs_free(env, h_{pn}); }}")
+            body.append(f"    if (h_{pn}) {{ if (res_ == 0 && c_{outp}) vmn_jrs_set_owner(h_{pn}, (void*)(intptr_t)c_{outp}[0]); else vmn_jrs_free(env, h_{pn}); }}")
         else:
             body.append(f"    if (h_{pn}) vmn_jrs_free(env, h_{pn});")
     body += post
     if jret_java == "String":
-        body.append("    return r ? (*env)->NewStringUTF(env, r) : NULL;")
+        body.append("    return res_ ? (*env)->NewStringUTF(env, res_) : NULL;")
     elif jret != "void":
-        body.append("    return r;")
+        body.append("    return res_;")
     body.append("}")
     return "\n".join(body)
 
@@ -247,6 +422,17 @@ C_HEAD = '''/* GENERATED by tools/gen_jni.py from include/%(header)s -- do not e
 _Static_assert(sizeof(jlong) == sizeof(size_t) && sizeof(jlong) == sizeof(void*) && sizeof(jlong) == sizeof(long),
                "the wrappers pass size_t / long / pointers through jlong");
 _Static_assert(sizeof(jint) == sizeof(uint32_t) && sizeof(jint) == sizeof(int), "int[] carries uint32_t tables");
+
+/* length checks of the wrappers: a null reference is the callee's business (optional parameters; it answers VMN_ERR_ARG) */
+static inline int vmnjni_len_ok(JNIEnv* env, jarray a, size_t need) { return !a || (size_t)(*env)->GetArrayLength(env, a) >= need; }
+static inline int vmnjni_cap_ok(JNIEnv* env, jobject b, size_t need) {
+    if (!b) return 1;
+    const jlong cap = (*env)->GetDirectBufferCapacity(env, b);
+    return cap >= 0 && (size_t)cap >= need;
+}
+static inline size_t vmnjni_eb(const vmn_group* g) { return g ? vmn_group_elem_bytes(g) : 0; }
+static inline size_t vmnjni_xb(const vmn_group* g) { return g ? vmn_group_exp_bytes(g) : 0; }
+static inline size_t vmnjni_coord(const vmn_group* g) { return !g ? 0 : vmn_group_kind(g) == 1 ? vmn_group_elem_bytes(g) / 2 : vmn_group_elem_bytes(g); }
 '''
 
 ITEM_BYTES = '''/* vmn_msg_item_bytes: the item's rows as one byte[] (count * width bytes); counts[0] = count, counts[1] = width. */
@@ -301,6 +487,7 @@ def main():
         open(os.path.join(ROOT, "jni", cfile), "w").write(c)
         open(os.path.join(ROOT, "java", PKG_PATH, cls + ".java"), "w").write(j)
         print(f"{header}: {len(names)} entry points -> jni/{cfile}, java/{PKG_PATH}/{cls}.java")
+    print("unchecked array parameters:", UNCHECKED)
 
 
 if __name__ == "__main__":

@@ -1237,6 +1237,8 @@ extern "C" void vmn_rarray_free(vmn_rarray* a) {
     free_to_owner(a->lane, LANE(a->grp->ctx), a->d, a->bytes);
     delete a;
 }
+extern "C" vmn_group* vmn_garray_group(const vmn_garray* a) { return a ? a->grp : nullptr; }
+extern "C" vmn_group* vmn_rarray_group(const vmn_rarray* a) { return a ? a->grp : nullptr; }
 extern "C" size_t vmn_garray_size(const vmn_garray* a) { return a ? a->n : 0; }
 extern "C" size_t vmn_rarray_size(const vmn_rarray* a) { return a ? a->n : 0; }
 

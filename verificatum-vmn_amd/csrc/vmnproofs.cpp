@@ -2479,6 +2479,18 @@ CREATE(vmn_ccpos, vmn_ccpos_create)
     if (!(p)) return fail(VMN_ERR_ARG, "%s: null proof object", __func__)
 
 void vmn_pos_free(vmn_pos* p) { delete p; }
+vmn_group* vmn_pos_group(const vmn_pos* p) { return p ? p->G.grp : nullptr; }
+vmn_group* vmn_posc_group(const vmn_posc* p) { return p ? p->G.grp : nullptr; }
+vmn_group* vmn_ccpos_group(const vmn_ccpos* p) { return p ? p->G.grp : nullptr; }
+vmn_group* vmn_decproof_group(const vmn_decproof* p) { return p ? p->G.grp : nullptr; }
+vmn_group* vmn_igen_group(const vmn_igen* p) { return p ? p->G.grp : nullptr; }
+size_t vmn_pos_size(const vmn_pos* p) { return p ? p->Ntot : 0; }
+size_t vmn_posc_size(const vmn_posc* p) { return p ? p->Ntot : 0; }
+size_t vmn_ccpos_size(const vmn_ccpos* p) { return p ? p->Ntot : 0; }
+size_t vmn_decproof_size(const vmn_decproof* p) { return p ? vmn_garray_size(p->u) : 0; }
+size_t vmn_igen_size(const vmn_igen* p) { return p ? p->N : 0; }
+int vmn_decproof_parties(const vmn_decproof* p) { return p ? p->k : 0; }
+int vmn_igen_parties(const vmn_igen* p) { return p ? p->threshold : 0; }
 int vmn_pos_precompute(vmn_pos* p, const uint8_t* g_be, const vmn_garray* h, const uint32_t* pi) {
     NONNULL(p);
     return p->precompute(g_be, h, pi);
