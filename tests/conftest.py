@@ -51,3 +51,14 @@ def oracle_for(entry):
 @pytest.fixture(scope="session")
 def gpu_ctx(vmn):
     return vmn.Context(0)
+
+
+@pytest.fixture(autouse=True)
+def gmp_backed_pyref(request, monkeypatch):
+    """GPU suite only: the four array exponentiations of oracle/pyref.py run in the C + GMP oracle (tests/fast_pyref.py).
+    Not active in the CPU suite, which pins the two oracles against each other and against the golden vectors."""
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import fast_pyref
+    for name, fn in fast_pyref.replacements().items():
+        monkeypatch.setattr(fast_pyref.pyref, name, fn)

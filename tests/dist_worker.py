@@ -272,6 +272,9 @@ def main():
     comm = par.Comm(dist, device)
     ec = backend.endswith("-ec")
     native = backend.startswith("hip") and not mirror
+    if backend.startswith("hip"):
+        import fast_pyref
+        fast_pyref.install()                   # GPU box: the oracle's array exponentiations through GMP (see the module)
     nat = load_native() if native else None
     if ec:
         from oracle.pyref_ec import Curve

@@ -13,7 +13,7 @@ implementations (the C++ drivers behind include/vmnproofs.h and their Python mir
 import pytest
 
 from conftest import load_golden
-from oracle import pyref_proofs as P
+from oracle import pyref, pyref_proofs as P
 from oracle.pyref_ec import Curve
 from proof_cases import check_ccpos, check_pos, ints_of, load_driver_modules, make_instance, same_msg
 from tape import Tape
@@ -308,7 +308,7 @@ def test_default_wire_widths_are_the_references(vmn, gpu_ctx, mods, entry):
         assert X.exp(E).toInts() == [pow(x, e, p) for x, e in zip(xs, es)]
     # a whole reply: ring leaves are exponent-wide, element leaves element-wide
     n, NV, NE, NR = 6, 100, 100, 50
-    h = [pow(g, x, p) for x in t.ring_array(n)]
+    h = pyref.exp_fixed(g, t.ring_array(n), p)
     r, pi, e, v = t.ring_array(n), t.permutation(n), t.int_array(n, NE), t.int_array(1, NV)[0]
     H, R = G.toElementArray(h), G.ringArray(r)
     U = nat.permutation_commitment_native(G, g, H, R, pi)

@@ -85,7 +85,7 @@ def test_threshold_decryption_recovers_plaintexts_and_proofs_verify(bits, n, k, 
     xs = [None] + [share(j) for j in range(1, k + 1)]
     ys = [None] + [pow(g, xj, p) for xj in xs[1:]]
     y = pow(g, x, p)
-    msgs = [pow(g, m, p) for m in t.ring_array(n)]
+    msgs = pyref.exp_fixed(g, t.ring_array(n), p)
     rs = t.ring_array(n)
     u = pyref.exp_fixed(g, rs, p)
     v = pyref.mul(msgs, pyref.exp_fixed(y, rs, p), p)

@@ -36,10 +36,10 @@ def make_instance(bits, n, width, seed):
     grp, _ = load_golden(bits)
     p, q, g = grp["p"], grp["q"], grp["g"]
     t = Tape(seed, q)
-    h = [pow(g, x, p) for x in t.ring_array(n)]
+    h = pyref.exp_fixed(g, t.ring_array(n), p)
     y = pow(g, t.ring_element(), p)
     pkey = [g] * width + [y] * width
-    msgs = [[pow(g, m, p) for m in t.ring_array(n)] for _ in range(width)]
+    msgs = [pyref.exp_fixed(g, t.ring_array(n), p) for _ in range(width)]
     enc_r = [t.ring_array(n) for _ in range(width)]
     w = [pyref.exp_fixed(g, enc_r[c], p) for c in range(width)] + \
         [pyref.mul(msgs[c], pyref.exp_fixed(y, enc_r[c], p), p) for c in range(width)]
