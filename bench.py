@@ -826,6 +826,158 @@ def mix_ccpos_sharded(entry, vmn, ctx, grp, label: str, n: int, seed: int, sync,
     return best
 
 
+def decrypt_leg(entry, vmn, ctx, grp, n: int, seed: int, sync, k: int = 3, threshold: int = 2):
+    """ciphertexts/s of the decryption half of `vmn -mix` as ONE party (j = 1 of k, threshold t) runs it, width 1, device-
+    resident arrays (the other parties' factors and proofs are inputs, made before the clock):
+      own decryption factors f_j = u^(-x_j / c)                       elgamal/DistrElGamalSession.java:365-385
+      own batched proof: A = prod u^e, y' = g^r, B' = A^r, reply      DistrElGamalSessionBasic.java:513-540, 595-598
+      check of every other party: B_l = prod f_l^e and the two equations   :642-727
+      combination f = prod_l f_l^(lambda_l) with the modified Lagrange integers (possibly negative)   :406-452, 465-503
+      plaintexts m = v f                                              DistrElGamalSession.java:536-538
+    n_e = n_v = 256; the batching vector is expanded on the device from a 32-byte seed."""
+    nat, mx = load_sub(entry, "native"), load_sub(entry, "mixnet")
+    NE = NV = 256
+    p, q, g = grp.p, grp.q, grp.g
+    rnd = mx.InsecureBulkRandomSource(seed, q, grp.exp_bytes)
+    coeffs = [rnd.ring_element() for _ in range(threshold)]              # Shamir sharing of the key over Z_q
+    share = lambda j: sum(c * pow(j, d, q) for d, c in enumerate(coeffs)) % q
+    xs = [None] + [share(j) for j in range(1, k + 1)]
+    ys = [None] + [pow(g, xj, p) for xj in xs[1:]]
+    y = pow(g, coeffs[0], p)
+    for base in (g, y):
+        grp.precomputeFixed(base, n, 16)
+    arr = lambda: grp.ringArrayFromPRG(rnd.array_seed(), n, q.bit_length() - 1)
+    T, Mx = arr(), arr()
+    U = grp.exp(g, T)
+    M, YT = grp.exp(g, Mx), grp.exp(y, T)
+    V = M.mul(YT)
+    for a in (T, Mx, YT):
+        a.free()
+    j = 1
+    e_seed = rnd.array_seed()
+    v = int.from_bytes(rnd.int_array(1, NV), "big")
+    # the other parties' work (inputs of party j): their factors, commitments and replies
+    F = [None] * (k + 1)
+    others = {}
+    for l in range(2, k + 1):
+        F[l] = nat.decryptionFactors(U, xs[l], q, k)
+    for l in range(2, k + 1):
+        pr = nat.DistrElGamalSessionBasic(grp, l, k, threshold, NE, rand=rnd)
+        fl = [None] * (k + 1)
+        fl[l] = F[l]
+        pr.setInstance(U, ys, fl)
+        pr.setBatchVectorSeed(e_seed)
+        pr.batchInput()
+        yp, Bp = pr.commit(xs[l])
+        others[l] = (yp, Bp, pr.reply(v))
+        pr.free()
+    best = None
+    for _ in range(2):
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        gc.collect()
+        sync()
+        t0 = time.perf_counter()
+        F[j] = nat.decryptionFactors(U, xs[j], q, k)
+        sync()
+        t1 = time.perf_counter()
+        me = nat.DistrElGamalSessionBasic(grp, j, k, threshold, NE, rand=rnd)
+        me.setInstance(U, ys, F)
+        me.setBatchVectorSeed(e_seed)
+        me.batchInput()
+        yp, Bp = me.commit(xs[j])
+        kx = me.reply(v)
+        sync()
+        t2 = time.perf_counter()
+        verdicts = [False] * (k + 1)
+        for l in range(2, k + 1):
+            me.setCommitment(l, others[l][0], others[l][1])
+            me.setReply(l, others[l][2])
+            me.batch(l)
+            verdicts[l] = me.verify(l, v)
+        sync()
+        t3 = time.perf_counter()
+        correct = [False] + [True] * k
+        comb = nat.combineDecryptionFactors(F, correct, k, threshold, q)
+        plain = nat.plaintexts(V, comb)
+        sync()
+        t4 = time.perf_counter()
+        ctx.timing_enable(False)
+        fam = ctx.timing_report()
+        ok = all(verdicts[2:]) and plain.equals(M)
+        cur = {"n": n, "parties": k, "threshold": threshold, "accepted_and_plaintexts_recovered": bool(ok),
+               "own_factors_ms": (t1 - t0) * 1e3, "own_proof_ms": (t2 - t1) * 1e3, "verify_others_ms": (t3 - t2) * 1e3,
+               "combine_and_plaintexts_ms": (t4 - t3) * 1e3, "total_ms": (t4 - t0) * 1e3, "roofline": leg_roofline(fam, (t4 - t0) * 1e3),
+               "kernel_ms_by_family": {kk: round(vv[1], 3) for kk, vv in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+        for a in (F[j], comb, plain):
+            a.free()
+        me.free()
+        if best is None or cur["total_ms"] < best["total_ms"]:
+            best = cur
+    for a in [U, V, M] + [F[l] for l in range(2, k + 1)]:
+        a.free()
+    best["ciphertexts_per_s"] = n / (best["total_ms"] / 1e3)
+    best["workload"] = (f"verifiable threshold decryption as one of k = {k} parties (threshold {threshold}), ModPGroup 2048-bit, width 1: own "
+                        "factors u^(-x_j/c), own batched proof, check of the other parties' proofs, combination with the modified "
+                        "Lagrange integers, plaintexts (n_e = n_v = 256)")
+    return best
+
+
+def cpu_decrypt(p, q, g, n: int, cores: int, k: int = 3, threshold: int = 2):
+    """CPU baseline of decrypt_leg (test infrastructure, never the product): the same op sequence on the C + GMP oracle
+    over `cores` OpenMP threads -- mpz_powm per element for the factors, Pippenger on GMP for the batches, the combination
+    with the (small) Lagrange integers by mpz_powm; single elements are Python integers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyref_proofs as P
+    from oracle.cbind import Oracle
+    from tape import Tape
+    orc = Oracle(p, q)
+    orc.set_threads(cores)
+    NE = NV = 256
+    cpip = max(4, min(12, n.bit_length() - 3))
+    t = Tape(b"cpu-dec", q)
+    coeffs = t.ring_array(threshold)
+    share = lambda j: sum(c * pow(j, d, q) for d, c in enumerate(coeffs)) % q
+    xs = [None] + [share(j) for j in range(1, k + 1)]
+    y = pow(g, coeffs[0], p)
+    tt = t.ring_array(n)
+    u = orc.exp_fixed(g, tt)
+    msgs = orc.exp_fixed(g, t.ring_array(n))
+    vv = orc.mul(msgs, orc.exp_fixed(y, tt))
+    e, chal = t.int_array(n, NE), t.int_array(1, NV)[0]
+    cinv = pow(P.prod_factor(q, k), -1, q)
+    fexp = lambda l: (-xs[l]) * cinv % q
+    f = [None, None] + [orc.exp_scalar(u, fexp(l)) for l in range(2, k + 1)]
+    ys = [None] + [pow(g, x, p) for x in xs[1:]]
+    A_o = orc.exp_prod(u, e, ebits=NE, pippenger_c=cpip)
+    others = {}
+    for l in range(2, k + 1):
+        r = t.ring_element()
+        others[l] = (pow(g, r, p), pow(A_o, r, p), (fexp(l) * chal + r) % q)
+    t0 = time.perf_counter()
+    f[1] = orc.exp_scalar(u, fexp(1))
+    A = orc.exp_prod(u, e, ebits=NE, pippenger_c=cpip)
+    r1 = t.ring_element()
+    yp1, Bp1, k1 = pow(g, r1, p), pow(A, r1, p), (fexp(1) * chal + r1) % q
+    ok = True
+    for l in range(2, k + 1):
+        Bl = orc.exp_prod(f[l], e, ebits=NE, pippenger_c=cpip)
+        ypl, Bpl, kl = others[l]
+        ok = ok and pow(pow(ys[l], -1, p), cinv * chal % q, p) * ypl % p == pow(g, kl, p) and pow(Bl, chal, p) * Bpl % p == pow(A, kl, p)
+    ints = P.lagrange_integers(q, [False] + [True] * k, k, threshold)
+    comb = None
+    for l, c in zip(range(1, threshold + 1), ints):
+        term = orc.exp_scalar(f[l], abs(c))
+        if c < 0:
+            term = [pow(x, -1, p) for x in term]
+        comb = term if comb is None else orc.mul(comb, term)
+    plain = orc.mul(vv, comb)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "ciphertexts/s", "cores": cores, "kind": "port", "accepted_and_plaintexts_recovered": bool(ok and plain == msgs),
+            "sample": f"{n} ciphertexts, 2048-bit group, k = {k}, threshold {threshold}: own factors (mpz_powm per element), batches "
+                      "(Pippenger on GMP), checks, combination, plaintexts; OpenMP static chunks"}
+
+
 def cpu_mix_prove(p, q, g, n: int, cores: int):
     """CPU baseline of the mix + prove leg (test infrastructure, never the product): the reference's op sequence
     (oracle/pyref_proofs.py: re-encrypt, PoS prove, PoS verify) with every array operation in the C + GMP oracle over
@@ -933,6 +1085,8 @@ def main() -> None:
                     help="proof drivers of the mix legs: the C++ drivers behind include/vmnproofs.h, or their Python mirror")
     ap.add_argument("--ccpos-elements", dest="ccpos_n", type=int, default=1_000_000,
                     help="ciphertexts of the 3072-bit CCPoS leg (BASELINE configs[2]; 0 = skip; single GPU only)")
+    ap.add_argument("--decrypt-elements", dest="dec_n", type=int, default=1_000_000,
+                    help="ciphertexts of the verifiable-decryption leg (k = 3, threshold 2; 0 = skip; single GPU only)")
     ap.add_argument("--no-e2e", dest="no_e2e", action="store_true", help="skip the end-to-end pass of the mix + prove leg (profiling runs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = --elements / --mix-elements PER GPU (BASELINE configs[1] on every GPU), strong = in TOTAL "
@@ -1223,8 +1377,14 @@ def main() -> None:
         sm["workload"] = "re-encrypt + PoS prove + verify at the reference's demo size (BASELINE.json configs[0]: 10^4 ciphertexts, 2048 bits, width 1)"
         result["mix_prove_n10000"] = sm
 
+    def leg_decrypt():
+        ctx.timing_reset()
+        result["decrypt_2048"] = decrypt_leg(entry, vmn, ctx, grp, args.dec_n, 999, barrier)
+
     if args.mix_n > 0:
         guarded("mix_prove", leg_mix_prove)
+    if args.dec_n > 0 and not distributed:
+        guarded("decrypt_2048", leg_decrypt)
     if args.mix_n >= 10000 and not distributed:
         guarded("mix_prove_n10000", leg_small)
     if args.ccpos_n > 0:
@@ -1255,6 +1415,11 @@ def main() -> None:
                 result["mix_prove"]["cpu_baseline"] = cpu_mix_prove(p, q, g, 30000, cores)
             except Exception as exc:                   # pragma: no cover
                 result["mix_prove"]["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if "decrypt_2048" in result and "error" not in result["decrypt_2048"]:
+            try:
+                result["decrypt_2048"]["cpu_baseline"] = cpu_decrypt(p, q, g, 20000, cores)
+            except Exception as exc:                   # pragma: no cover
+                result["decrypt_2048"]["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         print(json.dumps(result))
     if distributed:

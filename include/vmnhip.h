@@ -280,9 +280,11 @@ int vmn_rarray_from_prg(vmn_group* grp, const uint8_t* seed, size_t seedlen, siz
 int vmn_rarray_from_prg_range(vmn_group* grp, const uint8_t* seed, size_t seedlen, size_t first, size_t n, int bits, vmn_rarray** out);
 int vmn_rarray_from_prg_gather(vmn_group* grp, const uint8_t* seed, size_t seedlen, const uint32_t* idx, size_t n, int bits,
                                vmn_rarray** out);
-/* Independent generators: pGroup.randomElementArray(n, prg, rbitlen) of a safe-prime ModPGroup, generated on the
+/* Independent generators: pGroup.randomElementArray(n, prg, rbitlen) of a ModPGroup, generated on the
  * device.  ref: P/distr/IndependentGeneratorsRO.java:117-130 (seed = RO(globalPrefix || bytetree(sid))).
- * t_i = the i-th ceil((bits(p) + rbitlen)/8) bytes, leading bits cleared; h_i = t_i^((p-1)/q) = t_i^2 mod p.
+ * t_i = the i-th ceil((bits(p) + rbitlen)/8) bytes, leading bits cleared; h_i = t_i^((p-1)/q) mod p -- a squaring for
+ * the safe-prime groups the reference generates, a power with the group's own cofactor otherwise (the reference's
+ * ModPGroup_1024_256, demo/mixnet/group_descriptions:29; tests/test_bytetree.py).
  * ECqPGroup (P-256 is the reference's default group, demo/mixnet/.conf:153): the values are candidates for x = t mod p,
  * kept when x^3 - 3x + b is a square, with the smaller root as y; element i is the i-th kept candidate (candidates are
  * tested in parallel, the kept ones compacted in order).

@@ -61,6 +61,47 @@ __device__ __forceinline__ void f_norm(u32 (&r)[S], const u64 (&v)[S]) {
         c >>= LIMB_BITS;
     }
 }
+// The field primes of the two curves are known at compile time (S = 10 <=> P-256, S = 15 <=> P-384; the host refuses any
+// other prime of these sizes, vmn_ec_group_create): -p^-1 mod 2^28 is 1 for both, so the Montgomery quotient digit is the
+// low limb itself, and a reduction row skips the zero limbs of p -- three of P-256's ten (p = 2^256 - 2^224 + 2^192 +
+// 2^96 - 1 in radix 2^28 = fffffff fffffff fffffff 0000fff 0 0 1000000 0 fffffff 000000f), two of P-384's fifteen:
+// 7 multiply-adds per row instead of 10 and no multiplication for m.
+template <int S>
+struct FieldPrime {
+    static constexpr bool known = false;
+};
+template <>
+struct FieldPrime<10> {
+    static constexpr bool known = true;
+    static constexpr u32 limb[10] = {0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000fffu, 0u, 0u, 0x1000000u, 0u, 0xfffffffu, 0xfu};
+};
+template <>
+struct FieldPrime<15> {
+    static constexpr bool known = true;
+    static constexpr u32 limb[15] = {0xfffffffu, 0xfu, 0u, 0xffff000u, 0xffeffffu, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0xfffffffu,
+                                     0xfffffffu, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x00fffffu, 0u};
+};
+// one reduction row of a CIOS product: P <- (P + m p) / 2^28 with m = -P[0] / p mod 2^28; the top column is left to the caller
+template <int S>
+__device__ __forceinline__ void mont_row(u64 (&P)[S], const ECDev& E) {
+    using FP = FieldPrime<S>;
+    if constexpr (FP::known) {
+        const u32 m = (u32)P[0] & LIMB_MASK;                           // n0inv = 1
+        const u64 c = ((u64)m * FP::limb[0] + P[0]) >> LIMB_BITS;
+#pragma unroll
+        for (int j = 1; j < S; ++j) {
+            if (FP::limb[j] == 0) P[j - 1] = P[j];                     // (a register rename)
+            else P[j - 1] = (u64)m * FP::limb[j] + P[j];
+        }
+        P[0] += c;
+    } else {
+        const u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
+        const u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
+#pragma unroll
+        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
+        P[0] += c;
+    }
+}
 // r = a * b / R  (mod p), result < 2p for operands with a*b < R*p
 template <int S>
 __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const ECDev& E) {
@@ -72,11 +113,7 @@ __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 
             if (i == 0 || j == S - 1) P[j] = (u64)a[j] * b[i];
             else P[j] = (u64)a[j] * b[i] + P[j];
         }
-        u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
-        u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
-#pragma unroll
-        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
-        P[0] += c;
+        mont_row<S>(P, E);
     }
     P[S - 1] = 0;
     f_norm<S>(r, P);
@@ -97,11 +134,7 @@ __device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDe
             if (i == 0 || j == S - 1) P[j] = (u64)a[j] * mult;         // a fresh column (the top one is vacated by every shift)
             else P[j] = (u64)a[j] * mult + P[j];
         }
-        u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
-        u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
-#pragma unroll
-        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
-        P[0] += c;
+        mont_row<S>(P, E);
     }
     P[S - 1] = 0;
     f_norm<S>(r, P);
@@ -173,12 +206,8 @@ __device__ __forceinline__ bool f_is_zero(const u32 (&a)[S], const ECDev& E) {
     for (int j = 0; j < S; ++j) P[j] = a[j];
 #pragma unroll
     for (int i = 0; i < S; ++i) {
-        u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
-        u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;
-#pragma unroll
-        for (int j = 1; j < S; ++j) P[j - 1] = (u64)m * E.p[j] + P[j];
+        mont_row<S>(P, E);
         P[S - 1] = 0;
-        P[0] += c;
     }
     u32 t[S];
     f_norm<S>(t, P);

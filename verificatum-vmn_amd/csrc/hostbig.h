@@ -77,6 +77,29 @@ inline int bit_length(const Big& a) {
     return 0;
 }
 inline int get_bit(const Big& a, int k) { return (a[k / 32] >> (k % 32)) & 1; }
+// floor(a / b) by shift-and-subtract (setup-time only: the cofactor (p - 1) / q of a group); *rem = a mod b
+inline Big div(const Big& a, const Big& b, Big* rem = nullptr) {
+    const size_t nw = a.size() + 1;
+    Big q(a.size(), 0), r(nw, 0), bb(b);
+    bb.resize(nw, 0);
+    for (int k = bit_length(a) - 1; k >= 0; --k) {
+        uint32_t carry = (uint32_t)get_bit(a, k);                    // r = 2 r + bit
+        for (size_t i = 0; i < nw; ++i) {
+            const uint32_t top = r[i] >> 31;
+            r[i] = (r[i] << 1) | carry;
+            carry = top;
+        }
+        if (cmp(r, bb) >= 0) {
+            sub_in(r, bb);
+            q[k / 32] |= 1u << (k % 32);
+        }
+    }
+    if (rem) {
+        r.resize(b.size());
+        *rem = r;
+    }
+    return q;
+}
 
 // -n^{-1} mod 2^bits for odd n0 (bits <= 32)
 inline uint32_t neg_inv_pow2(uint32_t n0, int bits) {

@@ -169,11 +169,18 @@ static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double
     if (!ctx->timing) return 0;
     const double S = m.ec ? (double)m.ec->S : (double)m.S;              // columns
     const double Rw = m.ec ? S : (double)m.rows;                         // rows (< S in a wide geometry)
-    const double sq = m.ec ? 2 * S * S : Rw * S + Rw * (S + SQR_BLK * m.LPE) / 2;      // block-symmetric in every geometry
+    if (m.ec) {
+        // a field product: S^2 for the multiplication half + S x (non-zero limbs of p) for the reduction rows, which skip
+        // the zero limbs of the compile-time primes (ec_kernels.h FieldPrime: 7 of 10 for P-256, 13 of 15 for P-384)
+        const double nz = m.ec->S == 10 ? 7 : m.ec->S == 15 ? 13 : S;
+        ctx->next_mads = (products + squarings) * (S * S + S * nz);
+        return 0;
+    }
+    const double sq = Rw * S + Rw * (S + SQR_BLK * m.LPE) / 2;           // block-symmetric in every geometry
     ctx->next_mads = products * 2 * Rw * S + squarings * sq;
     return 0;                                   // (an int so that a launch inside a macro can be written  note_work(..) ? 0 : launch(..))
 }
-// in field products of 2 S^2 multiply-adds: a product 1, a squaring ~0.775 (symmetric), a zero test 0.5 (reduction only)
+// in field products (S^2 + S nz multiply-adds, see note_work): a product 1, a squaring ~0.775 (symmetric), a zero test 0.5 (reduction only)
 // add = 11M + 5S + zero test, mixed add = 7M + 4S + zero test, doubling = 3M + 5S, normalising one point ~7 + inversion / K
 static const double EC_ADD = 15.4, EC_MADD = 10.6, EC_DBL = 6.9, EC_NORM = 7.0, EC_INV = 380;
 
@@ -851,6 +858,16 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     c->gy_words = hostbig::from_be(gy.data(), gy.size(), NW);
     c->n0inv = hostbig::neg_inv_pow2(c->p_words[0] & LIMB_MASK, 28);
     const Big& pw = c->p_words;
+    {   // the kernels carry the primes of these two sizes as compile-time constants (ec_kernels.h FieldPrime): same prime?
+        const std::vector<uint32_t> lim = limbs_of(pw, S);
+        bool same = c->n0inv == 1;
+        if (S == 10) for (int j = 0; j < S; ++j) same = same && lim[j] == FieldPrime<10>::limb[j];
+        else if (S == 15) for (int j = 0; j < S; ++j) same = same && lim[j] == FieldPrime<15>::limb[j];
+        if ((S == 10 || S == 15) && !same) {
+            set_error("curve %s: a field prime of %d limbs other than the one compiled into the kernels", cp.name, S);
+            return VMN_ERR_UNSUPPORTED;
+        }
+    }
     Big one(NW, 0);
     one[0] = 1;
     Big r1 = shift_mod(one, 28 * S, pw);                 // R mod p
@@ -2538,16 +2555,22 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
     VMN_ENTER(ctx);
     if (grp->curve) return ec_random_points(grp, seed, seedlen, n, rbitlen, out);
     const vmn_modulus& m = grp->P;
-    {   // the cofactor (p-1)/q must be 2 (safe-prime groups: the elements are squared)
-        Big twoq = grp->Q.n_words;
-        hostbig::dbl_mod(twoq, m.n_words);          // 2q mod p = p - 1 for a safe prime
-        Big pm1 = m.n_words;
-        pm1[0] -= 1;                                // p is odd
-        if (hostbig::cmp(twoq, pm1) != 0) {
-            set_error("vmn_garray_from_prg: only safe-prime groups (p = 2q + 1) are supported");
-            return VMN_ERR_UNSUPPORTED;
+    // h_i = t_i^((p - 1) / q): the cofactor is 2 for a safe-prime group (the elements are squared); any other ModPGroup
+    // (demo/mixnet/group_descriptions:29, a 1024-bit p with a 256-bit q) raises to its own cofactor
+    Big pm1 = m.n_words, cof, rem;
+    pm1[0] -= 1;                                    // p is odd
+    {
+        Big qq = grp->Q.n_words;
+        while (qq.size() > 1 && qq.back() == 0) qq.pop_back();
+        Big qpad = qq;
+        qpad.resize(std::max(qq.size(), pm1.size()), 0);
+        cof = hostbig::div(pm1, qpad, &rem);
+        if (!hostbig::is_zero(rem)) {
+            set_error("vmn_garray_from_prg: q does not divide p - 1");
+            return VMN_ERR_ARG;
         }
     }
+    const bool squares = hostbig::bit_length(cof) == 2 && cof[0] == 2;
     PrgSeed w;
     VMN_TRY(prg_seed_words(seed, seedlen, w));
     const int vbits = m.nbits + rbitlen;
@@ -2558,11 +2581,19 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
         return VMN_OK;
     }
     const size_t Wd = elem_words(m);
-    DevTmp lo(ctx);
-    int rc = lo.alloc(n * Wd * sizeof(uint32_t));
-    if (rc == VMN_OK) rc = prg_residues(ctx, m, w, n, vbits, lo.as<uint32_t>());      // t_i mod p
-    // h_i = t_i^2  (cofactor 2)
-    if (rc == VMN_OK) rc = mul_arrays(ctx, m, lo.as<uint32_t>(), lo.as<uint32_t>(), Wd, n, r->d);
+    vmn_garray* t = nullptr;
+    int rc = new_garray(grp, n, &t);
+    if (rc == VMN_OK) rc = prg_residues(ctx, m, w, n, vbits, t->d);      // t_i mod p
+    if (rc == VMN_OK && squares) {
+        rc = mul_arrays(ctx, m, t->d, t->d, Wd, n, r->d);                 // cofactor 2
+    } else if (rc == VMN_OK) {
+        std::vector<uint8_t> cbe(4 * cof.size());
+        hostbig::to_be(cof, cbe.data(), cbe.size());
+        vmn_garray_free(r);
+        r = nullptr;
+        rc = vmn_garray_exp_scalar(t, cbe.data(), cbe.size(), &r);
+    }
+    vmn_garray_free(t);
     if (rc != VMN_OK) {
         vmn_garray_free(r);
         return rc;
