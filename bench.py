@@ -42,7 +42,7 @@ PEAK_TMACS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3
 HBM_PEAK_GBS = 8000.0
 
 
-def leg_roofline(fam: dict, wall_ms: float) -> dict:
+def leg_roofline(fam: dict, wall_ms: float, canonical_per_executed: float = None) -> dict:
     """Roofline object of a proof leg from the work its kernels EXECUTED: the library counts, per launch, the
     v_mad_u64_u32 multiply-adds its lanes perform (Montgomery products x 2 S^2, squarings, point additions as field
     products; csrc/vmnhip.hip note_work) -- not SURVEY.md's canonical count, which prices a fixed-base exponentiation at
@@ -54,20 +54,29 @@ def leg_roofline(fam: dict, wall_ms: float) -> dict:
     by = {k: {"ms": round(v[1], 3), "T_mads": round(v[2] / 1e12, 4),
               "frac": round(v[2] / (v[1] / 1e3) / 1e12 / PEAK_TMACS, 4) if v[1] > 0 else None}
           for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]) if v[2] > 0}
-    return {"bound": "valu-int", "unit": "T multiply-adds/s (v_mad_u64_u32 executed; 28-bit limbs)", "peak": PEAK_TMACS,
+    canon = {}
+    if canonical_per_executed:
+        # SURVEY.md §8d prices a field product of P-256 at M(8) = 2 * 8^2 + 8 = 136 multiply-adds (32-bit limbs); the kernels
+        # execute 160 per product (ten 28-bit limbs, six reduction products per row): against the canonical count a faster
+        # product shows as a higher fraction, against the executed count it does not
+        cm = mads * canonical_per_executed
+        canon = {"canonical_T_mads_survey_8d": cm / 1e12, "frac_canonical": cm / (wall_ms / 1e3) / 1e12 / PEAK_TMACS,
+                 "frac_canonical_kernel_time": cm / (kernel_ms / 1e3) / 1e12 / PEAK_TMACS if kernel_ms else None}
+    return {"bound": "valu-int", "unit": "T multiply-adds/s (v_mad_u64_u32 executed; 28-bit limbs)", "peak": PEAK_TMACS, **canon,
             "executed_T_mads": mads / 1e12, "achieved": mads / (wall_ms / 1e3) / 1e12, "frac": mads / (wall_ms / 1e3) / 1e12 / PEAK_TMACS,
             "kernel_ms": kernel_ms, "achieved_kernel_time": mads / (kernel_ms / 1e3) / 1e12 if kernel_ms else None,
             "frac_kernel_time": mads / (kernel_ms / 1e3) / 1e12 / PEAK_TMACS if kernel_ms else None,
-            "by_family": by, "profiles": "profiles/r02_pmc_*.json (rocprofv3 --pmc passes of the dominant kernels)"}
+            "by_family": by, "profiles": "profiles/r03_pmc_*.json (rocprofv3 --pmc passes of the dominant kernels)"}
 
 
-def source_fingerprint() -> str:
-    """sha256 (16 hex digits) over the kernel sources: PMC summaries under profiles/ carry the fingerprint of the build
-    they were measured on, and are used only when it still matches."""
+def source_fingerprint(names=("mont28.h", "modp_kernels.h", "gen/mont_rows.inc")) -> str:
+    """sha256 (16 hex digits) over the sources of the headline kernel's family (tools/summarize_pmc.py FAMILIES["modp"]):
+    PMC summaries under profiles/ carry the fingerprints of the build they were measured on, and the headline's counters
+    are used only when its family's still matches (a change to the curve kernels does not stale them)."""
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "verificatum-vmn_amd", "csrc")
-    for name in ("mont28.h", "modp_kernels.h", "light_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
+    for name in names:
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -628,7 +637,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
             "n": n, "drivers": drivers, "accepted": bool(ok), "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3,
             "ccpos_prove_ms": (t3 - t2) * 1e3, "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
             "ciphertexts_per_s_online": n / online,
-            "roofline": leg_roofline(fam, (t4 - t0) * 1e3),
+            "roofline": leg_roofline(fam, (t4 - t0) * 1e3, canonical_per_executed=(136.0 / 160.0 if curve == "P-256" else 300.0 / 405.0)),
             "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
@@ -1222,13 +1231,14 @@ def main() -> None:
     valu_busy = None
     pmc_instr = None
     n_launch = n
-    pmc_file = "profiles/r02_pmc_kernels.json"
+    pmc_file = "profiles/r03_pmc_kernels.json"
     pmc_note = None
     try:
         with open(os.path.join(ROOT, pmc_file)) as f:
             pmc_all = json.load(f)
-        if pmc_all.get("source_fingerprint") != source_fingerprint():
-            pmc_note = (f"{pmc_file} was measured on another build of the kernels (fingerprint {pmc_all.get('source_fingerprint')} != "
+        measured_on = pmc_all.get("family_fingerprints", {}).get("modp")
+        if measured_on != source_fingerprint():
+            pmc_note = (f"{pmc_file} was measured on another build of the headline kernel's sources (fingerprint {measured_on} != "
                         f"{source_fingerprint()}): its counters are not used; rerun tools/profile_pmc.sh")
             print("bench.py: " + pmc_note, file=sys.stderr)
         else:

@@ -16,10 +16,15 @@ PEAK = 256 * 4 * 16 * 2.4e9
 HEADLINE = "k_modpow<vmn::Cfg<74, 1>"
 
 
-def fingerprint():
+FAMILIES = {"modp": ("mont28.h", "modp_kernels.h", "gen/mont_rows.inc"), "ec": ("ec_kernels.h",), "light": ("light_kernels.h",)}
+
+
+def fingerprint(family=None):
+    """sha256 (16 hex digits) over the kernel sources of one family (the headline kernel lives in "modp"), or over all."""
     h = hashlib.sha256()
     base = os.path.join(ROOT, "verificatum-vmn_amd", "csrc")
-    for name in ("mont28.h", "modp_kernels.h", "light_kernels.h", "ec_kernels.h", "gen/mont_rows.inc"):
+    names = FAMILIES[family] if family else ("mont28.h", "modp_kernels.h", "light_kernels.h", "ec_kernels.h", "gen/mont_rows.inc")
+    for name in names:
         h.update(open(os.path.join(base, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -101,7 +106,7 @@ def main():
             kernels[HEADLINE] = e
     res = {"command": "tools/profile_pmc.sh (rocprofv3 --kernel-trace --stats ; --pmc FETCH_SIZE ; --pmc WRITE_SIZE ; --pmc SQ_* : separate passes; "
                       "run A = headline alone, run B = the proof legs)",
-           "source_fingerprint": fingerprint(), "elements": n, "kernels": kernels, "proof_leg_kernels": B}
+           "source_fingerprint": fingerprint(), "family_fingerprints": {f: fingerprint(f) for f in FAMILIES}, "elements": n, "kernels": kernels, "proof_leg_kernels": B}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1)[:6000])
 

@@ -32,6 +32,7 @@ struct ECDev {
     const u32* pm2;    // p - 2 as packed 32-bit words (Fermat inversion)
     const u32* pp14;   // (p + 1) / 4 as packed words: square roots (p = 3 mod 4 for P-256 and P-384)
     u32 n0inv;         // -p^{-1} mod 2^28
+    u32 p1p;           // p[1] + 1 (limb 1 of the prime, plus the carry fold of mont_row)
     int pwords;        // words of pm2
 };
 
@@ -86,14 +87,22 @@ template <int S>
 __device__ __forceinline__ void mont_row(u64 (&P)[S], const ECDev& E) {
     using FP = FieldPrime<S>;
     if constexpr (FP::known) {
+        // The VALUES of the non-zero limbs still come from E.p (scalar registers), not from the table: with literal
+        // constants the compiler "strength-reduces" m * 2^24 and m * 15 into shifts / 32-bit multiplies plus 64-bit adds --
+        // two or three issue slots where one v_mad_u64_u32 does it (seen in the ISA; every VALU instruction costs the
+        // same slot on this machine).  Only WHICH limbs are zero, and n0inv = 1, are compile-time knowledge.
+        // Both primes end in p[0] = 2^28 - 1, so the carry out of column 0 needs no product: P[0] + m (2^28 - 1) has the low
+        // limb cleared by construction and its upper part is (P[0] >> 28) + m; folded into column 1 that is
+        // m (p[1] + 1) + P[1] + (P[0] >> 28) -- one multiply-add (with p[1] + 1 from E.p1p), one shift, one 64-bit add.
+        static_assert(FP::limb[0] == LIMB_MASK && FP::limb[1] != 0, "the carry fold assumes p = -1 mod 2^28");
         const u32 m = (u32)P[0] & LIMB_MASK;                           // n0inv = 1
-        const u64 c = ((u64)m * FP::limb[0] + P[0]) >> LIMB_BITS;
+        const u64 up = P[0] >> LIMB_BITS;
+        P[0] = (u64)m * E.p1p + (P[1] + up);
 #pragma unroll
-        for (int j = 1; j < S; ++j) {
-            if (FP::limb[j] == 0) P[j - 1] = P[j];                     // (a register rename)
-            else P[j - 1] = (u64)m * FP::limb[j] + P[j];
+        for (int j = 2; j < S; ++j) {
+            if (FP::limb[j] == 0) P[j - 1] = P[j];                     // (the column simply gets no product in this row)
+            else P[j - 1] = (u64)m * E.p[j] + P[j];
         }
-        P[0] += c;
     } else {
         const u32 m = ((u32)P[0] * E.n0inv) & LIMB_MASK;
         const u64 c = ((u64)m * E.p[0] + P[0]) >> LIMB_BITS;

@@ -170,9 +170,9 @@ static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double
     const double S = m.ec ? (double)m.ec->S : (double)m.S;              // columns
     const double Rw = m.ec ? S : (double)m.rows;                         // rows (< S in a wide geometry)
     if (m.ec) {
-        // a field product: S^2 for the multiplication half + S x (non-zero limbs of p) for the reduction rows, which skip
-        // the zero limbs of the compile-time primes (ec_kernels.h FieldPrime: 7 of 10 for P-256, 13 of 15 for P-384)
-        const double nz = m.ec->S == 10 ? 7 : m.ec->S == 15 ? 13 : S;
+        // a field product: S^2 for the multiplication half + S x (non-zero limbs of p, less limb 0 whose carry is folded into
+        // column 1) for the reduction rows of the compile-time primes (ec_kernels.h mont_row: 6 of 10 for P-256, 12 of 15 for P-384)
+        const double nz = m.ec->S == 10 ? 6 : m.ec->S == 15 ? 12 : S;
         ctx->next_mads = (products + squarings) * (S * S + S * nz);
         return 0;
     }
@@ -774,6 +774,7 @@ static ECDev ecdev(const vmn_curve* c) {
     E.pm2 = c->d_pm2;
     E.pp14 = c->d_pp14;
     E.n0inv = c->n0inv;
+    E.p1p = c->p1p;
     E.pwords = c->NW;
     return E;
 }
@@ -858,6 +859,7 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     c->gy_words = hostbig::from_be(gy.data(), gy.size(), NW);
     c->n0inv = hostbig::neg_inv_pow2(c->p_words[0] & LIMB_MASK, 28);
     const Big& pw = c->p_words;
+    c->p1p = limbs_of(pw, S)[1] + 1;
     {   // the kernels carry the primes of these two sizes as compile-time constants (ec_kernels.h FieldPrime): same prime?
         const std::vector<uint32_t> lim = limbs_of(pw, S);
         bool same = c->n0inv == 1;
@@ -2967,7 +2969,14 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     const int nwin = (ebits + c - 1) / c;
     const size_t nb = (size_t)1 << c;
     const size_t nbuckets = (size_t)nwin * nb;
-    const uint32_t F = 8;                              // fan-in of the per-bucket product tree
+    // fan-in of the per-bucket product tree.  A lane sums one chunk of at most F items; the lanes of a wave wait for the longest
+    // chunk, so F is best a little above the typical bucket size n / 2^c (most buckets are then ONE chunk, the wave's longest
+    // chunk is close to its average, and hardly anything is left for the upper levels -- which run full additions on few lanes).
+    static const uint32_t F_env = [] {
+        const char* e = getenv("VMN_TREE_FANIN");
+        return e && *e ? (uint32_t)std::max(4, atoi(e)) : 0u;
+    }();
+    const uint32_t F = F_env ? F_env : 8;
     DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx);
     // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | per tree level l < LV: cnt_l[nb], off_l[nb+1] | bsum | misc.
     // The shape of the product trees depends on the exponents only, so the per-level counts and offsets are computed

@@ -105,6 +105,7 @@ struct vmn_curve {
     const uint32_t* d_pm2 = nullptr;
     const uint32_t* d_pp14 = nullptr;
     uint32_t n0inv = 0;
+    uint32_t p1p = 0;              // limb 1 of the prime + 1 (ec_kernels.h mont_row)
 };
 
 // Device-resident constants of one odd modulus in M28 form.
