@@ -35,7 +35,7 @@
     KW __global__ void vmn::k_scan_apply<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, const vmn::u32*, size_t,       \
                                                              size_t, size_t, int, const vmn::u32*, vmn::u32, const vmn::u32*);           \
     KW __global__ void vmn::k_fixed_level<vmn::Cfg<S_, LPE_>>(vmn::u32*, int, int, int, const vmn::u32*, vmn::u32);                      \
-    KW __global__ void vmn::k_fixed_exp<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, int, int, const vmn::u32*, int, size_t,          \
+    KW __global__ void vmn::k_fixed_exp<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, int, int, const vmn::u32*, int, size_t, int,     \
                                                             const vmn::u32*, vmn::u32);                                                  \
     KW __global__ void vmn::k_bucket_level<vmn::Cfg<S_, LPE_>, true>(vmn::u32*, const vmn::u32*, const vmn::u32*, const vmn::u32*,       \
                                                                      const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32,         \

@@ -954,33 +954,40 @@ k_fixed_level(u32* __restrict__ T, int w, int nwin, int l, const u32* __restrict
     if (live) store_elem<C>(row + (((size_t)1 << l) + r) * W, o, ln);
 }
 
-// out[i] = prod_k T[k][digit_k(e[i])]
+// out[i] = prod_k T[k][digit_k(e[i])].  parts > 1 (small arrays): the chain of nwin - 1 dependent products of an element is cut
+// into `parts` independent pieces -- item t = part * n + i multiplies the windows [part nwin / parts, (part + 1) nwin / parts)
+// of element i into out[t] -- and the caller multiplies the pieces together by a tree of element-wise products: a chain of
+// nwin / parts + log2(parts) products instead of nwin, on `parts` times as many lanes (which a small array leaves idle anyway).
 template <class C>
 __global__ void __launch_bounds__(BLOCK, C::MINW)
 k_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin, const u32* __restrict__ e, int ewords,
-            size_t n, const u32* __restrict__ nmod, u32 n0inv) {
+            size_t n, int parts, const u32* __restrict__ nmod, u32 n0inv) {
     constexpr int W = C::W;
     extern __shared__ u32 lds[];
     Lane<C> ln(lds);
     u32 nn[C::L];
     load_modulus<C>(nn, nmod, ln);
-    const size_t ntiles = (n + C::EPB - 1) / C::EPB;
+    const size_t items = n * (size_t)parts;
+    const size_t ntiles = (items + C::EPB - 1) / C::EPB;
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        size_t el = t * C::EPB + ln.eslot;
-        bool live = el < n;
-        size_t ec = live ? el : n - 1;
+        size_t it = t * C::EPB + ln.eslot;
+        bool live = it < items;
+        size_t ic = live ? it : items - 1;
+        const int part = (int)(ic / n);
+        const size_t ec = ic % n;
+        const int k0 = (int)((long)part * nwin / parts), k1 = (int)((long)(part + 1) * nwin / parts);
         const u32* ep = e + ec * ewords;
         u32 a[C::L];
-        u32 d = exp_digit(ep, ewords, 0, w);
-        load_elem<C>(a, T + (size_t)d * W, ln);
+        u32 d = exp_digit(ep, ewords, k0 * w, w);
+        load_elem<C>(a, T + (((size_t)k0 << w) + d) * W, ln);
 #pragma unroll 1
-        for (int k = 1; k < nwin; ++k) {
+        for (int k = k0 + 1; k < k1; ++k) {
             d = exp_digit(ep, ewords, k * w, w);
             load_elem_to_lds<C>(ln, T + (((size_t)k << w) + d) * W);
             mont_mul<C>(a, a, ln, nn, n0inv);
         }
         canonicalize<C>(a, nn, ln);
-        if (live) store_elem<C>(out + el * W, a, ln);
+        if (live) store_elem<C>(out + it * W, a, ln);
     }
 }
 

@@ -115,6 +115,18 @@ static size_t default_wide8_max() {
     }();
     return v;
 }
+// A fixed-base exponentiation over fewer elements than half of this is cut into pieces while n x pieces stays below it
+// (env VMN_FIXED_SPLIT_FILL; 0 = never split).  Measured on the PoS leg (profiles/r03_fixed_split_sweep.txt): the family's
+// kernel time at N = 10^4 / 4 x 10^4 / 10^5 / 3 x 10^5 is 9.5 / 23.8 / - / - ms unsplit and 4.2 / 13.9 / 41.3 / 108.9 ms with
+// 786 432 (47.4 / 110.7 with 196 608): more waves than the two per SIMD that fill the chip still pay, because the kernel waits
+// on its random 296-byte table rows.
+static size_t fixed_split_fill() {
+    static const size_t v = [] {
+        const char* env = getenv("VMN_FIXED_SPLIT_FILL");
+        return env ? (size_t)strtoull(env, nullptr, 10) : (size_t)786432;
+    }();
+    return v;
+}
 static const vmn_modulus& geom(const vmn_ctx* ctx, const vmn_modulus& m, size_t items, bool always = false) {
     const vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
     if (m.wide8 && root->wide8_max != 0 && (items <= root->wide8_max || (always && items <= root->wide_max))) return *m.wide8;
@@ -2835,26 +2847,40 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
     int rc = fixed_table(grp, base_be, ebits, n, &ft);
     if (rc == VMN_OK) rc = ew.alloc(n * (size_t)grp->Q.NW * sizeof(uint32_t));
     if (rc == VMN_OK) rc = to_words(ctx, grp->Q, e->d, n, ew.as<uint32_t>());
-    if (rc == VMN_OK) {
-        const vmn_modulus& m = geom(ctx, grp->P, n);
-        // one workgroup per tile rather than a persistent grid: a workgroup slot frees up every ~2 ms, so kernels of
-        // the other lane (a helper's exports) are scheduled between the tiles instead of behind the whole launch
-        unsigned grid = egrid(m, n);
+    if (rc == VMN_OK && grp->P.ec) {
+        const vmn_modulus& m = grp->P;
         rc = VMN_ERR_ARG;
-        if (m.ec) {
 #define X(S_, NW_)                                                                                                   \
     if (m.ec->S == S_)                                                                                               \
         rc = note_work(ctx, m, EC_MADD * (double)n * (ft->nwin - 1)) ? 0 : launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                           ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, ecdev(m.ec));
-            VMN_FOR_CURVES(X)
+        VMN_FOR_CURVES(X)
 #undef X
-        } else {
+    } else if (rc == VMN_OK) {
+        // Small arrays: an element's chain of nwin - 1 dependent products is cut into `parts` pieces on `parts` times as many
+        // lanes, multiplied together by a tree of element-wise products (k_fixed_exp) -- as many pieces as it takes to give
+        // every SIMD about one wave of the one-lane-per-element geometry (the geometry is then picked for n x parts items).
+        int parts = 1;
+        const size_t fill = fixed_split_fill();
+        while (parts < 16 && (size_t)(2 * parts) * n <= fill && ft->nwin / (2 * parts) >= 4) parts *= 2;
+        const size_t items = n * (size_t)parts, Wd = elem_words(grp->P);
+        const vmn_modulus& m = geom(ctx, grp->P, items);
+        DevTmp pieces(ctx);
+        if (parts > 1) rc = pieces.alloc(items * Wd * sizeof(uint32_t));
+        uint32_t* dst = parts > 1 ? pieces.as<uint32_t>() : r->d;
+        // one workgroup per tile rather than a persistent grid: a workgroup slot frees up every ~2 ms, so kernels of
+        // the other lane (a helper's exports) are scheduled between the tiles instead of behind the whole launch
+        unsigned grid = egrid(m, items);
+        if (rc == VMN_OK) rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
-        rc = note_work(ctx, m, (double)n * (ft->nwin - 1)) ? 0 : launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
-                    ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, m.d_n, m.n0inv);
+        rc = note_work(ctx, m, (double)n * (ft->nwin - parts)) ? 0 : launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), dst, (const uint32_t*)ft->d_tab, ft->wbits, \
+                    ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, parts, m.d_n, m.n0inv);
         VMN_FOR_SIZES(X)
 #undef X
+        for (int half = parts / 2; half >= 1 && rc == VMN_OK; half /= 2) {          // pieces [0, half) *= pieces [half, 2 half)
+            uint32_t* lo = pieces.as<uint32_t>();
+            rc = mul_arrays(ctx, grp->P, lo, lo + (size_t)half * n * Wd, Wd, (size_t)half * n, half == 1 ? r->d : lo);
         }
     }
     if (rc != VMN_OK) {
