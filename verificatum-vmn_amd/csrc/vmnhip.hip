@@ -2622,15 +2622,23 @@ extern "C" int vmn_garray_from_prg(vmn_group* grp, const uint8_t* seed, size_t s
 // the window that is best for one call (w = 16 at N = 10^6: 2.5 GB); a base that keeps coming back (g, the public
 // key) is rebuilt with the window that is best over its uses (w = 19: 17 GB at 2048 bits -- 288 GB of HBM are
 // there to be used), capped per table.
+static double fixed_table_cap_reuse() {
+    const char* env = getenv("VMN_FIXED_TABLE_CAP");            // bytes one table of a long-lived base may take
+    return env && *env ? atof(env) : 20e9;
+}
 static int pick_fixed_window(size_t n, int ebits, size_t row_bytes, int reuse = 1) {
     if (const char* env = getenv("VMN_FIXED_WINDOW")) {          // measurement knob: force the window
         int w = atoi(env);
         if (w >= 2 && w <= 22) return w;
     }
+    if (const char* env = reuse > 1 ? getenv("VMN_FIXED_WINDOW_REUSE") : nullptr) {   // the same for long-lived bases only
+        int w = atoi(env);
+        if (w >= 2 && w <= 22) return w;
+    }
     int best = 4;
     double best_cost = 1e300;
-    const double cap = reuse > 1 ? 20e9 : 6e9;
-    for (int w = 2; w <= 20; ++w) {
+    const double cap = reuse > 1 ? fixed_table_cap_reuse() : 6e9;
+    for (int w = 2; w <= 22; ++w) {
         int nwin = (ebits + w - 1) / w;
         double table_bytes = (double)nwin * (double)((size_t)1 << w) * (double)row_bytes;
         if (table_bytes > cap) break;
