@@ -16,7 +16,7 @@ def _load(path, name):
 
 def test_design_tables_are_those_of_the_committed_bench_line():
     dt = _load(os.path.join(ROOT, "tools", "design_tables.py"), "design_tables")
-    text = dt.render(os.path.join(ROOT, "profiles", "r02_bench_v2.json"))
+    text = dt.render(os.path.join(ROOT, "profiles", "r03_bench_v1.json"))
     s = open(os.path.join(ROOT, "DESIGN.md")).read()
     block = s[s.index(dt.BEGIN) + len(dt.BEGIN):s.index(dt.END)].strip()
     assert block == text.strip(), "DESIGN.md §6 is stale: run python3 tools/design_tables.py"
@@ -27,6 +27,6 @@ def test_pmc_summary_belongs_to_the_kernels_in_the_tree():
     null and says why) -- but said out loud."""
     import warnings
     bench = _load(os.path.join(ROOT, "bench.py"), "bench_for_fingerprint")
-    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
-    if pm["source_fingerprint"] != bench.source_fingerprint():
-        warnings.warn("profiles/r02_pmc_kernels.json was measured on another build of the kernels: rerun tools/profile_pmc.sh")
+    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")))
+    if pm["family_fingerprints"]["modp"] != bench.source_fingerprint():
+        warnings.warn("profiles/r03_pmc_kernels.json was measured on another build of the headline kernel: rerun tools/profile_pmc.sh")

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Regenerate the round-2 measurement tables of DESIGN.md §6 from the committed profiles
-(profiles/r02_bench_v<k>.json = one `python bench.py` line, profiles/r02_pmc_kernels.json = tools/summarize_pmc.py),
-between the markers <!-- r02-tables-begin --> and <!-- r02-tables-end -->.
+"""Regenerate the current round's measurement tables of DESIGN.md §6 from the committed profiles
+(profiles/r03_bench_v<k>.json = one `python bench.py` line, profiles/r03_pmc_kernels.json = tools/summarize_pmc.py),
+between the markers <!-- r03-tables-begin --> and <!-- r03-tables-end -->.  (The round-2 block of DESIGN.md was generated the
+same way from profiles/r02_bench_v2.json / r02_pmc_kernels.json and is frozen text now.)
 
-usage: tools/design_tables.py [profiles/r02_bench_v2.json]"""
+usage: tools/design_tables.py [profiles/r03_bench_v1.json]"""
 import json
 import os
 import sys
@@ -14,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def render(bench):
     """The generated block as text (tests/test_docs_consistency.py compares it with what DESIGN.md holds)."""
     r = json.load(open(bench))
-    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
-    mp, cc, ec = r["mix_prove"], r["mix_ccpos_3072"], r["mix_ec_p256"]
+    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")))
+    mp, cc, ec, dec = r["mix_prove"], r["mix_ccpos_3072"], r["mix_ec_p256"], r["decrypt_2048"]
     e2e = mp["end_to_end"]
     rel = os.path.relpath(bench, ROOT)
 
@@ -36,7 +37,7 @@ def render(bench):
     traffic = f"{rf['traffic'] / 1e9:.0f} GB" if rf.get("traffic") else "n/a"
     sm = r.get("mix_prove_n10000")
     small_row = (f"| the same at the reference's demo size, **configs[0]**: 10^4 ciphertexts | {sm['total_ms']:.1f} ms = **{sm['ciphertexts_per_s']:.3e} ciphertexts/s** "
-                 f"(prove {sm['prove_ms']:.1f} ms, verify {sm['verify_ms']:.1f} ms) | wide geometries (§5): kernels {sm['roofline']['kernel_ms']:.1f} ms of it, "
+                 f"(prove {sm['prove_ms']:.1f} ms, verify {sm['verify_ms']:.1f} ms) | wide geometries + fixed-base chains cut into pieces (§5): kernels {sm['roofline']['kernel_ms']:.1f} ms of it, "
                  f"latency-bound chains (frac {sm['roofline']['frac']:.2f}) |\n") if sm and "error" not in sm else ""
     text = f"""`python bench.py` on one MI355X (`{rel}`), every leg at its BASELINE configuration's size (10^6):
 
@@ -44,14 +45,15 @@ def render(bench):
 |---|---|---|
 | **headline**, configs[1]: 10^6 x 2048-bit modPow, 2047-bit exponents | **{r['value']:.3e} modexp/s**, {r['ms_per_step']:.1f} ms per step, kernel {rf['avg_kernel_ms']:.1f} ms (HIP events) | achieved {rf['achieved']:.2f} TMAC/s canonical (16 422 432 per modexp, SURVEY.md §8d) = **{rf['frac']:.3f}**; issued {issued} T lane-instr/s of the {rf['peak_measured']:.1f} T/s the hardware sustains for `v_mad_u64_u32` at two waves per SIMD; HBM traffic {traffic} per launch (PMC) against 0.77 GB algorithmic: the per-lane window tables, 2 % of the HBM roof |
 | **mix + prove**, 2048 bits, width 1: re-encrypt + PoS prove + verify (GPU arithmetic; the N-sized random arrays expanded on the device, scalars and the permutation from a tape) | {mp['total_ms']:.0f} ms = **{mp['ciphertexts_per_s']:.3e} ciphertexts/s** | executed {mp['roofline']['executed_T_mads']:.1f} T multiply-adds: frac **{mp['roofline']['frac']:.2f}** of the wall clock, {mp['roofline']['frac_kernel_time']:.2f} of the kernel time (fixed {fam(mp, 'fixed')}; modpow {fam(mp, 'modpow')}; expprod {fam(mp, 'expprod')}) |
-| the same END TO END (prover randomness on the device, Fiat-Shamir hashing, byte trees published and parsed, verifier as another party) | prove {e2e['prove_ms']:.0f} ms + verify {e2e['verify_ms']:.0f} ms = {e2e['total_ms']:.0f} ms = **{e2e['ciphertexts_per_s']:.2e} ciphertexts/s** ({e2e['ciphertexts_per_s_parties_in_parallel']:.2e} with prover and verifier on their own machines) | {e2e['hashed_bytes_per_party'] / 1e9:.2f} GB hashed per party (SHA-256, one host core, ~2.2 GB/s): the hash, not the GPU, is the critical path (see below) |
+| the same END TO END (prover randomness on the device, Fiat-Shamir hashing, byte trees published and parsed, verifier as another party) | prove {e2e['prove_ms']:.0f} ms + verify {e2e['verify_ms']:.0f} ms = {e2e['total_ms']:.0f} ms = **{e2e['ciphertexts_per_s_mean_of_passes']:.2e} ciphertexts/s** (mean of the two passes {e2e['passes_total_ms']}; {e2e['ciphertexts_per_s_parties_in_parallel']:.2e} with prover and verifier on their own machines) | {e2e['hashed_bytes_per_party'] / 1e9:.2f} GB hashed per party (SHA-256, one host core, ~2.2 GB/s): the hash, not the GPU, is the critical path (see below) |
 {small_row}| **configs[2]**: 3072 bits, CCPoS path | offline (commitment + PoSC) {cc['offline_ms']:.0f} ms, online (re-encrypt + CCPoS prove + verify) {cc['online_ms']:.0f} ms = **{cc['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac **{cc['roofline']['frac']:.2f}** wall / {cc['roofline']['frac_kernel_time']:.2f} kernel time (fixed {fam(cc, 'fixed')}; modpow {fam(cc, 'modpow')}; expprod {fam(cc, 'expprod')}) |
-| **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}; normalisation {fam(ec, 'normalize')}): 61 % of the issued instructions are multiply-adds, ~1000 launches (§5, curves) |
+| **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s** | executed-work frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}; normalisation {fam(ec, 'normalize')}); against SURVEY.md §8d's canonical field product M(8) = 136 (the kernels execute 160 per product): {ec['roofline']['frac_canonical']:.2f} wall / {ec['roofline']['frac_canonical_kernel_time']:.2f} kernel time (§5, curves, round 3) |
+| **decryption half** (row A6 / N3): one of k = 3 parties, threshold 2, 2048 bits, 10^6 ciphertexts | own factors {dec['own_factors_ms']:.0f} ms + own proof {dec['own_proof_ms']:.0f} ms + check of the others {dec['verify_others_ms']:.0f} ms + combination and plaintexts {dec['combine_and_plaintexts_ms']:.0f} ms = {dec['total_ms']:.0f} ms = **{dec['ciphertexts_per_s']:.3e} ciphertexts/s**; CPU (GMP, {dec['cpu_baseline']['cores']} cores, {dec['cpu_baseline']['sample'].split(',')[0]}): {dec['cpu_baseline']['value']:.0f} ciphertexts/s | frac **{dec['roofline']['frac']:.2f}** wall / {dec['roofline']['frac_kernel_time']:.2f} kernel time (modpow {fam(dec, 'modpow')}: one full-length power per ciphertext with the party's secret exponent) |
 | CPU beside it (GMP, {r['cpu_baseline']['cores']} cores of the box) | {r['cpu_baseline']['value']:.0f} modexp/s (`mpz_powm`, 96 000-element sample, bit-exact vs the GPU); mix + prove {mp['cpu_baseline']['value']:.0f} ciphertexts/s ({mp['cpu_baseline']['sample'].split(':')[0]}; fixed-base tables, Pippenger) | |
 
-PMC passes (`tools/profile_pmc.sh` -> `tools/summarize_pmc.py` -> `profiles/r02_pmc_kernels.json`; separate `--pmc` passes
+PMC passes (`tools/profile_pmc.sh` -> `tools/summarize_pmc.py` -> `profiles/r03_pmc_kernels.json`; separate `--pmc` passes
 for FETCH_SIZE, WRITE_SIZE and the SQ counters; 262 144 elements / ciphertexts; per-kernel durations of the same runs:
-`profiles/r02_pmc_runA_headline_kernel_stats.csv`, `r02_pmc_runB_proof_legs_kernel_stats.csv`).  "issue" = SQ_INSTS_VALU x 64 lanes
+`profiles/r03_pmc_runA_headline_kernel_stats.csv`, `r03_pmc_runB_proof_legs_kernel_stats.csv`).  "issue" = SQ_INSTS_VALU x 64 lanes
 / duration against 39.3 T/s; "busy" = VALU busy fraction from GRBM_GUI_ACTIVE:
 
 | kernel | calls | avg ms | issue | busy | HBM GB/s |
@@ -77,11 +79,11 @@ at {e2e['prover_phases_ms']['challenge_known']:.0f} ms, reply at {e2e['prover_ph
     return text
 
 
-BEGIN, END = "<!-- r02-tables-begin -->", "<!-- r02-tables-end -->"
+BEGIN, END = "<!-- r03-tables-begin -->", "<!-- r03-tables-end -->"
 
 
 def main():
-    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_v2.json")
+    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_v1.json")
     text = render(bench)
     path = os.path.join(ROOT, "DESIGN.md")
     s = open(path).read()
