@@ -106,12 +106,11 @@ size_t vmn_group_table_bytes(const vmn_group* grp);
  * size that holds it). */
 int vmn_modp_group_create(vmn_ctx* ctx, const uint8_t* p_be, const uint8_t* q_be, const uint8_t* g_be,
                           size_t nbytes, vmn_group** out);
-/* ECqPGroup over a named NIST curve: "P-256" and "P-384" -- the two north_star names -- and nothing else: any other name is
- * VMN_ERR_UNSUPPORTED.  The kernels assume a = -3 (dbl-2001-b) and carry the two field primes as compile-time
- * constants (csrc/ec_kernels.h FieldPrime), and the random-point derivation takes square roots as z^((p+1)/4)
- * (p = 3 mod 4).  The reference also offers P-192, P-224, P-521 and the brainpool curves (demo/mixnet/.conf:150-156), runs
- * its own `check` on P-224 (demo/mixnet/.checkbaseconf:59) and benchmarks on P-521 (benchmarks/bench_config:37): those are
- * NOT supported here (P-224 additionally needs Tonelli-Shanks roots, p = 1 mod 4; brainpool a general a).
+/* ECqPGroup over a named NIST prime curve: "P-256" and "P-384" -- the two north_star names, with the field primes compiled
+ * into the kernels (csrc/ec_kernels.h FieldPrime) -- and, untuned, "P-224" (the curve the reference runs its own `check` on,
+ * demo/mixnet/.checkbaseconf:59; square roots by Tonelli-Shanks, p = 1 mod 4) and "P-521" (benchmarks/bench_config:37).  Any
+ * other name is VMN_ERR_UNSUPPORTED: the kernels assume a = -3 (dbl-2001-b), so the brainpool curves the reference also
+ * offers (demo/mixnet/.conf:150-156) would need a general `a`, and P-192 is not instantiated.
  * ref: the default group of the reference, demo/mixnet/.conf:153 (P-256); SURVEY.md §2.3 K11.  Group elements cross the boundary as
  * x || y (elem_bytes = 2 * coordinate width, big-endian; the point at infinity is all 0xff bytes);
  * exponents are residues mod the group order.  Every vmn_garray_* call works on such groups with the

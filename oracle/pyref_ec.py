@@ -1,4 +1,4 @@
-"""pyref_ec.py — Python-integer reference for the elliptic-curve groups (ECqPGroup P-256 / P-384).
+"""pyref_ec.py — Python-integer reference for the elliptic-curve groups (ECqPGroup P-224 / P-256 / P-384 / P-521).
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 The reference tree only names the groups (default group P-256: demo/mixnet/.conf:153; P-224 in
@@ -17,6 +17,18 @@ from typing import List, Optional, Sequence, Tuple
 Point = Optional[Tuple[int, int]]
 
 CURVES = {
+    "P-224": dict(
+        p=2**224 - 2**96 + 1,
+        n=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFF16A2E0B8F03E13DD29455C5C2A3D,
+        b=0xB4050A850C04B3ABF54132565044B0B7D7BFD8BA270B39432355FFB4,
+        gx=0xB70E0CBD6BB4BF7F321390B94A03C1D356C21122343280D6115C1D21,
+        gy=0xBD376388B5F723FB4C22DFE6CD4375A05A07476444D5819985007E34),
+    "P-521": dict(
+        p=2**521 - 1,
+        n=0x01FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFA51868783BF2F966B7FCC0148F709A5D03BB5C9B8899C47AEBB6FB71E91386409,
+        b=0x0051953EB9618E1C9A1F929A21A0B68540EEA2DA725B99B315F3B8B489918EF109E156193951EC7E937B1652C0BD3BB1BF073573DF883D2C34F1EF451FD46B503F00,
+        gx=0x00C6858E06B70404E9CD9E3ECB662395B4429C648139053FB521F828AF606B4D3DBAA14B5E77EFE75928FE1DC127A2FFA8DE3348B3C1856A429BF97E7E31C2E5BD66,
+        gy=0x011839296A789A3BC0045C8A5FB42C7D1BD998F54449579B446817AFBD17273E662C97EE72995EF42640C550B9013FAD0761353C7086A272C24088BE94769FD16650),
     "P-256": dict(
         p=0xFFFFFFFF00000001000000000000000000000000FFFFFFFFFFFFFFFFFFFFFFFF,
         n=0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551,

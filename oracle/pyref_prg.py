@@ -46,11 +46,39 @@ def modp_generators(seed: bytes, n: int, p: int, q: int, rbitlen: int) -> List[i
     return [pow(t % p, cof, p) for t in random_integers(seed, n, p.bit_length() + rbitlen)]
 
 
+def sqrt_mod(a: int, p: int):
+    """A square root of a modulo the odd prime p, or None: a^((p+1)/4) when p = 3 mod 4, Tonelli-Shanks otherwise
+    (P-224: p - 1 = 2^96 (2^128 - 1)).  Which of the two roots comes out is irrelevant to the callers (they take the smaller)."""
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    if p % 4 == 3:
+        return pow(a, (p + 1) // 4, p)
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, c, t, x = s, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+    while t != 1:
+        i, tt = 0, t
+        while tt != 1:
+            tt = tt * tt % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c, t, x = i, b * b % p, t * b * b % p, x * b % p
+    return x
+
+
 def ec_generators(seed: bytes, n: int, curve, rbitlen: int, hashname: str = "sha256"):
     """ECqPGroup.randomElementArray(n, prg, rbitlen) as the product restates it from the verifier specification
     [NOT-IN-REF: VCR's procedure; unpinned]: candidate j = the j-th (bits(p) + rbitlen)-bit integer of the PRG stream,
-    x = t mod p; kept when x^3 + ax + b is a square mod p (p = 3 mod 4: z = rhs^((p+1)/4), z^2 = rhs), the point being
-    (x, min(z, p - z)); the array holds the first n kept candidates in order.  `curve`: oracle/pyref_ec.Curve."""
+    x = t mod p; kept when x^3 + ax + b is a square mod p (sqrt_mod), the point being (x, min(z, p - z)); the array holds the
+    first n kept candidates in order.  `curve`: oracle/pyref_ec.Curve."""
     p, a, b = curve.p, curve.a, curve.b
     bits = p.bit_length() + rbitlen
     vb = (bits + 7) // 8
@@ -64,7 +92,7 @@ def ec_generators(seed: bytes, n: int, curve, rbitlen: int, hashname: str = "sha
         j += 1
         x = t % p
         rhs = (x * x * x + a * x + b) % p
-        z = pow(rhs, (p + 1) // 4, p)
-        if z * z % p == rhs:
+        z = sqrt_mod(rhs, p)
+        if z is not None:
             out.append((x, min(z, p - z)))
     return out

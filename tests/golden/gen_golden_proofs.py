@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate the committed golden vectors for the curve groups and for whole proof transcripts
-(tests/golden/ec_p256.json, ec_p384.json, proofs_n8.json) from the Python restatements only (oracle/pyref_ec.py:
+(tests/golden/ec_p224.json, ec_p256.json, ec_p384.json, ec_p521.json, proofs_n8.json) from the Python restatements only (oracle/pyref_ec.py:
 affine textbook arithmetic; oracle/pyref_proofs.py: the proofs over Python integers / affine points).
 
 The reference holds no known-answer vectors for this path; these fixtures are what SURVEY.md §8c
@@ -295,8 +295,8 @@ def main():
     with open(path, "w") as f:
         json.dump(rec, f, separators=(",", ":"))
     print(path, len(rec["records"]), "records", os.path.getsize(path), "bytes")
-    for name, fname in (("P-256", "ec_p256.json"), ("P-384", "ec_p384.json")):
-        rec = ec_cases(name, [1, 2, 9, 64] if name == "P-256" else [1, 7, 33])
+    for name, fname in (("P-224", "ec_p224.json"), ("P-256", "ec_p256.json"), ("P-384", "ec_p384.json"), ("P-521", "ec_p521.json")):
+        rec = ec_cases(name, [1, 2, 9, 64] if name == "P-256" else [1, 7, 33] if name == "P-384" else [1, 7, 20])
         path = os.path.join(HERE, fname)
         with open(path, "w") as f:
             json.dump(rec, f, separators=(",", ":"))

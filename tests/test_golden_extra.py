@@ -35,7 +35,7 @@ def ints(vs):
 
 
 # ---------------------------------------------------------------------------------------------- CPU
-@pytest.mark.parametrize("fname", ["ec_p256.json", "ec_p384.json"])
+@pytest.mark.parametrize("fname", ["ec_p224.json", "ec_p256.json", "ec_p384.json", "ec_p521.json"])
 def test_curve_vectors_against_openssl_and_the_jacobian_model(fname):
     from test_oracle_ec import openssl_mul
     rec = load(fname)
@@ -57,7 +57,7 @@ def test_curve_vectors_against_openssl_and_the_jacobian_model(fname):
                 assert Z is None or c.on_curve(Z)
         if case["op"] in ("exp_array", "exp_scalar", "permute", "inv"):
             assert all(Q is None or c.on_curve(Q) for Q in pts(case["out"]))
-    assert checked >= 30
+    assert checked >= 25
 
 
 def test_proof_transcripts_are_reproducible_and_accepted_by_the_oracle_verifier():
@@ -110,7 +110,7 @@ def test_proof_transcripts_are_reproducible_and_accepted_by_the_oracle_verifier(
 
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("fname", ["ec_p256.json", "ec_p384.json"])
+@pytest.mark.parametrize("fname", ["ec_p224.json", "ec_p256.json", "ec_p384.json", "ec_p521.json"])
 def test_hip_curve_kernels_reproduce_the_golden_vectors(fname, vmn, gpu_ctx):
     rec = load(fname)
     G = vmn.ECqPGroup(gpu_ctx, rec["curve"])

@@ -8,7 +8,7 @@ import pytest
 
 from oracle.pyref_ec import Curve, jac_add, jac_dbl, jac_to_affine
 
-NIDS = {"P-256": 415, "P-384": 715}
+NIDS = {"P-224": 713, "P-256": 415, "P-384": 715, "P-521": 716}
 
 
 def openssl_mul(name, k):
@@ -18,20 +18,20 @@ def openssl_mul(name, k):
     grp = ctypes.c_void_p(lib.EC_GROUP_new_by_curve_name(NIDS[name]))
     pt = ctypes.c_void_p(lib.EC_POINT_new(grp))
     ctx = ctypes.c_void_p(lib.BN_CTX_new())
-    kb = k.to_bytes(64, "big")
+    kb = k.to_bytes(72, "big")
     bn = ctypes.c_void_p(lib.BN_bin2bn(kb, len(kb), None))
     assert lib.EC_POINT_mul(grp, pt, bn, None, None, ctx) == 1
     x, y = ctypes.c_void_p(lib.BN_new()), ctypes.c_void_p(lib.BN_new())
     assert lib.EC_POINT_get_affine_coordinates(grp, pt, x, y, ctx) == 1
     out = []
     for v in (x, y):
-        buf = ctypes.create_string_buffer(64)
+        buf = ctypes.create_string_buffer(80)
         n = lib.BN_bn2bin(v, buf)
         out.append(int.from_bytes(buf.raw[:n], "big"))
     return tuple(out)
 
 
-@pytest.mark.parametrize("name", ["P-256", "P-384"])
+@pytest.mark.parametrize("name", ["P-224", "P-256", "P-384", "P-521"])
 def test_reference_agrees_with_openssl(name):
     c = Curve(name)
     random.seed(7)
@@ -40,7 +40,7 @@ def test_reference_agrees_with_openssl(name):
     assert c.mul(c.n, c.g) is None
 
 
-@pytest.mark.parametrize("name", ["P-256", "P-384"])
+@pytest.mark.parametrize("name", ["P-224", "P-256", "P-384", "P-521"])
 def test_jacobian_model_with_exceptional_cases(name):
     c = Curve(name)
     random.seed(3)
@@ -53,3 +53,56 @@ def test_jacobian_model_with_exceptional_cases(name):
         z1, z2 = random.randrange(1, c.p), random.randrange(1, c.p)
         assert jac_to_affine(c, jac_add(c, J(P, z1), J(Q, z2))) == c.add(P, Q)
         assert jac_to_affine(c, jac_dbl(c, J(P, z1))) == c.add(P, P)
+
+
+def test_square_roots_for_both_residue_classes_of_p():
+    """oracle/pyref_prg.sqrt_mod: (p + 1) / 4 power for p = 3 mod 4, Tonelli-Shanks for P-224's p = 1 mod 4."""
+    from oracle.pyref_prg import sqrt_mod
+    random.seed(11)
+    for name in ("P-224", "P-256", "P-521"):
+        p = Curve(name).p
+        roots = 0
+        for _ in range(40):
+            a = random.randrange(p)
+            z = sqrt_mod(a, p)
+            if z is None:
+                assert pow(a, (p - 1) // 2, p) == p - 1
+            else:
+                assert z * z % p == a
+                roots += 1
+        assert 8 <= roots <= 32 and sqrt_mod(0, p) == 0 and sqrt_mod(4, p) in (2, p - 2)
+    assert Curve("P-224").p % 4 == 1
+
+
+@pytest.mark.parametrize("name", ["P-224", "P-256", "P-384", "P-521"])
+def test_curve_constants_are_openssls(name):
+    """p, b, the generator and the ORDER of every curve table in the tree (oracle/pyref_ec.py, the product's ecscalar.py) equal
+    libcrypto's: a mistyped order still satisfies n G = infinity in code that reduces scalars mod its own n."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    lib = ctypes.CDLL(ctypes.util.find_library("crypto") or "libcrypto.so.3")
+    for f in ("EC_GROUP_new_by_curve_name", "BN_new", "BN_CTX_new", "EC_GROUP_get0_generator", "EC_GROUP_get0_order"):
+        getattr(lib, f).restype = ctypes.c_void_p
+
+    def val(bn):
+        buf = ctypes.create_string_buffer(80)
+        n = lib.BN_bn2bin(ctypes.c_void_p(bn), buf)
+        return int.from_bytes(buf.raw[:n], "big")
+    grp, ctx = ctypes.c_void_p(lib.EC_GROUP_new_by_curve_name(NIDS[name])), ctypes.c_void_p(lib.BN_CTX_new())
+    p, a, b, x, y = (ctypes.c_void_p(lib.BN_new()) for _ in range(5))
+    assert lib.EC_GROUP_get_curve(grp, p, a, b, ctx) == 1
+    assert lib.EC_POINT_get_affine_coordinates(grp, ctypes.c_void_p(lib.EC_GROUP_get0_generator(grp)), x, y, ctx) == 1
+    want = dict(p=val(p.value), b=val(b.value), gx=val(x.value), gy=val(y.value), n=val(lib.EC_GROUP_get0_order(grp)))
+    assert val(a.value) == want["p"] - 3
+    spec = importlib.util.spec_from_file_location("ecscalar_consts", os.path.join(ROOT, "verificatum-vmn_amd", "ecscalar.py"))
+    ecs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ecs)
+    from oracle.pyref_ec import CURVES
+    assert CURVES[name] == want and ecs.CURVES[name] == want
+    # ... and the table compiled into the library (csrc/vmnhip.hip kCurves: p, n, b, gx, gy as hex)
+    import re
+    src = open(os.path.join(ROOT, "verificatum-vmn_amd", "csrc", "vmnhip.hip")).read()
+    blk = src[src.index('{"%s",' % name):]
+    hexes = [int(h, 16) for h in re.findall(r'"([0-9a-f]{40,})"', blk[:blk.index("}")])]
+    assert hexes == [want["p"], want["n"], want["b"], want["gx"], want["gy"]]

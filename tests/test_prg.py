@@ -142,7 +142,8 @@ def test_random_vector_over_a_curve_order(vmn, gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("curve_name,hashname,seedlen", [("P-256", "sha256", 32), ("P-384", "sha256", 32), ("P-256", "sha512", 64)])
+@pytest.mark.parametrize("curve_name,hashname,seedlen", [("P-256", "sha256", 32), ("P-384", "sha256", 32), ("P-256", "sha512", 64),
+                                                         ("P-224", "sha256", 32), ("P-521", "sha256", 32)])
 def test_independent_generators_over_curves(curve_name, hashname, seedlen, vmn, gpu_ctx):
     """IndependentGeneratorsRO over ECqPGroup (P-256 is the reference's default group): random points derived on the GPU,
     candidates tested in parallel and compacted in order, against the sequential Python restatement."""

@@ -1,5 +1,5 @@
 // ec_instances.h — the curve kernels of one field size as explicit instantiations (see modp_instances.h: the host unit
-// vmnhip.hip declares them `extern template`, csrc/inst_p256.hip / inst_p384.hip define them, compiled side by side).
+// vmnhip.hip declares them `extern template`, csrc/inst_p224.hip / inst_p256.hip / inst_p384.hip / inst_p521.hip define them, compiled side by side).
 #pragma once
 #include "ec_kernels.h"
 
@@ -29,5 +29,7 @@
     KW __global__ void vmn::k_ec_scan_apply<S_>(vmn::u32*, const vmn::u32*, const vmn::u32*, size_t, size_t, size_t, int, vmn::ECDev);   \
     KW __global__ void vmn::k_ec_horner<S_>(vmn::u32*, const vmn::u32*, int, int, int, vmn::ECDev);
 
+#define VMN_UNIT_P224(KW) VMN_EC_INSTANCES(KW, 9, 7)
 #define VMN_UNIT_P256(KW) VMN_EC_INSTANCES(KW, 10, 8)
 #define VMN_UNIT_P384(KW) VMN_EC_INSTANCES(KW, 15, 12)
+#define VMN_UNIT_P521(KW) VMN_EC_INSTANCES(KW, 21, 17)

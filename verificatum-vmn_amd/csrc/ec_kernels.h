@@ -1,4 +1,4 @@
-// ec_kernels.h — elliptic-curve groups (ECqPGroup: NIST P-256 / P-384, a = -3) on gfx950.
+// ec_kernels.h — elliptic-curve groups (ECqPGroup: NIST P-224 / P-256 / P-384 / P-521, a = -3) on gfx950.
 //
 // The reference's code is group-agnostic (every call site of K1-K7 is reached with
 // `pGroup` = ECqPGroup, the default group being P-256, demo/mixnet/.conf:153).  In VCR's multiplicative
@@ -30,7 +30,12 @@ struct ECDev {
     const u32* mp;     // 64 * p, normalised limbs (added before a subtraction so the result stays positive)
     const u32* mp2;    // 256 * p, for the few subtractions whose subtrahend is itself a difference (< 256 p)
     const u32* pm2;    // p - 2 as packed 32-bit words (Fermat inversion)
-    const u32* pp14;   // (p + 1) / 4 as packed words: square roots (p = 3 mod 4 for P-256 and P-384)
+    const u32* pp14;   // (p + 1) / 4 as packed words: square roots when p = 3 mod 4 (P-256, P-384, P-521)
+    // p = 1 mod 4 (P-224: p - 1 = 2^96 (2^128 - 1)): Tonelli-Shanks.  ts_s = 0 selects the (p + 1) / 4 power above.
+    int ts_s;          // p - 1 = 2^ts_s Q, Q odd
+    int ts_ewords;     // words of ts_e
+    const u32* ts_e;   // (Q - 1) / 2 as packed words
+    const u32* ts_c;   // z^Q for a fixed non-residue z, Montgomery form, S limbs
     u32 n0inv;         // -p^{-1} mod 2^28
     u32 p1p;           // p[1] + 1 (limb 1 of the prime, plus the carry fold of mont_row)
     int pwords;        // words of pm2
@@ -42,6 +47,7 @@ struct ECfg {
     static constexpr int FW = stride_for_limbs(S);
     static constexpr int ROW = 3 * FW;             // words per point row
     static constexpr int FLAG = ROW - 1;           // infinity flag word
+    static_assert(FW > S, "a point row keeps its infinity flag in the padding word behind Z: the limb count must not be a multiple of 4");
     // waves per SIMD the point kernels are compiled for (VGPR budget 512 / MINW): measured, see DESIGN.md §5
 #ifndef VMN_EC_MINW
 #define VMN_EC_MINW 2
@@ -244,6 +250,59 @@ __device__ void f_pow_words(u32 (&r)[S], const u32 (&a)[S], const u32* __restric
 template <int S>
 __device__ void f_inv(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
     f_pow_words<S>(r, a, E.pm2, E.pwords, E);
+}
+
+// z = a candidate square root of a (canonical Montgomery-form input): z^2 = a when a is a square; the caller checks.
+// p = 3 mod 4: z = a^((p+1)/4).  p = 1 mod 4: Tonelli-Shanks with p - 1 = 2^s Q -- x = a^((Q+1)/2), t = a^Q, then while
+// t != 1: i = the least exponent with t^(2^i) = 1, b = c^(2^(M-i-1)), x *= b, c = b^2, t *= c, M = i (c starts as z^Q for a
+// non-residue z).  The loops are data-dependent (lanes of a wave take the longest of their paths): only the derivation of
+// random points runs this, once per candidate.
+template <int S>
+__device__ void f_sqrt(u32 (&z)[S], const u32 (&a)[S], const ECDev& E) {
+    if (E.ts_s == 0) {
+        f_pow_words<S>(z, a, E.pp14, E.pwords, E);
+        return;
+    }
+    u32 one[S], u[S], x[S], t[S], c[S], b[S], tt[S], d[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        one[j] = E.one[j];
+        c[j] = E.ts_c[j];
+    }
+    auto is_one = [&](const u32 (&v)[S]) {
+        f_sub<S>(d, v, one, E);
+        return f_is_zero<S>(d, E);
+    };
+    f_pow_words<S>(u, a, E.ts_e, E.ts_ewords, E);          // a^((Q-1)/2)
+    f_mul<S>(x, a, u, E);                                  // a^((Q+1)/2)
+    f_mul<S>(t, x, u, E);                                  // a^Q
+    f_canon<S>(t, t, E);
+    int M = E.ts_s;
+    for (int guard = 0; guard <= E.ts_s; ++guard) {        // M strictly decreases: at most ts_s rounds
+        if (is_one(t) || f_is_zero<S>(t, E)) break;        // done (t = 0: a = 0, x = 0 is its root)
+        int i = 0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) tt[j] = t[j];
+        do {
+            f_sqr<S>(tt, tt, E);
+            f_canon<S>(tt, tt, E);
+            ++i;
+        } while (i < M && !is_one(tt));
+        if (i >= M) break;                                 // a is not a square: the caller's check rejects x
+#pragma unroll
+        for (int j = 0; j < S; ++j) b[j] = c[j];
+        for (int k = 0; k < M - i - 1; ++k) {
+            f_sqr<S>(b, b, E);
+            f_canon<S>(b, b, E);
+        }
+        f_mul<S>(x, x, b, E);
+        f_sqr<S>(c, b, E);
+        f_canon<S>(c, c, E);
+        f_mul<S>(t, t, c, E);
+        f_canon<S>(t, t, E);
+        M = i;
+    }
+    f_canon<S>(z, x, E);
 }
 
 // ---------------------------------------------------------------------------------------------

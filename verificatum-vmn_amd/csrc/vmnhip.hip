@@ -29,8 +29,10 @@ VMN_UNIT_3072(extern template)
 VMN_UNIT_4096(extern template)
 VMN_UNIT_8192(extern template)
 VMN_UNIT_16384(extern template)
+VMN_UNIT_P224(extern template)
 VMN_UNIT_P256(extern template)
 VMN_UNIT_P384(extern template)
+VMN_UNIT_P521(extern template)
 
 using namespace vmn;
 using vmn::hostbig::Big;
@@ -74,7 +76,7 @@ extern "C" const char* vmn_version(void) { return "vmnhip 0.1 (gfx950, radix-2^2
 #define VMN_FOR_SIZES(X) X(10, 8, 1) X(14, 12, 1) X(19, 16, 1) X(37, 32, 1) X(74, 64, 1) X(76, 64, 4) X(80, 64, 8) X(110, 96, 2) X(112, 96, 4) X(148, 128, 4) X(296, 256, 8) X(592, 512, 16)
 // elliptic curves: X(field limbs, packed words)
 // (field limbs are chosen so that R/p >= 2^24: the lazy operand bounds of the point formulas need it)
-#define VMN_FOR_CURVES(X) X(10, 8) X(15, 12)
+#define VMN_FOR_CURVES(X) X(9, 7) X(10, 8) X(15, 12) X(21, 17)
 
 static bool size_for_bits(int nbits, int* S, int* NW, int* LPE) {
     const int sizes[][4] = {{256, 10, 8, 1}, {384, 14, 12, 1}, {512, 19, 16, 1}, {1024, 37, 32, 1}, {2048, 74, 64, 1},
@@ -788,13 +790,18 @@ static ECDev ecdev(const vmn_curve* c) {
     E.n0inv = c->n0inv;
     E.p1p = c->p1p;
     E.pwords = c->NW;
+    E.ts_s = c->ts_s;
+    E.ts_ewords = c->ts_ewords;
+    E.ts_e = c->d_ts_e;
+    E.ts_c = c->d_ts_c;
     return E;
 }
 
 struct CurveParams {
     const char* name;
     int bits;
-    int field_limbs;
+    int field_limbs;   // 28-bit limbs of a field element: R / p >= 2^24 (the lazy operand bounds of the point formulas)
+    int words;         // 32-bit words of a coordinate
     const char* p;
     const char* n;
     const char* b;
@@ -802,17 +809,29 @@ struct CurveParams {
     const char* gy;
 };
 static const CurveParams kCurves[] = {
-    {"P-256", 256, 10, "ffffffff00000001000000000000000000000000ffffffffffffffffffffffff",
+    {"P-224", 224, 9, 7, "ffffffffffffffffffffffffffffffff000000000000000000000001",
+     "ffffffffffffffffffffffffffff16a2e0b8f03e13dd29455c5c2a3d",
+     "b4050a850c04b3abf54132565044b0b7d7bfd8ba270b39432355ffb4",
+     "b70e0cbd6bb4bf7f321390b94a03c1d356c21122343280d6115c1d21",
+     "bd376388b5f723fb4c22dfe6cd4375a05a07476444d5819985007e34"},
+    {"P-256", 256, 10, 8, "ffffffff00000001000000000000000000000000ffffffffffffffffffffffff",
      "ffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551",
      "5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b",
      "6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296",
      "4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5"},
-    {"P-384", 384, 15,
+    {"P-384", 384, 15, 12,
      "fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffeffffffff0000000000000000ffffffff",
      "ffffffffffffffffffffffffffffffffffffffffffffffffc7634d81f4372ddf581a0db248b0a77aecec196accc52973",
      "b3312fa7e23ee7e4988e056be3f82d19181d9c6efe8141120314088f5013875ac656398d8a2ed19d2a85c8edd3ec2aef",
      "aa87ca22be8b05378eb1c71ef320ad746e1d3b628ba79b9859f741e082542a385502f25dbf55296c3a545e3872760ab7",
      "3617de4a96262c6f5d9e98bf9292dc29f8f41dbd289a147ce9da3113b5f0b8c00a60b1ce1d7e819d7a431d7c90ea0e5f"},
+    // (odd hex lengths are padded with a leading zero nibble: 521 bits = 66 bytes on the wire)
+    {"P-521", 521, 21, 17,
+     "01ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff",
+     "01fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffa51868783bf2f966b7fcc0148f709a5d03bb5c9b8899c47aebb6fb71e91386409",
+     "0051953eb9618e1c9a1f929a21a0b68540eea2da725b99b315f3b8b489918ef109e156193951ec7e937b1652c0bd3bb1bf073573df883d2c34f1ef451fd46b503f00",
+     "00c6858e06b70404e9cd9e3ecb662395b4429c648139053fb521f828af606b4d3dbaa14b5e77efe75928fe1dc127a2ffa8de3348b3c1856a429bf97e7e31c2e5bd66",
+     "011839296a789a3bc0045c8a5fb42c7d1bd998f54449579b446817afbd17273e662c97ee72995ef42640c550b9013fad0761353c7086a272c24088be94769fd16650"},
 };
 
 static std::vector<uint8_t> hex_to_be(const char* h) {
@@ -862,6 +881,7 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     int S, NW, LPE;
     if (!size_for_bits(cp.bits, &S, &NW, &LPE) || LPE != 1) return VMN_ERR_UNSUPPORTED;
     S = cp.field_limbs;
+    NW = cp.words;
     c->S = S;
     c->NW = NW;
     auto pb = hex_to_be(cp.p), bb = hex_to_be(cp.b), gx = hex_to_be(cp.gx), gy = hex_to_be(cp.gy);
@@ -904,7 +924,7 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     size_t o_mp = put(limbs_of(times_small(pw, 64, NW + 1), S), FW);
     size_t o_mp2 = put(limbs_of(times_small(pw, 256, NW + 1), S), FW);
     size_t o_pm2 = put(std::vector<uint32_t>(pm2.begin(), pm2.end()), (NW + 3) & ~3);
-    Big pp14(NW + 1, 0);                                  // (p + 1) / 4: p = 3 mod 4 for both curves
+    Big pp14(NW + 1, 0);                                  // (p + 1) / 4: the square-root exponent when p = 3 mod 4
     {
         uint64_t c = 1;
         for (int i = 0; i < NW; ++i) {
@@ -917,7 +937,45 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
         pp14.resize(NW);
     }
     size_t o_pp14 = put(std::vector<uint32_t>(pp14.begin(), pp14.end()), (NW + 3) & ~3);
+    // Square roots when p = 1 mod 4 (P-224): Tonelli-Shanks constants -- p - 1 = 2^s Q, the exponent (Q - 1) / 2, and
+    // c = z^Q for the smallest non-residue z (Euler's criterion on the host), as field limbs in Montgomery form.
+    size_t o_tse = 0, o_tsc = 0;
+    c->ts_s = 0;
+    c->ts_ewords = 0;
+    if ((pw[0] & 3u) == 1u) {
+        Big q = pw;
+        q[0] -= 1;                                                  // p - 1
+        int s2 = 0;
+        while (!hostbig::get_bit(q, 0)) {
+            for (int i = 0; i < NW; ++i) q[i] = (q[i] >> 1) | (i + 1 < NW ? q[i + 1] << 31 : 0);
+            ++s2;
+        }
+        Big half = pw;                                              // (p - 1) / 2
+        half[0] -= 1;
+        for (int i = 0; i < NW; ++i) half[i] = (half[i] >> 1) | (i + 1 < NW ? half[i + 1] << 31 : 0);
+        hostbig::Mont hm(pw);
+        Big zc;
+        for (uint32_t z = 2; z < 200 && zc.empty(); ++z) {
+            Big zb(NW, 0);
+            zb[0] = z;
+            const Big zm = hm.to_mont(zb);
+            if (hostbig::cmp(hm.pow_m(zm, half), hm.one) != 0) zc = hm.from_mont(hm.pow_m(zm, q));     // z^((p-1)/2) = -1: a non-residue
+        }
+        if (zc.empty()) {
+            set_error("curve %s: no quadratic non-residue found", cp.name);
+            return VMN_ERR_UNSUPPORTED;
+        }
+        Big e = q;                                                  // (Q - 1) / 2
+        for (int i = 0; i < NW; ++i) e[i] = (e[i] >> 1) | (i + 1 < NW ? e[i + 1] << 31 : 0);
+        c->ts_s = s2;
+        c->ts_ewords = (hostbig::bit_length(e) + 31) / 32;
+        if (c->ts_ewords < 1) c->ts_ewords = 1;
+        o_tse = put(std::vector<uint32_t>(e.begin(), e.end()), (NW + 3) & ~3);
+        o_tsc = put(limbs_of(shift_mod(zc, 28 * S, pw), S), FW);   // z^Q R mod p
+    }
     VMN_TRY(upload_words(ctx, &c->d_consts, blob));
+    c->d_ts_e = c->d_consts + o_tse;
+    c->d_ts_c = c->d_consts + o_tsc;
     c->d_p = c->d_consts + o_p;
     c->d_one = c->d_consts + o_one;
     c->d_rr = c->d_consts + o_rr;
@@ -938,12 +996,12 @@ extern "C" int vmn_ec_group_create(vmn_ctx* ctx, const char* curve_name, vmn_gro
         if (strcmp(k.name, curve_name) == 0) cp = &k;
     }
     if (!cp) {
-        set_error("vmn_ec_group_create: unknown curve %s (known: P-256, P-384)", curve_name);
+        set_error("vmn_ec_group_create: unknown curve %s (known: P-224, P-256, P-384, P-521)", curve_name);
         return VMN_ERR_UNSUPPORTED;
     }
     std::unique_ptr<vmn_group> g(new vmn_group());
     g->ctx = ctx;
-    g->nbytes = (size_t)cp->bits / 8;
+    g->nbytes = ((size_t)cp->bits + 7) / 8;
     g->xbytes = g->nbytes;
     vmn_curve* curve = nullptr;
     VMN_TRY(curve_create(ctx, *cp, &curve));
@@ -2213,7 +2271,7 @@ k_ec_random_points(u32* __restrict__ rows, u32* __restrict__ keep, const uint32_
     f_add<S>(rhs, t2, bb);
     f_sub<S>(rhs, rhs, t, E);                          // x^3 - 3x + b
     f_canon<S>(rhs, rhs, E);
-    f_pow_words<S>(z, rhs, E.pp14, E.pwords, E);
+    f_sqrt<S>(z, rhs, E);
     f_sqr<S>(t, z, E);
     f_sub<S, true>(t2, t, rhs, E);
     const bool ok = f_is_zero<S>(t2, E);

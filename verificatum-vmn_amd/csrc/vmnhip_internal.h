@@ -106,6 +106,9 @@ struct vmn_curve {
     const uint32_t* d_pp14 = nullptr;
     uint32_t n0inv = 0;
     uint32_t p1p = 0;              // limb 1 of the prime + 1 (ec_kernels.h mont_row)
+    int ts_s = 0, ts_ewords = 0;   // Tonelli-Shanks (p = 1 mod 4): p - 1 = 2^ts_s Q; words of (Q - 1) / 2
+    const uint32_t* d_ts_e = nullptr;
+    const uint32_t* d_ts_c = nullptr;
 };
 
 // Device-resident constants of one odd modulus in M28 form.
