@@ -296,6 +296,8 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
                "kernel_launches": sum(v[0] for v in fam.values()),
                "reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
                "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "roofline": leg_roofline(fam, (t3 - t0) * 1e3)}
+        if drivers == "native":                        # size of the Fiat-Shamir proof: u, commitment, reply as byte trees (p(N) of the reference's analysis)
+            cur["proof_bytes"] = prover.u.byteTreeSize() + com.native.byteTreeSize() + rep.native.byteTreeSize()
         if best is None or cur["total_ms"] < best["total_ms"]:
             best = cur
         for a in WP + S + [com["B"], com["Bp"], rep["k_B"], rep["k_E"], prover.u]:
@@ -318,6 +320,26 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 1, dri
     # canonical cost, SURVEY.md §8d: ~3280 M(64) = 2.7e7 MAC per ciphertext (PoS path, n = 2048, width 1)
     best["canonical_TMACs_survey_8d"] = 3280 * 8256 * n / (best["total_ms"] / 1e3) / 1e12      # NOT a roofline fraction: see `roofline`
     return best
+
+
+def operation_length_fit(points):
+    """The reference's own metric shape (demo/mixnet/benchmarks/operation_length_analyze:70-108): running time of executing
+    e(N) and of verifying v(N) one shuffle, and the size p(N) of its Fiat-Shamir proof, as affine functions a N + b fitted
+    (least squares) over several numbers of ciphertexts.  `points`: mix_prove results at different n."""
+    import numpy as np
+    ns = np.array([p["n"] for p in points], dtype=float)
+
+    def fit(ys):
+        a, b = np.polyfit(ns, np.array(ys, dtype=float), 1)
+        return {"per_ciphertext": float(a), "constant": float(b)}
+    out = {"ciphertexts": [int(x) for x in ns],
+           "executing_ms": [p["reencrypt_ms"] + p["prove_ms"] for p in points], "verifying_ms": [p["verify_ms"] for p in points],
+           "e(N)_ms": fit([p["reencrypt_ms"] + p["prove_ms"] for p in points]), "v(N)_ms": fit([p["verify_ms"] for p in points]),
+           "shape": "e(N) = a N + b: shuffle (re-encrypt + permute) + prove; v(N): verify; arithmetic of the legs above (no hashing, no network)"}
+    if all("proof_bytes" in p for p in points):
+        out["proof_bytes"] = [p["proof_bytes"] for p in points]
+        out["p(N)_bytes"] = fit(out["proof_bytes"])
+    return out
 
 
 def mix_prove_e2e(entry, vmn, ctx, grp, n: int, seed: int, sync):
@@ -1387,6 +1409,16 @@ def main() -> None:
         sm["workload"] = "re-encrypt + PoS prove + verify at the reference's demo size (BASELINE.json configs[0]: 10^4 ciphertexts, 2048 bits, width 1)"
         result["mix_prove_n10000"] = sm
 
+    def leg_fit():
+        # e(N), v(N), p(N) as the reference's benchmark reports them: the two sizes already measured + two in between
+        pts = [result["mix_prove_n10000"]]
+        for n_mid in (100_000, 300_000):
+            if n_mid < args.mix_n:
+                ctx.timing_reset()
+                pts.append(mix_prove(entry, vmn, ctx, grp, n_mid, 777, barrier, steps=2, drivers=args.drivers))
+        pts.append(result["mix_prove"])
+        result["operation_length"] = operation_length_fit(pts)
+
     def leg_decrypt():
         ctx.timing_reset()
         result["decrypt_2048"] = decrypt_leg(entry, vmn, ctx, grp, args.dec_n, 999, barrier)
@@ -1397,6 +1429,8 @@ def main() -> None:
         guarded("decrypt_2048", leg_decrypt)
     if args.mix_n >= 10000 and not distributed:
         guarded("mix_prove_n10000", leg_small)
+        if "error" not in result.get("mix_prove", {"error": 1}) and "error" not in result.get("mix_prove_n10000", {"error": 1}) and args.mix_n > 10000:
+            guarded("operation_length", leg_fit)
     if args.ccpos_n > 0:
         guarded("mix_ccpos_3072", leg_ccpos_sharded if distributed else leg_ccpos)
     if args.ec_n > 0:

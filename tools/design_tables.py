@@ -35,6 +35,15 @@ def render(bench):
     rf = r["roofline"]
     issued = f"{rf['issued_Tlaneinstr_per_s']:.1f}" if rf.get("issued_Tlaneinstr_per_s") else "n/a"
     traffic = f"{rf['traffic'] / 1e9:.0f} GB" if rf.get("traffic") else "n/a"
+    ol = r.get("operation_length")
+    fit_text = ""
+    if ol and "error" not in ol:
+        e, v, pb = ol["e(N)_ms"], ol["v(N)_ms"], ol.get("p(N)_bytes")
+        fit_text = (f"\n\nThe reference's own metric shape (`demo/mixnet/benchmarks/operation_length_analyze:70-108`: affine fits over several "
+                    f"numbers of ciphertexts; `operation_length` of the line, N = {ol['ciphertexts']}): executing (shuffle + prove) "
+                    f"**e(N) = {e['per_ciphertext'] * 1e3:.4f} us x N + {e['constant']:.1f} ms**, verifying **v(N) = {v['per_ciphertext'] * 1e3:.4f} us x N + "
+                    f"{v['constant']:.1f} ms**" + (f", proof size p(N) = {pb['per_ciphertext']:.0f} x N + {pb['constant']:.0f} bytes" if pb else "") +
+                    " (arithmetic only: no hashing, no network).")
     sm = r.get("mix_prove_n10000")
     small_row = (f"| the same at the reference's demo size, **configs[0]**: 10^4 ciphertexts | {sm['total_ms']:.1f} ms = **{sm['ciphertexts_per_s']:.3e} ciphertexts/s** "
                  f"(prove {sm['prove_ms']:.1f} ms, verify {sm['verify_ms']:.1f} ms) | wide geometries + fixed-base chains cut into pieces (§5): kernels {sm['roofline']['kernel_ms']:.1f} ms of it, "
@@ -75,7 +84,7 @@ The headline kernel executes {hk['valu_instr_per_unit'] / 1e6:.2f} M VALU instru
 End-to-end timeline at N = 10^6 (prover): seed-independent GPU work done at {e2e['prover_phases_ms']['seed_independent_gpu_work_done']:.0f} ms, seed known at
 {e2e['prover_phases_ms']['seed_known']:.0f} ms (hash thread busy {e2e['instance_hash_thread_busy_ms'][0]:.0f} ms: fully overlapped, hash-bound), commitment published at {e2e['prover_phases_ms']['commitment_published']:.0f} ms, challenge
 at {e2e['prover_phases_ms']['challenge_known']:.0f} ms, reply at {e2e['prover_phases_ms']['reply_published']:.0f} ms; verifier: seed at {e2e['verifier_phases_ms']['seed_known']:.0f} ms, computeAF beside the challenge hash, verdict at
-{e2e['verifier_phases_ms']['verified']:.0f} ms.  GPU kernels are {e2e['gpu_kernel_ms']:.0f} ms of the {e2e['total_ms']:.0f} ms."""
+{e2e['verifier_phases_ms']['verified']:.0f} ms.  GPU kernels are {e2e['gpu_kernel_ms']:.0f} ms of the {e2e['total_ms']:.0f} ms.""" + fit_text
     return text
 
 

@@ -906,14 +906,19 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32*
     }
 }
 
-// K3 product-tree level (see k_bucket_level).  FIRST: `in` is a NORMALISED array (k_ec_normalize), read through `sorted`.
+// K3 product-tree level (see k_bucket_level, also for the arrays of one launch).  FIRST: the inputs are NORMALISED arrays
+// (k_ec_normalize), read through `sorted`.
 template <int S, bool FIRST>
-__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* __restrict__ out, const u32* __restrict__ in,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* __restrict__ out, size_t out_stride, LevelInputs ins,
+                                                           unsigned blocks_per_array,
                                                            const u32* __restrict__ sorted, const u32* __restrict__ off_in,
                                                            const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
                                                            size_t nbuckets, size_t total_out, u32 F, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned arr = blockIdx.x / blocks_per_array;          // (wave-uniform)
+    const u32* __restrict__ in = ins.p[arr];
+    out += (size_t)arr * out_stride;
+    size_t t = (size_t)(blockIdx.x % blocks_per_array) * BLOCK + threadIdx.x;
     if (t >= total_out) return;
     size_t lo = 0, hi = nbuckets;
     while (hi - lo > 1) {

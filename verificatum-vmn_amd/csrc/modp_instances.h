@@ -37,12 +37,12 @@
     KW __global__ void vmn::k_fixed_level<vmn::Cfg<S_, LPE_>>(vmn::u32*, int, int, int, const vmn::u32*, vmn::u32);                      \
     KW __global__ void vmn::k_fixed_exp<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, int, int, const vmn::u32*, int, size_t, int,     \
                                                             const vmn::u32*, vmn::u32);                                                  \
-    KW __global__ void vmn::k_bucket_level<vmn::Cfg<S_, LPE_>, true>(vmn::u32*, const vmn::u32*, const vmn::u32*, const vmn::u32*,       \
-                                                                     const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32,         \
-                                                                     const vmn::u32*, vmn::u32);                                         \
-    KW __global__ void vmn::k_bucket_level<vmn::Cfg<S_, LPE_>, false>(vmn::u32*, const vmn::u32*, const vmn::u32*, const vmn::u32*,      \
-                                                                      const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32,        \
-                                                                      const vmn::u32*, vmn::u32);
+    KW __global__ void vmn::k_bucket_level<vmn::Cfg<S_, LPE_>, true>(vmn::u32*, size_t, vmn::LevelInputs, unsigned, const vmn::u32*,     \
+                                                                     const vmn::u32*, const vmn::u32*, const vmn::u32*, size_t, size_t, \
+                                                                     vmn::u32, const vmn::u32*, vmn::u32);                               \
+    KW __global__ void vmn::k_bucket_level<vmn::Cfg<S_, LPE_>, false>(vmn::u32*, size_t, vmn::LevelInputs, unsigned, const vmn::u32*,    \
+                                                                      const vmn::u32*, const vmn::u32*, const vmn::u32*, size_t, size_t, \
+                                                                      vmn::u32, const vmn::u32*, vmn::u32);
 
 // subgroup membership: one element per lane (LPE = 1) or the element's own lanes (LPE > 1, base geometries only)
 #define VMN_MEMBER_INSTANCE_ONE_LANE(KW, S_, LPE_) \

@@ -996,9 +996,16 @@ k_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin, c
 // item, so a bucket of any size is spread over ceil(size/F) lanes: no lane ever walks a long bucket
 // (skewed digits -- a short top window, equal exponents -- would otherwise serialise on one lane).
 // FIRST: input items are rows of x selected through `sorted`; otherwise rows of `in`.
+// The arrays of one launch (a multi-exponentiation of k arrays under ONE exponent vector builds k trees of the same shape:
+// counts and offsets are shared, so one launch per level serves up to LEVEL_ARRAYS of them -- a seventh of the launches over
+// curves, and k times as many items in the thin upper levels).  Block b works for array b / blocks_per_array.
+constexpr int LEVEL_ARRAYS = 8;
+struct LevelInputs {
+    const u32* p[LEVEL_ARRAYS];
+};
 template <class C, bool FIRST>
 __global__ void __launch_bounds__(BLOCK, C::MINW)
-k_bucket_level(u32* __restrict__ out, const u32* __restrict__ in, const u32* __restrict__ sorted,
+k_bucket_level(u32* __restrict__ out, size_t out_stride, LevelInputs ins, unsigned blocks_per_array, const u32* __restrict__ sorted,
                const u32* __restrict__ off_in, const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
                size_t nbuckets, size_t total_out, u32 F, const u32* __restrict__ nmod, u32 n0inv) {
     constexpr int W = C::W;
@@ -1006,7 +1013,10 @@ k_bucket_level(u32* __restrict__ out, const u32* __restrict__ in, const u32* __r
     Lane<C> ln(lds);
     u32 nn[C::L];
     load_modulus<C>(nn, nmod, ln);
-    size_t t = (size_t)blockIdx.x * C::EPB + ln.eslot;
+    const unsigned arr = blockIdx.x / blocks_per_array;          // (wave-uniform)
+    const u32* __restrict__ in = ins.p[arr];
+    out += (size_t)arr * out_stride;
+    size_t t = (size_t)(blockIdx.x % blocks_per_array) * C::EPB + ln.eslot;
     bool live = t < total_out;
     size_t tc = live ? t : total_out - 1;
     // b = last bucket with off_out[b] <= tc  (empty buckets share their successor's offset)

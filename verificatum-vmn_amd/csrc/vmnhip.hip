@@ -3071,9 +3071,8 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     const uint32_t F = F_env ? F_env : 8;
     DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx);
     // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | per tree level l < LV: cnt_l[nb], off_l[nb+1] | bsum | misc.
-    // The shape of the product trees depends on the exponents only, so the per-level counts and offsets are computed
-    // for the FIRST array and kept: the other arrays of a multi-array call reuse them (four short launches per level and
-    // array less -- a tenth of a proof over curves).
+    // The shape of the product trees depends on the exponents only: the per-level counts and offsets are computed once,
+    // before any array goes through the levels (below).
     const int LV = 12;                               // fan-in 8: 8^12 items per bucket
     const size_t scan_blocks = (nbuckets + (size_t)BLOCK * SCAN_ITEMS - 1) / ((size_t)BLOCK * SCAN_ITEMS);
     VMN_TRY(meta.alloc(((3 + 2 * LV) * (nbuckets + 1) + scan_blocks + 16) * sizeof(uint32_t)));
@@ -3109,100 +3108,110 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
                          e_words, ewords, n, c, nwin, gx));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
-    // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item
-    std::vector<std::pair<uint32_t, uint32_t>> level_cache;      // (total items, max per bucket) per level, from the first array
+    // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item.  The SHAPE of the trees
+    // (items per bucket and level, offsets, totals) depends on the exponents only: it is computed first, once; then the
+    // arrays go through the levels in groups -- one launch per level for up to LEVEL_ARRAYS arrays (k_bucket_level).
+    std::vector<std::pair<uint32_t, uint32_t>> shape;             // (total items, max per bucket) per level
+    {
+        const uint32_t* cnt_in = counts;
+        for (int level = 0; level < LV; ++level) {
+            uint32_t hm2[2];
+            VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
+            VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_of(level), cnt_in, nbuckets, F, misc + 1));
+            VMN_TRY(scan_u32(off_of(level), (uint32_t*)nullptr, cnt_of(level)));
+            VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            VMN_HIP(hipStreamSynchronize(ctx->stream));
+            shape.emplace_back(hm2[0], hm2[1]);
+            cnt_in = cnt_of(level);
+            if (hm2[1] <= 1) break;
+            if (level + 1 == LV) {
+                set_error("multi-exponentiation: a bucket holds more than %u^%d items", F, LV);
+                return VMN_ERR_UNSUPPORTED;
+            }
+        }
+    }
     DevTmp normalised(ctx);                              // curves: the k arrays with Z = 1, so that the first level's additions are mixed
     if (m.ec) {
         VMN_TRY(normalised.alloc(k * n * Wd * sizeof(uint32_t)));
         VMN_TRY(ec_normalize(ctx, m, xs, k, n, normalised.as<uint32_t>()));
     }
-    for (size_t arr = 0; arr < k; ++arr) {
-    const uint32_t* x = m.ec ? normalised.as<uint32_t>() + arr * n * Wd : xs[arr];
-    const uint32_t* cnt_in = counts;
-    const uint32_t* off_in = off0;
-    const uint32_t* items_in = x;
-    bool first = true;
-    size_t cap = (size_t)nwin * n / F + nbuckets + 1;        // items of level 1 (later levels are smaller)
-    if (!itemsA.p) VMN_TRY(itemsA.alloc(cap * Wd * sizeof(uint32_t)));
-    uint32_t* items_out = itemsA.as<uint32_t>();
-    uint32_t* items_other = itemsB.p ? itemsB.as<uint32_t>() : nullptr;
-    int rc = VMN_ERR_ARG;
-    for (int level = 0; level < LV; ++level) {
-        uint32_t* cnt_out = cnt_of(level);
-        uint32_t* off_out = off_of(level);
-        uint32_t hm2[2];
-        if ((size_t)level < level_cache.size()) {            // same exponents => same tree shape: counts, offsets and totals are there
-            hm2[0] = level_cache[level].first;
-            hm2[1] = level_cache[level].second;
-        } else {
-            VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
-            VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_out, cnt_in, nbuckets, F, misc + 1));
-            VMN_TRY(scan_u32(off_out, (uint32_t*)nullptr, cnt_out));
-            VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            VMN_HIP(hipStreamSynchronize(ctx->stream));
-            level_cache.emplace_back(hm2[0], hm2[1]);
-        }
-        const size_t total_out = hm2[0];
-        const double level_in = level == 0 ? (double)nwin * (double)n : (double)level_cache[level - 1].first;
-        const double level_products = std::max(0.0, level_in - (double)total_out);
-        if (total_out > 0 && m.ec) {
-            rc = VMN_ERR_ARG;
+    // arrays per launch: as many as the aggregation group holds, the kernel takes and the level buffers allow (24 GB)
+    const size_t cap0 = (size_t)shape[0].first + 1, cap1 = shape.size() > 1 ? (size_t)shape[1].first + 1 : 1;
+    const size_t row_bytes = Wd * sizeof(uint32_t);
+    const size_t by_mem = std::max<size_t>(1, ((size_t)24 << 30) / ((cap0 + cap1) * row_bytes));
+    const size_t GL = std::max<size_t>(1, std::min<size_t>({G, (size_t)LEVEL_ARRAYS, by_mem}));
+    VMN_TRY(itemsA.alloc(GL * cap0 * row_bytes));
+    VMN_TRY(itemsB.alloc(GL * cap1 * row_bytes));
+    for (size_t arr0 = 0; arr0 < k; arr0 += GL) {
+        const size_t gl = std::min(GL, k - arr0);
+        const uint32_t* cnt_in = counts;
+        const uint32_t* off_in = off0;
+        LevelInputs ins{};
+        for (size_t a = 0; a < gl; ++a) ins.p[a] = m.ec ? normalised.as<uint32_t>() + (arr0 + a) * n * Wd : xs[arr0 + a];
+        uint32_t* items_out = itemsA.as<uint32_t>();
+        uint32_t* items_other = itemsB.as<uint32_t>();
+        size_t out_cap = cap0, other_cap = cap1;
+        bool first = true;
+        int rc = VMN_OK;
+        for (size_t level = 0; level < shape.size(); ++level) {
+            const size_t total_out = shape[level].first;
+            const double level_in = level == 0 ? (double)nwin * (double)n : (double)shape[level - 1].first;
+            const double level_products = std::max(0.0, level_in - (double)total_out) * (double)gl;
+            const size_t out_stride = out_cap * Wd;
+            if (total_out > 0 && m.ec) {
+                rc = VMN_ERR_ARG;
+                const unsigned bpa = grid_for(total_out);
 #define X(S_, NW_)                                                                                                     \
     if (m.ec->S == S_) {                                                                                               \
-        rc = note_work(ctx, m, (first ? EC_MADD : EC_ADD) * level_products) ? 0 : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, grid_for(total_out), items_out, items_in, \
-                                  (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out,    \
+        rc = note_work(ctx, m, (first ? EC_MADD : EC_ADD) * level_products) ? 0 : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, bpa * (unsigned)gl, items_out, out_stride, ins, bpa, \
+                                  (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_of((int)level),    \
                                   nbuckets, total_out, F, ecdev(m.ec))                                                 \
-                   : launch_light(ctx, "expprod", k_ec_bucket_level<S_, false>, grid_for(total_out), items_out,        \
-                                  items_in, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_out,        \
+                   : launch_light(ctx, "expprod", k_ec_bucket_level<S_, false>, bpa * (unsigned)gl, items_out, out_stride, ins, bpa,        \
+                                  (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_of((int)level),        \
                                   nbuckets, total_out, F, ecdev(m.ec));                                                \
     }
-            VMN_FOR_CURVES(X)
+                VMN_FOR_CURVES(X)
 #undef X
-            VMN_TRY(rc);
-        } else if (total_out > 0) {
-            rc = VMN_ERR_ARG;
+                VMN_TRY(rc);
+            } else if (total_out > 0) {
+                rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                      \
     if (m.S == S_) {                                                                                                    \
-        rc = note_work(ctx, m, level_products) ? 0 : first ? launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, true>, egrid(m, total_out), lds_bytes(m), items_out,    \
-                            items_in, (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_out, \
+        const unsigned bpa = egrid(m, total_out);                                                                       \
+        rc = note_work(ctx, m, level_products) ? 0 : first ? launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, true>, bpa * (unsigned)gl, lds_bytes(m), items_out, out_stride,    \
+                            ins, bpa, (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_of((int)level), \
                             nbuckets, total_out, F, m.d_n, m.n0inv)                                                     \
-                   : launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, false>, egrid(m, total_out), lds_bytes(m), items_out,   \
-                            items_in, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_out, nbuckets,     \
+                   : launch(ctx, "expprod", k_bucket_level<Cfg<S_, LPE_>, false>, bpa * (unsigned)gl, lds_bytes(m), items_out, out_stride,   \
+                            ins, bpa, (const uint32_t*)nullptr, off_in, cnt_in, (const uint32_t*)off_of((int)level), nbuckets,     \
                             total_out, F, m.d_n, m.n0inv);                                                              \
     }
-            VMN_DISPATCH(total_out, X)
+                VMN_DISPATCH(total_out * gl, X)
 #undef X
-            VMN_TRY(rc);
+                VMN_TRY(rc);
+            }
+            // the outputs become the next level's inputs
+            first = false;
+            for (size_t a = 0; a < gl; ++a) ins.p[a] = items_out + a * out_stride;
+            cnt_in = cnt_of((int)level);
+            off_in = off_of((int)level);
+            std::swap(items_out, items_other);
+            std::swap(out_cap, other_cap);
         }
-        // the outputs become the next level's inputs
-        first = false;
-        items_in = items_out;
-        cnt_in = cnt_out;
-        off_in = off_out;
-        if (hm2[1] <= 1) break;
-        if (!items_other) {
-            size_t cap2 = total_out / F + nbuckets + 1;
-            VMN_TRY(itemsB.alloc(cap2 * Wd * sizeof(uint32_t)));
-            items_other = itemsB.as<uint32_t>();
+        for (size_t a = 0; a < gl; ++a) {
+            const size_t arr = arr0 + a;
+            uint32_t* B = Ball + (arr % G) * nbuckets * Wd;
+            VMN_TRY(launch_light(ctx, "expprod_agg", k_bucket_finalize, light_grid(ctx, nbuckets * (Wd / 4)),
+                                 reinterpret_cast<uint4*>(B), reinterpret_cast<const uint4*>(ins.p[a]), off_in, cnt_in,
+                                 nbuckets, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
+            if (arr % G == G - 1 || arr + 1 == k) {
+                // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce -- for the group
+                const size_t gsz = arr % G + 1, first_arr = arr + 1 - gsz, segs = gsz * (size_t)nwin;
+                VMN_TRY(scan_affine(ctx, m, Ball, nullptr, segs * nb, nb, 1, Ssuf));
+                VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for(segs * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
+                                     nb, segs, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
+                VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, segs, true, wres.as<uint32_t>() + first_arr * (size_t)nwin * Wd));
+            }
         }
-        std::swap(items_out, items_other);
-        if (level + 1 == LV) {
-            set_error("multi-exponentiation: a bucket holds more than 8^%d items", LV);
-            return VMN_ERR_UNSUPPORTED;
-        }
-    }
-    uint32_t* B = Ball + (arr % G) * nbuckets * Wd;
-    VMN_TRY(launch_light(ctx, "expprod_agg", k_bucket_finalize, light_grid(ctx, nbuckets * (Wd / 4)),
-                         reinterpret_cast<uint4*>(B), reinterpret_cast<const uint4*>(items_in), off_in, cnt_in,
-                         nbuckets, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
-    if (arr % G == G - 1 || arr + 1 == k) {
-        // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce -- for the group
-        const size_t gsz = arr % G + 1, first_arr = arr + 1 - gsz, segs = gsz * (size_t)nwin;
-        VMN_TRY(scan_affine(ctx, m, Ball, nullptr, segs * nb, nb, 1, Ssuf));
-        VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for(segs * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
-                             nb, segs, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
-        VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, segs, true, wres.as<uint32_t>() + first_arr * (size_t)nwin * Wd));
-    }
     }
     // Horner over the windows, once for all k arrays: the chain of c * nwin doublings / squarings is sequential
     // (one lane per array on the GPU for curves; on the host for modular groups), so it is done for the k arrays
