@@ -461,3 +461,30 @@ def test_simultaneous_power_and_array_inverse(bits, groups, oracle_for):
         got = X.exp2(e, Y, G.ringArray(f), fbits).toInts()
         want = orc.mul(orc.exp_scalar(xs, e), orc.exp_array(ys, f))
         assert got == want, (e.bit_length(), fbits)
+
+
+@pytest.mark.parametrize("bits", [2048, 3072, 4096])
+def test_one_exponent_for_the_whole_array_sliding_window(bits, vmn, gpu_ctx, oracle_for, monkeypatch):
+    """K1b (csrc/modp_shared_exp.h): X.exp(e) with ONE exponent walks a host-made sliding-window schedule.  Exponents that
+    stress the schedule -- a single window, powers of two (trailing zeros only), all ones, alternating runs, the group order
+    minus one, a full-length secret like a decryption share -- in the base and the wide geometries, against GMP and against
+    the fixed-window kernel (VMN_SLIDING_WINDOW=0)."""
+    p, q, g = pyref.modp_group(bits)
+    orc = oracle_for(p, q)
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    n = 300
+    xs = [pow(1 + v % (p - 1), 2, p) for v in pyref.stream_ints(b"slide/x%d" % bits, n, p)]
+    xs[0], xs[1] = 1, p - 1
+    X = G.toElementArray(xs, checked=False)
+    full = pyref.stream_ints(b"slide/e%d" % bits, 1, q)[0] | (1 << (q.bit_length() - 2))
+    exps = [1 << 33, (1 << 33) + 1, 1 << 200, (1 << 127) - 1, (1 << 129) - 1, int("10" * 150, 2), int("1100" * 90, 2) << 7,
+            q - 1, q - 2, full, (1 << (bits - 2)) + 1]
+    for e in exps:
+        want = orc.exp_scalar(xs, e)
+        assert X.exp(e).toInts() == want, hex(e)[:20]
+    monkeypatch.setenv("VMN_SLIDING_WINDOW", "0")
+    # (the knob is read per call) the fixed-window kernel gives the same array
+    assert X.exp(full).toInts() == orc.exp_scalar(xs, full)
+    monkeypatch.delenv("VMN_SLIDING_WINDOW")
+    small = G.toElementArray(xs[:7], checked=False)            # a handful of elements: the widest geometry
+    assert small.exp(full).toInts() == orc.exp_scalar(xs[:7], full)

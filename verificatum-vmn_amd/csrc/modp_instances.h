@@ -7,6 +7,7 @@
 // object of the unit that instantiated it; nothing calls across units on the device.
 #pragma once
 #include "modp_kernels.h"
+#include "modp_shared_exp.h"
 
 // KW = `extern template` (declaration) or `template` (definition)
 #define VMN_MODP_INSTANCES(KW, S_, NW_, LPE_)                                                                                          \
@@ -22,6 +23,8 @@
     KW __global__ void vmn::k_modpow2<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, const vmn::u32*,  \
                                                           const vmn::u32*, int, size_t, int, int, size_t, const vmn::u32*, vmn::u32,      \
                                                           const vmn::u32*, vmn::u32*);                                                  \
+    KW __global__ void vmn::k_modpow_shared<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::SlideStep*, int, int, size_t,      \
+                                                                const vmn::u32*, vmn::u32, vmn::u32*);                                  \
     KW __global__ void vmn::k_reduce_strided<vmn::Cfg<S_, LPE_>, true>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t,               \
                                                                        const vmn::u32*, vmn::u32);                                       \
     KW __global__ void vmn::k_reduce_strided<vmn::Cfg<S_, LPE_>, false>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t,              \

@@ -1260,6 +1260,68 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x, 
     return rc;
 }
 
+// out[i] = x[i]^e for ONE exponent: left-to-right sliding window (csrc/modp_shared_exp.h).  Modular groups, exponents of
+// 33 bits and more (shorter ones, zero included, take the fixed-window kernel).
+static int sliding_window_bits(int ebits) {
+    if (const char* env = getenv("VMN_SLIDING_WINDOW")) {          // measurement knob; 0 = use the fixed window
+        int w = atoi(env);
+        if (w >= 0 && w <= 8) return w;
+    }
+    int best = 2;
+    long best_cost = 1L << 60;
+    for (int w = 2; w <= 8; ++w) {
+        long cost = (1L << (w - 1)) + ebits / (w + 1);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = w;
+        }
+    }
+    return best;
+}
+static int modpow_shared(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x, const Big& e, int ebits, size_t n, uint32_t* out) {
+    const int w = sliding_window_bits(ebits);
+    std::vector<SlideStep> steps;
+    int pending = 0;
+    long mults = 0, squarings = 0;
+    for (int i = ebits - 1; i >= 0;) {
+        if (!hostbig::get_bit(e, i)) {
+            ++pending;
+            --i;
+            continue;
+        }
+        int l = std::max(i - w + 1, 0);
+        while (!hostbig::get_bit(e, l)) ++l;                      // the window ends in a one: its value is odd
+        uint32_t val = 0;
+        for (int b = i; b >= l; --b) val = (val << 1) | (uint32_t)hostbig::get_bit(e, b);
+        steps.push_back(SlideStep{steps.empty() ? 0 : pending + (i - l + 1), (int)((val - 1) / 2)});
+        pending = 0;
+        i = l - 1;
+    }
+    if (pending) steps.push_back(SlideStep{pending, -1});
+    for (size_t k = 1; k < steps.size(); ++k) {
+        squarings += steps[k].sq;
+        mults += steps[k].idx >= 0 ? 1 : 0;
+    }
+    const int tsize = 1 << (w - 1);
+    const vmn_modulus& m = geom(ctx, m0, n);
+    const unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+    const unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
+    const size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * (size_t)tsize * elem_words(m) * sizeof(uint32_t);
+    VMN_TRY(ensure_scratch(ctx, tab_bytes));
+    DevTmp dsteps(ctx);
+    VMN_TRY(dsteps.alloc(steps.size() * sizeof(SlideStep)));
+    VMN_TRY(h2d(ctx, dsteps.p, steps.data(), steps.size() * sizeof(SlideStep)));
+    note_work(ctx, m, (double)n * (double)(mults + tsize - 1), (double)n * (double)(squarings + 1));
+    int rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                                 \
+    if (m.S == S_)                                                                                                 \
+        rc = launch(ctx, "modpow", k_modpow_shared<Cfg<S_, LPE_>>, grid, lds_bytes(m), out, x, (const SlideStep*)dsteps.as<SlideStep>(), \
+                    (int)steps.size(), tsize, n, m.d_n, m.n0inv, reinterpret_cast<uint32_t*>(ctx->scratch));
+    VMN_FOR_SIZES(X)
+#undef X
+    return rc;
+}
+
 // big-endian integers (ebytes each) -> packed little-endian words on the host
 static void be_ints_to_words(const uint8_t* be, size_t ebytes, size_t n, int ewords, std::vector<uint32_t>& out) {
     out.assign(n * (size_t)ewords, 0);
@@ -1499,7 +1561,10 @@ extern "C" int vmn_garray_exp_scalar(const vmn_garray* x, const uint8_t* e_be, s
     if (rc == VMN_OK) {
         rc = h2d(ctx, ew.p, e.data(), ewords * sizeof(uint32_t));
     }
-    if (rc == VMN_OK) rc = modpow_words(ctx, g->P, x->d, ew.as<uint32_t>(), ewords, 0, ebits, x->n, r->d);
+    if (rc == VMN_OK && !g->P.ec && ebits > 32 && x->n > 0 && sliding_window_bits(ebits) > 0)
+        rc = modpow_shared(ctx, g->P, x->d, e, ebits, x->n, r->d);                 // one exponent for all: sliding window
+    else if (rc == VMN_OK)
+        rc = modpow_words(ctx, g->P, x->d, ew.as<uint32_t>(), ewords, 0, ebits, x->n, r->d);
     if (rc != VMN_OK) {
         vmn_garray_free(r);
         return rc;
