@@ -60,6 +60,8 @@ def same_msg(a, b):
 @pytest.mark.parametrize("bits,n,width,nbits", [(512, 70, 1, (100, 100, 50)), (512, 33, 2, (100, 100, 50)),
                                                 (2048, 130, 1, (256, 256, 100)), (4096, 12, 1, (256, 256, 100))])
 def test_pos_transcript_matches_oracle(bits, n, width, nbits, vmn, gpu_ctx, mods, hv):
+    if hv is mods["hvzk"] and bits > 2048:
+        pytest.skip("the Python mirror of the drivers runs the 512- and 2048-bit shapes; the C++ drivers (the product) run every size")
     NV, NE, NR = nbits
     p, q, g, h, pkey, w, t = make_instance(bits, n, width, b"pos%d" % bits)
     pi = t.permutation(n)
