@@ -1092,6 +1092,10 @@ def self_launch(args) -> int:
     if have < args.gpus and "VMN_BENCH_BACKEND" not in env:
         print(f"bench.py: {have} GPU(s) visible for {args.gpus} ranks -- rehearsal: ranks share GPUs, collectives over gloo", file=sys.stderr)
         env["VMN_BENCH_BACKEND"] = "gloo"
+    if have and have < args.gpus:                   # ranks that share a GPU share its memory: each caches a share of the usual bounds
+        share = -(-args.gpus // have)
+        env.setdefault("VMN_POOL_LIMIT_BYTES", str((64 << 30) // share))
+        env.setdefault("VMN_FIXED_CACHE_BYTES", str((64 << 30) // share))
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -1175,22 +1179,37 @@ def main() -> None:
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        limit = datetime.timedelta(minutes=5)     # a rank that dies inside a leg must not hold the others for RCCL's default 10 min
+        limit = datetime.timedelta(seconds=150)   # a rank that dies inside a leg must not hold the others for RCCL's default 10 min
         with _stdout_to_stderr():
             if backend == "nccl":
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
                 try:
+                    # a first all-reduce on the device proves the RCCL path before anything depends on it
+                    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=limit)
+                    probe = torch.ones(1, device=torch.device("cuda", dev_index))
+                    dist.all_reduce(probe)
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != world:
+                        raise RuntimeError(f"RCCL all-reduce probe returned {probe.item()} for {world} ranks")
                     gloo_group = dist.new_group(backend="gloo")      # safety net of parallel.Comm (never used unless RCCL raises)
                     dist.barrier(group=gloo_group)                   # connect now, while stdout is diverted
-                except Exception as exc:      # pragma: no cover
-                    gloo_group = None
-                    print(f"bench.py: no gloo fallback group ({exc})", file=sys.stderr)
+                except Exception as exc:      # pragma: no cover - needs a broken RCCL
+                    nccl_failure = f"{type(exc).__name__}: {exc}"[:300]
+                    print(f"bench.py: RCCL could not be brought up ({nccl_failure}); the run continues over gloo and says so", file=sys.stderr)
+                    try:
+                        if dist.is_initialized():
+                            dist.destroy_process_group()
+                    except Exception:
+                        pass
+                    backend = "gloo (RCCL failed: " + nccl_failure + ")"
+                    dist.init_process_group(backend="gloo", timeout=limit)
+                    dist.barrier()
             else:
                 dist.init_process_group(backend=backend, timeout=limit)
                 dist.barrier()
     red_device = "cuda" if backend == "nccl" else "cpu"
     comm = load_sub(entry, "parallel").Comm(dist if distributed else None, torch.device("cuda", dev_index) if (distributed and backend == "nccl") else None,
                                             fallback=gloo_group)
+    sharded_leg_failed = []                       # (leg, error) of the first sharded leg that raised on THIS rank
 
     p, q, g = load_sub(entry, "stdgroups").modp_group(2048)      # RFC 3526 group 14
     nbytes = 256
@@ -1308,12 +1327,21 @@ def main() -> None:
 
     # The legs below are extra objects of the line; a failure in one of them must not cost the headline value.
     def guarded(name, fn):
+        # Sharded legs: every rank makes the same calls, so an error raised on one rank leaves the others waiting in the next
+        # exchange until the group's timeout -- after which THEY raise in the same leg.  Every rank therefore sees a failure
+        # in that leg (its own error or the timeout), and all of them skip the remaining sharded legs instead of blocking
+        # once more (seen in a three-ranks-on-one-GPU rehearsal: one rank ran out of memory for a table).
+        if distributed and sharded_leg_failed:
+            result[name] = {"error": f"skipped: the sharded leg {sharded_leg_failed[0][0]} failed on a rank ({sharded_leg_failed[0][1]})"}
+            return
         try:
             fn()
         except Exception as exc:                       # pragma: no cover - reported in the line
             import traceback
             traceback.print_exc(file=sys.stderr)
             result[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            if distributed:
+                sharded_leg_failed.append((name, f"{type(exc).__name__}: {exc}"[:200]))
 
     def leg_mix_prove():
         X.free()

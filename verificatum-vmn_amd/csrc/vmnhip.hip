@@ -247,7 +247,12 @@ static int ensure_scratch(vmn_ctx* ctx, size_t bytes) {
 }
 
 // ---- stream-ordered caching allocator ------------------------------------------------------------
-static const size_t POOL_LIMIT = (size_t)96 << 30;      // keep at most 96 GB of freed blocks cached
+// keep at most 96 GB of freed blocks cached (env VMN_POOL_LIMIT_BYTES: several processes sharing one GPU -- a rehearsal of a
+// multi-GPU run on one device -- must shrink it, each of them caches on its own)
+static const size_t POOL_LIMIT = [] {
+    const char* env = getenv("VMN_POOL_LIMIT_BYTES");
+    return env && *env ? (size_t)strtoull(env, nullptr, 10) : (size_t)96 << 30;
+}();
 
 static size_t block_class_of(vmn_ctx* ctx, const void* p, size_t fallback, bool forget);
 static void pool_release_all(vmn_ctx* ctx) {
@@ -2798,6 +2803,13 @@ static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
         (void)hipGetLastError();
         if (g->fixed.empty()) {
             if (over && hipMalloc(reinterpret_cast<void**>(out), bytes) == hipSuccess) return VMN_OK;   // one table larger than the bound
+            (void)hipGetLastError();
+            for (vmn_ctx* c : {g->ctx, g->ctx->helper}) {                     // the cached array blocks go before the call fails
+                if (!c) continue;
+                std::lock_guard<std::recursive_mutex> guard__(c->mu);
+                pool_release_all(c);
+            }
+            if (hipMalloc(reinterpret_cast<void**>(out), bytes) == hipSuccess) return VMN_OK;
             (void)hipGetLastError();
             set_error("fixed-base table allocation of %zu bytes failed", bytes);
             return VMN_ERR_NOMEM;
