@@ -166,7 +166,9 @@ def test_config0_size_10000_ciphertexts_2048bit(vmn, gpu_ctx, mods, oracle_for):
     grp, _ = load_golden(2048)
     p, q, g = grp["p"], grp["q"], grp["g"]
     G = vmn.ModPGroup(gpu_ctx, p, q, g)
-    K = GmpAdapter(oracle_for(p, q))
+    # (fixed-base exponentiations through the oracle's precomputed tables, what VCR + GMPMEE's fpowm do: the same values as
+    # mpz_powm per element -- tests/test_proofs_oracle.py pins the two against each other -- in a fifth of the time)
+    K = GmpAdapter(oracle_for(p, q), pippenger_c=10, fixed_tables=True)
     n = 10_000
     h, pkey, w, t = make_instance(K, g, n, 1, b"cfg0")
     check_pos("native", mods, G, K, g, h, pkey, w, t, (256, 256, 100))

@@ -160,7 +160,7 @@ def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, curve_name,
     K = P.ECAdapter(c)
     G = vmn.ECqPGroup(gpu_ctx, curve_name)
     NV, NE, NR = 128, 128, 64
-    n, width = 40, 1
+    n, width = sz(c, 40), 1
     t = Tape(b"ecgpu", c.n)
     g = c.g
     h = [c.mul(x, g) for x in t.ring_array(n)]
