@@ -105,11 +105,35 @@ __global__ void __launch_bounds__(BLOCK) k_fixed_seed(u32* __restrict__ T, const
 // counts[win][d] += 1 for every element; one thread per (element, window).
 // (grid = gx blocks per window: the window of a block is blockIdx.x / gx -- one scalar division per block instead of two
 // 64-bit divisions per item, which were most of this kernel's instructions)
+// A NARROW window -- the top one when c does not divide the exponent length: 1 bit at c = 15 for 256-bit exponents, all 10^6
+// elements on two counters -- is counted in LDS first and reaches the global counters once per block and digit
+// (NARROW_BITS; with global atomics alone that one window took longer than all the others together).
+constexpr int NARROW_BITS = 11;
+__device__ __forceinline__ int window_bits(int w, int c, int ebits) {
+    const int left = ebits - w * c;
+    return left < c ? (left < 1 ? 1 : left) : c;
+}
 __global__ void __launch_bounds__(BLOCK) k_bucket_hist(u32* __restrict__ counts, const u32* __restrict__ e, int ewords,
-                                                       size_t n, int c, int nwin, u32 gx) {
+                                                       size_t n, int c, int nwin, u32 gx, int ebits) {
+    __shared__ u32 h[1 << NARROW_BITS];
     const u32 w = blockIdx.x / gx, bx = blockIdx.x % gx;
     if ((int)w >= nwin) return;
     u32* __restrict__ cw = counts + ((size_t)w << c);
+    const int bw = window_bits((int)w, c, ebits);
+    if (bw <= NARROW_BITS) {
+        const u32 nd = 1u << bw;
+        for (u32 k = threadIdx.x; k < nd; k += BLOCK) h[k] = 0;
+        __syncthreads();
+        for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
+            u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
+            if (d < nd) atomicAdd(&h[d], 1u);
+            else atomicAdd(&cw[d], 1u);                // (an exponent wider than the caller declared: still its own bucket)
+        }
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < nd; k += BLOCK)
+            if (h[k]) atomicAdd(&cw[k], h[k]);
+        return;
+    }
     for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
         u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
         atomicAdd(&cw[d], 1u);
@@ -175,12 +199,39 @@ __global__ void __launch_bounds__(BLOCK) k_u32_scan_apply(u32* __restrict__ out,
     }
 }
 
-// sorted[cursor[bucket]++] = element index; one thread per (element, window); bucket = w*2^c + digit
+// sorted[cursor[bucket]++] = element index; one thread per (element, window); bucket = w*2^c + digit.  A narrow window (see
+// k_bucket_hist) is placed in two passes over the block's items: count in LDS, reserve one range per digit with a single
+// global atomic, then hand out the positions inside the ranges with LDS atomics.
 __global__ void __launch_bounds__(BLOCK) k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ cursor,
-                                                          const u32* __restrict__ e, int ewords, size_t n, int c, int nwin, u32 gx) {
+                                                          const u32* __restrict__ e, int ewords, size_t n, int c, int nwin, u32 gx,
+                                                          int ebits) {
+    __shared__ u32 h[1 << NARROW_BITS];
+    __shared__ u32 base[1 << NARROW_BITS];
     const u32 w = blockIdx.x / gx, bx = blockIdx.x % gx;
     if ((int)w >= nwin) return;
     u32* __restrict__ cw = cursor + ((size_t)w << c);
+    const int bw = window_bits((int)w, c, ebits);
+    if (bw <= NARROW_BITS) {
+        const u32 nd = 1u << bw;
+        for (u32 k = threadIdx.x; k < nd; k += BLOCK) h[k] = 0;
+        __syncthreads();
+        for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
+            u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
+            if (d < nd) atomicAdd(&h[d], 1u);
+        }
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < nd; k += BLOCK) {
+            base[k] = h[k] ? atomicAdd(&cw[k], h[k]) : 0u;
+            h[k] = 0;
+        }
+        __syncthreads();
+        for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
+            u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
+            u32 pos = d < nd ? base[d] + atomicAdd(&h[d], 1u) : atomicAdd(&cw[d], 1u);
+            sorted[pos] = (u32)i;
+        }
+        return;
+    }
     for (size_t i = (size_t)bx * BLOCK + threadIdx.x; i < n; i += (size_t)gx * BLOCK) {
         u32 d = exp_digit(e + i * ewords, ewords, (int)w * c, c);
         u32 pos = atomicAdd(&cw[d], 1u);

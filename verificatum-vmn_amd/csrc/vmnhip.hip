@@ -3095,10 +3095,12 @@ static double bucket_agg_weight() {
     const char* env = getenv("VMN_BUCKET_AGG_WEIGHT");           // tuning knob
     return env && *env ? atof(env) : 3.0;
 }
-static int pick_bucket_bits(size_t n, int ebits) {
+static int pick_bucket_bits(size_t n, int ebits, bool ec = false) {
     int best = 1;
     double best_cost = 1e300;
-    const double wagg = bucket_agg_weight();
+    // curves: a bucket of the aggregation (two full additions in low-occupancy scans) costs about eight insertions (mixed
+    // additions at full occupancy), measured: profiles/r03_bucket_weight_sweep.txt
+    const double wagg = getenv("VMN_BUCKET_AGG_WEIGHT") ? bucket_agg_weight() : ec ? 8.0 : 3.0;
     for (int c = 1; c <= 16; ++c) {
         int nwin = (ebits + c - 1) / c;
         double cost = (double)nwin * ((double)n + wagg * (double)((size_t)1 << c));
@@ -3134,7 +3136,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         return VMN_OK;
     }
     if (ebits < 1) ebits = 1;
-    const int c = pick_bucket_bits(n, ebits);
+    const int c = pick_bucket_bits(n, ebits, m.ec != nullptr);
     const int nwin = (ebits + c - 1) / c;
     const size_t nb = (size_t)1 << c;
     const size_t nbuckets = (size_t)nwin * nb;
@@ -3180,10 +3182,10 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     // counting sort of (window, digit)
     VMN_HIP(hipMemsetAsync(counts, 0, nbuckets * sizeof(uint32_t), ctx->stream));
     const unsigned gx = std::max<unsigned>(1, std::min<unsigned>((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)(ctx->num_cus * 8 / std::max(nwin, 1) + 1)));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx));
+    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx, ebits));
     VMN_TRY(scan_u32(off0, cursor, counts));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
-                         e_words, ewords, n, c, nwin, gx));
+                         e_words, ewords, n, c, nwin, gx, ebits));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
     // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item.  The SHAPE of the trees
     // (items per bucket and level, offsets, totals) depends on the exponents only: it is computed first, once; then the
