@@ -269,6 +269,21 @@ def main():
     else:                                      # "fake": CPU arrays; "hip-gloo": real kernels, all ranks share GPU 0
         dist.init_process_group("gloo")
     par = load_parallel()
+    if flow == "comm-fallback":
+        # parallel.Comm told to use a device path that cannot work here (no GPU in the CPU suite): the first exchange must fall
+        # back to the gloo group, say so, and keep returning the right blocks
+        c = par.Comm(dist, torch.device("cuda", 0), fallback=dist.group.WORLD)
+        got = c.all_gather_bytes(bytes([rank]) * 5)
+        again = c.all_gather_ints([rank + 7, 1 << 70], 16)
+        ok = (got == [bytes([k]) * 5 for k in range(world)] and again == [[k + 7, 1 << 70] for k in range(world)]
+              and c.fell_back is not None and c.backend_used == "gloo (fallback)" and c.max_over_ranks(float(rank)) == float(world - 1)
+              and c.all_true(True) and not c.all_true(rank != 0))
+        if rank == 0:
+            with open(out_path, "w") as f:
+                json.dump({"pass": bool(ok), "why": f"fell_back={c.fell_back!r} backend={c.backend_used}", "world": world, "exchanges": []}, f)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     comm = par.Comm(dist, device)
     ec = backend.endswith("-ec")
     native = backend.startswith("hip") and not mirror

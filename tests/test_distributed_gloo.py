@@ -65,6 +65,13 @@ def test_host_row_blocks_of_every_kind_are_sliced_alike(entry):
     assert par._take_rows(ints, idx, nb) == [ints[i] for i in idx]
 
 
+def test_comm_falls_back_to_gloo_when_the_device_path_raises(tmp_path):
+    """bench.py hands parallel.Comm a gloo group as a safety net for the never-yet-executed RCCL branch: when the device
+    all-gather raises, the communicator switches to it for good, records why, and the exchanges stay correct."""
+    res = run_world(2, "fake", 512, 4, 1, tmp_path, flow="comm-fallback")
+    assert res["pass"], res["why"]
+
+
 @pytest.mark.parametrize("world,n,width", [(2, 21, 1), (3, 10, 2)])
 def test_sharded_pos_matches_oracle_on_gloo(world, n, width, tmp_path):
     res = run_world(world, "fake", 512, n, width, tmp_path)
