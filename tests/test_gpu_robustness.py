@@ -226,3 +226,68 @@ def test_an_array_freed_by_the_helper_returns_to_the_lane_that_owns_it(vmn, gpu_
         assert got[:64] == want and got == first
         out.free()
     assert gpu_ctx.memory_stats()["live_bytes"] == live0        # the accounting of neither lane went negative / leaked
+
+
+def test_mutated_byte_trees_never_crash_the_parsers(vmn, gpu_ctx, mods):
+    """The byte trees of commitments, replies and arrays arrive from the bulletin board: whatever they hold, the readers must
+    answer "not a message" (None / ValueError) or hand back something the verifier then judges -- never fault, hang or read
+    past the buffer.  A few hundred seeded mutations of valid trees: truncations, flipped bytes, rewritten length fields
+    (also to huge values), swapped tags, appended garbage."""
+    import random
+    nat = mods["native"]
+    c = _pos_case(vmn, gpu_ctx, nat, n=20, seed=b"robust-fuzz")
+    G, rep, com, v, n = c["G"], c["rep"], c["com"], c["v"], 20
+    ver = c["verifier"]()
+    ver.setChallenge(v)
+    good_rep, good_com = rep.native.toByteTree(), com.native.toByteTree()
+    good_arr = com["B"].toByteTree()
+    rnd = random.Random(20261004)
+
+    def mutate(bt):
+        b = bytearray(bt)
+        kind = rnd.randrange(7)
+        if kind == 0:
+            return bytes(b[:rnd.randrange(len(b))])                           # truncated
+        if kind == 1:
+            for _ in range(rnd.randrange(1, 4)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)             # flipped bits
+            return bytes(b)
+        if kind == 2:                                                          # a length field rewritten
+            pos = rnd.choice([1, 6, 11] + [rnd.randrange(len(b) - 4)])
+            b[pos:pos + 4] = rnd.choice([bytes([255] * 4), bytes([127, 255, 255, 255]), bytes(4),
+                                         rnd.randrange(1 << 32).to_bytes(4, "big")])
+            return bytes(b)
+        if kind == 3:
+            b[rnd.choice([0, 5, 10])] ^= 1                                     # node <-> leaf tag
+            return bytes(b)
+        if kind == 4:
+            return bytes(b) + bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 40)))   # trailing garbage
+        if kind == 5:
+            i = rnd.randrange(len(b) - 8)
+            return bytes(b[:i] + b[i + rnd.randrange(1, 8):])                  # a few bytes cut out of the middle
+        return bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 64)))  # noise
+
+    accepted = parsed = 0
+    for _ in range(150):
+        m = ver.readReply(mutate(good_rep), n, 1)
+        if m is not None:
+            parsed += 1
+            accepted += bool(ver.verify(m))
+    assert accepted <= parsed                                                  # (a flip inside padding can leave a valid reply)
+    for _ in range(80):
+        m = ver.readCommitment(mutate(good_com), n, 1)
+        if m is not None:
+            try:
+                ver.setCommitment(m)
+            except vmn.VmnError as exc:
+                assert exc.status == -4                                        # not group elements: the caller's trivial-value path
+    for _ in range(80):
+        try:
+            a = G.toElementArrayFromByteTree(mutate(good_arr))
+            assert a.size() >= 0
+        except (ValueError, vmn.VmnError):
+            pass
+    # the verifier still works afterwards
+    ver2 = c["verifier"]()
+    ver2.setChallenge(v)
+    assert ver2.verify(ver2.readReply(good_rep, n, 1))
