@@ -207,6 +207,12 @@ int vmn_garray_inv(const vmn_garray* x, vmn_garray** out);
  * verifiers' check (B) of PoSBasicTW.java:1023-1042 in the form B_i^v (B_{i-1}^{-1})^{k_E,i} B'_i = g^{k_B,i}. */
 int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, const vmn_garray* y, const vmn_rarray* f, int fbits,
                     vmn_garray** out);
+/* out_x[i] = x[i]^e and out_y[i] = y[i]^f[i], the two powers of the same check in its separate form
+ * (PoSBasicTW.java:1028-1033: B.exp(v) and B_shift.exp(k_E)), as ONE launch when the arrays are too small to fill
+ * the device one after the other; otherwise (and over curves) exactly vmn_garray_exp_scalar + vmn_garray_exp_array.
+ * x and y may differ in length; f has y's. */
+int vmn_garray_exp_pair(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, const vmn_garray* y, const vmn_rarray* f, int fbits,
+                        vmn_garray** out_x, vmn_garray** out_y);
 /* K5  X.prod() -> one element.  ref: P/hvzk/PoSBasicTW.java:1013; P/hvzk/PoSCBasicTW.java:667. */
 int vmn_garray_prod(const vmn_garray* x, uint8_t* out_be);
 /* K6  X.equals(Y).  ref: P/hvzk/PoSBasicTW.java:1035; P/hvzk/PoSCBasicTW.java:697. */

@@ -463,6 +463,27 @@ def test_simultaneous_power_and_array_inverse(bits, groups, oracle_for):
         assert got == want, (e.bit_length(), fbits)
 
 
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
+def test_two_powers_in_one_launch(bits, groups, oracle_for):
+    """vmn_garray_exp_pair (k_modpow_jobs: x^e and y^f side by side in one grid) against the oracle: arrays of equal and of
+    different length (either job the longer one, ragged last tiles), e = 0 and 1, short and full-length exponents."""
+    G, grp, _ = groups[bits]
+    p, q = grp["p"], grp["q"]
+    orc = oracle_for(p, q)
+    xs, fs = _inputs(b"pair-%d" % bits, 150, p, q)
+    ys = [pow(x, 5, p) for x in xs[::-1]]
+    e256 = pyref.stream_ints(b"pair/e", 1, 1 << 256)[0]
+    for nx, ny, e, fbits in ((70, 70, e256, 613), (150, 3, e256, 613), (1, 150, e256, 40), (65, 129, 0, 613), (64, 64, 1, 1),
+                             (33, 90, q - 1, q.bit_length())):
+        f = [v % (1 << fbits) for v in fs[:ny]]
+        f[0] = 0
+        if ny > 1:
+            f[1] = (1 << (fbits - 1)) if fbits > 1 else 1
+        gx, gy = G.toElementArray(xs[:nx]).expPair(e, G.toElementArray(ys[:ny]), G.ringArray(f), fbits)
+        assert gx.toInts() == orc.exp_scalar(xs[:nx], e), (nx, ny, e.bit_length(), fbits)
+        assert gy.toInts() == orc.exp_array(ys[:ny], f), (nx, ny, e.bit_length(), fbits)
+
+
 @pytest.mark.parametrize("bits", [2048, 3072, 4096])
 def test_one_exponent_for_the_whole_array_sliding_window(bits, vmn, gpu_ctx, oracle_for, monkeypatch):
     """K1b (csrc/modp_shared_exp.h): X.exp(e) with ONE exponent walks a host-made sliding-window schedule.  Exponents that

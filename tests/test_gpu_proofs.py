@@ -492,8 +492,9 @@ def test_check_b_as_one_simultaneous_power_gives_the_same_verdicts(vmn, gpu_ctx,
              (tampered(com, "B", 3, 1, p), rep), (tampered(com, "Bp", 0, 5, p), rep),
              (tampered(com, "B", 11, 0, p), rep), (tampered(com, "B", n - 1, 0, p), rep)]       # the last two: a zero in B
     verdicts = {}
-    for mode in ("separate", "combined"):
+    for mode in ("separate", "paired", "combined"):                    # paired: both powers of the separate form in one launch
         monkeypatch.setenv("VMN_COMBINED_MIN", "1" if mode == "combined" else "1000000000")
+        monkeypatch.setenv("VMN_PAIR_MAX", "0" if mode == "separate" else "131072")
         out = []
         for c, rp in cases:
             ver = hv.PoSBasicTW(G, NV, NE, NR)
@@ -514,7 +515,7 @@ def test_check_b_as_one_simultaneous_power_gives_the_same_verdicts(vmn, gpu_ctx,
             ver.setChallenge(v)
             out.append((ver.verify(rp), None))
         verdicts[mode] = out
-    assert verdicts["separate"] == verdicts["combined"]
+    assert verdicts["separate"] == verdicts["combined"] == verdicts["paired"]
     assert verdicts["combined"][0] == (True, (True,) * 5) and verdicts["combined"][1] == (False, (True, False, True, True, True))
     assert [ok for ok, _ in verdicts["combined"][2:7]] == [False] * 5
     assert [ok for ok, _ in verdicts["combined"][7:]] == [True, False, False]

@@ -533,6 +533,14 @@ class PGroupElementArray(_ArrayBase):
         _check(lib().vmn_garray_exp2(self._h, int_to_be(e, nb), C.c_size_t(nb), y._h, f._h, C.c_int(fbits), C.byref(h)))
         return self._new(h)
 
+    def expPair(self, e: int, y: "PGroupElementArray", f: "PRingElementArray", fbits: int = 0):
+        """``vmn_garray_exp_pair``: (self[i]^e, y[i]^f[i]) -- two powers, one launch when the arrays are small."""
+        hx, hy = C.c_void_p(), C.c_void_p()
+        e = int(e)
+        nb = max(1, (e.bit_length() + 7) // 8)
+        _check(lib().vmn_garray_exp_pair(self._h, int_to_be(e, nb), C.c_size_t(nb), y._h, f._h, C.c_int(fbits), C.byref(hx), C.byref(hy)))
+        return self._new(hx), self._new(hy)
+
     # K1a / K1b
     def exp(self, e, ebits: int = 0) -> "PGroupElementArray":
         """``X.exp(PRingElementArray)`` (per-element exponents) or ``X.exp(int)`` (shared exponent)."""

@@ -1,4 +1,5 @@
-// modp_shared_exp.h — K1b with ONE exponent for the whole array: out[i] = x[i]^e.
+// modp_shared_exp.h — variants of K1 beside k_modpow: ONE exponent for the whole array (out[i] = x[i]^e, sliding window),
+// and two independent exponentiations of small arrays in one launch (k_modpow_jobs, at the end).
 //
 // The reference raises whole arrays to a single exponent in the decryption half of the mix-net -- the decryption factors
 // f = u^(-x_j / c), a full-length secret exponent per party (elgamal/DistrElGamalSession.java:365-385) -- and in the
@@ -68,6 +69,72 @@ k_modpow_shared(u32* __restrict__ out, const u32* __restrict__ x, const SlideSte
         canonicalize<C>(a, nn, ln);
         if (live) store_elem<C>(out + el * W, a, ln);
     }
+}
+
+// Two independent exponentiations in ONE launch (small arrays): job 0 = out0[i] = x0[i]^e0 (one exponent for all), job 1 =
+// out1[i] = x1[i]^e1[i] (per-element exponents).  A verifier's check (B) in its separate form needs B^v and B_shift^(k_E): at the
+// reference's demo size (10^4 ciphertexts) each of the two kernels alone leaves 40 % of the SIMDs without a wave, and they
+// used to run one after the other; as one grid (the first `tiles0` blocks work on job 0) they run side by side.  Fixed window
+// `wbits` for both, one tile per block, per-lane tables in `tab` (gridDim.x * EPB * 2^wbits rows).
+struct ModpowJob {
+    u32* out;
+    const u32* x;
+    const u32* e;
+    int ewords;
+    size_t estride;        // words between the exponents of consecutive elements; 0 = one shared exponent
+    int ebits;
+    size_t n;
+};
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_modpow_jobs(ModpowJob j0, ModpowJob j1, unsigned tiles0, int wbits, const u32* __restrict__ nmod, u32 n0inv,
+              const u32* __restrict__ one_m, u32* __restrict__ tab) {
+    constexpr int W = C::W;
+    extern __shared__ u32 lds[];
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const bool second = blockIdx.x >= tiles0;                        // (block-uniform)
+    const ModpowJob& J = second ? j1 : j0;
+    const size_t t = second ? blockIdx.x - tiles0 : blockIdx.x;
+    const int tsize = 1 << wbits;
+    u32* mytab = tab + ((size_t)blockIdx.x * C::EPB + ln.eslot) * (size_t)tsize * W;
+    const int nwin = (J.ebits + wbits - 1) / wbits;
+    size_t el = t * C::EPB + ln.eslot;
+    bool live = el < J.n;
+    size_t ec = live ? el : J.n - 1;
+    const u32* ep = J.e + ec * J.estride;
+    u32 a[C::L];
+    load_elem<C>(a, J.x + ec * W, ln);
+    {
+        u32 o[C::L];
+        load_modulus<C>(o, one_m, ln);
+        store_elem<C>(mytab, o, ln);
+    }
+    store_elem<C>(mytab + W, a, ln);
+    regs_to_lds<C>(ln, a);
+#pragma unroll 1
+    for (int k = 2; k < tsize; ++k) {
+        u32 r[C::L];
+        mont_mul<C>(r, a, ln, nn, n0inv);                            // x * tab[k-1]
+        store_elem<C>(mytab + (size_t)k * W, r, ln);
+        regs_to_lds<C>(ln, r);
+    }
+    u32 d = exp_digit(ep, J.ewords, (nwin - 1) * wbits, wbits);
+    load_elem<C>(a, mytab + (size_t)d * W, ln);
+#pragma unroll 1
+    for (int wi = nwin - 2; wi >= 0; --wi) {
+#pragma unroll 1
+        for (int s = 0; s < wbits; ++s) {
+            regs_to_lds<C>(ln, a);
+            mont_sqr<C>(a, a, ln, nn, n0inv);
+        }
+        d = exp_digit(ep, J.ewords, wi * wbits, wbits);
+        load_elem_to_lds<C>(ln, mytab + (size_t)d * W);
+        mont_mul<C>(a, a, ln, nn, n0inv);
+    }
+    canonicalize<C>(a, nn, ln);
+    if (live) store_elem<C>(J.out + el * W, a, ln);
 }
 
 }  // namespace vmn

@@ -1637,6 +1637,75 @@ extern "C" int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t 
     return VMN_OK;
 }
 
+// out_x[i] = x[i]^e and out_y[i] = y[i]^f[i] as ONE launch (k_modpow_jobs): the two powers of a verifier's check (B) in its
+// separate form, for arrays too small to fill the device alone.  The longer job's blocks come first in the grid, so that
+// they are placed on compute units of their own and the shorter job's blocks double up.  Curves, and arrays whose tiles
+// would not all be resident at once, take the two ordinary launches.
+extern "C" int vmn_garray_exp_pair(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, const vmn_garray* y, const vmn_rarray* f,
+                                   int fbits, vmn_garray** out_x, vmn_garray** out_y) {
+    ARG_CHECK(x && e_be && ebytes > 0 && y && f && out_x && out_y, "null argument");
+    ARG_CHECK(x->grp == y->grp && x->grp == f->grp && y->n == f->n, "arrays differ in group or size");
+    vmn_group* g = x->grp;
+    vmn_ctx* ctx = LANE(g->ctx);
+    {
+        VMN_ENTER(ctx);
+        if (fbits <= 0 || fbits > g->Q.nbits) fbits = g->Q.nbits;
+        const size_t nx = x->n, ny = y->n;
+        const vmn_modulus& m = geom(ctx, g->P, nx + ny);
+        const size_t tiles = (size_t)egrid(m, nx) + egrid(m, ny);
+        if (!g->P.ec && nx > 0 && ny > 0 && tiles <= (size_t)ctx->num_cus * 2 * blocks_per_cu(m)) {
+            int ewords = (int)((ebytes + 3) / 4);
+            Big e = hostbig::from_be(e_be, ebytes, ewords);
+            const int ebits = std::max(1, hostbig::bit_length(e));
+            ewords = (ebits + 31) / 32;
+            const int wbits = std::min(pick_window(std::max(ebits, fbits)), 5);
+            vmn_garray *rx = nullptr, *ry = nullptr;
+            VMN_TRY(new_garray(g, nx, &rx));
+            int rc = new_garray(g, ny, &ry);
+            DevTmp ew(ctx), fw(ctx);
+            if (rc == VMN_OK) rc = ew.alloc(ewords * sizeof(uint32_t));
+            if (rc == VMN_OK) rc = h2d(ctx, ew.p, e.data(), ewords * sizeof(uint32_t));
+            if (rc == VMN_OK) rc = fw.alloc(ny * (size_t)g->Q.NW * sizeof(uint32_t));
+            if (rc == VMN_OK) rc = to_words(ctx, g->Q, f->d, ny, fw.as<uint32_t>());
+            if (rc == VMN_OK) rc = ensure_scratch(ctx, tiles * (BLOCK / m.LPE) * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t));
+            if (rc == VMN_OK) {
+                ModpowJob jx{rx->d, x->d, ew.as<uint32_t>(), ewords, 0, ebits, nx};
+                ModpowJob jy{ry->d, y->d, fw.as<uint32_t>(), g->Q.NW, (size_t)g->Q.NW, fbits, ny};
+                const bool y_first = (double)fbits * ny >= (double)ebits * nx;
+                const ModpowJob& j0 = y_first ? jy : jx;
+                const ModpowJob& j1 = y_first ? jx : jy;
+                const int nwx = (ebits + wbits - 1) / wbits, nwy = (fbits + wbits - 1) / wbits;
+                note_work(ctx, m, (double)nx * (nwx - 1 + (1 << wbits) - 2) + (double)ny * (nwy - 1 + (1 << wbits) - 2),
+                          ((double)nx * (nwx - 1) + (double)ny * (nwy - 1)) * wbits);
+                rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                                     \
+    if (m.S == S_)                                                                                                           \
+        rc = launch(ctx, "modpow", k_modpow_jobs<Cfg<S_, LPE_>>, (unsigned)tiles, lds_bytes(m), j0, j1, egrid(m, j0.n), wbits, m.d_n, \
+                    m.n0inv, m.d_one, reinterpret_cast<uint32_t*>(ctx->scratch));
+                VMN_FOR_SIZES(X)
+#undef X
+            }
+            if (rc != VMN_OK) {
+                vmn_garray_free(rx);
+                if (ry) vmn_garray_free(ry);
+                return rc;
+            }
+            *out_x = rx;
+            *out_y = ry;
+            return VMN_OK;
+        }
+    }
+    vmn_garray* rx = nullptr;
+    VMN_TRY(vmn_garray_exp_scalar(x, e_be, ebytes, &rx));
+    int rc = vmn_garray_exp_array(y, f, fbits, out_y);
+    if (rc != VMN_OK) {
+        vmn_garray_free(rx);
+        return rc;
+    }
+    *out_x = rx;
+    return VMN_OK;
+}
+
 // ================================================================================================
 // second part: K2 fixed base, K3 multi-exponentiation, K5 reductions, K6 compare, K7 movement,
 // K8 ring operations

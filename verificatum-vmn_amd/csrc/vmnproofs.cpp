@@ -63,6 +63,14 @@ struct GA {
     GA(const GA&) = delete;
     GA& operator=(const GA&) = delete;
     GA(GA&& o) noexcept : p(o.p) { o.p = nullptr; }
+    GA& operator=(GA&& o) noexcept {
+        if (this != &o) {
+            reset();
+            p = o.p;
+            o.p = nullptr;
+        }
+        return *this;
+    }
     ~GA() { reset(); }
     void reset() {
         if (p) vmn_garray_free(p);
@@ -821,11 +829,12 @@ struct ProofBase {
     // for invertible B_{i-1}; the squarings of the 256-bit and the 613-bit exponent are shared (vmn_garray_exp2) and the
     // inverses of the whole array cost a few products per element (vmn_garray_inv).  *done = 0 when some B is not invertible
     // (the residue 0 -- no group element): the caller then evaluates the two sides separately, as the reference does.
-    // (small arrays are latency-bound: the inversion's scans and its host round trip cost more than the squarings they
-    // save; VMN_COMBINED_MIN moves the threshold -- the tests run the combined form at their sizes with it)
+    // (arrays that do not fill the device twice over are latency-bound: the inversion's scans and its host round trip cost
+    // more than the squarings they save, and the paired launch below does better -- profiles/r03_pair_sweep.txt;
+    // VMN_COMBINED_MIN moves the threshold -- the tests run the combined form at their sizes with it)
     bool combined_form_pays() const {
         const char* env = getenv("VMN_COMBINED_MIN");
-        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)32768;
+        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)131073;
         return !G.ec && N >= min_n;
     }
     int bridging_combined(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
@@ -846,6 +855,23 @@ struct ProofBase {
         TRY(vmn_group_exp_fixed(G.grp, g.data(), k_B, right.out()));
         *done = 1;
         return VMN_OK;
+    }
+    // Both sides at once for arrays that do not fill the device (modular groups, verify() called with the challenge set):
+    // B^v and B_shift^(k_E) share one launch (vmn_garray_exp_pair) -- each alone leaves a third of the device idle at the
+    // reference's demo size.  Up to 2 x 131 072 elements = every slot of the device once; VMN_PAIR_MAX moves the bound (0 = never).
+    bool pair_form_pays() const {
+        const char* env = getenv("VMN_PAIR_MAX");
+        const size_t max_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)131072;
+        return !G.ec && N > 0 && N <= max_n;
+    }
+    int bridging_pair(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
+                      const vmn_rarray* k_E, int kE_bits, GA& left, GA& right) {
+        GA g_exp_k_B, B_shift, B_exp_v, B_shift_exp_k_E;
+        TRY(vmn_group_exp_fixed(G.grp, g.data(), k_B, g_exp_k_B.out()));
+        TRY(vmn_garray_shift_push(B, prev.data(), B_shift.out()));
+        TRY(vmn_garray_exp_pair(B, v_be.data(), v_be.size(), B_shift, k_E, kE_bits, B_exp_v.out(), B_shift_exp_k_E.out()));
+        TRY(vmn_garray_mul(B_exp_v, Bp, left.out()));
+        return vmn_garray_mul(g_exp_k_B, B_shift_exp_k_E, right.out());
     }
     // left side B_i^v B'_i: needs the challenge
     int bridging_left(const vmn_garray* B, const vmn_garray* Bp, GA& left) {
@@ -1155,8 +1181,9 @@ struct vmn_pos : ProofBase {
         bool malformed = false;             // a ring scalar of the reply is >= q: the verdict is false, nothing else was computed
         Bytes gkA, gkC, gkD, C, D;
         std::vector<Bytes> kE_prods, pkpow;
-        GA right;
-        bool deferred = false;             // the reply side of check (B) was left to verify() (which then uses the combined form)
+        GA right, left;
+        bool paired = false;               // verify() itself asked (the challenge is known): both sides of (B) were queued as a pair, `left` too
+        bool deferred = false;             // the reply side of check (B) was left to verify() (which then takes the combined form, or the paired launch)
         Bytes prev;
         int kE_bits = 0;
         void clear() {
@@ -1164,6 +1191,8 @@ struct vmn_pos : ProofBase {
             serial = 0;
             malformed = false;
             right.reset();
+            left.reset();
+            paired = false;
             kE_prods.clear();
             pkpow.clear();
             deferred = false;
@@ -1220,7 +1249,9 @@ struct vmn_pos : ProofBase {
         prep.deferred = defer_bridge && combined_form_pays();
         prep.prev = prev;
         prep.kE_bits = kE_bits;
-        if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
+        prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
+        if (prep.paired) TRY(bridging_pair(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right));
+        else if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
@@ -1253,7 +1284,8 @@ struct vmn_pos : ProofBase {
                 TRY(bridging_combined(g, prep.prev, cB, cBp, ikB->ra, ikE->ra, prep.kE_bits, left, prep.right, &combined));
                 if (!combined) TRY(bridging_right(g, prep.prev, cB, ikB->ra, ikE->ra, prep.kE_bits, prep.right));
             }
-            if (!combined) TRY(bridging_left(cB, cBp, left));                     // :1028-1029
+            if (prep.paired) left = std::move(prep.left);
+            else if (!combined) TRY(bridging_left(cB, cBp, left));                     // :1028-1029
             TRY(vmn_garray_equals(left, prep.right, &vB));
             TRY(jobs.join());
         }
@@ -1414,7 +1446,8 @@ struct vmn_posc : ProofBase {
         uint64_t serial = 0, epoch = 0;
         bool malformed = false;             // a ring scalar of the reply is >= q: the verdict is false, nothing else was computed
         Bytes gkA, gkC, gkD, A, C, D, hk;
-        GA right;
+        GA right, left;
+        bool paired = false;               // verify() itself asked (the challenge is known): both sides of (B) were queued as a pair, `left` too
         bool deferred = false;             // see vmn_pos
         Bytes prev;
         int kE_bits = 0;
@@ -1423,6 +1456,8 @@ struct vmn_posc : ProofBase {
             serial = 0;
             malformed = false;
             right.reset();
+            left.reset();
+            paired = false;
             deferred = false;
         }
     } prep;
@@ -1471,7 +1506,9 @@ struct vmn_posc : ProofBase {
         prep.deferred = defer_bridge && combined_form_pays();
         prep.prev = prev;
         prep.kE_bits = kE_bits;
-        if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));  // the reply side of (B) :685-715
+        prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
+        if (prep.paired) TRY(bridging_pair(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right));
+        else if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
@@ -1502,7 +1539,8 @@ struct vmn_posc : ProofBase {
                 TRY(bridging_combined(g, prep.prev, cB, cBp, ikB->ra, ikE->ra, prep.kE_bits, left, prep.right, &combined));
                 if (!combined) TRY(bridging_right(g, prep.prev, cB, ikB->ra, ikE->ra, prep.kE_bits, prep.right));
             }
-            if (!combined) TRY(bridging_left(cB, cBp, left));
+            if (prep.paired) left = std::move(prep.left);
+            else if (!combined) TRY(bridging_left(cB, cBp, left));
             TRY(vmn_garray_equals(left, prep.right, &vB));
             TRY(jobs.join());
         }
