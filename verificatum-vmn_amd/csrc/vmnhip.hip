@@ -225,11 +225,24 @@ static int launch_light(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs..
     return VMN_OK;
 }
 
-static int read_flag(vmn_ctx* ctx, uint32_t* out) {
-    VMN_HIP(hipMemcpyAsync(out, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+// Device -> host on the lane's stream, complete on return.  Up to STAGE_BYTES through the lane's pinned buffer (a copy into
+// pageable memory takes the runtime's slow path: 27 us against 16 us for a verdict word or one element behind a short
+// kernel); callers hold the lane's mutex.
+constexpr size_t STAGE_BYTES = 32768;
+static int d2h(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return VMN_OK;
+    if (bytes <= STAGE_BYTES) {
+        if (!ctx->stage) VMN_HIP(hipHostMalloc(&ctx->stage, STAGE_BYTES, hipHostMallocDefault));
+        VMN_HIP(hipMemcpyAsync(ctx->stage, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        VMN_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(dst, ctx->stage, bytes);
+        return VMN_OK;
+    }
+    VMN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VMN_HIP(hipStreamSynchronize(ctx->stream));
     return VMN_OK;
 }
+static int read_flag(vmn_ctx* ctx, uint32_t* out) { return d2h(ctx, out, ctx->flags, sizeof(uint32_t)); }
 
 
 static int ensure_scratch(vmn_ctx* ctx, size_t bytes) {
@@ -341,12 +354,6 @@ static int h2d(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
     VMN_HIP(hipStreamSynchronize(ctx->stream));          // src is pageable / may go out of scope
     return VMN_OK;
 }
-static int d2h(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
-    if (!bytes) return VMN_OK;
-    VMN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    VMN_HIP(hipStreamSynchronize(ctx->stream));
-    return VMN_OK;
-}
 
 // RAII device temporary on the context stream
 struct DevTmp {
@@ -416,6 +423,7 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
     pool_release_all(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1101,8 +1109,7 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     }
     VMN_TRY(rc);
     uint32_t fl = 0;
-    VMN_HIP(hipMemcpyAsync(&fl, ctx->flags, sizeof(fl), hipMemcpyDeviceToHost, ctx->stream));
-    VMN_HIP(hipStreamSynchronize(ctx->stream));
+    VMN_TRY(read_flag(ctx, &fl));
     if (all_in_range) *all_in_range = (fl & 1u) ? 0 : 1;
     if (format_ok) *format_ok = (fl & 4u) ? 0 : 1;
     return VMN_OK;
@@ -1133,9 +1140,7 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 #undef X
     }
     VMN_TRY(rc);
-    VMN_HIP(hipMemcpyAsync(be, raw.p, n * stride, hipMemcpyDeviceToHost, ctx->stream));
-    VMN_HIP(hipStreamSynchronize(ctx->stream));
-    return VMN_OK;
+    return d2h(ctx, be, raw.p, n * stride);
 }
 
 // byte tree of an array: node header on the host, leaves framed on the device
@@ -1908,7 +1913,10 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
         return VMN_OK;
     }
     const size_t max_lanes = (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
-    // first pass: as many lanes as the machine holds, then halve
+    // first pass: as many lanes as the machine holds; then every pass folds R values per lane.  The tail passes are short
+    // launches whose cost is the launch itself, so R trades passes (17 when halving from 131 072 lanes) against the chain of
+    // R - 1 operations inside a lane: 16 for the cheap ones (sums and products mod q), 4 for group elements.
+    const size_t R = (!m.ec && m.S <= 20) ? 16 : 4;
     size_t L = std::min(std::max<size_t>(max_lanes / std::max<size_t>(nseg, 1), 1), (len + 1) / 2);
     if (len == 1) L = 1;
     DevTmp buf(ctx);
@@ -1942,7 +1950,7 @@ static int reduce_segments(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x
         if (L == 1) break;
         src = dst;
         cur = L;
-        L = (cur + 1) / 2;
+        L = (cur + R - 1) / R;
         std::swap(ping, pong);
     }
     return VMN_OK;
@@ -3223,7 +3231,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     // before any array goes through the levels (below).
     const int LV = 12;                               // fan-in 8: 8^12 items per bucket
     const size_t scan_blocks = (nbuckets + (size_t)BLOCK * SCAN_ITEMS - 1) / ((size_t)BLOCK * SCAN_ITEMS);
-    VMN_TRY(meta.alloc(((3 + 2 * LV) * (nbuckets + 1) + scan_blocks + 16) * sizeof(uint32_t)));
+    VMN_TRY(meta.alloc(((3 + 2 * LV) * (nbuckets + 1) + scan_blocks + 2 * LV + 16) * sizeof(uint32_t)));
     uint32_t* counts = meta.as<uint32_t>();
     uint32_t* cursor = counts + (nbuckets + 1);
     uint32_t* off0 = cursor + (nbuckets + 1);
@@ -3231,7 +3239,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     auto cnt_of = [&](int level) { return levels0 + (size_t)(2 * level) * (nbuckets + 1); };
     auto off_of = [&](int level) { return levels0 + (size_t)(2 * level + 1) * (nbuckets + 1); };
     uint32_t* bsum = levels0 + (size_t)(2 * LV) * (nbuckets + 1);
-    uint32_t* misc = bsum + scan_blocks;             // [0] = total, [1] = max count
+    uint32_t* misc = bsum + scan_blocks;             // per tree level: [2 l] = total, [2 l + 1] = max count
     VMN_TRY(sorted.alloc((size_t)nwin * n * sizeof(uint32_t)));
     // The bucket aggregation (suffix scan + reduction over nwin x 2^c rows per array) is a handful of short launches: it
     // runs once for a GROUP of arrays (all k when their buckets fit 16 GB), not once per array -- over curves, where a
@@ -3242,44 +3250,63 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     VMN_TRY(wres.alloc(k * (size_t)nwin * Wd * sizeof(uint32_t)));      // window results of all k arrays
     uint32_t* Ball = buckets.as<uint32_t>();
     uint32_t* Ssuf = Ball + G * nbuckets * Wd;
-    auto scan_u32 = [&](uint32_t* out, uint32_t* out2, const uint32_t* in) -> int {
+    auto scan_u32 = [&](uint32_t* out, uint32_t* out2, const uint32_t* in, uint32_t* total) -> int {
         VMN_TRY(launch_light(ctx, "expprod_sort", k_u32_blocksum, (unsigned)scan_blocks, bsum, in, nbuckets));
-        hipLaunchKernelGGL(k_u32_scan_top, dim3(1), dim3(64), 0, ctx->stream, bsum, scan_blocks, misc);
+        hipLaunchKernelGGL(k_u32_scan_top, dim3(1), dim3(64), 0, ctx->stream, bsum, scan_blocks, total);
         VMN_HIP(hipGetLastError());
         return launch_light(ctx, "expprod_sort", k_u32_scan_apply, (unsigned)scan_blocks, out, out2, in, (const uint32_t*)bsum, nbuckets);
     };
     // counting sort of (window, digit)
+    {
+    VMN_TRACE("expprod:sort");
     VMN_HIP(hipMemsetAsync(counts, 0, nbuckets * sizeof(uint32_t), ctx->stream));
     const unsigned gx = std::max<unsigned>(1, std::min<unsigned>((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)(ctx->num_cus * 8 / std::max(nwin, 1) + 1)));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx, ebits));
-    VMN_TRY(scan_u32(off0, cursor, counts));
+    VMN_TRY(scan_u32(off0, cursor, counts, misc + 2 * LV));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
                          e_words, ewords, n, c, nwin, gx, ebits));
     VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
+    }
     // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item.  The SHAPE of the trees
     // (items per bucket and level, offsets, totals) depends on the exponents only: it is computed first, once; then the
     // arrays go through the levels in groups -- one launch per level for up to LEVEL_ARRAYS arrays (k_bucket_level).
     std::vector<std::pair<uint32_t, uint32_t>> shape;             // (total items, max per bucket) per level
     {
+        VMN_TRACE("expprod:shape");
+        // Two round trips to the host, not one per level: the largest bucket after level 0 says how many levels there are
+        // (the largest bucket of level l + 1 is ceil(largest of level l / F)); they are then queued together and their totals
+        // come back in one copy.
         const uint32_t* cnt_in = counts;
-        for (int level = 0; level < LV; ++level) {
-            uint32_t hm2[2];
-            VMN_HIP(hipMemsetAsync(misc + 1, 0, sizeof(uint32_t), ctx->stream));
-            VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_of(level), cnt_in, nbuckets, F, misc + 1));
-            VMN_TRY(scan_u32(off_of(level), (uint32_t*)nullptr, cnt_of(level)));
-            VMN_HIP(hipMemcpyAsync(hm2, misc, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            VMN_HIP(hipStreamSynchronize(ctx->stream));
-            shape.emplace_back(hm2[0], hm2[1]);
+        uint32_t hm[2 * LV] = {0};
+        VMN_HIP(hipMemsetAsync(misc, 0, 2 * LV * sizeof(uint32_t), ctx->stream));
+        auto queue_level = [&](int level) -> int {
+            VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_of(level), cnt_in, nbuckets, F, misc + 2 * level + 1));
+            VMN_TRY(scan_u32(off_of(level), (uint32_t*)nullptr, cnt_of(level), misc + 2 * level));
             cnt_in = cnt_of(level);
-            if (hm2[1] <= 1) break;
-            if (level + 1 == LV) {
+            return VMN_OK;
+        };
+        VMN_TRY(queue_level(0));
+        VMN_TRY(d2h(ctx, hm, misc, 2 * sizeof(uint32_t)));
+        int levels = 1;
+        for (uint32_t mx = hm[1]; mx > 1; mx = (mx + F - 1) / F) {
+            if (levels == LV) {
                 set_error("multi-exponentiation: a bucket holds more than %u^%d items", F, LV);
                 return VMN_ERR_UNSUPPORTED;
             }
+            VMN_TRY(queue_level(levels++));
+        }
+        if (levels > 1) {
+            VMN_TRY(d2h(ctx, hm + 2, misc + 2, 2 * (levels - 1) * sizeof(uint32_t)));
+        }
+        for (int level = 0; level < levels; ++level) shape.emplace_back(hm[2 * level], hm[2 * level + 1]);
+        if (shape.back().second > 1) {
+            set_error("multi-exponentiation: the bucket trees did not close after %d levels", levels);
+            return VMN_ERR_DEVICE;
         }
     }
     DevTmp normalised(ctx);                              // curves: the k arrays with Z = 1, so that the first level's additions are mixed
     if (m.ec) {
+        VMN_TRACE("expprod:normalise");
         VMN_TRY(normalised.alloc(k * n * Wd * sizeof(uint32_t)));
         VMN_TRY(ec_normalize(ctx, m, xs, k, n, normalised.as<uint32_t>()));
     }
@@ -3291,6 +3318,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     VMN_TRY(itemsA.alloc(GL * cap0 * row_bytes));
     VMN_TRY(itemsB.alloc(GL * cap1 * row_bytes));
     for (size_t arr0 = 0; arr0 < k; arr0 += GL) {
+        VMN_TRACE("expprod:levels_and_aggregation");
         const size_t gl = std::min(GL, k - arr0);
         const uint32_t* cnt_in = counts;
         const uint32_t* off_in = off0;
@@ -3365,6 +3393,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     // (one lane per array on the GPU for curves; on the host for modular groups), so it is done for the k arrays
     // together and the k results leave in one copy.
     if (m.ec) {
+        VMN_TRACE("expprod:horner_device");
         DevTmp res(ctx);
         VMN_TRY(res.alloc(k * Wd * sizeof(uint32_t)));
         int rc = VMN_ERR_ARG;
@@ -3378,7 +3407,10 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         return export_be(ctx, m, g->nbytes, res.as<uint32_t>(), k, out_be);
     }
     std::vector<uint8_t> wbe(k * (size_t)nwin * g->nbytes);
-    VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, wbe.data()));
+    {
+        VMN_TRACE("expprod:export_windows");
+        VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, wbe.data()));
+    }
     VMN_TRACE("expprod:horner_host");
     const num64::Mod& hm = *m.hm64;
     auto horner = [&](size_t arr) {

@@ -75,6 +75,8 @@ struct vmn_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     uint32_t* flags = nullptr;            // small device word array for verdicts / range flags
+    void* stage = nullptr;                // pinned host buffer (vmn::STAGE_BYTES): small device-to-host copies land here first --
+                                          //   16 us instead of 27 us per read-back (tools/micro/copy_latency.hip); allocated on first use
     // stream-ordered caching allocator: freed device blocks are kept by size and handed out again
     // (all work of a context is on one stream, so reuse is ordered after the previous user)
     std::map<size_t, std::vector<void*>> pool;

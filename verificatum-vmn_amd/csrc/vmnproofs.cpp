@@ -1617,6 +1617,7 @@ struct vmn_ccpos : ProofBase {
     Bytes Ap_;
     std::vector<Bytes> Bp_;
     int commit_prepare() {
+        VMN_TRACE("ccpos:commit_prepare");
         REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
         TRY(draw_ring_element(alpha));                                            // :360-375
         TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
@@ -1641,6 +1642,7 @@ struct vmn_ccpos : ProofBase {
         return VMN_OK;
     }
     int commit(vmn_msg** out) {
+        VMN_TRACE("ccpos:commit");
         REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
         if (!prepared) TRY(commit_prepare());
         TRY(permuted_batch_vector(e, piinv, ipe));                                // :350
@@ -1651,6 +1653,7 @@ struct vmn_ccpos : ProofBase {
         return VMN_OK;
     }
     int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
+        VMN_TRACE("ccpos:reply");
         REQUIRE(out && ipe.p && r && s.size() == width, "reply needs commit()");
         TRY(set_challenge(vb, vbytes));
         Bytes ab(G.xb), bsum(G.xb);
@@ -1678,6 +1681,7 @@ struct vmn_ccpos : ProofBase {
         return VMN_OK;
     }
     int set_commitment(const vmn_msg* m) {
+        VMN_TRACE("ccpos:set_commitment");
         touch();
         const vmn_msg::Item *iAp = item_of(m, 0, VMN_ITEM_ELEMENTS), *iBp = item_of(m, 1, VMN_ITEM_ELEMENTS);
         REQUIRE(m && m->items.size() == 2 && iAp && iBp && iAp->count == 1 && iBp->count == 2 * width && iAp->width == G.eb &&
@@ -1694,6 +1698,7 @@ struct vmn_ccpos : ProofBase {
     }
     GA ru_own;
     int compute_ab(const vmn_garray* raisedu) {
+        VMN_TRACE("ccpos:compute_ab");
         touch();
         REQUIRE(u && e.p && width, "computeAB needs the instance and the batching vector");
         raised = raisedu != nullptr;
@@ -1747,6 +1752,7 @@ struct vmn_ccpos : ProofBase {
         }
     } prep;
     int verify_prepare(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes) {
+        VMN_TRACE("ccpos:verify_prepare");
         REQUIRE(have_commitment && have_ab, "verify_prepare needs computeAB and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RING),
                             *ikE = item_of(rep, 2, VMN_ITEM_RARRAY);
@@ -1799,6 +1805,7 @@ struct vmn_ccpos : ProofBase {
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes, int* verdict) {
+        VMN_TRACE("ccpos:verify");
         REQUIRE(verdict && have_commitment && have_ab && !v_be.empty(), "verify needs computeAB, setCommitment and setChallenge");
         *verdict = 0;
         if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch || !prep.same_raised(raisedh, rho_be, rho_bytes))
