@@ -194,6 +194,16 @@ int vmn_garray_expprod_ints(const vmn_garray* x, const uint8_t* exps_be, size_t 
  * PPGroupElementArray.expProd, ref: P/hvzk/PoSBasicTW.java:409, 690, 1063; P/hvzk/CCPoSBasicW.java:391, 498, 567):
  * the exponent digits are sorted once; out_be receives k elements. */
 int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, const vmn_rarray* e, int ebits, uint8_t* out_be);
+/* The same in two halves.  _begin queues the device part and returns a handle; vmn_pending_finish waits for it, completes
+ * the k elements into out_be and releases the handle (also when it fails); vmn_pending_free abandons a handle that is not
+ * finished.  Between the two the caller queues its other device work: the tail of a multi-exponentiation over a modular
+ * group is a chain of squarings on the host (one per exponent bit), during which the device would otherwise have nothing
+ * to do -- at the reference's demo size (10^4 ciphertexts) a tenth of a proof.  The arrays must stay alive until finish. */
+typedef struct vmn_pending vmn_pending;
+int vmn_garray_expprod_multi_begin(const vmn_garray* const* xs, size_t k, const vmn_rarray* e, int ebits, vmn_pending** out);
+int vmn_pending_finish(vmn_pending* p, uint8_t* out_be);
+size_t vmn_pending_bytes(const vmn_pending* p);   /* what finish writes: k elements */
+void vmn_pending_free(vmn_pending* p);
 /* K4  X.mul(Y).  ref: P/mixnet/ShufflerElGamalSession.java:273, 789, 850 (the re-encryption);
  * P/hvzk/PoSBasicTW.java:448, 610, 648, 1029, 1033. */
 int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out);

@@ -463,6 +463,41 @@ def test_simultaneous_power_and_array_inverse(bits, groups, oracle_for):
         assert got == want, (e.bit_length(), fbits)
 
 
+@pytest.mark.parametrize("kind", ["modp2048", "modp3072", "P-256"])
+def test_multi_exponentiation_in_two_halves(kind, vmn, gpu_ctx, groups):
+    """vmn_garray_expprod_multi_begin / vmn_pending_finish: the products are those of the one-call form (itself checked against
+    the oracle above) -- with other device work queued in between, a second begin while one is in flight (computed at once),
+    an abandoned handle, an empty array."""
+    if kind == "P-256":
+        from oracle.pyref_ec import Curve
+        G, q = vmn.ECqPGroup(gpu_ctx, "P-256"), Curve("P-256").n
+        base = Curve("P-256").g
+    else:
+        G, grp, _ = groups[int(kind[4:])]
+        q, base = grp["q"], grp["g"]
+    n = 333
+    draws = pyref.stream_ints(b"halves-" + kind.encode(), 4 * n, q)
+    es = [v >> (0 if i % 3 else 200) for i, v in enumerate(draws[:n])]
+    E = G.ringArray(es)
+    X = [G.exp(base, G.ringArray(draws[(a + 1) * n:(a + 2) * n])) for a in range(3)]
+    want = vmn.expProdMulti(X, E)
+    want1 = vmn.expProdMulti(X[:1], E)
+    first = vmn.PendingExpProd(X, E)
+    busy = X[0].mul(X[1]).exp(E)                        # device work behind the first half
+    second = vmn.PendingExpProd(X[:1], E)               # a second one in flight: computed at once
+    assert second.finish() == want1
+    assert first.finish() == want
+    assert busy.equals(X[0].exp(E).mul(X[1].exp(E)))
+    dropped = vmn.PendingExpProd(X, E)                  # abandoned: its landing buffer is free again afterwards
+    del dropped
+    again = vmn.PendingExpProd(X, E)
+    assert again.finish() == want
+    empty = vmn.PendingExpProd([G.toElementArray([])], G.ringArray([]))
+    assert empty.finish() == vmn.expProdMulti([G.toElementArray([])], G.ringArray([]))
+    with pytest.raises(RuntimeError):
+        again.finish()
+
+
 @pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096])
 def test_two_powers_in_one_launch(bits, groups, oracle_for):
     """vmn_garray_exp_pair (k_modpow_jobs: x^e and y^f side by side in one grid) against the oracle: arrays of equal and of

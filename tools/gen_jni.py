@@ -43,7 +43,7 @@ PKG_PATH = PKG.replace(".", "/")
 PKG_JNI = PKG.replace(".", "_")
 
 HANDLES = ("vmn_ctx", "vmn_group", "vmn_garray", "vmn_rarray", "vmn_msg", "vmn_pos", "vmn_posc", "vmn_ccpos", "vmn_decproof",
-           "vmn_igen")
+           "vmn_igen", "vmn_pending")
 BULK = {"vmn_garray_from_be": ["be"], "vmn_rarray_from_be": ["be"], "vmn_garray_to_be": ["be_out"], "vmn_rarray_to_be": ["be_out"],
         "vmn_garray_to_bytetree": ["out"], "vmn_rarray_to_bytetree": ["out"], "vmn_garray_from_bytetree": ["bt"],
         "vmn_rarray_from_bytetree": ["bt"], "vmn_msg_to_bytetree": ["out"], "vmn_msg_from_bytetree": ["bt"]}
@@ -261,6 +261,8 @@ def need_expr(name, ptype, pname, plist):
             return f"((size_t)vmn_decproof_parties({pobj}) + 1) * {EB}"
         if pname == "abs_be":
             return f"(size_t)threshold * {XB}"
+        if pname == "out_be" and name == "vmn_pending_finish":
+            return f"vmn_pending_bytes({hcast('vmn_pending*', plist[0][1])})"
         if pname == "out_be" and name == "vmn_garray_expprod_multi":
             return f"(size_t)k * {EB}"
         ring_names = {"last_be", "kx_out", "kx_be", "ka_out", "ka_be", "x_be", "secret_be", "c_be"}

@@ -79,8 +79,9 @@ def lib() -> C.CDLL:
         _lib.vmn_last_error.restype = C.c_char_p
         _lib.vmn_version.restype = C.c_char_p
         _lib.vmn_ctx_get_stream.restype = C.c_void_p
+        _lib.vmn_pending_free.restype = None
         for name in ("vmn_group_elem_bytes", "vmn_group_exp_bytes", "vmn_garray_size", "vmn_rarray_size", "vmn_group_table_bytes",
-                     "vmn_garray_bytetree_size", "vmn_rarray_bytetree_size"):
+                     "vmn_garray_bytetree_size", "vmn_rarray_bytetree_size", "vmn_pending_bytes"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 
@@ -635,6 +636,33 @@ def expProdMulti(arrays, e: "PRingElementArray", ebits: int = 0) -> list:
     _check(lib().vmn_garray_expprod_multi(hs, C.c_size_t(k), e._h, C.c_int(ebits), out))
     eb = grp.elem_bytes
     return [grp.dec_el(out.raw[i * eb:(i + 1) * eb]) for i in range(k)]
+
+
+class PendingExpProd:
+    """``vmn_garray_expprod_multi_begin``: the device part of ``expProdMulti`` is queued; ``finish()`` waits for it and returns
+    the k elements.  Device work queued in between runs while the host completes the products."""
+
+    def __init__(self, arrays, e: "PRingElementArray", ebits: int = 0):
+        self.group = arrays[0].group
+        self.k = len(arrays)
+        hs = (C.c_void_p * self.k)(*[a._h for a in arrays])
+        self._h = C.c_void_p()
+        _check(lib().vmn_garray_expprod_multi_begin(hs, C.c_size_t(self.k), e._h, C.c_int(ebits), C.byref(self._h)))
+
+    def finish(self) -> list:
+        if not self._h:
+            raise RuntimeError("finish() was already called")
+        h, self._h = self._h, None
+        nbytes = lib().vmn_pending_bytes(h)
+        out = C.create_string_buffer(nbytes)
+        _check(lib().vmn_pending_finish(h, out))
+        eb = self.group.elem_bytes
+        return [self.group.dec_el(out.raw[i * eb:(i + 1) * eb]) for i in range(self.k)]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vmn_pending_free(self._h)
+            self._h = None
 
 
 class PRingElementArray(_ArrayBase):

@@ -424,6 +424,7 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->stage_pending) (void)hipHostFree(ctx->stage_pending);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1115,8 +1116,9 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     return VMN_OK;
 }
 
+// (pinned_async: `be` is pinned host memory and the copy is only queued -- the caller orders itself behind it)
 static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be,
-                     int leaf_hdr = 0) {
+                     int leaf_hdr = 0, bool pinned_async = false) {
     if (n == 0) return VMN_OK;
     // a curve point in a byte tree is node(leaf(x), leaf(y)): 15 framing bytes around the two coordinates
     const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
@@ -1140,6 +1142,10 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 #undef X
     }
     VMN_TRY(rc);
+    if (pinned_async) {
+        VMN_HIP(hipMemcpyAsync(be, raw.p, n * stride, hipMemcpyDeviceToHost, ctx->stream));    // (raw: reuse is ordered on this stream)
+        return VMN_OK;
+    }
     return d2h(ctx, be, raw.p, n * stride);
 }
 
@@ -3189,16 +3195,104 @@ static int pick_bucket_bits(size_t n, int ebits, bool ec = false) {
     return best;
 }
 
+// A multi-exponentiation whose device part is queued and whose result has not been fetched yet (vmn_garray_expprod_multi_begin /
+// vmn_pending_finish): what is left is a copy into pinned memory behind an event and -- for modular groups -- the Horner chain
+// over the window results on the host (c * nwin squarings, sequential: ~1 ms at 2048 bits, during which a caller with other
+// work for the device queues that work first).
+struct vmn_pending {
+    vmn_group* g = nullptr;
+    vmn_ctx* lane = nullptr;
+    size_t k = 0;
+    int nwin = 0, c = 0;
+    bool staged = false;                   // the results are on their way to lane->stage_pending; else `result` holds them
+    size_t staged_bytes = 0;
+    hipEvent_t ev = nullptr;
+    std::vector<uint8_t> result;
+};
+
+// Horner over the window results of k arrays (big-endian, nwin per array) -> k elements
+static void horner_windows(const vmn_group* g, const uint8_t* wbe, size_t k, int nwin, int c, uint8_t* out_be) {
+    VMN_TRACE("expprod:horner_host");
+    const num64::Mod& hm = *g->P.hm64;
+    auto horner = [&](size_t arr) {
+        num64::Num acc = hm.one_m;
+        for (int w = nwin - 1; w >= 0; --w) {
+            for (int s2 = 0; s2 < c; ++s2) hm.mmul(acc, acc, acc);
+            num64::Num ww = hm.to_m(num64::from_be(wbe + (arr * (size_t)nwin + w) * g->nbytes, g->nbytes, hm.nl));
+            hm.mmul(acc, acc, ww);
+        }
+        num64::to_be(hm.from_m(acc), out_be + arr * g->nbytes, g->nbytes);
+    };
+    std::vector<std::future<void>> others;                 // one chain per array: the arrays beyond the first on threads of their own
+    for (size_t arr = 1; arr < k; ++arr) {
+        try {
+            others.emplace_back(std::async(std::launch::async, horner, arr));
+        } catch (const std::system_error&) {             // no thread to be had: this chain runs here
+            horner(arr);
+        }
+    }
+    horner(0);
+    for (auto& f : others) f.get();
+}
+
+// the lane's landing buffer for a pending result, if it is free (one multi-exponentiation in flight per lane)
+static uint8_t* claim_pending_stage(vmn_ctx* ctx, size_t bytes) {
+    if (ctx->stage_pending_busy) return nullptr;
+    if (ctx->stage_pending_bytes < bytes) {
+        if (ctx->stage_pending) (void)hipHostFree(ctx->stage_pending);
+        ctx->stage_pending = nullptr;
+        ctx->stage_pending_bytes = 0;
+        const size_t want = std::max<size_t>(bytes, (size_t)1 << 18);
+        if (hipHostMalloc(&ctx->stage_pending, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->stage_pending = nullptr;
+            return nullptr;
+        }
+        ctx->stage_pending_bytes = want;
+    }
+    ctx->stage_pending_busy = true;
+    return static_cast<uint8_t*>(ctx->stage_pending);
+}
+
+// queue export + copy of `rows` rows into the claimed landing buffer and the event that says they have arrived
+static int stage_pending(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_rows, size_t rows, uint8_t* land,
+                         vmn_pending* pend) {
+    int rc = export_be(ctx, m, nbytes, d_rows, rows, land, 0, true);
+    if (rc == VMN_OK && hipEventCreateWithFlags(&pend->ev, hipEventDisableTiming) != hipSuccess) rc = VMN_ERR_DEVICE;
+    if (rc == VMN_OK && hipEventRecord(pend->ev, ctx->stream) != hipSuccess) rc = VMN_ERR_DEVICE;
+    if (rc != VMN_OK) {
+        if (rc == VMN_ERR_DEVICE) set_error("multi-exponentiation: recording the completion event failed");
+        (void)hipStreamSynchronize(ctx->stream);          // the copy may be queued: the buffer is free again once it has run
+        if (pend->ev) (void)hipEventDestroy(pend->ev);
+        pend->ev = nullptr;
+        ctx->stage_pending_busy = false;
+        return rc;
+    }
+    pend->staged = true;
+    return VMN_OK;
+}
+
 // prod_i x[i]^e[i] with packed-word exponents on the device -> big-endian element on the host
 // k arrays with the SAME exponents (the 2*width components of a ciphertext array, or u / h / w' under one
 // batching vector): the counting sort of the exponent digits and the shape of the product trees are computed
 // once and reused for every array; out_be receives k elements.
+// (pend: queue the device part only and leave the rest to vmn_pending_finish; out_be is then not written)
 static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, const uint32_t* e_words, int ewords,
-                         int ebits, size_t n, uint8_t* out_be) {
+                         int ebits, size_t n, uint8_t* out_be, vmn_pending* pend = nullptr) {
     vmn_ctx* ctx = LANE(g->ctx);
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     const size_t ebytes_out = m.ec ? 2 * g->nbytes : g->nbytes;
+    std::vector<uint8_t> direct;                       // pend: results that are known at once
+    if (pend) {
+        pend->g = g;
+        pend->lane = ctx;
+        pend->k = k;
+        if (n == 0) {
+            direct.resize(k * ebytes_out);
+            out_be = direct.data();
+        }
+    }
     if (n == 0) {
         for (size_t a = 0; a < k; ++a) {
             uint8_t* o = out_be + a * ebytes_out;
@@ -3210,6 +3304,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
                 hostbig::to_be(one, o, g->nbytes);
             }
         }
+        if (pend) pend->result = std::move(direct);
         return VMN_OK;
     }
     if (ebits < 1) ebits = 1;
@@ -3392,6 +3487,10 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     // Horner over the windows, once for all k arrays: the chain of c * nwin doublings / squarings is sequential
     // (one lane per array on the GPU for curves; on the host for modular groups), so it is done for the k arrays
     // together and the k results leave in one copy.
+    if (pend) {
+        pend->nwin = nwin;
+        pend->c = c;
+    }
     if (m.ec) {
         VMN_TRACE("expprod:horner_device");
         DevTmp res(ctx);
@@ -3404,34 +3503,29 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         VMN_FOR_CURVES(X)
 #undef X
         VMN_TRY(rc);
+        if (pend) {
+            pend->staged_bytes = k * ebytes_out;
+            if (uint8_t* land = claim_pending_stage(ctx, pend->staged_bytes))
+                return stage_pending(ctx, m, g->nbytes, res.as<uint32_t>(), k, land, pend);
+            pend->result.resize(k * ebytes_out);
+            out_be = pend->result.data();
+        }
         return export_be(ctx, m, g->nbytes, res.as<uint32_t>(), k, out_be);
     }
-    std::vector<uint8_t> wbe(k * (size_t)nwin * g->nbytes);
+    const size_t wbytes = k * (size_t)nwin * g->nbytes;
+    if (pend) {
+        pend->staged_bytes = wbytes;
+        if (uint8_t* land = claim_pending_stage(ctx, wbytes))
+            return stage_pending(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, land, pend);
+        pend->result.resize(k * ebytes_out);
+        out_be = pend->result.data();
+    }
+    std::vector<uint8_t> wbe(wbytes);
     {
         VMN_TRACE("expprod:export_windows");
         VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, wbe.data()));
     }
-    VMN_TRACE("expprod:horner_host");
-    const num64::Mod& hm = *m.hm64;
-    auto horner = [&](size_t arr) {
-        num64::Num acc = hm.one_m;
-        for (int w = nwin - 1; w >= 0; --w) {
-            for (int s2 = 0; s2 < c; ++s2) hm.mmul(acc, acc, acc);
-            num64::Num ww = hm.to_m(num64::from_be(wbe.data() + (arr * (size_t)nwin + w) * g->nbytes, g->nbytes, hm.nl));
-            hm.mmul(acc, acc, ww);
-        }
-        num64::to_be(hm.from_m(acc), out_be + arr * ebytes_out, g->nbytes);
-    };
-    std::vector<std::future<void>> others;                 // one chain per array: the arrays beyond the first on threads of their own
-    for (size_t arr = 1; arr < k; ++arr) {
-        try {
-            others.emplace_back(std::async(std::launch::async, horner, arr));
-        } catch (const std::system_error&) {             // no thread to be had: this chain runs here
-            horner(arr);
-        }
-    }
-    horner(0);
-    for (auto& f : others) f.get();
+    horner_windows(g, wbe.data(), k, nwin, c, out_be);
     return VMN_OK;
 }
 
@@ -3477,6 +3571,73 @@ extern "C" int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, c
     std::vector<const uint32_t*> ptrs(k);
     for (size_t a = 0; a < k; ++a) ptrs[a] = xs[a]->d;
     return expprod_words(g, ptrs.data(), k, ew.as<uint32_t>(), g->Q.NW, ebits, e->n, out_be);
+}
+
+// The same in two halves: _begin queues the device part and returns; vmn_pending_finish waits for it and completes the result
+// (modular groups: the Horner chain over the windows, on the host).  Between the two the caller queues whatever else it has for
+// the device -- a proof's fixed-base powers run while the host squares.  One multi-exponentiation per lane can be in flight;
+// a second _begin computes its result at once (finish then only hands it over).
+extern "C" int vmn_garray_expprod_multi_begin(const vmn_garray* const* xs, size_t k, const vmn_rarray* e, int ebits, vmn_pending** out) {
+    ARG_CHECK(xs && k > 0 && e && out, "null argument");
+    vmn_group* g = e->grp;
+    for (size_t a = 0; a < k; ++a) ARG_CHECK(xs[a] && xs[a]->grp == g && xs[a]->n == e->n, "arrays differ in group or size");
+    vmn_ctx* ctx = LANE(g->ctx);
+    VMN_ENTER(ctx);
+    if (ebits <= 0 || ebits > g->Q.nbits) ebits = g->Q.nbits;
+    DevTmp ew(ctx);
+    VMN_TRY(ew.alloc(std::max<size_t>(e->n, 1) * (size_t)g->Q.NW * sizeof(uint32_t)));
+    VMN_TRY(to_words(ctx, g->Q, e->d, e->n, ew.as<uint32_t>()));
+    std::vector<const uint32_t*> ptrs(k);
+    for (size_t a = 0; a < k; ++a) ptrs[a] = xs[a]->d;
+    std::unique_ptr<vmn_pending> p(new vmn_pending());
+    VMN_TRY(expprod_words(g, ptrs.data(), k, ew.as<uint32_t>(), g->Q.NW, ebits, e->n, nullptr, p.get()));
+    *out = p.release();
+    return VMN_OK;
+}
+static void pending_release(vmn_pending* p) {
+    if (p->staged) {
+        std::lock_guard<std::recursive_mutex> guard__(p->lane->mu);
+        (void)hipSetDevice(p->lane->device);
+        if (p->ev) (void)hipEventSynchronize(p->ev);      // the copy into the landing buffer must not outlive the claim
+        p->lane->stage_pending_busy = false;
+        p->staged = false;
+    }
+    if (p->ev) (void)hipEventDestroy(p->ev);
+    p->ev = nullptr;
+}
+extern "C" int vmn_pending_finish(vmn_pending* p, uint8_t* out_be) {
+    ARG_CHECK(p && out_be, "null argument");
+    std::unique_ptr<vmn_pending> own(p);
+    const size_t ebytes_out = p->g->P.ec ? 2 * p->g->nbytes : p->g->nbytes;
+    if (!p->staged) {
+        memcpy(out_be, p->result.data(), p->k * ebytes_out);
+        return VMN_OK;
+    }
+    std::vector<uint8_t> landed(p->staged_bytes);
+    {
+        VMN_TRACE("expprod:wait_pending");
+        std::lock_guard<std::recursive_mutex> guard__(p->lane->mu);
+        hipError_t he = hipSetDevice(p->lane->device);
+        if (he == hipSuccess) he = hipEventSynchronize(p->ev);
+        if (he == hipSuccess) memcpy(landed.data(), p->lane->stage_pending, p->staged_bytes);
+        p->lane->stage_pending_busy = false;
+        p->staged = false;
+        (void)hipEventDestroy(p->ev);
+        p->ev = nullptr;
+        if (he != hipSuccess) {
+            set_error("vmn_pending_finish: waiting for the device failed: %s", hipGetErrorString(he));
+            return VMN_ERR_DEVICE;
+        }
+    }
+    if (p->g->P.ec) memcpy(out_be, landed.data(), p->staged_bytes);
+    else horner_windows(p->g, landed.data(), p->k, p->nwin, p->c, out_be);
+    return VMN_OK;
+}
+extern "C" size_t vmn_pending_bytes(const vmn_pending* p) { return p ? p->k * (p->g->P.ec ? 2 * p->g->nbytes : p->g->nbytes) : 0; }
+extern "C" void vmn_pending_free(vmn_pending* p) {
+    if (!p) return;
+    pending_release(p);
+    delete p;
 }
 
 // ---- membership, partials ----------------------------------------------------------------------------

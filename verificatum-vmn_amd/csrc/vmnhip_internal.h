@@ -77,6 +77,9 @@ struct vmn_ctx {
     uint32_t* flags = nullptr;            // small device word array for verdicts / range flags
     void* stage = nullptr;                // pinned host buffer (vmn::STAGE_BYTES): small device-to-host copies land here first --
                                           //   16 us instead of 27 us per read-back (tools/micro/copy_latency.hip); allocated on first use
+    void* stage_pending = nullptr;        // pinned landing buffer of the ONE multi-exponentiation in flight on this lane (vmn_pending)
+    size_t stage_pending_bytes = 0;
+    bool stage_pending_busy = false;
     // stream-ordered caching allocator: freed device blocks are kept by size and handed out again
     // (all work of a context is on one stream, so reuse is ordered after the previous user)
     std::map<size_t, std::vector<void*>> pool;

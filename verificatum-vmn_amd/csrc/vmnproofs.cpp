@@ -930,6 +930,32 @@ struct ProofBase {
         for (size_t k = 0; k < xs.size(); ++k) out.emplace_back(flat.begin() + k * G.eb, flat.begin() + (k + 1) * G.eb);
         return VMN_OK;
     }
+    // The same in two halves (vmn_garray_expprod_multi_begin / vmn_pending_finish): between begin() and finish() the caller
+    // queues the device work that does not need the products -- the host-side tail of a multi-exponentiation (one squaring per
+    // exponent bit, ~1 ms at 2048 bits) then runs beside it instead of in front of it.
+    struct PendingProds {
+        vmn_pending* p = nullptr;
+        size_t k = 0;
+        PendingProds() {}
+        PendingProds(const PendingProds&) = delete;
+        PendingProds& operator=(const PendingProds&) = delete;
+        ~PendingProds() {
+            if (p) vmn_pending_free(p);
+        }
+        int begin(const std::vector<const vmn_garray*>& xs, const vmn_rarray* e, int bits) {
+            k = xs.size();
+            return vmn_garray_expprod_multi_begin(xs.data(), k, e, bits, &p);
+        }
+        int finish(const HostGroup& G, std::vector<Bytes>& out) {
+            Bytes flat(k * G.eb);
+            vmn_pending* q = p;
+            p = nullptr;
+            TRY(vmn_pending_finish(q, flat.data()));
+            out.clear();
+            for (size_t i = 0; i < k; ++i) out.emplace_back(flat.begin() + i * G.eb, flat.begin() + (i + 1) * G.eb);
+            return VMN_OK;
+        }
+    };
     // the 2w components of a ciphertext array, each this rank's shard (cut from whole arrays where those were handed in)
     int local_components(const vmn_garray* const* arr, size_t k, std::vector<GA>& own, std::vector<const vmn_garray*>& out, const char* what) {
         if (!arr) return fail(VMN_ERR_ARG, "%s: null", what);
@@ -1009,6 +1035,11 @@ struct vmn_pos : ProofBase {
         Bytes hp(G.eb), ga;
         HostJobs jobs;
         jobs.start([&] { return gexp(g, alpha, ga); });
+        // :481  A' = g^alpha prod h_i^eps_i -- its device part is queued first, the permutation commitment behind it: the
+        // fixed-base powers of u then run while the host finishes the product
+        PendingProds hp_pending;
+        std::vector<Bytes> hp_out;
+        TRY(hp_pending.begin({h}, epsilon, eps_bits));
         if (!sharded) {
             TRY(vmn_permutation_commitment(G.grp, g.data(), h_, r, pi.data(), u_own.out()));
         } else {
@@ -1017,8 +1048,8 @@ struct vmn_pos : ProofBase {
             TRY(permutation_commitment_rows(G.grp, g.data(), h_, r_perm, pi.data() + lo, N, u_own.out()));
         }
         u = u_own;
-        // :481  A' = g^alpha prod h_i^eps_i
-        TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        TRY(hp_pending.finish(G, hp_out));
+        hp = hp_out[0];
         Round rd(*this);
         rd.product(hp);
         TRY(rd.run());
@@ -1045,8 +1076,12 @@ struct vmn_pos : ProofBase {
     bool prepared = false;
     Bytes Cp_, Dp_;
     std::vector<Bytes> Fp_;
-    int commit_prepare() {
-        VMN_TRACE("pos:commit_prepare");
+    struct CommitPrep {                    // between the two halves of commit_prepare (declared in this order: the jobs are joined first)
+        std::vector<Bytes> pkpow;
+        PendingProds prods;
+        HostJobs jobs;
+    };
+    int commit_prepare_begin(CommitPrep& cp) {
         REQUIRE(prover && width && !prepared, "commit_prepare needs a prover with the instance set, once per proof");
         // randomness in the reference's order: b :583, beta :612, gamma :667, delta :673, phi :687
         TRY(draw_ring_array(b));
@@ -1055,30 +1090,43 @@ struct vmn_pos : ProofBase {
         TRY(draw_ring_element(delta));
         phi.resize(width);
         for (auto& ph : phi) TRY(draw_ring_element(ph));
-        std::vector<Bytes> prods, pkpow;
-        HostJobs jobs;
-        jobs.start([&] { return gexp(g, gamma, Cp_); });                          // :667-679
-        jobs.start([&] { return gexp(g, delta, Dp_); });
-        pk_powers(jobs, pkey, phi, pkpow);                                        // :687-690
-        TRY(expprod_multi(wp, epsilon, eps_bits, prods));                         // :690
+        cp.jobs.start([&] { return gexp(g, gamma, Cp_); });                       // :667-679
+        cp.jobs.start([&] { return gexp(g, delta, Dp_); });
+        pk_powers(cp.jobs, pkey, phi, cp.pkpow);                                  // :687-690
+        return cp.prods.begin(wp, epsilon, eps_bits);                             // :690 (the device part)
+    }
+    int commit_prepare_finish(CommitPrep& cp) {
+        std::vector<Bytes> prods;
+        TRY(cp.prods.finish(G, prods));
         Round rd(*this);
         rd.products(prods);
         TRY(rd.run());
-        TRY(jobs.join());
-        TRY(pk_finish(pkpow, prods, Fp_));
+        TRY(cp.jobs.join());
+        TRY(pk_finish(cp.pkpow, prods, Fp_));
         prepared = true;
         return VMN_OK;
+    }
+    int commit_prepare() {
+        VMN_TRACE("pos:commit_prepare");
+        CommitPrep cp;
+        TRY(commit_prepare_begin(cp));
+        return commit_prepare_finish(cp);
     }
     int commit(vmn_msg** out) {
         VMN_TRACE("pos:commit");
         REQUIRE(out && prover && e.p && width, "commit needs a prover with instance and batching vector set");
-        if (!prepared) TRY(commit_prepare());
+        // not prepared ahead: F' is begun here and finished behind the bridging commitments, whose fixed-base powers keep the
+        // device busy while the host completes the product
+        CommitPrep cp;
+        const bool prepare_here = !prepared;
+        if (prepare_here) TRY(commit_prepare_begin(cp));
         TRY(permuted_batch_vector(e, piinv, ipe));                                // :552-554
         RA x, y;
         Bytes x_in, y_in;
         TRY(scans(b, ipe, x, y, d, x_in, y_in));                                  // :583-604
         GA B, Bp;
         TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp)); // :606-648 (queued)
+        if (prepare_here) TRY(commit_prepare_finish(cp));
         std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push(B);
         m->push_element(Ap);
@@ -1229,7 +1277,21 @@ struct vmn_pos : ProofBase {
         xs.insert(xs.end(), wp.begin(), wp.end());
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
-        TRY(expprod_multi(xs, ikE->ra, kE_bits, prep.kE_prods));                  // :1021, :1063 — one sort of k_E
+        PendingProds kE_pending;
+        TRY(kE_pending.begin(xs, ikE->ra, kE_bits));                              // :1021, :1063 — one sort of k_E (the device part)
+        // The reply side of check (B) :1030-1033 -- unless verify() follows at once and takes the combined form.  It needs the
+        // element in front of this shard's B: h0 when there is one shard, and then it is queued here, behind the device part
+        // of the products and in front of their host part (which it hides); with several shards it waits for the exchange.
+        prep.deferred = defer_bridge && combined_form_pays();
+        prep.kE_bits = kE_bits;
+        prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
+        auto queue_bridge = [&](const Bytes& front) -> int {
+            if (prep.paired) return bridging_pair(g, front, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right);
+            if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
+            return VMN_OK;
+        };
+        if (!sharded) TRY(queue_bridge(h0));
+        TRY(kE_pending.finish(G, prep.kE_prods));
         // ... completed over the ranks in ONE exchange ...
         std::vector<Bytes> lasts;
         Round rd(*this);
@@ -1245,13 +1307,8 @@ struct vmn_pos : ProofBase {
             TRY(G.el_exp(h0, eprod, t_h0));
             return G.el_div(Blast, t_h0, prep.D);
         });
-        // ... then the reply side of check (B) is queued :1030-1033 -- unless verify() follows at once and takes the combined form
-        prep.deferred = defer_bridge && combined_form_pays();
         prep.prev = prev;
-        prep.kE_bits = kE_bits;
-        prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
-        if (prep.paired) TRY(bridging_pair(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right));
-        else if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
+        if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
@@ -1354,7 +1411,12 @@ struct vmn_posc : ProofBase {
     // the part of commit() that does not depend on the batching vector (see vmn_pos::commit_prepare)
     bool prepared = false;
     Bytes Ap_, Cp_, Dp_;
-    int commit_prepare() {
+    struct CommitPrep {                    // between the two halves of commit_prepare (see vmn_pos; the jobs are joined first)
+        Bytes ga;
+        PendingProds prod;
+        HostJobs jobs;                     // the three host exponentiations run beside the multi-exponentiation
+    };
+    int commit_prepare_begin(CommitPrep& cp) {
         REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
         // randomness in the reference's order: b, alpha, epsilon, beta, gamma, delta (PoSCBasicTW.java:400-500)
         TRY(draw_ring_array(b));
@@ -1363,29 +1425,39 @@ struct vmn_posc : ProofBase {
         TRY(draw_ring_array(beta));
         TRY(draw_ring_element(gamma));
         TRY(draw_ring_element(delta));
-        Bytes hp(G.eb), ga;
-        HostJobs jobs;                                 // the three host exponentiations run beside the multi-exponentiation
-        jobs.start([&] { return gexp(g, alpha, ga); });
-        jobs.start([&] { return gexp(g, gamma, Cp_); });
-        jobs.start([&] { return gexp(g, delta, Dp_); });
-        TRY(vmn_garray_expprod(h, epsilon, eps_bits, hp.data()));
+        cp.jobs.start([this, &cp] { return gexp(g, alpha, cp.ga); });
+        cp.jobs.start([&] { return gexp(g, gamma, Cp_); });
+        cp.jobs.start([&] { return gexp(g, delta, Dp_); });
+        return cp.prod.begin({h}, epsilon, eps_bits);
+    }
+    int commit_prepare_finish(CommitPrep& cp) {
+        std::vector<Bytes> hp;
+        TRY(cp.prod.finish(G, hp));
         Round rd(*this);
-        rd.product(hp);
+        rd.product(hp[0]);
         TRY(rd.run());
-        TRY(jobs.join());
-        TRY(G.el_mul(ga, hp, Ap_));
+        TRY(cp.jobs.join());
+        TRY(G.el_mul(cp.ga, hp[0], Ap_));
         prepared = true;
         return VMN_OK;
     }
+    int commit_prepare() {
+        CommitPrep cp;
+        TRY(commit_prepare_begin(cp));
+        return commit_prepare_finish(cp);
+    }
     int commit(vmn_msg** out) {
         REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
-        if (!prepared) TRY(commit_prepare());
+        CommitPrep cp;                                                            // (see vmn_pos::commit)
+        const bool prepare_here = !prepared;
+        if (prepare_here) TRY(commit_prepare_begin(cp));
         TRY(permuted_batch_vector(e, piinv, ipe));
         RA x, y;
         Bytes x_in, y_in;
         TRY(scans(b, ipe, x, y, d, x_in, y_in));
         GA B, Bp;
         TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp));
+        if (prepare_here) TRY(commit_prepare_finish(cp));
         std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push(B);
         m->push_element(Ap_);
@@ -1487,7 +1559,20 @@ struct vmn_posc : ProofBase {
         eprod = G.ring_from(eprod_b.data());
         int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
-        TRY(vmn_garray_expprod(h, ikE->ra, kE_bits, prep.hk.data()));
+        PendingProds hk_pending;                                                  // (see vmn_pos::verify_prepare)
+        std::vector<Bytes> hk_out;
+        TRY(hk_pending.begin({h}, ikE->ra, kE_bits));
+        prep.deferred = defer_bridge && combined_form_pays();
+        prep.kE_bits = kE_bits;
+        prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
+        auto queue_bridge = [&](const Bytes& front) -> int {
+            if (prep.paired) return bridging_pair(g, front, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right);
+            if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
+            return VMN_OK;
+        };
+        if (!sharded) TRY(queue_bridge(h0));
+        TRY(hk_pending.finish(G, hk_out));
+        prep.hk = hk_out[0];
         std::vector<Bytes> lasts;
         Round rd(*this);
         rd.product(prep.A);
@@ -1503,12 +1588,8 @@ struct vmn_posc : ProofBase {
             TRY(G.el_exp(h0, eprod, t_h0));
             return G.el_div(Blast, t_h0, prep.D);
         });
-        prep.deferred = defer_bridge && combined_form_pays();
         prep.prev = prev;
-        prep.kE_bits = kE_bits;
-        prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
-        if (prep.paired) TRY(bridging_pair(g, prev, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right));
-        else if (!prep.deferred) TRY(bridging_right(g, prev, cB, ikB->ra, ikE->ra, kE_bits, prep.right));
+        if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
         prep.rep = rep;
         prep.serial = rep->serial;
