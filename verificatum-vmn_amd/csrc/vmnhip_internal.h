@@ -77,6 +77,8 @@ struct vmn_ctx {
     uint32_t* flags = nullptr;            // small device word array for verdicts / range flags
     void* stage = nullptr;                // pinned host buffer (vmn::STAGE_BYTES): small device-to-host copies land here first --
                                           //   16 us instead of 27 us per read-back (tools/micro/copy_latency.hip); allocated on first use
+    hipEvent_t stage_read = nullptr;      // recorded behind the latest host-to-device copy out of `stage` (the host waits for it before writing there again)
+    bool stage_read_pending = false;
     void* stage_pending = nullptr;        // pinned landing buffer of the ONE multi-exponentiation in flight on this lane (vmn_pending)
     size_t stage_pending_bytes = 0;
     bool stage_pending_busy = false;
