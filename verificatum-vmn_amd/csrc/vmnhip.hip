@@ -445,7 +445,8 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->stage_read) (void)hipEventDestroy(ctx->stage_read);
-    if (ctx->stage_pending) (void)hipHostFree(ctx->stage_pending);
+    for (void* sp : ctx->stage_pending)
+        if (sp) (void)hipHostFree(sp);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -3225,7 +3226,8 @@ struct vmn_pending {
     vmn_ctx* lane = nullptr;
     size_t k = 0;
     int nwin = 0, c = 0;
-    bool staged = false;                   // the results are on their way to lane->stage_pending; else `result` holds them
+    bool staged = false;                   // the results are on their way to lane->stage_pending[slot]; else `result` holds them
+    int slot = -1;
     size_t staged_bytes = 0;
     hipEvent_t ev = nullptr;
     std::vector<uint8_t> result;
@@ -3256,23 +3258,27 @@ static void horner_windows(const vmn_group* g, const uint8_t* wbe, size_t k, int
     for (auto& f : others) f.get();
 }
 
-// the lane's landing buffer for a pending result, if it is free (one multi-exponentiation in flight per lane)
-static uint8_t* claim_pending_stage(vmn_ctx* ctx, size_t bytes) {
-    if (ctx->stage_pending_busy) return nullptr;
-    if (ctx->stage_pending_bytes < bytes) {
-        if (ctx->stage_pending) (void)hipHostFree(ctx->stage_pending);
-        ctx->stage_pending = nullptr;
-        ctx->stage_pending_bytes = 0;
+// a landing buffer of the lane for a pending result, if one is free (PENDING_SLOTS multi-exponentiations in flight per lane)
+static uint8_t* claim_pending_stage(vmn_ctx* ctx, size_t bytes, vmn_pending* pend) {
+    int k = -1;
+    for (int i = 0; i < vmn_ctx::PENDING_SLOTS && k < 0; ++i)
+        if (!ctx->stage_pending_busy[i]) k = i;
+    if (k < 0) return nullptr;
+    if (ctx->stage_pending_bytes[k] < bytes) {
+        if (ctx->stage_pending[k]) (void)hipHostFree(ctx->stage_pending[k]);
+        ctx->stage_pending[k] = nullptr;
+        ctx->stage_pending_bytes[k] = 0;
         const size_t want = std::max<size_t>(bytes, (size_t)1 << 18);
-        if (hipHostMalloc(&ctx->stage_pending, want, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(&ctx->stage_pending[k], want, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
-            ctx->stage_pending = nullptr;
+            ctx->stage_pending[k] = nullptr;
             return nullptr;
         }
-        ctx->stage_pending_bytes = want;
+        ctx->stage_pending_bytes[k] = want;
     }
-    ctx->stage_pending_busy = true;
-    return static_cast<uint8_t*>(ctx->stage_pending);
+    ctx->stage_pending_busy[k] = true;
+    pend->slot = k;
+    return static_cast<uint8_t*>(ctx->stage_pending[k]);
 }
 
 // queue export + copy of `rows` rows into the claimed landing buffer and the event that says they have arrived
@@ -3286,7 +3292,7 @@ static int stage_pending(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, cons
         (void)hipStreamSynchronize(ctx->stream);          // the copy may be queued: the buffer is free again once it has run
         if (pend->ev) (void)hipEventDestroy(pend->ev);
         pend->ev = nullptr;
-        ctx->stage_pending_busy = false;
+        ctx->stage_pending_busy[pend->slot] = false;
         return rc;
     }
     pend->staged = true;
@@ -3526,7 +3532,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         VMN_TRY(rc);
         if (pend) {
             pend->staged_bytes = k * ebytes_out;
-            if (uint8_t* land = claim_pending_stage(ctx, pend->staged_bytes))
+            if (uint8_t* land = claim_pending_stage(ctx, pend->staged_bytes, pend))
                 return stage_pending(ctx, m, g->nbytes, res.as<uint32_t>(), k, land, pend);
             pend->result.resize(k * ebytes_out);
             out_be = pend->result.data();
@@ -3536,7 +3542,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     const size_t wbytes = k * (size_t)nwin * g->nbytes;
     if (pend) {
         pend->staged_bytes = wbytes;
-        if (uint8_t* land = claim_pending_stage(ctx, wbytes))
+        if (uint8_t* land = claim_pending_stage(ctx, wbytes, pend))
             return stage_pending(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, land, pend);
         pend->result.resize(k * ebytes_out);
         out_be = pend->result.data();
@@ -3596,8 +3602,8 @@ extern "C" int vmn_garray_expprod_multi(const vmn_garray* const* xs, size_t k, c
 
 // The same in two halves: _begin queues the device part and returns; vmn_pending_finish waits for it and completes the result
 // (modular groups: the Horner chain over the windows, on the host).  Between the two the caller queues whatever else it has for
-// the device -- a proof's fixed-base powers run while the host squares.  One multi-exponentiation per lane can be in flight;
-// a second _begin computes its result at once (finish then only hands it over).
+// the device -- a proof's fixed-base powers run while the host squares.  Two multi-exponentiations per lane can be in flight;
+// a third _begin computes its result at once (finish then only hands it over).
 extern "C" int vmn_garray_expprod_multi_begin(const vmn_garray* const* xs, size_t k, const vmn_rarray* e, int ebits, vmn_pending** out) {
     ARG_CHECK(xs && k > 0 && e && out, "null argument");
     vmn_group* g = e->grp;
@@ -3620,7 +3626,7 @@ static void pending_release(vmn_pending* p) {
         std::lock_guard<std::recursive_mutex> guard__(p->lane->mu);
         (void)hipSetDevice(p->lane->device);
         if (p->ev) (void)hipEventSynchronize(p->ev);      // the copy into the landing buffer must not outlive the claim
-        p->lane->stage_pending_busy = false;
+        p->lane->stage_pending_busy[p->slot] = false;
         p->staged = false;
     }
     if (p->ev) (void)hipEventDestroy(p->ev);
@@ -3640,8 +3646,8 @@ extern "C" int vmn_pending_finish(vmn_pending* p, uint8_t* out_be) {
         std::lock_guard<std::recursive_mutex> guard__(p->lane->mu);
         hipError_t he = hipSetDevice(p->lane->device);
         if (he == hipSuccess) he = hipEventSynchronize(p->ev);
-        if (he == hipSuccess) memcpy(landed.data(), p->lane->stage_pending, p->staged_bytes);
-        p->lane->stage_pending_busy = false;
+        if (he == hipSuccess) memcpy(landed.data(), p->lane->stage_pending[p->slot], p->staged_bytes);
+        p->lane->stage_pending_busy[p->slot] = false;
         p->staged = false;
         (void)hipEventDestroy(p->ev);
         p->ev = nullptr;

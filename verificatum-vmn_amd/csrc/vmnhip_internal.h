@@ -79,9 +79,10 @@ struct vmn_ctx {
                                           //   16 us instead of 27 us per read-back (tools/micro/copy_latency.hip); allocated on first use
     hipEvent_t stage_read = nullptr;      // recorded behind the latest host-to-device copy out of `stage` (the host waits for it before writing there again)
     bool stage_read_pending = false;
-    void* stage_pending = nullptr;        // pinned landing buffer of the ONE multi-exponentiation in flight on this lane (vmn_pending)
-    size_t stage_pending_bytes = 0;
-    bool stage_pending_busy = false;
+    static constexpr int PENDING_SLOTS = 2;          // multi-exponentiations in flight on this lane (vmn_pending): a verifier's A, F and its k_E products
+    void* stage_pending[PENDING_SLOTS] = {nullptr, nullptr};     // their pinned landing buffers
+    size_t stage_pending_bytes[PENDING_SLOTS] = {0, 0};
+    bool stage_pending_busy[PENDING_SLOTS] = {false, false};
     // stream-ordered caching allocator: freed device blocks are kept by size and handed out again
     // (all work of a context is on one stream, so reuse is ordered after the previous user)
     std::map<size_t, std::vector<void*>> pool;

@@ -1183,8 +1183,20 @@ struct vmn_pos : ProofBase {
         REQUIRE(u && e.p && width, "computeAF needs u, the instance and the batching vector");
         std::vector<const vmn_garray*> xs{u};
         xs.insert(xs.end(), w.begin(), w.end());
+        A.clear();
+        F.clear();
+        af_pending.reset(new PendingProds());
+        return af_pending->begin(xs, e, e_bits);                                  // one sort of e for u and w (the device part)
+    }
+    // A and F are completed where they are first needed -- in verify_prepare, behind the reply side of check (B), whose powers
+    // then run on the device while the host finishes these products (and the sharded form exchanges them)
+    std::unique_ptr<PendingProds> af_pending;
+    bool af_begun() const { return af_pending || !A.empty(); }
+    int finish_af() {
+        if (!af_pending) return VMN_OK;
+        std::unique_ptr<PendingProds> pend(std::move(af_pending));
         std::vector<Bytes> res;
-        TRY(expprod_multi(xs, e, e_bits, res));                                   // one sort of e for u and w
+        TRY(pend->finish(G, res));
         Round rd(*this);
         rd.products(res);
         TRY(rd.run());
@@ -1248,7 +1260,7 @@ struct vmn_pos : ProofBase {
     } prep;
     int verify_prepare(const vmn_msg* rep, bool defer_bridge = false) {
         VMN_TRACE("pos:verify_prepare");
-        REQUIRE(cB && !A.empty(), "verify_prepare needs computeAF and setCommitment");
+        REQUIRE(cB && af_begun(), "verify_prepare needs computeAF and setCommitment");
         const vmn_msg::Item *ikA = item_of(rep, 0, VMN_ITEM_RING), *ikB = item_of(rep, 1, VMN_ITEM_RARRAY),
                             *ikC = item_of(rep, 2, VMN_ITEM_RING), *ikD = item_of(rep, 3, VMN_ITEM_RING),
                             *ikE = item_of(rep, 4, VMN_ITEM_RARRAY), *ikF = item_of(rep, 5, VMN_ITEM_RING);
@@ -1291,6 +1303,7 @@ struct vmn_pos : ProofBase {
             return VMN_OK;
         };
         if (!sharded) TRY(queue_bridge(h0));
+        TRY(finish_af());
         TRY(kE_pending.finish(G, prep.kE_prods));
         // ... completed over the ranks in ONE exchange ...
         std::vector<Bytes> lasts;
@@ -1317,8 +1330,9 @@ struct vmn_pos : ProofBase {
     }
     int verify(const vmn_msg* rep, int* verdict, int* five) {
         VMN_TRACE("pos:verify");
-        REQUIRE(verdict && cB && !A.empty() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
+        REQUIRE(verdict && cB && af_begun() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
         if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch) TRY(verify_prepare(rep, true));
+        TRY(finish_af());
         if (prep.malformed) {                                                     // a ring scalar >= q: not a reply (:985-989)
             prep.clear();
             if (five) five[0] = five[1] = five[2] = five[3] = five[4] = 0;
