@@ -264,6 +264,9 @@ int vmn_rarray_rec_lin(const vmn_rarray* b, const vmn_rarray* e, vmn_rarray** ou
 int vmn_rarray_prods(const vmn_rarray* e, vmn_rarray** out);
 int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y, uint8_t* out_be);
 int vmn_rarray_sum(const vmn_rarray* x, uint8_t* out_be);
+/* k of those in ONE round trip: out_be[i] = <xs[i], ys[i]>, or the sum of xs[i] where ys[i] is NULL (a reply's <r, e'>,
+ * sum r and <s_c, e>, ref: P/hvzk/PoSBasicTW.java:856-888).  out_be receives k ring elements. */
+int vmn_rarray_inner_products(const vmn_rarray* const* xs, const vmn_rarray* const* ys, size_t k, uint8_t* out_be);
 int vmn_rarray_prod(const vmn_rarray* x, uint8_t* out_be);
 int vmn_rarray_permute(const vmn_rarray* x, const uint32_t* perm_host, vmn_rarray** out);
 int vmn_rarray_gather(const vmn_rarray* x, const uint32_t* idx_host, size_t n_out, vmn_rarray** out);

@@ -463,6 +463,19 @@ def test_simultaneous_power_and_array_inverse(bits, groups, oracle_for):
         assert got == want, (e.bit_length(), fbits)
 
 
+def test_inner_products_in_one_round_trip(vmn, groups):
+    """vmn_rarray_inner_products against Python: products and plain sums mixed, arrays of different lengths (1 element, one
+    beyond a reduction pass, empty)."""
+    G, grp, _ = groups[2048]
+    q = grp["q"]
+    vals = pyref.stream_ints(b"inner-products", 3000, q)
+    cases = [(vals[:1000], vals[1000:2000]), (vals[:1000], None), (vals[2000:2001], vals[5:6]), (vals[:777], vals[1:778]), ([], None), ([], [])]
+    pairs = [(G.ringArray(x), G.ringArray(y) if y is not None else None) for x, y in cases]
+    want = [sum(a * b for a, b in zip(x, y)) % q if y is not None else sum(x) % q for x, y in cases]
+    assert vmn.innerProducts(pairs) == want
+    assert vmn.innerProducts(pairs[:1]) == want[:1]
+
+
 @pytest.mark.parametrize("kind", ["modp2048", "modp3072", "P-256"])
 def test_multi_exponentiation_in_two_halves(kind, vmn, gpu_ctx, groups):
     """vmn_garray_expprod_multi_begin / vmn_pending_finish: the products are those of the one-call form (itself checked against

@@ -175,7 +175,7 @@ def need_expr(name, ptype, pname, plist):
     if k == "handles_out":
         return {"wp_out": "2 * (size_t)width", "s_out": "(size_t)width"}.get(pname, "1")
     if k == "handles_in":
-        if pname == "xs":
+        if pname in ("xs", "ys"):
             return "(size_t)k"
         if pname in ("w", "wp", "w_full"):
             return "2 * (size_t)width"
@@ -261,6 +261,8 @@ def need_expr(name, ptype, pname, plist):
             return f"((size_t)vmn_decproof_parties({pobj}) + 1) * {EB}"
         if pname == "abs_be":
             return f"(size_t)threshold * {XB}"
+        if pname == "out_be" and name == "vmn_rarray_inner_products":
+            return f"(size_t)k * vmnjni_xb((c_xs && c_xs[0]) ? vmn_rarray_group((const vmn_rarray*)(intptr_t)c_xs[0]) : NULL)"
         if pname == "out_be" and name == "vmn_pending_finish":
             return f"vmn_pending_bytes({hcast('vmn_pending*', plist[0][1])})"
         if pname == "out_be" and name == "vmn_garray_expprod_multi":

@@ -638,6 +638,17 @@ def expProdMulti(arrays, e: "PRingElementArray", ebits: int = 0) -> list:
     return [grp.dec_el(out.raw[i * eb:(i + 1) * eb]) for i in range(k)]
 
 
+def innerProducts(pairs) -> list:
+    """``vmn_rarray_inner_products``: [<x, y> mod q for (x, y) in pairs] in one round trip; y = None gives the sum of x."""
+    k = len(pairs)
+    xs = (C.c_void_p * k)(*[x._h for x, _ in pairs])
+    ys = (C.c_void_p * k)(*[(y._h if y is not None else None) for _, y in pairs])
+    xb = pairs[0][0].group.exp_bytes
+    out = C.create_string_buffer(k * xb)
+    _check(lib().vmn_rarray_inner_products(xs, ys, C.c_size_t(k), out))
+    return [int.from_bytes(out.raw[i * xb:(i + 1) * xb], "big") for i in range(k)]
+
+
 class PendingExpProd:
     """``vmn_garray_expprod_multi_begin``: the device part of ``expProdMulti`` is queued; ``finish()`` waits for it and returns
     the k elements.  Device work queued in between runs while the host completes the products."""

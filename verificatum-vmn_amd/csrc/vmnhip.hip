@@ -2024,6 +2024,31 @@ extern "C" int vmn_rarray_inner_product(const vmn_rarray* x, const vmn_rarray* y
     return reduce_to_host(LANE(g->ctx), g->Q, g->xbytes, prod.as<uint32_t>(), x->n, false, out_be);
 }
 
+// k scalars in one round trip: out[i] = <xs[i], ys[i]> mod q, or the sum of xs[i] where ys[i] is null -- a prover's reply takes
+// <r, e'>, sum r and <s_c, e> per column (PoSBasicTW.java:856-888); each alone ends in a read-back that drains the stream.
+extern "C" int vmn_rarray_inner_products(const vmn_rarray* const* xs, const vmn_rarray* const* ys, size_t k, uint8_t* out_be) {
+    ARG_CHECK(xs && ys && k > 0 && out_be, "null argument");
+    ARG_CHECK(xs[0], "null array");
+    vmn_group* g = xs[0]->grp;
+    for (size_t i = 0; i < k; ++i)
+        ARG_CHECK(xs[i] && xs[i]->grp == g && (!ys[i] || (ys[i]->grp == g && ys[i]->n == xs[i]->n)), "arrays differ in group or size");
+    vmn_ctx* ctx = LANE(g->ctx);
+    VMN_ENTER(ctx);
+    const size_t Wd = elem_words(g->Q);
+    DevTmp res(ctx), prod(ctx);
+    VMN_TRY(res.alloc(k * Wd * sizeof(uint32_t)));
+    for (size_t i = 0; i < k; ++i) {
+        const uint32_t* src = xs[i]->d;
+        if (ys[i]) {
+            VMN_TRY(prod.alloc(std::max<size_t>(xs[i]->n, 1) * Wd * sizeof(uint32_t)));
+            VMN_TRY(mul_arrays(ctx, g->Q, xs[i]->d, ys[i]->d, Wd, xs[i]->n, prod.as<uint32_t>()));
+            src = prod.as<uint32_t>();
+        }
+        VMN_TRY(reduce_segments(ctx, g->Q, src, xs[i]->n, 1, false, res.as<uint32_t>() + i * Wd));
+    }
+    return export_be(ctx, g->Q, g->xbytes, res.as<uint32_t>(), k, out_be);
+}
+
 // ---- K8 element-wise -------------------------------------------------------------------------------
 static int ring_elementwise(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, const uint32_t* v,
                             int op, size_t n, uint32_t* out) {

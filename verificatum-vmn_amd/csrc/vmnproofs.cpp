@@ -930,6 +930,14 @@ struct ProofBase {
         for (size_t k = 0; k < xs.size(); ++k) out.emplace_back(flat.begin() + k * G.eb, flat.begin() + (k + 1) * G.eb);
         return VMN_OK;
     }
+    // <xs[i], ys[i]> (or the sum of xs[i] where ys[i] is null) for several pairs, one round trip
+    int inner_products(const std::vector<const vmn_rarray*>& xs, const std::vector<const vmn_rarray*>& ys, std::vector<Num>& out) const {
+        Bytes flat(xs.size() * G.xb);
+        TRY(vmn_rarray_inner_products(xs.data(), ys.data(), xs.size(), flat.data()));
+        out.clear();
+        for (size_t i = 0; i < xs.size(); ++i) out.push_back(G.ring_from(flat.data() + i * G.xb));
+        return VMN_OK;
+    }
     // The same in two halves (vmn_garray_expprod_multi_begin / vmn_pending_finish): between begin() and finish() the caller
     // queues the device work that does not need the products -- the host-side tail of a multi-exponentiation (one squaring per
     // exponent bit, ~1 ms at 2048 bits) then runs beside it instead of in front of it.
@@ -1141,15 +1149,15 @@ struct vmn_pos : ProofBase {
         VMN_TRACE("pos:reply");
         REQUIRE(out && prover && ipe.p && s.size() == width, "reply needs commit() and the re-encryption exponents");
         TRY(set_challenge(vb, vbytes));
-        Bytes ab(G.xb), cb(G.xb), fb(G.xb);
-        TRY(vmn_rarray_inner_product(r, ipe, ab.data()));
-        TRY(vmn_rarray_sum(r, cb.data()));
-        Num a = G.ring_from(ab.data()), c = G.ring_from(cb.data());
-        std::vector<Num> f(width);
-        for (size_t col = 0; col < width; ++col) {                               // product-ring inner product: per column
-            TRY(vmn_rarray_inner_product(s[col], e, fb.data()));
-            f[col] = G.ring_from(fb.data());
+        std::vector<const vmn_rarray*> xs{r, r}, ys{ipe, nullptr};                 // <r, e'>, sum r, and per column <s_c, e>
+        for (size_t col = 0; col < width; ++col) {                               // (product-ring inner product: per column)
+            xs.push_back(s[col]);
+            ys.push_back(e);
         }
+        std::vector<Num> scal;
+        TRY(inner_products(xs, ys, scal));
+        Num a = scal[0], c = scal[1];
+        std::vector<Num> f(scal.begin() + 2, scal.end());
         Round rd(*this);
         rd.sum(a);
         rd.sum(c);
@@ -1484,10 +1492,9 @@ struct vmn_posc : ProofBase {
     int reply(const uint8_t* vb, size_t vbytes, vmn_msg** out) {
         REQUIRE(out && ipe.p && r, "reply needs commit()");
         TRY(set_challenge(vb, vbytes));
-        Bytes ab(G.xb), cb(G.xb);
-        TRY(vmn_rarray_inner_product(r, ipe, ab.data()));
-        TRY(vmn_rarray_sum(r, cb.data()));
-        Num a = G.ring_from(ab.data()), c = G.ring_from(cb.data());
+        std::vector<Num> scal;
+        TRY(inner_products({r, r}, {ipe, nullptr}, scal));
+        Num a = scal[0], c = scal[1];
         Round rd(*this);
         rd.sum(a);
         rd.sum(c);
@@ -1751,14 +1758,15 @@ struct vmn_ccpos : ProofBase {
         VMN_TRACE("ccpos:reply");
         REQUIRE(out && ipe.p && r && s.size() == width, "reply needs commit()");
         TRY(set_challenge(vb, vbytes));
-        Bytes ab(G.xb), bsum(G.xb);
-        TRY(vmn_rarray_inner_product(r, ipe, ab.data()));
-        Num a = G.ring_from(ab.data());
-        std::vector<Num> f(width);
+        std::vector<const vmn_rarray*> xs{r}, ys{ipe};
         for (size_t col = 0; col < width; ++col) {
-            TRY(vmn_rarray_inner_product(s[col], e, bsum.data()));
-            f[col] = G.ring_from(bsum.data());
+            xs.push_back(s[col]);
+            ys.push_back(e);
         }
+        std::vector<Num> scal;
+        TRY(inner_products(xs, ys, scal));
+        Num a = scal[0];
+        std::vector<Num> f(scal.begin() + 1, scal.end());
         Round rd(*this);
         rd.sum(a);
         for (auto& fc : f) rd.sum(fc);
