@@ -124,6 +124,34 @@ def test_multi_exponentiation_and_movement(ecg):
     assert G.exp(base[0], G.ringArray(es)).toInts() == [c.mul(e, base[0]) for e in es]
 
 
+def test_signed_window_recoding_of_the_multi_exponentiation(ecg):
+    """Curves sort the exponents by SIGNED window digits (light_kernels.h signed_digit): exponents whose digits sit on the
+    recoding's edges for every window width the library may pick -- every digit exactly 2^(c-1) (a carry arrives or not), one
+    above and one below, all ones (a carry through every window), the top bits of the order -- against the oracle."""
+    G, c = ecg
+    rnd = random.Random(77)
+    nbits = c.n.bit_length()
+    es = [0, 1, 2, c.n - 1, c.n - 2, (1 << (nbits - 1)) - 1, 1 << (nbits - 1)]
+    for w in range(2, 18):
+        half = sum((1 << (w - 1)) << (w * k) for k in range(nbits // w + 1))
+        ones = (1 << (w * (nbits // w))) - 1
+        for e in (half, half + 1, half - 1, half << 1, ones, ones - (1 << (w - 1)), half ^ (1 << (w * 3 + w - 1))):
+            es.append(e % c.n)
+    xs = pts(c, 4242, len(es))
+    want = c.exp_prod(xs, es)
+    X, E = G.toElementArray(xs), G.ringArray(es)
+    assert X.expProd(E) == want
+    # many more elements than buckets, so that the library picks a wide window; the edge exponents among random ones
+    n = 3000
+    more = es + [rnd.randrange(c.n) for _ in range(n - len(es))]
+    base = pts(c, 4243, 16)
+    ys = [base[i % 16] for i in range(n)]
+    coeff = [0] * 16
+    for i, e in enumerate(more):
+        coeff[i % 16] = (coeff[i % 16] + e) % c.n
+    assert G.toElementArray(ys).expProd(G.ringArray(more)) == c.exp_prod(base, coeff)
+
+
 def test_scalar_field_arrays(ecg):
     G, c = ecg
     rnd = random.Random(9)

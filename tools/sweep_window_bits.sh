@@ -1,0 +1,12 @@
+#!/bin/bash
+# P-256 CCPoS leg with the window width of the multi-exponentiation forced (VMN_WINDOW_BITS), signed and unsigned digits.   (gpurun)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for sw in 1 0; do
+for c in ${WIDTHS:-11 12 13 14 15 16}; do
+  VMN_SIGNED_WINDOWS=$sw VMN_WINDOW_BITS=$c python3 bench.py --steps 1 --warmup 0 --elements 2048 --mix-elements 0 --ccpos-elements 0 --ec-elements ${1:-1000000} --decrypt-elements 0 --skip-cpu --no-e2e 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.readline()); m=r['mix_ec_p256']
+k=m['kernel_ms_by_family']
+print('signed=$sw c=$c online_ms=%.2f ct/s=%.4g expprod=%.2f agg=%.2f sort=%.2f scan=%.2f reduce=%.2f' % (m['online_ms'], m['ciphertexts_per_s_online'], k['expprod'], k['expprod_agg'], k['expprod_sort'], k['scan'], k['reduce']))"
+done
+done

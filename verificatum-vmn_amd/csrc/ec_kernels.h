@@ -184,6 +184,21 @@ __device__ __forceinline__ void f_sub(u32 (&r)[S], const u32 (&a)[S], const u32 
         }
     }
 }
+// r = -a + 64p  (a < 64p)
+template <int S>
+__device__ __forceinline__ void f_neg(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
+    int32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        int32_t v = (int32_t)E.mp[j] - (int32_t)a[j] + c;
+        if (j == S - 1) {
+            r[j] = (u32)v;
+        } else {
+            r[j] = (u32)v & LIMB_MASK;
+            c = v >> LIMB_BITS;
+        }
+    }
+}
 // r = k * a for a small constant k (k * limb < 2^32)
 template <int S, int K>
 __device__ __forceinline__ void f_small(u32 (&r)[S], const u32 (&a)[S]) {
@@ -930,12 +945,18 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* _
     u32 start = off_in[b] + j * F;
     u32 end = off_in[b] + cnt_in[b];
     if (end > start + F) end = start + F;
-    auto row = [&](u32 k) -> const u32* { return FIRST ? in + (size_t)sorted[k] * ROW : in + (size_t)k * ROW; };
+    // FIRST: an entry of `sorted` is the element's index, bit 31 set when its digit in this window is negative (signed
+    // windows, vmnhip.hip expprod_words): the point then enters with -Y
+    auto row = [&](u32 k) -> const u32* { return FIRST ? in + (size_t)(sorted[k] & 0x7fffffffu) * ROW : in + (size_t)k * ROW; };
     Pt<S> A, B;
     pt_load<S>(A, row(start));
+    if constexpr (FIRST) {
+        if (sorted[start] >> 31) f_neg<S>(A.Y, A.Y, E);
+    }
     for (u32 k = start + 1; k < end; ++k) {
         if constexpr (FIRST) {                         // the first level adds rows of the (normalised) input array
             pt_load_normalised<S>(B, row(k));
+            if (sorted[k] >> 31) f_neg<S>(B.Y, B.Y, E);
             pt_madd<S>(A, A, B, E);
         } else {
             pt_load<S>(B, row(k));

@@ -3231,15 +3231,30 @@ static double bucket_agg_weight() {
     const char* env = getenv("VMN_BUCKET_AGG_WEIGHT");           // tuning knob
     return env && *env ? atof(env) : 3.0;
 }
-static int pick_bucket_bits(size_t n, int ebits, bool ec = false) {
+// curves recode the windows to signed digits (light_kernels.h: signed_digit): 2^(c-1) buckets per c-bit window, one more
+// bit of the exponent to hold the last carry.  VMN_SIGNED_WINDOWS=0 turns that off (measurement).
+static bool signed_windows(const vmn_modulus& m) {
+    static const bool off = [] {
+        const char* e = getenv("VMN_SIGNED_WINDOWS");
+        return e && *e == '0';
+    }();
+    return m.ec != nullptr && !off;
+}
+static int pick_bucket_bits(size_t n, int ebits, bool ec = false, bool sgn = false) {
+    if (const char* env = getenv("VMN_WINDOW_BITS")) {           // measurement knob: the window width itself
+        const int c = atoi(env);
+        if (c >= 2 && c <= 16) return c;
+    }
     int best = 1;
     double best_cost = 1e300;
     // curves: a bucket of the aggregation (two full additions in low-occupancy scans) costs about eight insertions (mixed
     // additions at full occupancy), measured: profiles/r03_bucket_weight_sweep.txt
-    const double wagg = getenv("VMN_BUCKET_AGG_WEIGHT") ? bucket_agg_weight() : ec ? 8.0 : 3.0;
-    for (int c = 1; c <= 16; ++c) {
-        int nwin = (ebits + c - 1) / c;
-        double cost = (double)nwin * ((double)n + wagg * (double)((size_t)1 << c));
+    // (signed windows: 24 -- the sweep of the window width itself, profiles/r03_window_bits_sweep.txt: 13 bits at 10^6 points,
+    // 10 bits at 10^5; beyond 2^12 buckets per window the counting sort also leaves its LDS-privatised path)
+    const double wagg = getenv("VMN_BUCKET_AGG_WEIGHT") ? bucket_agg_weight() : ec ? (sgn ? 24.0 : 8.0) : 3.0;
+    for (int c = sgn ? 2 : 1; c <= (sgn ? 17 : 16); ++c) {
+        int nwin = sgn ? (ebits + c) / c : (ebits + c - 1) / c;
+        double cost = (double)nwin * ((double)n + wagg * (double)((size_t)1 << (sgn ? c - 1 : c)));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -3366,9 +3381,16 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         return VMN_OK;
     }
     if (ebits < 1) ebits = 1;
-    const int c = pick_bucket_bits(n, ebits, m.ec != nullptr);
-    const int nwin = (ebits + c - 1) / c;
-    const size_t nb = (size_t)1 << c;
+    const bool sgn = signed_windows(m);
+    if (sgn) ebits = 32 * ewords;                      // everything the words can hold: the recoding must not lose a carry
+    if (m.ec && n >= ((size_t)1 << 31)) {
+        set_error("multi-exponentiation over a curve: at most 2^31 - 1 points per array");
+        return VMN_ERR_UNSUPPORTED;
+    }
+    const int c = pick_bucket_bits(n, ebits, m.ec != nullptr, sgn);
+    const int nwin = sgn ? (ebits + c) / c : (ebits + c - 1) / c;     // signed: ebits + 1 bits
+    const int cb = sgn ? c - 1 : c;                    // bucket bits of a window; bucket j of a signed window holds the digits +-(j + 1)
+    const size_t nb = (size_t)1 << cb;
     const size_t nbuckets = (size_t)nwin * nb;
     // fan-in of the per-bucket product tree.  A lane sums one chunk of at most F items; the lanes of a wave wait for the longest
     // chunk, so F is best a little above the typical bucket size n / 2^c (most buckets are then ONE chunk, the wave's longest
@@ -3414,11 +3436,18 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     VMN_TRACE("expprod:sort");
     VMN_HIP(hipMemsetAsync(counts, 0, nbuckets * sizeof(uint32_t), ctx->stream));
     const unsigned gx = std::max<unsigned>(1, std::min<unsigned>((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)(ctx->num_cus * 8 / std::max(nwin, 1) + 1)));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx, ebits));
-    VMN_TRY(scan_u32(off0, cursor, counts, misc + 2 * LV));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
-                         e_words, ewords, n, c, nwin, gx, ebits));
-    VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
+    if (sgn) {
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist<true>, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx, ebits));
+        VMN_TRY(scan_u32(off0, cursor, counts, misc + 2 * LV));
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter<true>, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
+                             e_words, ewords, n, c, nwin, gx, ebits));           // (zero digits were never inserted)
+    } else {
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist<false>, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx, ebits));
+        VMN_TRY(scan_u32(off0, cursor, counts, misc + 2 * LV));
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_scatter<false>, gx * (unsigned)nwin, sorted.as<uint32_t>(), cursor,
+                             e_words, ewords, n, c, nwin, gx, ebits));
+        VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_drop_zero, grid_for(nwin), counts, c, nwin));
+    }
     }
     // per-bucket product tree with fan-in F, level by level until every bucket holds <= 1 item.  The SHAPE of the trees
     // (items per bucket and level, offsets, totals) depends on the exponents only: it is computed first, once; then the
@@ -3536,8 +3565,9 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
                 // W_win = prod_{d>=1} B[d]^d = prod_{d>=1} (suffix product S_d): suffix scan, blank d = 0, reduce -- for the group
                 const size_t gsz = arr % G + 1, first_arr = arr + 1 - gsz, segs = gsz * (size_t)nwin;
                 VMN_TRY(scan_affine(ctx, m, Ball, nullptr, segs * nb, nb, 1, Ssuf));
-                VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for(segs * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
-                                     nb, segs, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
+                if (!sgn)                              // (signed windows: bucket 0 holds the digits +-1 and counts)
+                    VMN_TRY(launch_light(ctx, "expprod_agg", k_set_segment_heads, grid_for(segs * (Wd / 4)), reinterpret_cast<uint4*>(Ssuf),
+                                         nb, segs, reinterpret_cast<const uint4*>(m.d_one), (int)(Wd / 4)));
                 VMN_TRY(reduce_segments(ctx, m, Ssuf, nb, segs, true, wres.as<uint32_t>() + first_arr * (size_t)nwin * Wd));
             }
         }
