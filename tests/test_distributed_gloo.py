@@ -99,9 +99,9 @@ def test_sharded_ccpos_matches_oracle_on_gloo(world, n, width, backend, tmp_path
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flow,backend,bits,n,width", [("pos", "hip-gloo", 2048, 150, 1), ("ccpos", "hip-gloo", 2048, 90, 2),
-                                                       ("posc", "hip-gloo", 512, 77, 1), ("ccpos", "hip-gloo-ec", 256, 40, 3),
-                                                       ("pos", "hip-gloo-ec", 256, 60, 1)])
+@pytest.mark.parametrize("flow,backend,bits,n,width", [("pos", "hip-gloo", 2048, 150, 1), ("posc", "hip-gloo", 512, 77, 1),
+                                                       ("ccpos", "hip-gloo-ec", 256, 40, 3), ("pos", "hip-gloo-ec", 256, 60, 1)])
+# (CCPoS over a modular group at width 2: the three-rank test and the seeded 2048-bit case below)
 def test_sharded_cxx_drivers_two_ranks_one_gpu(flow, backend, bits, n, width, tmp_path):
     """The sharded C++ drivers (vmn_pos / vmn_posc / vmn_ccpos with a communicator, include/vmnproofs.h) on the real
     kernels: two ranks share the one GPU of the test box, gloo carries the all-gather callback (on an 8-GPU node the
