@@ -530,6 +530,17 @@ def test_two_powers_in_one_launch(bits, groups, oracle_for):
         gx, gy = G.toElementArray(xs[:nx]).expPair(e, G.toElementArray(ys[:ny]), G.ringArray(f), fbits)
         assert gx.toInts() == orc.exp_scalar(xs[:nx], e), (nx, ny, e.bit_length(), fbits)
         assert gy.toInts() == orc.exp_array(ys[:ny], f), (nx, ny, e.bit_length(), fbits)
+    if bits == 2048:
+        # above the eight-lane threshold the two jobs run in DIFFERENT geometries (k_modpow_jobs_mixed: the longer chain eight
+        # lanes per element, the shorter four): either job the longer one, ragged tiles in both
+        big = 7001
+        xs, fs = _inputs(b"pair-mixed", big, p, q)
+        ys = xs[::-1]
+        for nx, ny, e, fbits in ((6500, big, e256, 613), (big, 6300, q - 1, 100)):
+            f = [v % (1 << fbits) for v in fs[:ny]]
+            gx, gy = G.toElementArray(xs[:nx]).expPair(e, G.toElementArray(ys[:ny]), G.ringArray(f), fbits)
+            assert gx.toInts() == orc.exp_scalar(xs[:nx], e), (nx, ny)
+            assert gy.toInts() == orc.exp_array(ys[:ny], f), (nx, ny)
 
 
 @pytest.mark.parametrize("bits", [2048, 3072, 4096])

@@ -61,7 +61,10 @@
     VMN_MODP_INSTANCES(KW, 37, 32, 1) VMN_MEMBER_INSTANCE_ONE_LANE(KW, 10, 1) VMN_MEMBER_INSTANCE_ONE_LANE(KW, 14, 1)     \
     VMN_MEMBER_INSTANCE_ONE_LANE(KW, 19, 1) VMN_MEMBER_INSTANCE_ONE_LANE(KW, 37, 1)
 #define VMN_UNIT_2048(KW) VMN_MODP_INSTANCES(KW, 74, 64, 1) VMN_MEMBER_INSTANCE_ONE_LANE(KW, 74, 1)
-#define VMN_UNIT_2048_WIDE(KW) VMN_MODP_INSTANCES(KW, 76, 64, 4) VMN_MODP_INSTANCES(KW, 80, 64, 8)
+#define VMN_UNIT_2048_WIDE(KW)                                                                                         \
+    VMN_MODP_INSTANCES(KW, 76, 64, 4) VMN_MODP_INSTANCES(KW, 80, 64, 8)                                                \
+    KW __global__ void vmn::k_modpow_jobs_mixed<vmn::Cfg<80, 8>, vmn::Cfg<76, 4>>(vmn::ModpowJob, vmn::ModpowJob, unsigned, int,       \
+                                                                                 const vmn::u32*, vmn::u32, const vmn::u32*, vmn::u32*);
 #define VMN_UNIT_3072(KW) VMN_MODP_INSTANCES(KW, 110, 96, 2) VMN_MODP_INSTANCES(KW, 112, 96, 4) VMN_MEMBER_INSTANCE_LANES(KW, 110, 2)
 #define VMN_UNIT_4096(KW) VMN_MODP_INSTANCES(KW, 148, 128, 4) VMN_MEMBER_INSTANCE_LANES(KW, 148, 4)
 #define VMN_UNIT_8192(KW) VMN_MODP_INSTANCES(KW, 296, 256, 8) VMN_MEMBER_INSTANCE_LANES(KW, 296, 8)

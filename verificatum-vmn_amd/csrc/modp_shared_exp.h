@@ -85,20 +85,16 @@ struct ModpowJob {
     int ebits;
     size_t n;
 };
+// one tile (C::EPB elements) of a job; `blocktab`: this block's table rows
 template <class C>
-__global__ void __launch_bounds__(BLOCK, C::MINW)
-k_modpow_jobs(ModpowJob j0, ModpowJob j1, unsigned tiles0, int wbits, const u32* __restrict__ nmod, u32 n0inv,
-              const u32* __restrict__ one_m, u32* __restrict__ tab) {
+__device__ __forceinline__ void modpow_job_tile(const ModpowJob& J, size_t t, int wbits, const u32* __restrict__ nmod, u32 n0inv,
+                                                const u32* __restrict__ one_m, u32* __restrict__ blocktab, u32* lds) {
     constexpr int W = C::W;
-    extern __shared__ u32 lds[];
     Lane<C> ln(lds);
     u32 nn[C::L];
     load_modulus<C>(nn, nmod, ln);
-    const bool second = blockIdx.x >= tiles0;                        // (block-uniform)
-    const ModpowJob& J = second ? j1 : j0;
-    const size_t t = second ? blockIdx.x - tiles0 : blockIdx.x;
     const int tsize = 1 << wbits;
-    u32* mytab = tab + ((size_t)blockIdx.x * C::EPB + ln.eslot) * (size_t)tsize * W;
+    u32* mytab = blocktab + (size_t)ln.eslot * (size_t)tsize * W;
     const int nwin = (J.ebits + wbits - 1) / wbits;
     size_t el = t * C::EPB + ln.eslot;
     bool live = el < J.n;
@@ -135,6 +131,31 @@ k_modpow_jobs(ModpowJob j0, ModpowJob j1, unsigned tiles0, int wbits, const u32*
     }
     canonicalize<C>(a, nn, ln);
     if (live) store_elem<C>(J.out + el * W, a, ln);
+}
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_modpow_jobs(ModpowJob j0, ModpowJob j1, unsigned tiles0, int wbits, const u32* __restrict__ nmod, u32 n0inv,
+              const u32* __restrict__ one_m, u32* __restrict__ tab) {
+    extern __shared__ u32 lds[];
+    const bool second = blockIdx.x >= tiles0;                        // (block-uniform)
+    u32* blocktab = tab + (size_t)blockIdx.x * C::EPB * ((size_t)1 << wbits) * C::W;
+    if (second) modpow_job_tile<C>(j1, blockIdx.x - tiles0, wbits, nmod, n0inv, one_m, blocktab, lds);
+    else modpow_job_tile<C>(j0, blockIdx.x, wbits, nmod, n0inv, one_m, blocktab, lds);
+}
+// The same with the two jobs in DIFFERENT geometries of the same rows: the long job eight lanes per element, the short one
+// four.  At 10^4 elements each the long chain (766 dependent products at 613 bits) sets the time of the launch; with eight
+// lanes a product of that chain takes two thirds of the time, and the short job's four-lane tiles still fit beside it.
+template <class CA, class CB>
+__global__ void __launch_bounds__(BLOCK, (CA::MINW < CB::MINW ? CA::MINW : CB::MINW))
+k_modpow_jobs_mixed(ModpowJob j0, ModpowJob j1, unsigned tiles0, int wbits, const u32* __restrict__ nmod, u32 n0inv,
+                    const u32* __restrict__ one_m, u32* __restrict__ tab) {
+    static_assert(CA::W == CB::W, "the two geometries read the same rows");
+    extern __shared__ u32 lds[];
+    constexpr int EPBMAX = CA::EPB > CB::EPB ? CA::EPB : CB::EPB;
+    const bool second = blockIdx.x >= tiles0;                        // (block-uniform)
+    u32* blocktab = tab + (size_t)blockIdx.x * EPBMAX * ((size_t)1 << wbits) * CA::W;
+    if (second) modpow_job_tile<CB>(j1, blockIdx.x - tiles0, wbits, nmod, n0inv, one_m, blocktab, lds);
+    else modpow_job_tile<CA>(j0, blockIdx.x, wbits, nmod, n0inv, one_m, blocktab, lds);
 }
 
 }  // namespace vmn

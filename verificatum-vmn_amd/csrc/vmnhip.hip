@@ -1691,7 +1691,15 @@ extern "C" int vmn_garray_exp_pair(const vmn_garray* x, const uint8_t* e_be, siz
         if (mp == g->P.wide8 && g->P.wide && (size_t)egrid(*mp, nx) + egrid(*mp, ny) > (size_t)ctx->num_cus * blocks_per_cu(*mp)) mp = g->P.wide;
         if (mp == g->P.wide && (size_t)egrid(*mp, nx) + egrid(*mp, ny) > 2 * (size_t)ctx->num_cus * blocks_per_cu(*mp)) mp = &g->P;   // (a third round: no)
         const vmn_modulus& m = *mp;
-        const size_t tiles = (size_t)egrid(m, nx) + egrid(m, ny);
+        size_t tiles = (size_t)egrid(m, nx) + egrid(m, ny);
+        // Mixed form (2048-bit rows): when four lanes per element were chosen and the LONGER job's tiles at eight lanes still fit
+        // beside the shorter job's at four, the longer chain -- which sets the time of the launch -- gets the eight
+        // (k_modpow_jobs_mixed; VMN_PAIR_MIXED=0 turns it off).
+        static const bool mixed_off = [] {
+            const char* e = getenv("VMN_PAIR_MIXED");
+            return e && *e == '0';
+        }();
+        const bool mixed_fits = !mixed_off && !g->P.ec && mp == g->P.wide && g->P.wide8 && g->P.S == 74 && nx > 0 && ny > 0;
         if (!g->P.ec && nx > 0 && ny > 0 && tiles <= (size_t)ctx->num_cus * 2 * blocks_per_cu(m)) {
             int ewords = (int)((ebytes + 3) / 4);
             Big e = hostbig::from_be(e_be, ebytes, ewords);
@@ -1716,6 +1724,18 @@ extern "C" int vmn_garray_exp_pair(const vmn_garray* x, const uint8_t* e_be, siz
                 const int nwx = (ebits + wbits - 1) / wbits, nwy = (fbits + wbits - 1) / wbits;
                 note_work(ctx, m, (double)nx * (nwx - 1 + (1 << wbits) - 2) + (double)ny * (nwy - 1 + (1 << wbits) - 2),
                           ((double)nx * (nwx - 1) + (double)ny * (nwy - 1)) * wbits);
+                const vmn_modulus& m8 = mixed_fits ? *g->P.wide8 : m;
+                const size_t tiles_mixed = (size_t)egrid(m8, j0.n) + egrid(m, j1.n);
+                // (up to one and a half workgroups per compute unit: beyond, too many eight-lane tiles share their SIMDs with another
+                // wave -- 8 000 elements each 5.7 against 6.6 ms, 10 000 8.5 against 6.9, profiles/r03_pair_sweep.txt)
+                if (mixed_fits && 2 * tiles_mixed <= 3 * (size_t)ctx->num_cus) {
+                    // (scratch: tiles_mixed blocks x the larger tile; sized above for `tiles` blocks of the four-lane tile)
+                    rc = ensure_scratch(ctx, tiles_mixed * (BLOCK / m.LPE) * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t));
+                    if (rc == VMN_OK)
+                        rc = launch(ctx, "modpow", k_modpow_jobs_mixed<Cfg<80, 8>, Cfg<76, 4>>, (unsigned)tiles_mixed,
+                                    std::max(lds_bytes(m8), lds_bytes(m)), j0, j1, egrid(m8, j0.n), wbits, m.d_n, m.n0inv, m.d_one,
+                                    reinterpret_cast<uint32_t*>(ctx->scratch));
+                } else {
                 rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                     \
     if (m.S == S_)                                                                                                           \
@@ -1723,6 +1743,7 @@ extern "C" int vmn_garray_exp_pair(const vmn_garray* x, const uint8_t* e_be, siz
                     m.n0inv, m.d_one, reinterpret_cast<uint32_t*>(ctx->scratch));
                 VMN_FOR_SIZES(X)
 #undef X
+                }
             }
             if (rc != VMN_OK) {
                 vmn_garray_free(rx);
