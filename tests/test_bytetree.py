@@ -65,7 +65,7 @@ def test_the_references_own_benchmark_group_is_supported(vmn, gpu_ctx, eio, orac
     p, q, g, _, width = eio.unmarshal_modpgroup(fixture_bytes())
     orc = oracle_for(p, q)
     G = vmn.ModPGroup(gpu_ctx, p, q, g, nbytes=width)
-    n = 12
+    n = 6
     es = pyref.stream_ints(b"big/e", n, q)
     fs = pyref.stream_ints(b"big/f", n, 1 << 400)
     X = G.exp(g, G.ringArray(es))

@@ -182,7 +182,7 @@ def test_proof_of_shuffle_over_rfc3526_group_18(vmn, gpu_ctx, mods, oracle_for):
     p, q, g = pyref.modp_group(8192)
     G = vmn.ModPGroup(gpu_ctx, p, q, g)
     K = GmpAdapter(oracle_for(p, q))
-    h, pkey, w, t = make_instance(K, g, 14, 1, b"rfc18")
+    h, pkey, w, t = make_instance(K, g, 8, 1, b"rfc18")
     check_pos("native", mods, G, K, g, h, pkey, w, t, (256, 256, 100))
 
 
