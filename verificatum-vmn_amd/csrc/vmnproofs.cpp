@@ -1805,16 +1805,12 @@ struct vmn_ccpos : ProofBase {
         touch();
         REQUIRE(u && e.p && width, "computeAB needs the instance and the batching vector");
         raised = raisedu != nullptr;
+        // the products are begun here and finished in verify_prepare, behind the device part of the k_E products (see vmn_pos)
+        ab_pending.reset(new PendingProds());
         if (!raised) {
             std::vector<const vmn_garray*> xs{u};
             xs.insert(xs.end(), w.begin(), w.end());
-            std::vector<Bytes> res;
-            TRY(expprod_multi(xs, e, e_bits, res));
-            Round rd(*this);
-            rd.products(res);
-            TRY(rd.run());
-            A = res[0];
-            B.assign(res.begin() + 1, res.end());
+            TRY(ab_pending->begin(xs, e, e_bits));
         } else {
             const vmn_garray* ru = nullptr;
             TRY(local_garray(raisedu, ru_own, &ru, "raised commitment"));
@@ -1825,12 +1821,26 @@ struct vmn_ccpos : ProofBase {
                 TRY(vmn_garray_mul(w[c], ru, tmp[c].out()));
                 xs.push_back(tmp[c]);
             }
-            TRY(expprod_multi(xs, e, e_bits, AB));
-            Round rd(*this);
-            rd.products(AB);
-            TRY(rd.run());
+            TRY(ab_pending->begin(xs, e, e_bits));         // (the products w u^rho are queued; their blocks return to the pool in stream order)
         }
         have_ab = true;
+        return VMN_OK;
+    }
+    std::unique_ptr<PendingProds> ab_pending;
+    int finish_ab() {
+        if (!ab_pending) return VMN_OK;
+        std::unique_ptr<PendingProds> pend(std::move(ab_pending));
+        std::vector<Bytes> res;
+        TRY(pend->finish(G, res));
+        Round rd(*this);
+        rd.products(res);
+        TRY(rd.run());
+        if (!raised) {
+            A = res[0];
+            B.assign(res.begin() + 1, res.end());
+        } else {
+            AB = res;
+        }
         return VMN_OK;
     }
     // verification in two parts, as in vmn_pos: verify_prepare(reply, raisedh, rho) = everything that needs no challenge --
@@ -1876,7 +1886,10 @@ struct vmn_ccpos : ProofBase {
             jobs.start([&] { return gexp(g, k_A, prep.gkA); });
             std::vector<const vmn_garray*> xs{h};
             xs.insert(xs.end(), wp.begin(), wp.end());
-            TRY(expprod_multi(xs, ikE->ra, kE_bits, prep.kE_prods));
+            PendingProds kE_pending;
+            TRY(kE_pending.begin(xs, ikE->ra, kE_bits));
+            TRY(finish_ab());
+            TRY(kE_pending.finish(G, prep.kE_prods));
             Round rd(*this);
             rd.products(prep.kE_prods);
             TRY(rd.run());
@@ -1894,7 +1907,10 @@ struct vmn_ccpos : ProofBase {
                 TRY(vmn_garray_mul(wp[c], rh, tmp[c].out()));
                 xs.push_back(tmp[c]);
             }
-            TRY(expprod_multi(xs, ikE->ra, kE_bits, prep.prods));
+            PendingProds kE_pending;
+            TRY(kE_pending.begin(xs, ikE->ra, kE_bits));
+            TRY(finish_ab());
+            TRY(kE_pending.finish(G, prep.prods));
             Round rd(*this);
             rd.products(prep.prods);
             TRY(rd.run());
@@ -1913,6 +1929,7 @@ struct vmn_ccpos : ProofBase {
         *verdict = 0;
         if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch || !prep.same_raised(raisedh, rho_be, rho_bytes))
             TRY(verify_prepare(rep, raisedh, rho_be, rho_bytes));
+        TRY(finish_ab());
         REQUIRE(raised == (raisedh != nullptr) && raised == (rho_be != nullptr), "raised / plain form must match computeAB");
         if (prep.malformed) {                                                     // a ring scalar >= q: not a reply
             prep.clear();
