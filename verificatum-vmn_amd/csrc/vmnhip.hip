@@ -1102,8 +1102,9 @@ static int alloc_elems(vmn_ctx* ctx, const vmn_modulus& m, size_t n, uint32_t** 
 }
 
 // leaf_hdr: every value is preceded by its 5-byte byte-tree leaf header (checked on the device; *format_ok)
+// (checked_on_host: the caller has validated the values itself -- the conversion is only queued, no verdict is read back)
 static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* be, size_t n, uint32_t* d_out,
-                     int* all_in_range, int leaf_hdr = 0, int* format_ok = nullptr) {
+                     int* all_in_range, int leaf_hdr = 0, int* format_ok = nullptr, bool checked_on_host = false) {
     if (all_in_range) *all_in_range = 1;
     if (format_ok) *format_ok = 1;
     if (n == 0) return VMN_OK;
@@ -1111,7 +1112,8 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
-    VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
+    if (checked_on_host) VMN_TRY(h2d(ctx, raw.p, be, n * stride));           // (small: through the pinned buffer, queued)
+    else VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
     VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
     note_work(ctx, m, (m.ec ? 7.0 : 1.0) * (double)n);
     int rc = VMN_ERR_ARG;
@@ -1131,6 +1133,7 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
 #undef X
     }
     VMN_TRY(rc);
+    if (checked_on_host) return VMN_OK;
     uint32_t fl = 0;
     VMN_TRY(read_flag(ctx, &fl));
     if (all_in_range) *all_in_range = (fl & 1u) ? 0 : 1;
@@ -1196,10 +1199,25 @@ static int bytetree_header(const uint8_t* bt, size_t len, size_t nbytes, size_t 
 }
 
 // one element (big-endian) -> device, M28 form
+// (residues and scalars: "0 <= value < modulus" is decided on the host, so the conversion is queued without a read-back --
+// a pushed element or a scalar operand in front of a kernel no longer drains the stream; curve points keep the device's
+// on-curve verdict)
 static int import_one(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint8_t* be, uint32_t** d_out) {
+    bool host_checked = false;
+    if (!m.ec) {
+        bool in_range = true;
+        for (size_t i = 0; i + 4 * (size_t)m.NW < nbytes; ++i) in_range = in_range && be[i] == 0;       // bytes above the packed words
+        in_range = in_range && hostbig::cmp(hostbig::from_be(be, nbytes, m.NW), m.n_words) < 0;
+        if (!in_range) {
+            set_error("scalar operand out of range");
+            *d_out = nullptr;
+            return VMN_ERR_FORMAT;
+        }
+        host_checked = true;
+    }
     VMN_TRY(alloc_elems(ctx, m, 1, d_out));
     int ok = 1;
-    int rc = import_be(ctx, m, nbytes, be, 1, *d_out, &ok);
+    int rc = import_be(ctx, m, nbytes, be, 1, *d_out, &ok, 0, nullptr, host_checked);
     if (rc == VMN_OK && !ok) {
         set_error("scalar operand out of range");
         rc = VMN_ERR_FORMAT;
