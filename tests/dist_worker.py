@@ -56,8 +56,16 @@ def gather_and_check(dist, rank, world, mine, expect, out_path):
             json.dump({"pass": all(checks.values()), "why": json.dumps(checks), "world": world,
                        "exchanges": [gsh.get("exchanges") for gsh in gathered]}, f)
     dist.barrier()
-    dist.destroy_process_group()
-    sys.exit(0)
+    raise CaseDone(0)
+
+
+class CaseDone(Exception):
+    """A case has written its result: the launch goes on with the next one (several cases share one process group -- starting
+    the ranks costs more than most cases)."""
+
+    def __init__(self, code=0):
+        Exception.__init__(self, code)
+        self.code = code
 
 
 def flow_ccpos_or_posc(flow, native, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, t, q, n, width, bits3, out_path):
@@ -252,22 +260,42 @@ def flow_seeded(flow, par, nat, comm, dist, rank, world, G, K, g, h, pkey, w, q,
 
 
 def main():
-    backend, bits, n, width, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    flow = sys.argv[6] if len(sys.argv) > 6 else "pos"
-    mirror = backend.endswith("-mirror")
-    if mirror:
-        backend = backend[: -len("-mirror")]
+    """argv: backend bits n width out_path [flow], or `--cases FILE` (a JSON list of such argument lists: the cases of one
+    launch, run one after the other on the same process group; all of them over gloo or all over RCCL)."""
+    if sys.argv[1] == "--cases":
+        cases = json.load(open(sys.argv[2]))
+    else:
+        cases = [sys.argv[1:]]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("VMN_COMBINED_MIN", "1")     # the sharded verifiers take check (B) in its combined form (with the carried-in B) too
-    rank = int(os.environ["RANK"])
-    world = int(os.environ["WORLD_SIZE"])
     device = None
-    if backend in ("hip", "hip-ec"):           # one GPU per rank, RCCL
+    first_backend = cases[0][0][: -len("-mirror")] if cases[0][0].endswith("-mirror") else cases[0][0]
+    if first_backend in ("hip", "hip-ec"):     # one GPU per rank, RCCL
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", device_id=device)
     else:                                      # "fake": CPU arrays; "hip-gloo": real kernels, all ranks share GPU 0
         dist.init_process_group("gloo")
+    code = 0
+    for case in cases:
+        try:
+            run_case(device, *case)
+        except CaseDone as done:
+            code = code or done.code
+        if code:
+            break
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(code)
+
+
+def run_case(device, backend, bits, n, width, out_path, flow="pos"):
+    bits, n, width = int(bits), int(n), int(width)
+    mirror = backend.endswith("-mirror")
+    if mirror:
+        backend = backend[: -len("-mirror")]
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
     par = load_parallel()
     if flow == "comm-fallback":
         # parallel.Comm told to use a device path that cannot work here (no GPU in the CPU suite): the first exchange must fall
@@ -282,8 +310,7 @@ def main():
             with open(out_path, "w") as f:
                 json.dump({"pass": bool(ok), "why": f"fell_back={c.fell_back!r} backend={c.backend_used}", "world": world, "exchanges": []}, f)
         dist.barrier()
-        dist.destroy_process_group()
-        sys.exit(0 if ok else 1)
+        raise CaseDone(0 if ok else 1)
     comm = par.Comm(dist, device)
     ec = backend.endswith("-ec")
     native = backend.startswith("hip") and not mirror
@@ -406,8 +433,7 @@ def main():
         with open(out_path, "w") as f:
             json.dump(result, f)
     dist.barrier()
-    dist.destroy_process_group()
-    sys.exit(0)
+    raise CaseDone(0)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,24 @@ def run_world(world, backend, bits, n, width, tmp_path, timeout=600, flow="pos")
     return json.load(open(out))
 
 
+def run_cases(world, cases, tmp_path, timeout=900):
+    """Several cases (backend, bits, n, width, flow) in ONE launch of `world` ranks (tests/dist_worker.py --cases): the
+    ranks' start-up costs more than most cases.  Returns the cases' results in order."""
+    outs, argv = [], []
+    for k, (backend, bits, n, width, flow) in enumerate(cases):
+        outs.append(tmp_path / f"dist_{k}_{backend}_{flow}_{world}_{n}.json")
+        argv.append([backend, str(bits), str(n), str(width), str(outs[-1]), flow])
+    spec = tmp_path / f"cases_{world}_{len(cases)}.json"
+    spec.write_text(json.dumps(argv))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--cases", str(spec)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, env=env)
+    assert proc.returncode == 0, proc.stdout.decode()[-3000:]
+    return [json.load(open(o)) for o in outs]
+
+
 def test_shard_bounds_cover_everything(entry):
     import importlib.util
     spec = importlib.util.spec_from_file_location("par", os.path.join(entry.PKG_DIR, "parallel.py"))
@@ -99,48 +117,41 @@ def test_sharded_ccpos_matches_oracle_on_gloo(world, n, width, backend, tmp_path
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flow,backend,bits,n,width", [("pos", "hip-gloo", 2048, 150, 1), ("posc", "hip-gloo", 512, 77, 1),
-                                                       ("ccpos", "hip-gloo-ec", 256, 40, 3), ("pos", "hip-gloo-ec", 256, 60, 1)])
-# (CCPoS over a modular group at width 2: the three-rank test and the seeded 2048-bit case below)
-def test_sharded_cxx_drivers_two_ranks_one_gpu(flow, backend, bits, n, width, tmp_path):
+def test_sharded_cxx_drivers_two_ranks_one_gpu(tmp_path):
     """The sharded C++ drivers (vmn_pos / vmn_posc / vmn_ccpos with a communicator, include/vmnproofs.h) on the real
     kernels: two ranks share the one GPU of the test box, gloo carries the all-gather callback (on an 8-GPU node the
-    backend is nccl = RCCL).  P-256 at width 3 is BASELINE configs[4]'s shape."""
-    res = run_world(2, backend, bits, n, width, tmp_path, timeout=900, flow=flow)
-    assert res["pass"], res["why"]
-    assert all(x is None or x <= 12 for x in res["exchanges"]), res["exchanges"]      # a handful of exchanges per proof
+    backend is nccl = RCCL).  P-256 at width 3 is BASELINE configs[4]'s shape.  (CCPoS over a modular group at width 2: the
+    three-rank test and the seeded 2048-bit case below.)  Four cases, one launch."""
+    cases = [("hip-gloo", 2048, 150, 1, "pos"), ("hip-gloo", 512, 77, 1, "posc"), ("hip-gloo-ec", 256, 40, 3, "ccpos"),
+             ("hip-gloo-ec", 256, 60, 1, "pos")]
+    for case, res in zip(cases, run_cases(2, cases, tmp_path)):
+        assert res["pass"], (case, res["why"])
+        assert all(x is None or x <= 12 for x in res["exchanges"]), (case, res["exchanges"])      # a handful of exchanges per proof
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flow,backend,bits,n,width,world", [("pos-seeded", "hip-gloo", 2048, 131, 1, 2), ("pos-seeded", "hip-gloo", 512, 5, 2, 3),
-                                                             ("ccpos-seeded", "hip-gloo-ec", 256, 50, 3, 2),
-                                                             ("ccpos-seeded", "hip-gloo", 2048, 64, 1, 3)])
-def test_sharded_cxx_drivers_generate_only_their_rows_of_the_prg_arrays(flow, backend, bits, n, width, world, tmp_path):
+@pytest.mark.parametrize("world,cases", [(2, [("hip-gloo", 2048, 131, 1, "pos-seeded"), ("hip-gloo-ec", 256, 50, 3, "ccpos-seeded")]),
+                                         (3, [("hip-gloo", 512, 5, 2, "pos-seeded"), ("hip-gloo", 2048, 64, 1, "ccpos-seeded")])])
+def test_sharded_cxx_drivers_generate_only_their_rows_of_the_prg_arrays(world, cases, tmp_path):
     """The form bench.py's multi-GPU legs run: r, s, b, beta, epsilon and the batching vector are 32-byte seeds, and a rank
     expands just its positions and the rows it reads through the permutation (struct Draw, csrc/vmnproofs.cpp;
     vmn_shuffle_reencrypt_shard_seeded, vmn_permutation_commitment_shard_seeded).  Transcript, u, w', r, s shards == the
     oracle run on the fully expanded arrays."""
-    res = run_world(world, backend, bits, n, width, tmp_path, timeout=900, flow=flow)
-    assert res["pass"], res["why"]
+    for case, res in zip(cases, run_cases(world, cases, tmp_path)):
+        assert res["pass"], (case, res["why"])
 
 
 @pytest.mark.gpu
 def test_sharded_cxx_drivers_three_ranks_ragged_and_empty(tmp_path):
-    res = run_world(3, "hip-gloo", 512, 2, 1, tmp_path, timeout=900, flow="pos")      # one rank owns nothing
-    assert res["pass"], res["why"]
-    res = run_world(3, "hip-gloo", 512, 10, 2, tmp_path, timeout=900, flow="ccpos")
-    assert res["pass"], res["why"]
+    cases = [("hip-gloo", 512, 2, 1, "pos"), ("hip-gloo", 512, 10, 2, "ccpos")]          # (the first: one rank owns nothing)
+    for case, res in zip(cases, run_cases(3, cases, tmp_path)):
+        assert res["pass"], (case, res["why"])
 
 
 @pytest.mark.gpu
 def test_sharded_pos_real_kernels_two_ranks_one_gpu(tmp_path):
     """The same sharded proof with the HIP library doing the arithmetic: two ranks share the one GPU of
     the test box (gloo carries the small exchanges; on an 8-GPU node the backend is nccl = RCCL)."""
-    res = run_world(2, "hip-gloo-mirror", 2048, 150, 1, tmp_path, timeout=900)         # the Python mirror on the real kernels
-    assert res["pass"], res["why"]
-
-
-@pytest.mark.gpu
-def test_sharded_pos_p256_real_kernels_two_ranks_one_gpu(tmp_path):
-    res = run_world(2, "hip-gloo-ec-mirror", 256, 60, 1, tmp_path, timeout=900)
-    assert res["pass"], res["why"]
+    cases = [("hip-gloo-mirror", 2048, 150, 1, "pos"), ("hip-gloo-ec-mirror", 256, 60, 1, "pos")]     # the Python mirror on the real kernels; P-256
+    for case, res in zip(cases, run_cases(2, cases, tmp_path)):
+        assert res["pass"], (case, res["why"])
