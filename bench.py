@@ -195,6 +195,36 @@ def proof_drivers(entry, drivers: str):
     return load_sub(entry, "native") if drivers == "native" else load_sub(entry, "hvzk")
 
 
+def precomputed_factors_fields(drv, mx, grp, pkey, W, S, pi, n, sync, prove_verify_s):
+    """The re-encryption as the reference's precomputed shuffle splits it (ShufflerElGamalSession.java:645-661: the factors
+    pk^s in `vmn -precomp`; :789-792: input.mul(factors).permute(inverse) when the ciphertexts arrive), timed on its own AFTER
+    the leg's timed pass (which re-encrypts in one call, BASELINE's "full mix"): what a mix server with precomputed factors
+    does online = applying them + CCPoS prove + verify."""
+    sync()
+    t0 = time.perf_counter()
+    if hasattr(drv, "reencryption_factors_native"):
+        factors = drv.reencryption_factors_native(grp, pkey, S)
+        sync()
+        t1 = time.perf_counter()
+        WP = drv.apply_factors_native(grp, W, factors, pi)
+    else:
+        factors = mx.reencFactors(grp, pkey, S)
+        sync()
+        t1 = time.perf_counter()
+        WP = mx.reencrypt(W, factors, pi)
+    sync()
+    t2 = time.perf_counter()
+    for a in list(factors) + list(WP):
+        a.free()
+    rest = (t2 - t1) + prove_verify_s
+    return {"reencrypt_factors_ms": (t1 - t0) * 1e3, "reencrypt_apply_factors_ms": (t2 - t1) * 1e3,
+            "online_ms_factors_precomputed": rest * 1e3, "ciphertexts_per_s_online_factors_precomputed": n / rest,
+            "factors_precomputed_note": "the reference's precomputed shuffle computes the re-encryption factors in `vmn -precomp` "
+                                        "(ShufflerElGamalSession.java:645-661) and only multiplies and permutes online (:789-792); "
+                                        "online_ms_factors_precomputed = reencrypt_apply_factors_ms (timed after the pass) + "
+                                        "ccpos_prove_ms + ccpos_verify_ms (of the pass)"}
+
+
 def do_reencrypt(drv, mx, grp, pkey, W, S, pi):
     if hasattr(drv, "reencrypt_native"):
         return drv.reencrypt_native(grp, pkey, W, S, pi)
@@ -571,12 +601,14 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, driver
     ctx.timing_enable(False)
     fam = ctx.timing_report()
     online = t4 - t1
+    pre = precomputed_factors_fields(hv, mx, grp, pkey, W, S, pi, n, sync, t4 - t2)
     return {"workload": f"BASELINE.json configs[2]: ModPGroup {bits}-bit, width 1, CCPoS path; offline = permutation commitment + PoSC "
                         "prove+verify, online = re-encrypt + CCPoS prove+verify (n_e = n_v = 256, n_r = 100)",
             "n": n, "drivers": drivers, "accepted": bool(ok and ok_posc),
             "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3, "ccpos_prove_ms": (t3 - t2) * 1e3,
             "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
             "ciphertexts_per_s_online": n / online, "ciphertexts_per_s_total": n / (t4 - t0),
+            **pre,
             # SURVEY.md §8d canonical cost: 1090 M(96) per ciphertext online (M(96) = 18528 MAC)
             "canonical_TMACs_online_survey_8d": 1090 * 18528 * n / online / 1e12,      # NOT a roofline fraction: see `roofline`
             "roofline": leg_roofline(fam, (t4 - t0) * 1e3),          # offline + online: the counters cover the whole pass
@@ -654,11 +686,13 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
     ctx.timing_enable(False)
     fam = ctx.timing_report()
     online = t4 - t1
+    pre = precomputed_factors_fields(hv, mx, grp, pkey, W, S, pi, n, sync, t4 - t2)
     return {"workload": f"BASELINE.json configs[4] on one GPU: ECqPGroup {curve}, width {width}; offline = permutation commitment, "
                         "online = re-encrypt + CCPoS prove+verify (n_e = n_v = 256, n_r = 100)",
             "n": n, "drivers": drivers, "accepted": bool(ok), "offline_ms": (t1 - t0) * 1e3, "reencrypt_ms": (t2 - t1) * 1e3,
             "ccpos_prove_ms": (t3 - t2) * 1e3, "ccpos_verify_ms": (t4 - t3) * 1e3, "online_ms": online * 1e3,
             "ciphertexts_per_s_online": n / online,
+            **pre,
             "roofline": leg_roofline(fam, (t4 - t0) * 1e3, canonical_per_executed=(136.0 / 160.0 if curve == "P-256" else 300.0 / 405.0)),
             "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 

@@ -11,7 +11,7 @@
  *                 verify :646-727, short-circuiting)
  *   vmn_ccpos_*  CCPoSBasicW   hvzk/CCPoSBasicW.java (commit :344-396, reply :462-485, computeAB :493-506,
  *                 verify :519-584, plain and "raised" form)
- *   vmn_shuffle_reencrypt        mixnet/ShufflerElGamalSession.java:400-409, 273-278
+ *   vmn_shuffle_reencrypt        mixnet/ShufflerElGamalSession.java:400-409, 273-278 (_reencryption_factors / _apply_factors: :645-661, :789-792)
  *   vmn_permutation_commitment   mixnet/PermutationCommitment.java:189-215
  *   vmn_decryption_factors, vmn_combine_decryption_factors, vmn_decproof_*
  *                                elgamal/DistrElGamalSession.java:365-385, elgamal/DistrElGamalSessionBasic.java
@@ -317,6 +317,15 @@ int vmn_element_inv(vmn_group* grp, const uint8_t* a_be, uint8_t* out_be);
  * (input.mul(reencFactors), permute(inverse), reencFactors.free()).  wp_out receives 2w new arrays. */
 int vmn_shuffle_reencrypt(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_garray* const* w,
                           const vmn_rarray* const* s, const uint32_t* pi, vmn_garray** wp_out);
+/* The same in the two steps of the reference's precomputed shuffle (`vmn -precomp`, then the committed shuffle): the
+ * re-encryption factors pk^s -- ShufflerElGamalSession.java:645-661 (reencFactors = widePublicKey.exp(reencExponents),
+ * written to file) -- and, when the ciphertexts arrive, w' = permute(w * factors, pi^-1) -- :789-792.  factors_out and
+ * wp_out receive 2w new arrays each; fewer ciphertexts than were precomputed for: cut the factors with
+ * vmn_garray_copy_range first (:673-712). */
+int vmn_shuffle_reencryption_factors(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_rarray* const* s,
+                                     vmn_garray** factors_out);
+int vmn_shuffle_apply_factors(vmn_group* grp, size_t width, const vmn_garray* const* w, const vmn_garray* const* factors,
+                              const uint32_t* pi, vmn_garray** wp_out);
 /* u = permute(h * g^r, pi): PermutationCommitment.java:189-215 (:200 g.exp(exponents), :201 generators.mul, :215). */
 int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h, const vmn_rarray* r,
                                const uint32_t* pi, vmn_garray** u_out);

@@ -116,6 +116,13 @@ def test_config2_3072bit_precompute_shrink_ccpos(impl, vmn, gpu_ctx, mods):
     wp_o = P.g_reencrypt(K, w, P.g_reenc_factors(K, pkey, s), pi_s_o)
     if impl == "native":
         WP = nat.reencrypt_native(G, pkey, W, S, pi_s)
+        # the precomputed form (ShufflerElGamalSession.java:645-661, 673-712, 789-792): factors for more ciphertexts than
+        # arrive, cut with copyOfRange(0, n), applied when the ciphertexts are there -- the same w'
+        s_long = [c + t.ring_array(5) for c in s]
+        F = nat.reencryption_factors_native(G, pkey, [G.ringArray(c) for c in s_long])
+        assert [f.toInts()[:n] for f in F] == P.g_reenc_factors(K, pkey, s)
+        WP2 = nat.apply_factors_native(G, W, [f.copyOfRange(0, n) for f in F], pi_s)
+        assert [c.toInts() for c in WP2] == wp_o
     else:
         WP = mx.reencrypt(W, mx.reencFactors(G, pkey, S), pi_s)
     assert [c.toInts() for c in WP] == wp_o

@@ -44,6 +44,11 @@ def render(bench):
                     f"**e(N) = {e['per_ciphertext'] * 1e3:.4f} us x N + {e['constant']:.1f} ms**, verifying **v(N) = {v['per_ciphertext'] * 1e3:.4f} us x N + "
                     f"{v['constant']:.1f} ms**" + (f", proof size p(N) = {pb['per_ciphertext']:.0f} x N + {pb['constant']:.0f} bytes" if pb else "") +
                     " (arithmetic only: no hashing, no network).")
+    def pre_text(leg):                       # the reference's precomputed shuffle: factors offline (bench.py: precomputed_factors_fields)
+        if "online_ms_factors_precomputed" not in leg:
+            return ""
+        return (f"; with the re-encryption factors precomputed as in `vmn -precomp` ({leg['reencrypt_factors_ms']:.0f} ms, offline) the online "
+                f"part is {leg['online_ms_factors_precomputed']:.0f} ms = {leg['ciphertexts_per_s_online_factors_precomputed']:.3e} ciphertexts/s")
     sm = r.get("mix_prove_n10000")
     small_row = (f"| the same at the reference's demo size, **configs[0]**: 10^4 ciphertexts | {sm['total_ms']:.1f} ms = **{sm['ciphertexts_per_s']:.3e} ciphertexts/s** "
                  f"(prove {sm['prove_ms']:.1f} ms, verify {sm['verify_ms']:.1f} ms) | wide geometries + fixed-base chains cut into pieces (§5): kernels {sm['roofline']['kernel_ms']:.1f} ms of it, "
@@ -55,8 +60,8 @@ def render(bench):
 | **headline**, configs[1]: 10^6 x 2048-bit modPow, 2047-bit exponents | **{r['value']:.3e} modexp/s**, {r['ms_per_step']:.1f} ms per step, kernel {rf['avg_kernel_ms']:.1f} ms (HIP events) | achieved {rf['achieved']:.2f} TMAC/s canonical (16 422 432 per modexp, SURVEY.md §8d) = **{rf['frac']:.3f}**; issued {issued} T lane-instr/s of the {rf['peak_measured']:.1f} T/s the hardware sustains for `v_mad_u64_u32` at two waves per SIMD; HBM traffic {traffic} per launch (PMC) against 0.77 GB algorithmic: the per-lane window tables, 2 % of the HBM roof |
 | **mix + prove**, 2048 bits, width 1: re-encrypt + PoS prove + verify (GPU arithmetic; the N-sized random arrays expanded on the device, scalars and the permutation from a tape) | {mp['total_ms']:.0f} ms = **{mp['ciphertexts_per_s']:.3e} ciphertexts/s** | executed {mp['roofline']['executed_T_mads']:.1f} T multiply-adds: frac **{mp['roofline']['frac']:.2f}** of the wall clock, {mp['roofline']['frac_kernel_time']:.2f} of the kernel time (fixed {fam(mp, 'fixed')}; modpow {fam(mp, 'modpow')}; expprod {fam(mp, 'expprod')}) |
 | the same END TO END (prover randomness on the device, Fiat-Shamir hashing, byte trees published and parsed, verifier as another party) | prove {e2e['prove_ms']:.0f} ms + verify {e2e['verify_ms']:.0f} ms = {e2e['total_ms']:.0f} ms = **{e2e['ciphertexts_per_s_mean_of_passes']:.2e} ciphertexts/s** (mean of the two passes {e2e['passes_total_ms']}; {e2e['ciphertexts_per_s_parties_in_parallel']:.2e} with prover and verifier on their own machines) | {e2e['hashed_bytes_per_party'] / 1e9:.2f} GB hashed per party (SHA-256, one host core, ~2.2 GB/s): the hash, not the GPU, is the critical path (see below) |
-{small_row}| **configs[2]**: 3072 bits, CCPoS path | offline (commitment + PoSC) {cc['offline_ms']:.0f} ms, online (re-encrypt + CCPoS prove + verify) {cc['online_ms']:.0f} ms = **{cc['ciphertexts_per_s_online']:.3e} ciphertexts/s** | frac **{cc['roofline']['frac']:.2f}** wall / {cc['roofline']['frac_kernel_time']:.2f} kernel time (fixed {fam(cc, 'fixed')}; modpow {fam(cc, 'modpow')}; expprod {fam(cc, 'expprod')}) |
-| **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s** | executed-work frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}; normalisation {fam(ec, 'normalize')}); against SURVEY.md §8d's canonical field product M(8) = 136 (the kernels execute 160 per product): {ec['roofline']['frac_canonical']:.2f} wall / {ec['roofline']['frac_canonical_kernel_time']:.2f} kernel time (§5, curves, round 3) |
+{small_row}| **configs[2]**: 3072 bits, CCPoS path | offline (commitment + PoSC) {cc['offline_ms']:.0f} ms, online (re-encrypt + CCPoS prove + verify) {cc['online_ms']:.0f} ms = **{cc['ciphertexts_per_s_online']:.3e} ciphertexts/s**{pre_text(cc)} | frac **{cc['roofline']['frac']:.2f}** wall / {cc['roofline']['frac_kernel_time']:.2f} kernel time (fixed {fam(cc, 'fixed')}; modpow {fam(cc, 'modpow')}; expprod {fam(cc, 'expprod')}) |
+| **configs[4]** on one GPU: P-256, width 3, CCPoS | online {ec['online_ms']:.0f} ms = **{ec['ciphertexts_per_s_online']:.3e} ciphertexts/s**{pre_text(ec)} | executed-work frac {ec['roofline']['frac']:.2f} wall / {ec['roofline']['frac_kernel_time']:.2f} kernel time (expprod {fam(ec, 'expprod')}; scans {fam(ec, 'scan')}; normalisation {fam(ec, 'normalize')}); against SURVEY.md §8d's canonical field product M(8) = 136 (the kernels execute 160 per product): {ec['roofline']['frac_canonical']:.2f} wall / {ec['roofline']['frac_canonical_kernel_time']:.2f} kernel time (§5, curves, round 3) |
 | **decryption half** (row A6 / N3): one of k = 3 parties, threshold 2, 2048 bits, 10^6 ciphertexts | own factors {dec['own_factors_ms']:.0f} ms + own proof {dec['own_proof_ms']:.0f} ms + check of the others {dec['verify_others_ms']:.0f} ms + combination and plaintexts {dec['combine_and_plaintexts_ms']:.0f} ms = {dec['total_ms']:.0f} ms = **{dec['ciphertexts_per_s']:.3e} ciphertexts/s**; CPU (GMP, {dec['cpu_baseline']['cores']} cores, {dec['cpu_baseline']['sample'].split(',')[0]}): {dec['cpu_baseline']['value']:.0f} ciphertexts/s | frac **{dec['roofline']['frac']:.2f}** wall / {dec['roofline']['frac_kernel_time']:.2f} kernel time (modpow {fam(dec, 'modpow')}: one full-length power per ciphertext with the party's secret exponent) |
 | CPU beside it (GMP, {r['cpu_baseline']['cores']} cores of the box) | {r['cpu_baseline']['value']:.0f} modexp/s (`mpz_powm`, 96 000-element sample, bit-exact vs the GPU); mix + prove {mp['cpu_baseline']['value']:.0f} ciphertexts/s ({mp['cpu_baseline']['sample'].split(':')[0]}; fixed-base tables, Pippenger) | |
 

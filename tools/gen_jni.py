@@ -173,11 +173,11 @@ def need_expr(name, ptype, pname, plist):
     proof = next((pt for pt in PROOF_TYPES if name.startswith(pt + "_")), None)
     pobj = hcast(proof + "*", plist[0][1]) if proof else None
     if k == "handles_out":
-        return {"wp_out": "2 * (size_t)width", "s_out": "(size_t)width"}.get(pname, "1")
+        return {"wp_out": "2 * (size_t)width", "factors_out": "2 * (size_t)width", "s_out": "(size_t)width"}.get(pname, "1")
     if k == "handles_in":
         if pname in ("xs", "ys"):
             return "(size_t)k"
-        if pname in ("w", "wp", "w_full"):
+        if pname in ("w", "wp", "w_full", "factors"):
             return "2 * (size_t)width"
         if pname in ("s", "s_full"):
             return "(size_t)width"

@@ -2503,6 +2503,37 @@ int vmn_shuffle_reencrypt(vmn_group* grp, const uint8_t* pkey_be, size_t width, 
     return VMN_OK;
 }
 
+// The same in the two steps of the reference's precomputed shuffle: the factors in `vmn -precomp`
+// (ShufflerElGamalSession.java:645-661: reencFactors = widePublicKey.exp(reencExponents)), the rest when the ciphertexts
+// arrive (:789-792: input.mul(reencFactors), permute(permutation.inv())).
+int vmn_shuffle_reencryption_factors(vmn_group* grp, const uint8_t* pkey_be, size_t width, const vmn_rarray* const* s,
+                                     vmn_garray** factors_out) {
+    if (!grp || !pkey_be || !width || !s || !factors_out) return fail(VMN_ERR_ARG, "vmn_shuffle_reencryption_factors: null argument");
+    const size_t eb = vmn_group_elem_bytes(grp);
+    std::vector<GA> res(2 * width);
+    for (size_t c = 0; c < 2 * width; ++c) TRY(vmn_group_exp_fixed(grp, pkey_be + c * eb, s[c % width], res[c].out()));
+    for (size_t c = 0; c < 2 * width; ++c) factors_out[c] = res[c].release();
+    return VMN_OK;
+}
+int vmn_shuffle_apply_factors(vmn_group* grp, size_t width, const vmn_garray* const* w, const vmn_garray* const* factors,
+                              const uint32_t* pi, vmn_garray** wp_out) {
+    if (!grp || !width || !w || !factors || !pi || !wp_out) return fail(VMN_ERR_ARG, "vmn_shuffle_apply_factors: null argument");
+    for (size_t c = 0; c < 2 * width; ++c)
+        if (!w[c] || !factors[c] || vmn_garray_size(w[c]) != vmn_garray_size(w[0]) || vmn_garray_size(factors[c]) != vmn_garray_size(w[0]))
+            return fail(VMN_ERR_ARG, "vmn_shuffle_apply_factors: arrays differ in size");
+    const size_t n = vmn_garray_size(w[0]);
+    if (!is_permutation(pi, n)) return fail(VMN_ERR_ARG, "vmn_shuffle_apply_factors: pi is not a permutation of [0, N)");
+    std::vector<uint32_t> inv = inverse_permutation(pi, n);
+    std::vector<GA> res(2 * width);
+    for (size_t c = 0; c < 2 * width; ++c) {
+        GA reenc;
+        TRY(vmn_garray_mul(w[c], factors[c], reenc.out()));                       // input.mul(reencFactors) :789
+        TRY(vmn_garray_permute(reenc, inv.data(), res[c].out()));                 // permute(permutation.inv()) :792
+    }
+    for (size_t c = 0; c < 2 * width; ++c) wp_out[c] = res[c].release();
+    return VMN_OK;
+}
+
 int vmn_permutation_commitment(vmn_group* grp, const uint8_t* g_be, const vmn_garray* h, const vmn_rarray* r, const uint32_t* pi,
                                vmn_garray** u_out) {
     if (!grp || !g_be || !h || !r || !pi || !u_out) return fail(VMN_ERR_ARG, "vmn_permutation_commitment: null argument");

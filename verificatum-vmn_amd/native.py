@@ -510,6 +510,23 @@ def reencrypt_native(group, pkey, w, s, pi):
     return [PGroupElementArray(group, C.c_void_p(h)) for h in out]
 
 
+def reencryption_factors_native(group, pkey, s):
+    """``vmn_shuffle_reencryption_factors``: pk^s, the offline half of a precomputed shuffle (ShufflerElGamalSession.java:645-661)."""
+    width = len(pkey) // 2
+    out = (C.c_void_p * (2 * width))()
+    _check(plib().vmn_shuffle_reencryption_factors(group._h, group.enc_els(pkey), C.c_size_t(width), _ptr_array(s), out))
+    return [PGroupElementArray(group, C.c_void_p(h)) for h in out]
+
+
+def apply_factors_native(group, w, factors, pi):
+    """``vmn_shuffle_apply_factors``: w' = permute(w * factors, pi^-1), the online half (ShufflerElGamalSession.java:789-792)."""
+    width = len(w) // 2
+    out = (C.c_void_p * (2 * width))()
+    ptr, keep = _u32_array(pi)
+    _check(plib().vmn_shuffle_apply_factors(group._h, C.c_size_t(width), _ptr_array(w), _ptr_array(factors), ptr, out))
+    return [PGroupElementArray(group, C.c_void_p(h)) for h in out]
+
+
 def reencrypt_shard_native(group, pkey, w_full, s_full, pi, lo: int, hi: int):
     """``vmn_shuffle_reencrypt_shard``: positions [lo, hi) of w' = permute(w * pk^s, pi^-1), out of the whole w and s."""
     width = len(pkey) // 2
