@@ -291,3 +291,42 @@ def test_mutated_byte_trees_never_crash_the_parsers(vmn, gpu_ctx, mods):
     ver2 = c["verifier"]()
     ver2.setChallenge(v)
     assert ver2.verify(ver2.readReply(good_rep, n, 1))
+
+
+def test_round_three_entry_points_at_their_edges(vmn, gpu_ctx, mods):
+    """The calls added for the small-array work take the ordinary path where their fast one does not apply, and refuse what
+    does not fit: the paired powers over a curve and over empty arrays, several inner products with a mismatched pair, the
+    precomputed re-encryption factors with arrays of different length, a verifier freed with its A / F still in flight."""
+    nat = mods["native"]
+    from oracle.pyref_ec import Curve
+    c = Curve("P-256")
+    E = vmn.ECqPGroup(gpu_ctx, "P-256")
+    pts = [c.mul(k + 2, c.g) for k in range(9)]
+    es = [3 * k + 1 for k in range(9)]
+    gx, gy = E.toElementArray(pts).expPair(5, E.toElementArray(pts[::-1]), E.ringArray(es))      # curves: two ordinary launches
+    assert gx.toInts() == [c.mul(5, P_) for P_ in pts] and gy.toInts() == [c.mul(e, P_) for e, P_ in zip(es, pts[::-1])]
+    case = _pos_case(vmn, gpu_ctx, nat, n=24, seed=b"edges")
+    G, q, p = case["G"], case["q"], case["p"]
+    none = G.toElementArray([])
+    ex, ey = none.expPair(7, G.toElementArray([]), G.ringArray([]))
+    assert ex.toInts() == [] and ey.toInts() == []
+    xs = [pow(case["g"], k + 1, p) for k in range(5)]
+    ex, ey = G.toElementArray(xs).expPair(0, none, G.ringArray([]))                             # one side empty
+    assert ex.toInts() == [1] * 5 and ey.toInts() == []
+    a, b = G.ringArray([1, 2, 3]), G.ringArray([4, 5])
+    with pytest.raises(vmn.VmnError):
+        vmn.innerProducts([(a, a), (a, b)])
+    assert vmn.innerProducts([(a, a), (b, None)]) == [14, 9]
+    W, S = case["W"], case["keep"][0]
+    F = nat.reencryption_factors_native(G, case["pkey"], S)
+    pi = list(range(24))
+    with pytest.raises(vmn.VmnError):
+        nat.apply_factors_native(G, W, [f.copyOfRange(0, 23) for f in F], pi)
+    with pytest.raises(vmn.VmnError):
+        nat.apply_factors_native(G, W, F, [0] * 24)                                             # not a permutation
+    assert [x.toInts() for x in nat.apply_factors_native(G, W, F, pi)] == [x.toInts() for x in nat.reencrypt_native(G, case["pkey"], W, S, pi)]
+    ver = case["verifier"]()                                                                    # computeAF has begun A and F ...
+    ver.free()                                                                                  # ... and the handle goes with the verifier
+    again = case["verifier"]()
+    again.setChallenge(case["v"])
+    assert again.verify(case["rep"])                                                            # the landing buffers were released
