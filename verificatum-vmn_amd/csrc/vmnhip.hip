@@ -908,6 +908,7 @@ static Big times_small(const Big& a, uint32_t k, size_t nw) {
 static void curve_destroy(vmn_curve* c) {
     if (!c) return;
     if (c->d_consts) (void)hipFree(c->d_consts);
+    delete c->f64;
     delete c;
 }
 
@@ -926,6 +927,10 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     c->gx_words = hostbig::from_be(gx.data(), gx.size(), NW);
     c->gy_words = hostbig::from_be(gy.data(), gy.size(), NW);
     c->n0inv = hostbig::neg_inv_pow2(c->p_words[0] & LIMB_MASK, 28);
+    c->f64 = new num64::Mod(num64::from_be(pb.data(), pb.size(), (pb.size() + 7) / 8));
+    c->host.F = c->f64;
+    c->host.cb = ((size_t)cp.bits + 7) / 8;
+    c->host.fl = c->f64->nl;
     const Big& pw = c->p_words;
     c->p1p = limbs_of(pw, S)[1] + 1;
     {   // the kernels carry the primes of these two sizes as compile-time constants (ec_kernels.h FieldPrime): same prime?
@@ -3343,6 +3348,37 @@ static void horner_windows(const vmn_group* g, const uint8_t* wbe, size_t k, int
     for (auto& f : others) f.get();
 }
 
+// The same over a curve: the window results arrive as affine points (x || y, the identity all 0xff), the chain of c * nwin
+// doublings and nwin additions runs in Jacobian coordinates on 64-bit limbs (csrc/hostcurve.h) -- ~0.3 ms at P-256, where the
+// one GPU lane per array of k_ec_horner took 1.3 ms with the device otherwise empty.
+static void horner_windows_ec(const vmn_group* g, const uint8_t* wbe, size_t k, int nwin, int c, uint8_t* out_be) {
+    VMN_TRACE("expprod:horner_host");
+    num64::HostCurve hc = g->P.ec->host;
+    hc.cb = g->nbytes;                                   // the wire width of a coordinate (may be the Java width)
+    const size_t pb = 2 * g->nbytes;
+    auto horner = [&](size_t arr) {
+        num64::HostCurve::Jac acc;
+        for (int w = nwin - 1; w >= 0; --w) {
+            for (int s2 = 0; s2 < c; ++s2) acc = hc.dbl(acc);
+            const uint8_t* pt = wbe + (arr * (size_t)nwin + w) * pb;
+            num64::Num x, y;
+            if (hc.decode(num64::Bytes(pt, pt + pb), x, y)) acc = hc.add_affine(acc, x, y);
+        }
+        num64::Bytes enc = hc.encode(acc);
+        memcpy(out_be + arr * pb, enc.data(), pb);
+    };
+    std::vector<std::future<void>> others;
+    for (size_t arr = 1; arr < k; ++arr) {
+        try {
+            others.emplace_back(std::async(std::launch::async, horner, arr));
+        } catch (const std::system_error&) {
+            horner(arr);
+        }
+    }
+    horner(0);
+    for (auto& f : others) f.get();
+}
+
 // a landing buffer of the lane for a pending result, if one is free (PENDING_SLOTS multi-exponentiations in flight per lane)
 static uint8_t* claim_pending_stage(vmn_ctx* ctx, size_t bytes, vmn_pending* pend) {
     int k = -1;
@@ -3618,7 +3654,11 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         pend->nwin = nwin;
         pend->c = c;
     }
-    if (m.ec) {
+    static const bool horner_on_device = [] {          // measurement knob: the one-lane-per-array kernel of round 2
+        const char* e = getenv("VMN_EC_HORNER_DEVICE");
+        return e && *e == '1';
+    }();
+    if (m.ec && horner_on_device) {
         VMN_TRACE("expprod:horner_device");
         DevTmp res(ctx);
         VMN_TRY(res.alloc(k * Wd * sizeof(uint32_t)));
@@ -3631,6 +3671,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
 #undef X
         VMN_TRY(rc);
         if (pend) {
+            pend->nwin = 0;                            // (finish: the staged bytes ARE the results)
             pend->staged_bytes = k * ebytes_out;
             if (uint8_t* land = claim_pending_stage(ctx, pend->staged_bytes, pend))
                 return stage_pending(ctx, m, g->nbytes, res.as<uint32_t>(), k, land, pend);
@@ -3639,7 +3680,8 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         }
         return export_be(ctx, m, g->nbytes, res.as<uint32_t>(), k, out_be);
     }
-    const size_t wbytes = k * (size_t)nwin * g->nbytes;
+    // the window results leave the device (curves: as affine points) and the chain over them runs on the host
+    const size_t wbytes = k * (size_t)nwin * ebytes_out;
     if (pend) {
         pend->staged_bytes = wbytes;
         if (uint8_t* land = claim_pending_stage(ctx, wbytes, pend))
@@ -3652,7 +3694,8 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         VMN_TRACE("expprod:export_windows");
         VMN_TRY(export_be(ctx, m, g->nbytes, wres.as<uint32_t>(), k * (size_t)nwin, wbe.data()));
     }
-    horner_windows(g, wbe.data(), k, nwin, c, out_be);
+    if (m.ec) horner_windows_ec(g, wbe.data(), k, nwin, c, out_be);
+    else horner_windows(g, wbe.data(), k, nwin, c, out_be);
     return VMN_OK;
 }
 
@@ -3756,7 +3799,8 @@ extern "C" int vmn_pending_finish(vmn_pending* p, uint8_t* out_be) {
             return VMN_ERR_DEVICE;
         }
     }
-    if (p->g->P.ec) memcpy(out_be, landed.data(), p->staged_bytes);
+    if (p->nwin == 0) memcpy(out_be, landed.data(), p->staged_bytes);            // (the device did the chain: VMN_EC_HORNER_DEVICE)
+    else if (p->g->P.ec) horner_windows_ec(p->g, landed.data(), p->k, p->nwin, p->c, out_be);
     else horner_windows(p->g, landed.data(), p->k, p->nwin, p->c, out_be);
     return VMN_OK;
 }
