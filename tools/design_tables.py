@@ -4,7 +4,7 @@
 between the markers <!-- r03-tables-begin --> and <!-- r03-tables-end -->.  (The round-2 block of DESIGN.md was generated the
 same way from profiles/r02_bench_v2.json / r02_pmc_kernels.json and is frozen text now.)
 
-usage: tools/design_tables.py [profiles/r03_bench_v9.json]"""
+usage: tools/design_tables.py [profiles/r03_bench_v10.json]"""
 import json
 import os
 import sys
@@ -97,7 +97,7 @@ BEGIN, END = "<!-- r03-tables-begin -->", "<!-- r03-tables-end -->"
 
 
 def main():
-    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_v9.json")
+    bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_v10.json")
     text = render(bench)
     path = os.path.join(ROOT, "DESIGN.md")
     s = open(path).read()
