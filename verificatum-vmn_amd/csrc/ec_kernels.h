@@ -766,8 +766,10 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_mulvar(u32* __restr
 }
 
 // sq[j] = 2^j * base, j < count: the doubling chain of a fixed-base table, one lane (count ~ 256-400 doublings)
+// (launch bounds: without them the compiler budgets registers for 1024 threads per block and the point doubling spills --
+// the chain then took 27 us per doubling instead of 5)
 template <int S>
-__global__ void k_ec_chain(u32* __restrict__ sq, const u32* __restrict__ base, int count, ECDev E) {
+__global__ void __launch_bounds__(64) k_ec_chain(u32* __restrict__ sq, const u32* __restrict__ base, int count, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     Pt<S> A;
@@ -1027,7 +1029,7 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_scan_apply(u32* __r
 // Horner over the window results of a multi-exponentiation: out[a] = sum_w 2^(c w) W[a][w]; one lane per array
 // (the chain of c * nwin doublings is sequential, so the k arrays of a multi-array call share its latency)
 template <int S>
-__global__ void k_ec_horner(u32* __restrict__ out, const u32* __restrict__ wres, int nwin, int c, int k, ECDev E) {
+__global__ void __launch_bounds__(BLOCK) k_ec_horner(u32* __restrict__ out, const u32* __restrict__ wres, int nwin, int c, int k, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= k) return;
