@@ -328,7 +328,9 @@ int vmn_ctx_timing_enable(vmn_ctx* ctx, int on);
 int vmn_ctx_timing_reset(vmn_ctx* ctx);
 /* family: "modpow", "modmul", "fixed", "expprod", ...; returns launches and total ms. */
 int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launches, double* total_ms);
-/* All families as text lines "family launches total_ms\n" into buf (truncated to len-1 bytes). */
+/* All families as text lines "family launches total_ms executed_mads canonical_macs\n" into buf (truncated to len-1 bytes):
+ * executed_mads = v_mad_u64_u32 multiply-adds of the 28-bit-limb kernels, canonical_macs = the same products priced at
+ * SURVEY.md 8d's M(s) = 2 s^2 + s / Q(s) on s = bits / 32 limbs (the unit of the headline roofline). */
 int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len);
 
 #ifdef __cplusplus

@@ -25,20 +25,14 @@ from tape import SeedTape, Tape
 
 
 def load_parallel():
-    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.parallel", os.path.join(entry.PKG_DIR, "parallel.py"))
-    m = importlib.util.module_from_spec(spec)
-    sys.modules[spec.name] = m
-    spec.loader.exec_module(m)
-    return m
+    """The product's Comm / shard_bounds together with the test-only Python mirror of the sharded drivers."""
+    import mirror
+    return mirror.load(entry, ("parallel_mirror",))["parallel_mirror"]
 
 
 def load_native():
-    entry.load_package()                       # native.py imports from its package
-    spec = importlib.util.spec_from_file_location("verificatum_vmn_amd.native", os.path.join(entry.PKG_DIR, "native.py"))
-    m = importlib.util.module_from_spec(spec)
-    sys.modules[spec.name] = m
-    spec.loader.exec_module(m)
-    return m
+    import mirror
+    return mirror.load(entry, ("native",))["native"]
 
 
 def gather_and_check(dist, rank, world, mine, expect, out_path):
@@ -53,10 +47,20 @@ def gather_and_check(dist, rank, world, mine, expect, out_path):
         for key, want in expect["flags"].items():
             checks[key] = all(gsh["flags"][key] == want for gsh in gathered)
         with open(out_path, "w") as f:
-            json.dump({"pass": all(checks.values()), "why": json.dumps(checks), "world": world,
+            json.dump({"pass": all(checks.values()), "why": json.dumps(checks), "world": world, "comm": comm_state(),
                        "exchanges": [gsh.get("exchanges") for gsh in gathered]}, f)
     dist.barrier()
     raise CaseDone(0)
+
+
+_COMM = []
+
+
+def comm_state():
+    """Which transport the case's communicator really used (rank 0's view)."""
+    c = _COMM[-1] if _COMM else None
+    return {"backend_used": getattr(c, "backend_used", None), "fell_back": getattr(c, "fell_back", None),
+            "torch_backend": dist.get_backend() if dist.is_initialized() else None}
 
 
 class CaseDone(Exception):
@@ -311,7 +315,10 @@ def run_case(device, backend, bits, n, width, out_path, flow="pos"):
                 json.dump({"pass": bool(ok), "why": f"fell_back={c.fell_back!r} backend={c.backend_used}", "world": world, "exchanges": []}, f)
         dist.barrier()
         raise CaseDone(0 if ok else 1)
-    comm = par.Comm(dist, device)
+    # on the device path (RCCL) the communicator gets a gloo group as its safety net, as in bench.py: the constructor's
+    # probe exchange + the ranks' collective decision run here too
+    comm = par.Comm(dist, device, fallback=dist.new_group(backend="gloo") if device is not None else None)
+    _COMM.append(comm)
     ec = backend.endswith("-ec")
     native = backend.startswith("hip") and not mirror
     if backend.startswith("hip"):
@@ -428,7 +435,7 @@ def run_case(device, backend, bits, n, width, out_path, flow="pos"):
             "accept": all(gsh["ok"] for gsh in gathered),
             "reject_tampered": all(not gsh["bad_ok"] and gsh["bad_verdicts"] == [True, False, True, True, True] for gsh in gathered),
         }
-        result = {"pass": all(checks.values()), "why": json.dumps(checks), "world": world,
+        result = {"pass": all(checks.values()), "why": json.dumps(checks), "world": world, "comm": comm_state(),
                   "exchanges": [gsh.get("exchanges") for gsh in gathered]}
         with open(out_path, "w") as f:
             json.dump(result, f)

@@ -10,14 +10,9 @@ from tape import Tape
 
 
 def load_driver_modules(entry):
-    """hvzk / mixnet / native of the package (its directory name has a hyphen: loaded by path)."""
-    out = {}
-    for name in ("hvzk", "mixnet", "native", "elgamal"):
-        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
-        m = importlib.util.module_from_spec(spec)
-        sys.modules[spec.name] = m
-        spec.loader.exec_module(m)
-        out[name] = m
+    """The C++ drivers' bindings (native) and the test-only Python mirror (tests/mirror: hvzk, mixnet, elgamal)."""
+    import mirror
+    out = mirror.load(entry, ("hvzk", "mixnet", "native", "elgamal"))
     return out
 
 

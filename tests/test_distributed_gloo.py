@@ -51,9 +51,8 @@ def run_cases(world, cases, tmp_path, timeout=900):
 
 def test_shard_bounds_cover_everything(entry):
     import importlib.util
-    spec = importlib.util.spec_from_file_location("par", os.path.join(entry.PKG_DIR, "parallel.py"))
-    par = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(par)
+    import mirror
+    par = mirror.load(entry, ("parallel",))["parallel"]
     for n in (0, 1, 7, 8, 9, 1000003):
         for world in (1, 2, 3, 8):
             spans = [par.shard_bounds(n, world, r) for r in range(world)]
@@ -68,9 +67,8 @@ def test_host_row_blocks_of_every_kind_are_sliced_alike(entry):
     import importlib.util
     import numpy as np
     import torch
-    spec = importlib.util.spec_from_file_location("par_rows", os.path.join(entry.PKG_DIR, "parallel.py"))
-    par = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(par)
+    import mirror
+    par = mirror.load(entry, ("parallel_mirror",))["parallel_mirror"]
     nb, n = 32, 50
     raw = bytes(range(256)) * (nb * n // 256 + 1)
     raw = raw[: nb * n]
@@ -139,6 +137,21 @@ def test_sharded_cxx_drivers_generate_only_their_rows_of_the_prg_arrays(world, c
     oracle run on the fully expanded arrays."""
     for case, res in zip(cases, run_cases(world, cases, tmp_path)):
         assert res["pass"], (case, res["why"])
+
+
+@pytest.mark.gpu
+def test_sharded_cxx_drivers_over_rccl_world_size_one(tmp_path):
+    """The RCCL branch of parallel.Comm on real hardware: torch.distributed backend `nccl` (= RCCL), world size 1 on the test
+    box's GPU (RCCL needs one GPU per rank; the box has one), communicator built as bench.py builds it (device + gloo safety
+    net, so the constructor's probe exchange runs).  The sharded C++ drivers then run a PoS and a seeded CCPoS through it:
+    every all-gather callback goes pinned host -> device -> all_gather_into_tensor -> pinned host.  The transcript must be
+    the oracle's, the transport must be RCCL, and the fallback must not have been taken."""
+    cases = [("hip", 2048, 96, 1, "pos"), ("hip", 2048, 64, 1, "ccpos-seeded")]
+    for case, res in zip(cases, run_cases(1, cases, tmp_path)):
+        assert res["pass"], (case, res["why"])
+        assert res["comm"]["torch_backend"] == "nccl", res["comm"]
+        assert res["comm"]["backend_used"] == "nccl" and res["comm"]["fell_back"] is None, res["comm"]
+        assert all(x is None or x > 0 for x in res["exchanges"]), res["exchanges"]
 
 
 @pytest.mark.gpu

@@ -134,7 +134,7 @@ def _same(msg, want):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 def test_drivers_reproduce_the_config2_record(impl, vmn, gpu_ctx, entry):
     from proof_cases import load_driver_modules
     mods = load_driver_modules(entry)
@@ -190,7 +190,7 @@ def test_drivers_reproduce_the_config2_record(impl, vmn, gpu_ctx, entry):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 def test_drivers_reproduce_the_config4_record(impl, vmn, gpu_ctx, entry):
     from proof_cases import load_driver_modules
     mods = load_driver_modules(entry)

@@ -144,13 +144,8 @@ def test_hip_curve_kernels_reproduce_the_golden_vectors(fname, vmn, gpu_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("impl", ["python", "native"])
 def test_proof_drivers_reproduce_the_golden_transcripts(impl, vmn, gpu_ctx, entry):
-    mods = {}
-    for name in ("hvzk", "mixnet", "native"):
-        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
-        m = importlib.util.module_from_spec(spec)
-        sys.modules[spec.name] = m
-        spec.loader.exec_module(m)
-        mods[name] = m
+    import mirror
+    mods = mirror.load(entry, ("hvzk", "mixnet", "native"))
     hv = mods["hvzk" if impl == "python" else "native"]
     rec = load("proofs_n8.json")
     p, q, g = (int(rec["modp512"][k], 16) for k in ("p", "q", "g"))

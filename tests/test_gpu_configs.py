@@ -65,7 +65,7 @@ def check_posc(impl, mods, G, p, q, g, h, H, u_o, U, r, R, pi, t, bits3):
     assert ov.verify({k: ints_of(x) for k, x in rep.items()}, v)
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 def test_config2_3072bit_precompute_shrink_ccpos(impl, vmn, gpu_ctx, mods):
     """BASELINE configs[2] on its own group size: offline phase for N_max ciphertexts, online phase for N < N_max."""
     bits3 = (256, 256, 100)
@@ -129,7 +129,7 @@ def test_config2_3072bit_precompute_shrink_ccpos(impl, vmn, gpu_ctx, mods):
     check_ccpos(impl, mods, G, K, g, h[:n], H_s, u_s_o, U_s, pkey, w, W, wp_o, WP, r[:n], R_s, pi_s_o, s, S, t, bits3, rho=rho)
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 @pytest.mark.parametrize("width", [3, 4])
 def test_modp_widths_3_and_4(width, impl, vmn, gpu_ctx, mods):
     """Widths 3 and 4 (DemoShufflerElGamal.java:163-265 runs 1-4), PoS and CCPoS plain + raised, 512-bit group."""
@@ -147,7 +147,7 @@ def test_modp_widths_3_and_4(width, impl, vmn, gpu_ctx, mods):
     check_ccpos(impl, mods, G, K, g, h, H, u_o, U, pkey, w, W, wp_o, WP, r, R, pi, s, S, t, bits3, rho=rho)
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 def test_config4_p256_width3(impl, vmn, gpu_ctx, mods):
     """BASELINE configs[4]'s group and width: ECqPGroup P-256, width 3 (six point arrays per ciphertext array)."""
     bits3 = (128, 128, 64)
@@ -201,7 +201,7 @@ class WideEpsilonTape(Tape):
         return self.ring_array(n) if bits > 200 else Tape.int_array(self, n, bits)
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 def test_verifier_uses_every_bit_of_received_exponents(impl, vmn, gpu_ctx, mods):
     """The reference parses k_E as full field elements and uses every bit (PoSBasicTW.java:985-989, 1021, 1032;
     CCPoSBasicW.java:533-544, 554-580): a VALID proof whose k_E is wider than an honest prover's must be accepted, and

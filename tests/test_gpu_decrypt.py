@@ -30,11 +30,9 @@ class _NativeFacade:
 
 @pytest.fixture(scope="module", params=["python", "native"])
 def eg(request, entry, vmn, gpu_ctx):
+    import mirror
     name = "elgamal" if request.param == "python" else "native"
-    spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
-    m = importlib.util.module_from_spec(spec)
-    sys.modules[spec.name] = m
-    spec.loader.exec_module(m)
+    m = mirror.load(entry, (name,))[name]
     if request.param == "python":
         return m
     groups = {}

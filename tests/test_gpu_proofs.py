@@ -14,14 +14,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def mods(entry, vmn):
     import importlib.util, os, sys
-    out = {}
-    for name in ("hvzk", "mixnet", "native"):
-        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}",
-                                                      os.path.join(entry.PKG_DIR, f"{name}.py"))
-        m = importlib.util.module_from_spec(spec)
-        sys.modules[spec.name] = m
-        spec.loader.exec_module(m)
-        out[name] = m
+    import mirror
+    out = mirror.load(entry, ("hvzk", "mixnet", "native"))
     return out
 
 

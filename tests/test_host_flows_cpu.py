@@ -17,13 +17,8 @@ from tape import Tape
 
 @pytest.fixture(scope="module")
 def mods(entry):
-    out = {}
-    for name in ("hvzk", "mixnet"):
-        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
-        m = importlib.util.module_from_spec(spec)
-        sys.modules[spec.name] = m
-        spec.loader.exec_module(m)
-        out[name] = m
+    import mirror
+    out = mirror.load(entry, ("hvzk", "mixnet"))
     return out
 
 

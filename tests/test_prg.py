@@ -160,20 +160,15 @@ def test_independent_generators_over_curves(curve_name, hashname, seedlen, vmn, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("impl", ["native"])
 def test_proof_with_the_batching_vector_derived_from_a_seed(impl, vmn, gpu_ctx, entry):
     """setBatchVector(byte[] prgSeed) as the reference calls it: both drivers derive e on the GPU and produce the
     transcript of the oracle run on e = the PRG integers."""
     import importlib.util, sys
     from oracle import pyref_proofs as P
     from tape import Tape
-    mods = {}
-    for name in ("hvzk", "native"):
-        spec = importlib.util.spec_from_file_location(f"verificatum_vmn_amd.{name}", os.path.join(entry.PKG_DIR, f"{name}.py"))
-        m = importlib.util.module_from_spec(spec)
-        sys.modules[spec.name] = m
-        spec.loader.exec_module(m)
-        mods[name] = m
+    import mirror
+    mods = mirror.load(entry, ("hvzk", "native"))
     hv = mods["hvzk" if impl == "python" else "native"]
     grp, _ = load_golden(512)
     p, q, g = grp["p"], grp["q"], grp["g"]

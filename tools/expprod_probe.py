@@ -7,7 +7,7 @@ import __graft_entry__ as entry
 vmn = entry.load_package()
 from oracle import pyref
 import importlib.util
-spec = importlib.util.spec_from_file_location("mx", os.path.join(entry.PKG_DIR, "mixnet.py")); mx = importlib.util.module_from_spec(spec); spec.loader.exec_module(mx)
+spec = importlib.util.spec_from_file_location("mx", os.path.join(entry.PKG_DIR, "randomsource.py")); mx = importlib.util.module_from_spec(spec); spec.loader.exec_module(mx)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 bits = int(sys.argv[2]) if len(sys.argv) > 2 else 613

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 vmn = entry.load_package()
-spec = importlib.util.spec_from_file_location("mx", os.path.join(entry.PKG_DIR, "mixnet.py")); mx = importlib.util.module_from_spec(spec); spec.loader.exec_module(mx)
+spec = importlib.util.spec_from_file_location("mx", os.path.join(entry.PKG_DIR, "randomsource.py")); mx = importlib.util.module_from_spec(spec); spec.loader.exec_module(mx)
 spec = importlib.util.spec_from_file_location("sg", os.path.join(entry.PKG_DIR, "stdgroups.py")); sg = importlib.util.module_from_spec(spec); spec.loader.exec_module(sg)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 p, q, g = sg.modp_group(2048)

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 vmn = entry.load_package()
 from oracle import pyref
-spec = importlib.util.spec_from_file_location("mx", os.path.join(entry.PKG_DIR, "mixnet.py")); mx = importlib.util.module_from_spec(spec); spec.loader.exec_module(mx)
+spec = importlib.util.spec_from_file_location("mx", os.path.join(entry.PKG_DIR, "randomsource.py")); mx = importlib.util.module_from_spec(spec); spec.loader.exec_module(mx)
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 p, q, g = pyref.modp_group(bits)

@@ -9,7 +9,7 @@ import bench
 
 vmn = entry.load_package()
 ctx = vmn.Context(0)
-nat, mx = bench.load_sub(entry, "native"), bench.load_sub(entry, "mixnet")
+nat, mx = bench.load_sub(entry, "native"), bench.load_sub(entry, "randomsource")
 n, width = 400_000, 3
 for rep in range(3):
     grp = vmn.ECqPGroup(ctx, "P-256")

@@ -183,13 +183,15 @@ class Context:
         _check(lib().vmn_ctx_timing_reset(self._h))
 
     def timing_report(self) -> dict:
-        """{family: (launches, total_ms, executed multiply-adds)} of every kernel family since the last reset."""
+        """{family: (launches, total_ms, executed multiply-adds, the same products in canonical 32-bit multiply-accumulates)}
+        of every kernel family since the last reset."""
         buf = C.create_string_buffer(16384)
         _check(lib().vmn_ctx_timing_report(self._h, buf, C.c_size_t(len(buf))))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, cnt, ms, mads = line.split()
-            out[name] = (int(cnt), float(ms), float(mads))       # mads: v_mad_u64_u32 multiply-adds executed (work accounting)
+            name, cnt, ms, mads, canon = line.split()
+            # mads: v_mad_u64_u32 executed (28-bit limbs); canon: SURVEY.md §8d's M(s) = 2 s^2 + s per product, s = bits / 32
+            out[name] = (int(cnt), float(ms), float(mads), float(canon))
         return out
 
     def timing_get(self, family: str):
@@ -386,6 +388,10 @@ class ModPGroup:
         """Session setup: build the fixed-base table of a long-lived base (generator, public key) sized for about
         ``uses_hint`` calls on arrays of about ``n_hint`` exponents (``vmn_group_precompute_fixed``)."""
         _check(lib().vmn_group_precompute_fixed(self._h, self.enc_el(base), C.c_size_t(n_hint), C.c_int(uses_hint)))
+
+    def tableBytes(self) -> int:
+        """Bytes of HBM the cached fixed-base tables of this group hold (``vmn_group_table_bytes``)."""
+        return int(lib().vmn_group_table_bytes(self._h))
 
     def mulPartials(self, partials):
         out = C.create_string_buffer(self.elem_bytes)

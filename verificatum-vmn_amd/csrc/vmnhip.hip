@@ -160,11 +160,12 @@ static int launch(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), un
     if (ctx->timing) {
         rec.family = family;
         rec.mads = ctx->next_mads;
+        rec.canon = ctx->next_canon;
         VMN_HIP(hipEventCreate(&rec.start));
         VMN_HIP(hipEventCreate(&rec.stop));
         VMN_HIP(hipEventRecord(rec.start, ctx->stream));
     }
-    ctx->next_mads = 0;
+    ctx->next_mads = ctx->next_canon = 0;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, ctx->stream, static_cast<KArgs>(args)...);
     VMN_HIP(hipGetLastError());
     if (ctx->timing) {
@@ -183,6 +184,10 @@ static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double
     if (!ctx->timing) return 0;
     const double S = m.ec ? (double)m.ec->S : (double)m.S;              // columns
     const double Rw = m.ec ? S : (double)m.rows;                         // rows (< S in a wide geometry)
+    // the same products priced in SURVEY.md §8d's unit: 32 x 32-bit multiply-accumulates of a product / squaring on
+    // s = ceil(bits / 32) limbs, M(s) = 2 s^2 + s, Q(s) = s (s + 1) / 2 + s^2 + s -- the unit of the headline's roofline
+    const double s32 = (double)((m.nbits + 31) / 32);
+    ctx->next_canon = products * (2 * s32 * s32 + s32) + squarings * (m.ec ? 2 * s32 * s32 + s32 : s32 * (s32 + 1) / 2 + s32 * s32 + s32);
     if (m.ec) {
         // a field product: S^2 for the multiplication half + S x (non-zero limbs of p, less limb 0 whose carry is folded into
         // column 1) for the reduction rows of the compile-time primes (ec_kernels.h mont_row: 6 of 10 for P-256, 12 of 15 for P-384)
@@ -211,11 +216,12 @@ static int launch_light(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs..
     if (ctx->timing) {
         rec.family = family;
         rec.mads = ctx->next_mads;
+        rec.canon = ctx->next_canon;
         VMN_HIP(hipEventCreate(&rec.start));
         VMN_HIP(hipEventCreate(&rec.stop));
         VMN_HIP(hipEventRecord(rec.start, ctx->stream));
     }
-    ctx->next_mads = 0;
+    ctx->next_mads = ctx->next_canon = 0;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, static_cast<KArgs>(args)...);
     VMN_HIP(hipGetLastError());
     if (ctx->timing) {
@@ -575,6 +581,7 @@ static int timing_collect(vmn_ctx* ctx) {
         acc.first += 1;
         acc.second += ms;
         ctx->work_acc[r.family] += r.mads;
+        ctx->canon_acc[r.family] += r.canon;
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
@@ -594,6 +601,7 @@ extern "C" int vmn_ctx_timing_reset(vmn_ctx* ctx) {
     VMN_TRY(timing_collect(ctx));
     ctx->timing_acc.clear();
     ctx->work_acc.clear();
+    ctx->canon_acc.clear();
     return VMN_OK;
 }
 extern "C" int vmn_ctx_timing_get(vmn_ctx* ctx, const char* family, long* launches, double* total_ms) {
@@ -613,7 +621,8 @@ extern "C" int vmn_ctx_timing_report(vmn_ctx* ctx, char* buf, size_t len) {
     std::string out;
     for (auto& kv : ctx->timing_acc) {
         char line[160];
-        snprintf(line, sizeof(line), "%s %ld %.4f %.6e\n", kv.first.c_str(), kv.second.first, kv.second.second, ctx->work_acc[kv.first]);
+        snprintf(line, sizeof(line), "%s %ld %.4f %.6e %.6e\n", kv.first.c_str(), kv.second.first, kv.second.second, ctx->work_acc[kv.first],
+                 ctx->canon_acc[kv.first]);
         out += line;
     }
     size_t k = std::min(out.size(), len - 1);

@@ -51,6 +51,7 @@ struct TimingRec {
     std::string family;
     hipEvent_t start, stop;
     double mads = 0;           // v_mad_u64_u32 multiply-adds the launch executes (products x 2 S^2 ...), noted by the launch site
+    double canon = 0;          // the same products in SURVEY.md §8d's canonical 32-bit multiply-accumulates (M(s) = 2 s^2 + s per product)
 };
 
 }  // namespace vmn
@@ -96,6 +97,8 @@ struct vmn_ctx {
     std::vector<vmn::TimingRec> recs;
     std::map<std::string, std::pair<long, double>> timing_acc;
     std::map<std::string, double> work_acc;    // executed multiply-adds per kernel family (while timing is on)
+    std::map<std::string, double> canon_acc;   // the same in canonical 32-bit multiply-accumulates
+    double next_canon = 0;                     // the same work in canonical 32-bit multiply-accumulates
     double next_mads = 0;                      // set by note_work() just before a launch, consumed by it
 };
 
