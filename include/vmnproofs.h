@@ -203,6 +203,16 @@ int vmn_pos_set_challenge(vmn_pos* p, const uint8_t* v_be, size_t vbytes);      
 int vmn_pos_verify_prepare(vmn_pos* p, const vmn_msg* reply);
 /* :1000-1066; all five checks are evaluated; verdicts5 (may be NULL) = A, B, C, D, F */
 int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts5);
+/* The verifier's intermediate values, as the reference exposes them: getA PoSBasicTW.java:716, getF :761 (after computeAF;
+ * 2 * width elements), getC :949, getD :958 (after verify).  `vmnv -t PoS.A,PoS.F,PoS.C,PoS.D` prints exactly these
+ * (mixnet/MixNetElGamalVerifyFiatShamirSession.java:880-932): tools/vmnv_vectors.py does the same from a proof directory.
+ * The other getters of the reference (getB, getAp ... getFp, getk_A ... getk_F, :707-770, 895-940) are the items of the
+ * commitment / reply messages (vmn_msg_scalar, vmn_msg_garray, vmn_msg_rarray).  out_be: elem_bytes per element. */
+int vmn_pos_get_A(vmn_pos* p, uint8_t* out_be);
+int vmn_pos_get_F(vmn_pos* p, uint8_t* out_be);
+int vmn_pos_get_C(vmn_pos* p, uint8_t* out_be);
+int vmn_pos_get_D(vmn_pos* p, uint8_t* out_be);
+size_t vmn_pos_width(const vmn_pos* p);              /* omega of the instance (0 before set_instance) */
 
 /* ---- PoSCBasicTW -------------------------------------------------------------------------------------------- */
 typedef struct vmn_posc vmn_posc;
@@ -221,6 +231,11 @@ int vmn_posc_set_commitment(vmn_posc* p, const vmn_msg* commitment);
 int vmn_posc_set_challenge(vmn_posc* p, const uint8_t* v_be, size_t vbytes);
 int vmn_posc_verify_prepare(vmn_posc* p, const vmn_msg* reply);                      /* the reply side of verify(), see vmn_pos_verify_prepare */
 int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict);                 /* :646-727 */
+/* A = u.expProd(e) (:676), C (:718-723), D (:724-727) of the verifier, after verify / verify_prepare (private fields in the
+ * reference; exposed for the intermediate-value tests and the test-vector dump) */
+int vmn_posc_get_A(vmn_posc* p, uint8_t* out_be);
+int vmn_posc_get_C(vmn_posc* p, uint8_t* out_be);
+int vmn_posc_get_D(vmn_posc* p, uint8_t* out_be);
 
 /* ---- CCPoSBasicW -------------------------------------------------------------------------------------------- */
 typedef struct vmn_ccpos vmn_ccpos;
@@ -241,6 +256,10 @@ int vmn_ccpos_set_commitment(vmn_ccpos* p, const vmn_msg* commitment);
 int vmn_ccpos_set_challenge(vmn_ccpos* p, const uint8_t* v_be, size_t vbytes);
 /* computeAB :493-506; raisedu = u^rho selects the single-equation form (NULL = plain) */
 int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu);
+/* The values of computeAB: plain form A then B (1 + 2 width elements), raised form AB (2 width); *count = elements written
+ * (out_be must hold 1 + 2 width).  Private fields in the reference (CCPoSBasicW.java:493-506). */
+int vmn_ccpos_get_AB(vmn_ccpos* p, uint8_t* out_be, size_t* count);
+size_t vmn_ccpos_width(const vmn_ccpos* p);
 /* verify :519-584; raisedh / rho_be = NULL for the plain form */
 /* The reply side of verify() (here: ALL its array work, the multi-exponentiations with k_E); same raisedh / rho as the
  * verify() that follows.  See vmn_pos_verify_prepare. */

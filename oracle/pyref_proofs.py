@@ -227,6 +227,7 @@ class PoS(_Base):
         for t in self.e:
             eprod = eprod * t % q
         D = self._div(self.B[self.size - 1], pow(h0, eprod, p))
+        self.C, self.D = C, D            # the verifier's intermediates (getC / getD, PoSBasicTW.java:949, 958)
         verdictA = (pow(self.A, v, p) * self.Ap % p) == (pow(g, k_A, p) * pyref.exp_prod(h, k_E, p) % p)
         left = pyref.mul(pyref.exp_scalar(self.B, v, p), self.Bp, p)
         right = pyref.mul(pyref.exp_fixed(g, k_B, p), pyref.exp_array(pyref.shift_push(self.B, h0), k_E, p), p)
@@ -290,12 +291,13 @@ class PoSC(_Base):
         p, q, g, h = self.p, self.q, self.g, self.h
         k_A, k_B, k_C, k_D, k_E = (reply[k] for k in ("k_A", "k_B", "k_C", "k_D", "k_E"))
         h0 = h[0]
-        A = pyref.exp_prod(self.u, self.e, p)
+        A = self.A = pyref.exp_prod(self.u, self.e, p)
         C = self._div(pyref.prod(self.u, p), pyref.prod(h, p))
         eprod = 1
         for t in self.e:
             eprod = eprod * t % q
         D = self._div(self.B[self.size - 1], pow(h0, eprod, p))
+        self.C, self.D = C, D            # the verifier's intermediates (getC / getD, PoSBasicTW.java:949, 958)
         if (pow(A, v, p) * self.Ap % p) != (pow(g, k_A, p) * pyref.exp_prod(h, k_E, p) % p):
             return False
         left = pyref.mul(pyref.exp_scalar(self.B, v, p), self.Bp, p)
@@ -520,6 +522,7 @@ class GPoS:
         for t in self.e:
             eprod = eprod * t % q
         D = K.mul(self.B[self.size - 1], K.inv(K.exp(h0, eprod)))
+        self.C, self.D = C, D            # the verifier's intermediates (getC / getD, PoSBasicTW.java:949, 958)
         verdictA = K.mul(K.exp(self.A, v), self.Ap) == K.mul(K.exp(g, k_A), K.exp_prod(h, k_E))
         left = K.mul_arrays(K.exp_scalar(self.B, v), self.Bp)
         right = K.mul_arrays(K.exp_fixed(g, k_B), K.exp_array(pyref.shift_push(self.B, h0), k_E))

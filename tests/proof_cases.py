@@ -99,6 +99,11 @@ def check_pos(impl, mods, G, K, g, h, pkey, w, t, bits3, tamper=True):
     ov.computeAF()
     ov.setCommitment({k: ints_of(x) for k, x in com.items()})
     assert ov.verify({k: ints_of(x) for k, x in rep.items()}, v)
+    if impl == "native":
+        # the verifier's intermediates equal the oracle's (getA :716, getF :761, getC :949, getD :958 of PoSBasicTW.java: what
+        # `vmnv -t PoS.A,PoS.F,PoS.C,PoS.D` prints); read after the last verify() -- the tampered reply changes none of them
+        assert ver.getA() == ov.A and list(ver.getF()) == list(ov.F), "PoS.A / PoS.F differ from the oracle"
+        assert ver.getC() == ov.C and ver.getD() == ov.D, "PoS.C / PoS.D differ from the oracle"
     return H, W, WP, wp_o, s, S, pi
 
 
@@ -137,6 +142,9 @@ def check_ccpos(impl, mods, G, K, g, h, H, u_o, U, pkey, w, W, wp_o, WP, r, R, p
     ov.setCommitment({k: ints_of(x) for k, x in cc.items()})
     ov.computeAB()
     assert ov.verify({k: ints_of(x) for k, x in cr.items()}, v)
+    if impl == "native":
+        A_gpu, B_gpu = cv.getAB()                      # computeAB's values (CCPoSBasicW.java:493-506), plain form
+        assert A_gpu == ov.A and list(B_gpu) == list(ov.B), "CCPoS A / B differ from the oracle"
     if rho is not None:
         RU, RH = U.exp(rho), H.exp(rho)
         cv2 = hv.CCPoSBasicW(G, NV, NE, NR)
@@ -155,4 +163,7 @@ def check_ccpos(impl, mods, G, K, g, h, H, u_o, U, pkey, w, W, wp_o, WP, r, R, p
         ov2.setCommitment({k: ints_of(x) for k, x in cc.items()})
         ov2.computeAB(K.exp_scalar(u_o, rho))
         assert ov2.verify({k: ints_of(x) for k, x in cr.items()}, v, K.exp_scalar(h, rho), rho)
+        if impl == "native":
+            none, AB_gpu = cv2.getAB()                 # raised form: AB = (w u^rho).expProd(e)
+            assert none is None and list(AB_gpu) == list(ov2.AB), "CCPoS AB (raised form) differs from the oracle"
     return cc, cr

@@ -10,7 +10,7 @@ from conftest import ROOT
 def declared_symbols(header="vmnhip.h"):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vmn_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(vmn_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_hot_path_surface():

@@ -1,0 +1,128 @@
+"""GPU suite: the reference's proof directory around one shuffle (verificatum-vmn_amd/proofdir.py, tools/vmnv_vectors.py).
+
+The C++ prover writes proofs/PermutationCommitment01.bt, PoSCommitment01.bt, PoSReply01.bt and Ciphertexts01.bt next to
+Ciphertexts.bt / FullPublicKey.bt (hvzk/PoSTW.java:95-165, 281-307; mixnet/ShufflerElGamalSession.java:1077-1101); the verifier
+reads them back as MixNetElGamalVerifyFiatShamirSession.verifyPoS does (:843-937), and every test vector `vmnv -t` would print
+is compared with the oracle's value computed from the SAME files by the Python restatement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import pyref, pyref_prg, pyref_proofs as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(p, q, g, bits):
+    return {"version": "3.1.0", "sid": "SessionID", "auxsid": "default", "rbitlen": 100, "vbitlenro": 256, "ebitlenro": 256,
+            "prg": "SHA-256", "rohash": "SHA-256", "rohash_name": "SHA-256", "width": 1,
+            "pgroup": f"ModPGroup({bits})", "group": {"kind": "modp", "p": format(p, "x"), "q": format(q, "x"), "g": format(g, "x")}}
+
+
+def _leaves(buf, width_bytes):
+    """The integers of an array byte tree node(N leaves)."""
+    n = int.from_bytes(buf[1:5], "big")
+    out, pos = [], 5
+    for _ in range(n):
+        ln = int.from_bytes(buf[pos + 1:pos + 5], "big")
+        out.append(int.from_bytes(buf[pos + 5:pos + 5 + ln], "big"))
+        pos += 5 + ln
+    return out, pos
+
+
+def test_proof_directory_round_trip_and_test_vectors(entry, vmn, gpu_ctx, tmp_path):
+    import mirror
+    mods = mirror.load(entry, ("proofdir", "randomsource", "fiatshamir"))
+    pd, rs, fs = mods["proofdir"], mods["randomsource"], mods["fiatshamir"]
+    grpd, _ = load_golden(2048)
+    p, q, g = grpd["p"], grpd["q"], grpd["g"]
+    n = 60
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)                     # the reference's wire widths (257-byte elements, 256-byte exponents)
+    params = _params(p, q, g, 2048)
+    tape = rs.InsecureShaRandomSource(b"proofdir", q)
+    y = pow(g, tape.ring_element(), p)
+    pkey = [g, y]
+    t_enc, msgs = tape.ring_array(n), tape.ring_array(n)
+    w = [pyref.exp_fixed(g, t_enc, p), pyref.mul(pyref.exp_fixed(g, msgs, p), pyref.exp_fixed(y, t_enc, p), p)]
+    W = [G.toElementArray(c) for c in w]
+    nizkp = str(tmp_path / "nizkp")
+    pd.write_inputs(nizkp, G, params, pkey, W)
+    WP = pd.write_shuffle(nizkp, 1, G, params, pkey, W, rs.InsecureShaRandomSource(b"proofdir-prover", q))
+    for name in ("PermutationCommitment01.bt", "PoSCommitment01.bt", "PoSReply01.bt", "Ciphertexts01.bt"):
+        assert os.path.getsize(os.path.join(nizkp, "proofs", name)) > 0
+    tv = {}
+    assert pd.verify_shuffle(nizkp, 1, G, params, pkey, tv, with_arrays=True)
+    assert tv["verdicts(A,B,C,D,F)"] == str((True,) * 5)
+
+    # ---- the same directory through the oracle: every printed value must be the oracle's
+    rho = pd.global_prefix(params)
+    assert tv["der.rho"] == rho.hex()
+    seed_h = pyref_prg.random_oracle(rho + fs.leaf(b"generators"), 256)
+    h = pyref_prg.modp_generators(seed_h, n, p, q, 100)
+    assert tv["bas.h"] == "(" + ", ".join(format(x, "x") for x in h) + ")"
+    eb = G.elem_bytes
+    u, _ = _leaves(open(pd.pc_file(nizkp, 1), "rb").read(), eb)
+    l1 = open(pd.l_file(nizkp, 1), "rb").read()
+    wp0, used = _leaves(l1[5:], eb)
+    wp1, _ = _leaves(l1[5 + used:], eb)
+    assert [wp0, wp1] == [c.toInts() for c in WP]
+    inst = b"\x00\x00\x00\x00\x06" + fs.leaf(G.enc_el(g)) + G.toElementArray(h).toByteTree() + open(pd.pc_file(nizkp, 1), "rb").read() + \
+        fs.element_tree(G, pkey) + open(pd.l_file(nizkp, 0), "rb").read() + l1
+    seed = pyref_prg.random_oracle(rho + inst, 256)
+    assert tv["PoS.s"] == seed.hex()
+    e = pyref_prg.random_integers(seed, n, 256)
+    com_bt = open(pd.posc_file(nizkp, 1), "rb").read()
+    v = int.from_bytes(pyref_prg.random_oracle(rho + b"\x00\x00\x00\x00\x02" + fs.leaf(seed) + com_bt, 256), "big")
+    assert tv["PoS.v"] == format(v, "x")
+    nat = mirror.load(entry, ("native",))["native"]
+    com = nat.Message.fromByteTree(G, com_bt, nat.PoSBasicTW._com_kinds, [n, 1, n, 1, 1, 2])
+    rep = nat.Message.fromByteTree(G, open(pd.posr_file(nizkp, 1), "rb").read(), nat.PoSBasicTW._rep_kinds, [1, n, 1, 1, n, 1])
+    val = lambda x: x.toInts() if hasattr(x, "toInts") else x
+    com_o = {k: val(com.item(i)) for i, k in enumerate(("B", "Ap", "Bp", "Cp", "Dp", "Fp"))}
+    com_o["Ap"], com_o["Cp"], com_o["Dp"] = com_o["Ap"][0], com_o["Cp"][0], com_o["Dp"][0]
+    rep_o = {k: val(rep.item(i)) for i, k in enumerate(("k_A", "k_B", "k_C", "k_D", "k_E", "k_F"))}
+    rep_o["k_A"], rep_o["k_C"], rep_o["k_D"] = rep_o["k_A"][0], rep_o["k_C"][0], rep_o["k_D"][0]
+    ov = P.GPoS(P.ModPAdapter(p, q), 256, 256, 100)
+    ov.precompute(g, h)
+    ov.u = u
+    ov.setInstance(pkey, w, [wp0, wp1])
+    ov.setBatchVector(e)
+    ov.computeAF()
+    ov.setCommitment(com_o)
+    assert ov.verify(rep_o, v)
+    hx = lambda x: format(x, "x")
+    assert (tv["PoS.A"], tv["PoS.C"], tv["PoS.D"]) == (hx(ov.A), hx(ov.C), hx(ov.D))
+    assert tv["PoS.F"] == "(" + ", ".join(hx(x) for x in ov.F) + ")"
+    assert tv["PoS.k_A"] == hx(rep_o["k_A"]) and tv["PoS.Ap"] == hx(com_o["Ap"])
+
+    # ---- a bit flipped in a file: rejected (a value in the reply), and a truncated file: rejected (no exception)
+    path = pd.posr_file(nizkp, 1)
+    good = open(path, "rb").read()
+    bad = bytearray(good)
+    bad[-1] ^= 1
+    open(path, "wb").write(bytes(bad))
+    assert not pd.verify_shuffle(nizkp, 1, G, params, pkey)
+    open(path, "wb").write(good[:-3])
+    assert not pd.verify_shuffle(nizkp, 1, G, params, pkey)
+    open(path, "wb").write(good)
+    assert pd.verify_shuffle(nizkp, 1, G, params, pkey)
+
+
+def test_vmnv_vectors_tool_prints_the_reference_format(entry, tmp_path):
+    """The CLI writes a demo directory with the C++ prover (os.urandom randomness), verifies it and prints
+    `TEST VECTOR / <name> - <description> / <value>` blocks."""
+    nizkp = str(tmp_path / "demo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vmnv_vectors.py"), "--demo", nizkp, "-n", "40", "--bits", "2048",
+                          "-t", "der.rho,PoS"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert "\nTEST VECTOR\nder.rho - Derived prefix bytes to all random oracle queries.\n" in text
+    for name in ("PoS.s", "PoS.A", "PoS.F", "PoS.Ap", "PoS.v", "PoS.C", "PoS.D", "PoS.k_A", "PoS.k_F"):
+        assert f"\nTEST VECTOR\n{name} - " in text, name
+    assert "PoS.k_E" not in text                      # N-sized vectors only with --arrays
+    assert "accepted" in text
+    assert json.load(open(os.path.join(nizkp, "params.json")))["vbitlenro"] == 256

@@ -156,7 +156,16 @@ def test_posc_and_permutation_commitment(vmn, gpu_ctx, mods, hv):
         ver.setBatchVector(e)
         ver.setCommitment(com)
         ver.setChallenge(v)
-        return ver.verify(rep)
+        ok = ver.verify(rep)
+        if hv is mods["native"]:
+            # the verifier's intermediates against the oracle's (private fields A, C, D of PoSCBasicTW.java:676, 718-727)
+            ov = P.PoSC(p, q, NV, NE, NR)
+            ov.setInstance(g, h, u_o)
+            ov.setBatchVector(e)
+            ov.setCommitment({k: (x.toInts() if hasattr(x, "toInts") else x) for k, x in com.items()})
+            assert ov.verify({k: (x.toInts() if hasattr(x, "toInts") else x) for k, x in rep.items()}, v) == ok
+            assert (ver.getA(), ver.getC(), ver.getD()) == (ov.A, ov.C, ov.D)
+        return ok
 
     assert run(r)
     assert not run([(x + x) % q for x in r])          # TestPoSCBasicTW.java:109-111

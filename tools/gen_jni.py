@@ -267,6 +267,10 @@ def need_expr(name, ptype, pname, plist):
             return f"vmn_pending_bytes({hcast('vmn_pending*', plist[0][1])})"
         if pname == "out_be" and name == "vmn_garray_expprod_multi":
             return f"(size_t)k * {EB}"
+        if pname == "out_be" and name == "vmn_pos_get_F":
+            return f"2 * vmn_pos_width({pobj}) * {EB}"
+        if pname == "out_be" and name == "vmn_ccpos_get_AB":
+            return f"(1 + 2 * vmn_ccpos_width({pobj})) * {EB}"
         ring_names = {"last_be", "kx_out", "kx_be", "ka_out", "ka_be", "x_be", "secret_be", "c_be"}
         if pname in ring_names or (on_rarray and pname in ("out_be", "el_be", "v_be")):
             return XB

@@ -3203,12 +3203,14 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
         // one workgroup per tile rather than a persistent grid: a workgroup slot frees up every ~2 ms, so kernels of
         // the other lane (a helper's exports) are scheduled between the tiles instead of behind the whole launch
         unsigned grid = egrid(m, items);
-        if (rc == VMN_OK) rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
         rc = note_work(ctx, m, (double)n * (ft->nwin - parts)) ? 0 : launch(ctx, "fixed", k_fixed_exp<Cfg<S_, LPE_>>, grid, lds_bytes(m), dst, (const uint32_t*)ft->d_tab, ft->wbits, \
                     ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, parts, m.d_n, m.n0inv);
-        VMN_FOR_SIZES(X)
+        if (rc == VMN_OK) {                          // (a failed allocation of the pieces must not reach the launch: dst would be null)
+            rc = VMN_ERR_ARG;
+            VMN_FOR_SIZES(X)
+        }
 #undef X
         for (int half = parts / 2; half >= 1 && rc == VMN_OK; half /= 2) {          // pieces [0, half) *= pieces [half, 2 half)
             uint32_t* lo = pieces.as<uint32_t>();

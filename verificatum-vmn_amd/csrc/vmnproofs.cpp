@@ -1331,15 +1331,45 @@ struct vmn_pos : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        lastC = prep.C;
+        lastD = prep.D;
         prep.rep = rep;
         prep.serial = rep->serial;
         prep.epoch = epoch;
+        return VMN_OK;
+    }
+    // The verifier's intermediate values, as PoSBasicTW exposes them (getA :716, getF :761, getC :949, getD :958; printed by
+    // `vmnv -t PoS.A,...`, MixNetElGamalVerifyFiatShamirSession.java:880-932).  A and F exist after computeAF (its products
+    // are finished here if they are still pending), C and D after verify / verify_prepare.
+    Bytes lastC, lastD;
+    int get_A(uint8_t* out) {
+        REQUIRE(out && af_begun(), "getA needs computeAF");
+        TRY(finish_af());
+        memcpy(out, A.data(), G.eb);
+        return VMN_OK;
+    }
+    int get_F(uint8_t* out) {
+        REQUIRE(out && af_begun(), "getF needs computeAF");
+        TRY(finish_af());
+        for (size_t c = 0; c < F.size(); ++c) memcpy(out + c * G.eb, F[c].data(), G.eb);
+        return VMN_OK;
+    }
+    int get_CD(uint8_t* out, bool want_d) {
+        const Bytes& x = want_d ? lastD : lastC;
+        REQUIRE(out && x.size() == G.eb, "getC / getD need a verify (or verify_prepare) that got as far as the reply");
+        memcpy(out, x.data(), G.eb);
         return VMN_OK;
     }
     int verify(const vmn_msg* rep, int* verdict, int* five) {
         VMN_TRACE("pos:verify");
         REQUIRE(verdict && cB && af_begun() && !v_be.empty(), "verify needs computeAF, setCommitment and setChallenge");
         if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch) TRY(verify_prepare(rep, true));
+        // the reply side is used ONCE, whatever happens below: with `paired` set its left side depends on the challenge, so a
+        // verify() that fails half way must not leave it behind for a later call with another challenge
+        struct ClearPrep {
+            Prepared& p;
+            ~ClearPrep() { p.clear(); }
+        } clear_prep{prep};
         TRY(finish_af());
         if (prep.malformed) {                                                     // a ring scalar >= q: not a reply (:985-989)
             prep.clear();
@@ -1617,10 +1647,26 @@ struct vmn_posc : ProofBase {
         prep.epoch = epoch;
         return VMN_OK;
     }
+    // A, C, D of the verifier (private fields of PoSCBasicTW: A = u.expProd(e) :676, C :718-723, D :724-727), for tests and a
+    // test-vector dump; available after verify / verify_prepare
+    Bytes lastA, lastC, lastD;
+    int get_ACD(uint8_t* out, int which) {
+        const Bytes& x = which == 0 ? lastA : which == 1 ? lastC : lastD;
+        REQUIRE(out && x.size() == G.eb, "getA / getC / getD need a verify (or verify_prepare) that got as far as the reply");
+        memcpy(out, x.data(), G.eb);
+        return VMN_OK;
+    }
     int verify(const vmn_msg* rep, int* verdict) {
         REQUIRE(verdict && cB && e.p && !v_be.empty(), "verify needs the batching vector, setCommitment and setChallenge");
         *verdict = 0;
         if (!rep || prep.rep != rep || prep.serial != rep->serial || prep.epoch != epoch) TRY(verify_prepare(rep, true));
+        struct ClearPrep {                     // used once, on every exit path (see vmn_pos::verify)
+            Prepared& p;
+            ~ClearPrep() { p.clear(); }
+        } clear_prep{prep};
+        lastA = prep.A;
+        lastC = prep.C;
+        lastD = prep.D;
         if (prep.malformed) {                                                     // a ring scalar >= q: not a reply
             prep.clear();
             *verdict = 0;
@@ -1841,6 +1887,21 @@ struct vmn_ccpos : ProofBase {
         } else {
             AB = res;
         }
+        return VMN_OK;
+    }
+    // A and B of computeAB (:493-506): plain form A (1 element) then B (2 width); raised form AB (2 width elements)
+    int get_AB(uint8_t* out, size_t* count) {
+        REQUIRE(out && count && have_ab, "getAB needs computeAB");
+        TRY(finish_ab());
+        std::vector<const Bytes*> els;
+        if (!raised) {
+            els.push_back(&A);
+            for (auto& b : B) els.push_back(&b);
+        } else {
+            for (auto& ab : AB) els.push_back(&ab);
+        }
+        for (size_t c = 0; c < els.size(); ++c) memcpy(out + c * G.eb, els[c]->data(), G.eb);
+        *count = els.size();
         return VMN_OK;
     }
     // verification in two parts, as in vmn_pos: verify_prepare(reply, raisedh, rho) = everything that needs no challenge --
@@ -2761,6 +2822,23 @@ int vmn_pos_verify(vmn_pos* p, const vmn_msg* reply, int* verdict, int* verdicts
     NONNULL(p);
     return p->verify(reply, verdict, verdicts5);
 }
+int vmn_pos_get_A(vmn_pos* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_A(out_be);
+}
+int vmn_pos_get_F(vmn_pos* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_F(out_be);
+}
+int vmn_pos_get_C(vmn_pos* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_CD(out_be, false);
+}
+int vmn_pos_get_D(vmn_pos* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_CD(out_be, true);
+}
+size_t vmn_pos_width(const vmn_pos* p) { return p ? p->width : 0; }
 
 void vmn_posc_free(vmn_posc* p) { delete p; }
 int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u, const vmn_rarray* r,
@@ -2800,6 +2878,18 @@ int vmn_posc_verify(vmn_posc* p, const vmn_msg* reply, int* verdict) {
     NONNULL(p);
     return p->verify(reply, verdict);
 }
+int vmn_posc_get_A(vmn_posc* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_ACD(out_be, 0);
+}
+int vmn_posc_get_C(vmn_posc* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_ACD(out_be, 1);
+}
+int vmn_posc_get_D(vmn_posc* p, uint8_t* out_be) {
+    NONNULL(p);
+    return p->get_ACD(out_be, 2);
+}
 
 void vmn_ccpos_free(vmn_ccpos* p) { delete p; }
 int vmn_ccpos_set_instance(vmn_ccpos* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u, const uint8_t* pkey_be,
@@ -2836,6 +2926,11 @@ int vmn_ccpos_compute_ab(vmn_ccpos* p, const vmn_garray* raisedu) {
     NONNULL(p);
     return p->compute_ab(raisedu);
 }
+int vmn_ccpos_get_AB(vmn_ccpos* p, uint8_t* out_be, size_t* count) {
+    NONNULL(p);
+    return p->get_AB(out_be, count);
+}
+size_t vmn_ccpos_width(const vmn_ccpos* p) { return p ? p->width : 0; }
 int vmn_ccpos_verify_prepare(vmn_ccpos* p, const vmn_msg* reply, const vmn_garray* raisedh, const uint8_t* rho_be, size_t rho_bytes) {
     NONNULL(p);
     return p->verify_prepare(reply, raisedh, rho_be, rho_bytes);

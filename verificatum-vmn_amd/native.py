@@ -78,7 +78,7 @@ def plib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise VmnError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build()")
         _plib = C.CDLL(LIB_PATH)
-        for name in ("vmn_msg_items", "vmn_msg_bytetree_size"):
+        for name in ("vmn_msg_items", "vmn_msg_bytetree_size", "vmn_pos_width", "vmn_ccpos_width"):
             getattr(_plib, name).restype = C.c_size_t
         for name in ("vmn_msg_item_garray", "vmn_msg_item_rarray", "vmn_pos_permutation_commitment"):
             getattr(_plib, name).restype = C.c_void_p
@@ -412,6 +412,28 @@ class PoSBasicTW(_NativeProof):
         self.verdicts = tuple(bool(x) for x in five)
         return bool(verdict.value)
 
+    def _get(self, name: str, count: int = 1):
+        out = C.create_string_buffer(count * self.G.elem_bytes)
+        self._call(f"get_{name}", out)
+        els = self.G.dec_els(out.raw)
+        return els[0] if count == 1 else els
+
+    def getA(self):
+        """``getA()`` (:716): A = u.expProd(e), after computeAF."""
+        return self._get("A")
+
+    def getF(self):
+        """``getF()`` (:761): F = w.expProd(e) as its 2 * width components, after computeAF."""
+        return list(self._get("F", 2 * int(plib().vmn_pos_width(self._h))))
+
+    def getC(self):
+        """``getC()`` (:949): prod u_i / prod h_i, after verify."""
+        return self._get("C")
+
+    def getD(self):
+        """``getD()`` (:958): B_{N-1} / h_0^(prod e_i), after verify."""
+        return self._get("D")
+
     def readCommitment(self, bt, n: int, width: int):
         """``setCommitment(ByteTreeReader)`` (:780-823): parse the published byte tree (framing, range and subgroup
         membership of every element, on the GPU); malformed input gives None -- the caller substitutes trivial values."""
@@ -453,6 +475,21 @@ class PoSCBasicTW(_NativeProof):
         self._call("verify", m._h, C.byref(verdict))
         return bool(verdict.value)
 
+    def _get(self, name: str):
+        out = C.create_string_buffer(self.G.elem_bytes)
+        self._call(f"get_{name}", out)
+        return self.G.dec_el(out.raw)
+
+    def getA(self):
+        """A = u.expProd(e) (PoSCBasicTW.java:676), after verify."""
+        return self._get("A")
+
+    def getC(self):
+        return self._get("C")
+
+    def getD(self):
+        return self._get("D")
+
 
 class CCPoSBasicW(_NativeProof):
     """``vmn_ccpos_*`` — ref: hvzk/CCPoSBasicW.java."""
@@ -480,6 +517,15 @@ class CCPoSBasicW(_NativeProof):
 
     def computeAB(self, raisedu=None):
         self._call("compute_ab", raisedu._h if raisedu is not None else None)
+
+    def getAB(self):
+        """The values of computeAB (CCPoSBasicW.java:493-506): plain form (A, [B components]), raised form (None, [AB components])."""
+        width = int(plib().vmn_ccpos_width(self._h))
+        out = C.create_string_buffer((1 + 2 * width) * self.G.elem_bytes)
+        cnt = C.c_size_t(0)
+        self._call("get_AB", out, C.byref(cnt))
+        els = self.G.dec_els(out.raw[: cnt.value * self.G.elem_bytes])
+        return (els[0], els[1:]) if cnt.value == 1 + 2 * width else (None, els)
 
     def verifyPrepare(self, reply, raisedh=None, raisedExponent: Optional[int] = None) -> None:
         """``vmn_ccpos_verify_prepare``: the reply side of verify() -- all its array work; same arguments as the verify() that follows."""
