@@ -130,6 +130,7 @@ int vmn_group_set_wire_bytes(vmn_group* grp, size_t elem_bytes, size_t exp_bytes
  * bit length), getg() (P/mixnet/PermutationCommitment.java:200), and the modulus / field prime.
  * kind: 0 = ModPGroup, 1 = ECqPGroup.  order / modulus: exp_bytes big-endian bytes; generator: elem_bytes. */
 int vmn_group_kind(const vmn_group* grp);
+vmn_ctx* vmn_group_ctx(const vmn_group* grp);        /* the context (main lane) the group was created in */
 int vmn_group_get_order(const vmn_group* grp, uint8_t* q_be);
 int vmn_group_get_modulus(const vmn_group* grp, uint8_t* p_be);
 int vmn_group_get_generator(const vmn_group* grp, uint8_t* g_be);

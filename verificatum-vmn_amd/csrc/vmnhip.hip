@@ -489,6 +489,7 @@ static int helper_create(vmn_ctx* ctx) {
     VMN_HIP(hipMalloc(&h->flags, 64 * sizeof(uint32_t)));
     VMN_HIP(hipMemsetAsync(h->flags, 0, 64 * sizeof(uint32_t), h->stream));
     VMN_HIP(hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming));
+    h->timing = ctx->timing;
     ctx->helper = h.release();
     return VMN_OK;
 }
@@ -541,6 +542,7 @@ extern "C" int vmn_ctx_helper_end(vmn_ctx* ctx) {
 }
 
 extern "C" int vmn_ctx_num_cus(vmn_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+extern "C" vmn_ctx* vmn_group_ctx(const vmn_group* grp) { return grp ? grp->ctx : nullptr; }
 extern "C" int vmn_ctx_set_small_array_threshold(vmn_ctx* ctx, size_t items) {
     ARG_CHECK(ctx, "null ctx");
     vmn_ctx* root = ctx->parent ? ctx->parent : ctx;
@@ -571,28 +573,40 @@ extern "C" int vmn_ctx_memory_stats(vmn_ctx* ctx, size_t* pool_bytes, size_t* po
     return VMN_OK;
 }
 
-static int timing_collect(vmn_ctx* ctx) {
-    if (ctx->recs.empty()) return VMN_OK;
-    VMN_HIP(hipStreamSynchronize(ctx->stream));
-    for (auto& r : ctx->recs) {
+// The launches of BOTH lanes are accounted in the main lane's tables (a driver may run an independent chain of a proof on
+// the helper lane: the sum of kernel durations then exceeds the device-busy time, which is what concurrency means).
+static int timing_collect_lane(vmn_ctx* into, vmn_ctx* lane) {
+    std::lock_guard<std::recursive_mutex> guard__(lane->mu);
+    if (lane->recs.empty()) return VMN_OK;
+    VMN_HIP(hipStreamSynchronize(lane->stream));
+    for (auto& r : lane->recs) {
         float ms = 0;
         VMN_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
-        auto& acc = ctx->timing_acc[r.family];
+        auto& acc = into->timing_acc[r.family];
         acc.first += 1;
         acc.second += ms;
-        ctx->work_acc[r.family] += r.mads;
-        ctx->canon_acc[r.family] += r.canon;
+        into->work_acc[r.family] += r.mads;
+        into->canon_acc[r.family] += r.canon;
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
-    ctx->recs.clear();
+    lane->recs.clear();
+    return VMN_OK;
+}
+static int timing_collect(vmn_ctx* ctx) {
+    VMN_TRY(timing_collect_lane(ctx, ctx));
+    if (ctx->helper) VMN_TRY(timing_collect_lane(ctx, ctx->helper));
     return VMN_OK;
 }
 extern "C" int vmn_ctx_timing_enable(vmn_ctx* ctx, int on) {
-    ARG_CHECK(ctx, "null ctx");
+    ARG_CHECK(ctx && !ctx->parent, "null ctx or a helper lane");
     std::lock_guard<std::recursive_mutex> guard__(ctx->mu);
     VMN_TRY(timing_collect(ctx));
     ctx->timing = on != 0;
+    if (ctx->helper) {
+        std::lock_guard<std::recursive_mutex> hguard__(ctx->helper->mu);
+        ctx->helper->timing = ctx->timing;
+    }
     return VMN_OK;
 }
 extern "C" int vmn_ctx_timing_reset(vmn_ctx* ctx) {
@@ -3013,18 +3027,47 @@ static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
 
 // Table for (base, window) cached in the group; built on the GPU from the host squaring chain.
 static int ec_normalize(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* const* ins, size_t k, size_t n, uint32_t* out);
-static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out, int reuse_hint = 1) {
+// The squaring chain base^(2^j), j < chain, of a new table over a modular group: sequential host work (64-bit limbs, ~2 us
+// per squaring at 2048 bits: 4 ms for a full-length exponent).  vmn_group_precompute_fixed runs it BEFORE it takes the
+// table lock, so that the other lane's fixed-base calls are not held up behind it.
+static int fixed_chain_host(const vmn_group* g, const uint8_t* base_be, size_t chain, std::vector<uint8_t>& sq_be) {
+    const vmn_modulus& m = g->P;
+    Big base = hostbig::from_be(base_be, g->nbytes, m.NW);
+    if (hostbig::cmp(base, m.n_words) >= 0) {
+        set_error("fixed base out of range");
+        return VMN_ERR_FORMAT;
+    }
+    VMN_TRACE("fixed_table:chain_host");
+    const num64::Mod& hm = *m.hm64;
+    num64::Num cur = hm.to_m(num64::from_be(base_be, g->nbytes, hm.nl));
+    sq_be.resize(chain * g->nbytes);
+    for (size_t j = 0; j < chain; ++j) {
+        num64::to_be(hm.from_m(cur), sq_be.data() + j * g->nbytes, g->nbytes);
+        hm.mmul(cur, cur, cur);
+    }
+    return VMN_OK;
+}
+static int fixed_window_for(vmn_group* g, size_t n, int ebits, int reuse_hint) {
     vmn_ctx* ctx = LANE(g->ctx);
     const vmn_modulus& m = g->P;
-    const size_t Wd = elem_words(m);
-    std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
     // A launch over fewer elements than the chip holds lanes costs as much as a full one (the per-lane chain of
     // products is what takes the time), so small arrays are priced at the lane capacity: the window grows and the
     // chain shortens (N = 3 x 10^4: w = 12 -> 14, 171 -> 147 sequential products per exponentiation).
     const size_t lanes = m.ec ? (size_t)ctx->num_cus * 4 * 64 * 2 : (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
+    return pick_fixed_window(std::max(n, lanes), ebits, elem_words(m) * sizeof(uint32_t), reuse_hint);
+}
+// probe = true: *out = the cached table when it serves, nullptr when one would have to be built (nothing is built)
+static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n, vmn_group::FixedTable** out, int reuse_hint = 1,
+                       bool probe = false, const std::vector<uint8_t>* chain_be = nullptr) {
+    vmn_ctx* ctx = LANE(g->ctx);
+    const vmn_modulus& m = g->P;
+    const size_t Wd = elem_words(m);
+    std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
+    const size_t lanes = m.ec ? (size_t)ctx->num_cus * 4 * 64 * 2 : (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
     n = std::max(n, lanes);
-    int w = pick_fixed_window(n, ebits, Wd * sizeof(uint32_t), reuse_hint);
+    int w = fixed_window_for(g, n, ebits, reuse_hint);
     int carry_uses = 1;
+    *out = nullptr;
     auto it = g->fixed.find(key);
     if (it != g->fixed.end()) {
         vmn_group::FixedTable& ft = it->second;
@@ -3041,12 +3084,17 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
             *out = &ft;
             return VMN_OK;
         }
+        if (probe) {
+            ft.uses -= 1;                                // (a probe is not a use)
+            return VMN_OK;
+        }
         if (grow) {
             w = w_many;
             carry_uses = ft.uses;
         }
         fixed_drop(g, it);
     }
+    if (probe) return VMN_OK;
     int nwin = (ebits + w - 1) / w;
     if (m.ec) {
         // doubling chain on one lane, then the same level-by-level table build with point additions
@@ -3104,21 +3152,15 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         *out = &ins.first->second;
         return VMN_OK;
     }
-    // host: sq[j] = base^(2^j) mod p, j < nwin*w   (sequential chain, 32-bit-word Montgomery)
-    Big base = hostbig::from_be(base_be, g->nbytes, m.NW);
-    if (hostbig::cmp(base, m.n_words) >= 0) {
-        set_error("fixed base out of range");
-        return VMN_ERR_FORMAT;
-    }
+    // host: sq[j] = base^(2^j) mod p, j < nwin*w   (sequential chain; handed in when the caller ran it ahead of the lock)
     VMN_TRACE("fixed_table:build");
-    const num64::Mod& hm = *m.hm64;                      // 64-bit limbs: the chain is sequential host work per new base
-    num64::Num cur = hm.to_m(num64::from_be(base_be, g->nbytes, hm.nl));
     const size_t chain = (size_t)nwin * w;
-    std::vector<uint8_t> sq_be(chain * g->nbytes);
-    for (size_t j = 0; j < chain; ++j) {
-        num64::to_be(hm.from_m(cur), sq_be.data() + j * g->nbytes, g->nbytes);
-        hm.mmul(cur, cur, cur);
+    std::vector<uint8_t> own_chain;
+    if (!chain_be || chain_be->size() != chain * g->nbytes) {
+        VMN_TRY(fixed_chain_host(g, base_be, chain, own_chain));
+        chain_be = &own_chain;
     }
+    const std::vector<uint8_t>& sq_be = *chain_be;
     DevTmp sq(ctx);
     VMN_TRY(sq.alloc(chain * Wd * sizeof(uint32_t)));
     int ok = 1;
@@ -3155,9 +3197,24 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
 extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be, size_t n_hint, int uses_hint) {
     ARG_CHECK(grp && base_be && n_hint > 0, "bad argument");
     VMN_ENTER(LANE(grp->ctx));
-    std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
+    const int uses = uses_hint < 1 ? 1 : (uses_hint > 16 ? 16 : uses_hint);
+    const int ebits = grp->Q.nbits;
     vmn_group::FixedTable* ft = nullptr;
-    return fixed_table(grp, base_be, grp->Q.nbits, n_hint, &ft, uses_hint < 1 ? 1 : (uses_hint > 16 ? 16 : uses_hint));
+    std::vector<uint8_t> chain;
+    if (!grp->P.ec) {
+        // Is there anything to build?  If so the squaring chain -- milliseconds of host work -- runs here, outside the table
+        // lock: a caller that prepares the table of a per-proof base on the helper lane (the proof drivers do, for h_0) must
+        // not stall the protocol thread's own fixed-base calls behind it.
+        {
+            std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
+            VMN_TRY(fixed_table(grp, base_be, ebits, n_hint, &ft, uses, true));
+            if (ft) return VMN_OK;
+        }
+        const int w = fixed_window_for(grp, n_hint, ebits, uses);
+        VMN_TRY(fixed_chain_host(grp, base_be, (size_t)((ebits + w - 1) / w) * w, chain));
+    }
+    std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
+    return fixed_table(grp, base_be, ebits, n_hint, &ft, uses, false, chain.empty() ? nullptr : &chain);
 }
 
 extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out) {

@@ -160,6 +160,48 @@ struct HostJobs {
     ~HostJobs() { (void)join(); }
 };
 
+// An independent chain of ARRAY calls of a phase on the context's second lane (vmn_ctx_helper_*: its own stream, pool and
+// lock), beside the calls the phase makes on the protocol thread's lane.  Below ~10^5 elements no kernel of a proof fills the
+// device and a phase is the sum of the latencies of its dependent chains (at N = 10^4 a verifier's paired power of check (B)
+// is one 7 ms launch on a third of the compute units while its multi-exponentiations wait behind it): two chains that do not
+// depend on each other then run side by side.  start(): everything the calling thread has queued so far is what the job
+// may rely on (vmn_ctx_helper_mark); join(): the job's stream has drained, its results can be used on any lane.
+// Declare a LaneJob AFTER the objects its job writes (it joins in its destructor).  `enabled` false: the job runs inline.
+struct LaneJob {
+    std::future<int> fut;
+    template <class F>
+    int start(vmn_group* grp, bool enabled, F&& f) {
+        vmn_ctx* ctx = enabled ? vmn_group_ctx(grp) : nullptr;
+        if (!ctx || vmn_ctx_helper_mark(ctx) != VMN_OK) return f();
+        try {
+            fut = std::async(std::launch::async, [ctx, f]() -> int {
+                int rc = vmn_ctx_helper_begin(ctx);
+                if (rc != VMN_OK) return rc;
+                rc = f();
+                const int rc2 = vmn_ctx_helper_end(ctx);
+                return rc != VMN_OK ? rc : rc2;
+            });
+        } catch (const std::system_error&) {        // no thread to be had: the job runs here and now, on this lane
+            return f();
+        }
+        return VMN_OK;
+    }
+    int join() {
+        if (!fut.valid()) return VMN_OK;
+        VMN_TRACE("lane:join");
+        return fut.get();
+    }
+    ~LaneJob() { (void)join(); }
+};
+// arrays of at most this many elements leave the device idle enough for a second lane to pay (VMN_LANE_OVERLAP_MAX; 0 = never)
+inline size_t lane_overlap_max() {
+    static const size_t v = [] {
+        const char* e = getenv("VMN_LANE_OVERLAP_MAX");
+        return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t)262144;
+    }();
+    return v;
+}
+
 struct HostGroup {
     vmn_group* grp = nullptr;
     bool ec = false;
@@ -569,6 +611,18 @@ struct ProofBase {
             return VMN_OK;
         }
         return fail(VMN_ERR_ARG, "%s: %zu elements, expected this rank's %zu or all %zu", what, n, N, Ntot);
+    }
+    bool overlap_lanes() const { return N > 0 && N <= lane_overlap_max(); }
+    // the table of a per-proof base (h_0), built on the second lane as soon as the base is known: its squaring chain is
+    // milliseconds of sequential host work that would otherwise sit in front of the first use (commit's bridging commitments)
+    LaneJob h0_table_job;
+    int prepare_base_table(const Bytes& base) {
+        if (G.ec || !overlap_lanes()) return VMN_OK;        // (curves build their chains on the device; large arrays hide the chain)
+        (void)h0_table_job.join();
+        const Bytes b = base;                                // (a copy: the job may outlive the derived object's fields)
+        vmn_group* grp = G.grp;
+        const size_t n = N;
+        return h0_table_job.start(grp, true, [grp, b, n] { return vmn_group_precompute_fixed(grp, b.data(), n, 2); });
     }
     int need_rs() const { return has_rs ? VMN_OK : fail(VMN_ERR_ARG, "this proof object was created without a random source (verifier)"); }
     // N-sized draws: `out` is this rank's shard; `full` (may be null) remembers the draw for reads through the permutation.
@@ -1043,17 +1097,26 @@ struct vmn_pos : ProofBase {
         Bytes hp(G.eb), ga;
         HostJobs jobs;
         jobs.start([&] { return gexp(g, alpha, ga); });
+        TRY(prepare_base_table(h0));                             // the table of h_0 (used by commit): built beside this phase
         // :481  A' = g^alpha prod h_i^eps_i -- its device part is queued first, the permutation commitment behind it: the
-        // fixed-base powers of u then run while the host finishes the product
+        // fixed-base powers of u then run while the host finishes the product (small arrays: on the second lane, beside it)
         PendingProds hp_pending;
         std::vector<Bytes> hp_out;
-        TRY(hp_pending.begin({h}, epsilon, eps_bits));
-        if (!sharded) {
-            TRY(vmn_permutation_commitment(G.grp, g.data(), h_, r, pi.data(), u_own.out()));
-        } else {
+        auto make_u = [&]() -> int {
+            if (!sharded) return vmn_permutation_commitment(G.grp, g.data(), h_, r, pi.data(), u_own.out());
             RA r_perm;                                           // r_{pi(i)}, i in [lo, hi)
             TRY(r_draw.rows(G.grp, pi.data() + lo, N, r_perm));
-            TRY(permutation_commitment_rows(G.grp, g.data(), h_, r_perm, pi.data() + lo, N, u_own.out()));
+            return permutation_commitment_rows(G.grp, g.data(), h_, r_perm, pi.data() + lo, N, u_own.out());
+        };
+        if (overlap_lanes()) {
+            LaneJob u_job;
+            TRY(u_job.start(G.grp, true, make_u));
+            const int rc_begin = hp_pending.begin({h}, epsilon, eps_bits);
+            TRY(u_job.join());
+            TRY(rc_begin);
+        } else {
+            TRY(hp_pending.begin({h}, epsilon, eps_bits));
+            TRY(make_u());
         }
         u = u_own;
         TRY(hp_pending.finish(G, hp_out));
@@ -1089,8 +1152,7 @@ struct vmn_pos : ProofBase {
         PendingProds prods;
         HostJobs jobs;
     };
-    int commit_prepare_begin(CommitPrep& cp) {
-        REQUIRE(prover && width && !prepared, "commit_prepare needs a prover with the instance set, once per proof");
+    int commit_draws() {
         // randomness in the reference's order: b :583, beta :612, gamma :667, delta :673, phi :687
         TRY(draw_ring_array(b));
         TRY(draw_ring_array(beta));
@@ -1098,6 +1160,11 @@ struct vmn_pos : ProofBase {
         TRY(draw_ring_element(delta));
         phi.resize(width);
         for (auto& ph : phi) TRY(draw_ring_element(ph));
+        return VMN_OK;
+    }
+    int commit_prepare_begin(CommitPrep& cp, bool draw = true) {
+        REQUIRE(prover && width && !prepared, "commit_prepare needs a prover with the instance set, once per proof");
+        if (draw) TRY(commit_draws());
         cp.jobs.start([&] { return gexp(g, gamma, Cp_); });                       // :667-679
         cp.jobs.start([&] { return gexp(g, delta, Dp_); });
         pk_powers(cp.jobs, pkey, phi, cp.pkpow);                                  // :687-690
@@ -1127,14 +1194,30 @@ struct vmn_pos : ProofBase {
         // device busy while the host completes the product
         CommitPrep cp;
         const bool prepare_here = !prepared;
-        if (prepare_here) TRY(commit_prepare_begin(cp));
-        TRY(permuted_batch_vector(e, piinv, ipe));                                // :552-554
-        RA x, y;
-        Bytes x_in, y_in;
-        TRY(scans(b, ipe, x, y, d, x_in, y_in));                                  // :583-604
         GA B, Bp;
-        TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp)); // :606-648 (queued)
-        if (prepare_here) TRY(commit_prepare_finish(cp));
+        auto bridge = [&]() -> int {
+            TRY(permuted_batch_vector(e, piinv, ipe));                            // :552-554
+            RA x, y;
+            Bytes x_in, y_in;
+            TRY(scans(b, ipe, x, y, d, x_in, y_in));                              // :583-604
+            return bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp);   // :606-648 (queued)
+        };
+        TRY(h0_table_job.join());                                                 // (the table of h_0, begun in precompute)
+        if (prepare_here && overlap_lanes() && !sharded) {
+            // small arrays: the scans and the bridging commitments (a chain of short launches and four fixed-base powers) on the
+            // second lane, F' (a multi-exponentiation over w') on this one -- neither fills the device
+            TRY(commit_draws());
+            LaneJob bridge_job;
+            TRY(bridge_job.start(G.grp, true, bridge));
+            int rc = commit_prepare_begin(cp, false);
+            if (rc == VMN_OK) rc = commit_prepare_finish(cp);
+            TRY(bridge_job.join());
+            TRY(rc);
+        } else {
+            if (prepare_here) TRY(commit_prepare_begin(cp));
+            TRY(bridge());
+            if (prepare_here) TRY(commit_prepare_finish(cp));
+        }
         std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push(B);
         m->push_element(Ap);
@@ -1282,26 +1365,19 @@ struct vmn_pos : ProofBase {
         for (auto& bts : split(*ikF)) k_F.push_back(G.ring_from(bts.data()));
         Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), t_h0, Blast, prev;
         Num eprod;
+        int kE_bits = 0;
         HostJobs jobs;                                                            // (after everything its jobs touch)
+        LaneJob bridge_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // (A) :1016-1021
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });                       // (C) :1045-1048
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });                       // (D) :1051-1054
         pk_powers(jobs, pkey, k_F, prep.pkpow);                                   // (F) :1057-1063
-        // scalars that come back from the GPU (each blocks on the stream) ...
-        TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
-        TRY(vmn_garray_prod(h, hprod.data()));
-        TRY(last_local(cB, mylast));
-        TRY(vmn_rarray_prod(e, eprod_b.data()));                                  // :1014
-        eprod = G.ring_from(eprod_b.data());
-        std::vector<const vmn_garray*> xs{h};
-        xs.insert(xs.end(), wp.begin(), wp.end());
-        int kE_bits = 0;
-        TRY(received_bits(ikE->ra, &kE_bits));
-        PendingProds kE_pending;
-        TRY(kE_pending.begin(xs, ikE->ra, kE_bits));                              // :1021, :1063 — one sort of k_E (the device part)
         // The reply side of check (B) :1030-1033 -- unless verify() follows at once and takes the combined form.  It needs the
         // element in front of this shard's B: h0 when there is one shard, and then it is queued here, behind the device part
         // of the products and in front of their host part (which it hides); with several shards it waits for the exchange.
+        // Small arrays: the powers of check (B) are ONE long launch that fills a third of the device -- they go to the second
+        // lane first, and everything else of this phase runs beside them.
+        TRY(received_bits(ikE->ra, &kE_bits));
         prep.deferred = defer_bridge && combined_form_pays();
         prep.kE_bits = kE_bits;
         prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
@@ -1310,7 +1386,19 @@ struct vmn_pos : ProofBase {
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
-        if (!sharded) TRY(queue_bridge(h0));
+        const bool bridge_aside = !sharded && overlap_lanes() && !prep.deferred;
+        if (bridge_aside) TRY(bridge_job.start(G.grp, true, [&]() -> int { return queue_bridge(h0); }));
+        // scalars that come back from the GPU (each blocks on the stream) ...
+        TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
+        TRY(vmn_garray_prod(h, hprod.data()));
+        TRY(last_local(cB, mylast));
+        TRY(vmn_rarray_prod(e, eprod_b.data()));                                  // :1014
+        eprod = G.ring_from(eprod_b.data());
+        std::vector<const vmn_garray*> xs{h};
+        xs.insert(xs.end(), wp.begin(), wp.end());
+        PendingProds kE_pending;
+        TRY(kE_pending.begin(xs, ikE->ra, kE_bits));                              // :1021, :1063 — one sort of k_E (the device part)
+        if (!sharded && !bridge_aside) TRY(queue_bridge(h0));
         TRY(finish_af());
         TRY(kE_pending.finish(G, prep.kE_prods));
         // ... completed over the ranks in ONE exchange ...
@@ -1331,6 +1419,7 @@ struct vmn_pos : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        TRY(bridge_job.join());
         lastC = prep.C;
         lastD = prep.D;
         prep.rep = rep;
@@ -1457,6 +1546,7 @@ struct vmn_posc : ProofBase {
             TRY(local_rarray(r_, r_own, &r, "r"));
             REQUIRE(is_permutation(pi_, Ntot), "pi is not a permutation of [0, N)");
             piinv = inverse_permutation(pi_, Ntot);
+            TRY(prepare_base_table(h0));                         // a prover will raise h_0 to N exponents in commit()
         }
         return VMN_OK;
     }
@@ -1468,15 +1558,18 @@ struct vmn_posc : ProofBase {
         PendingProds prod;
         HostJobs jobs;                     // the three host exponentiations run beside the multi-exponentiation
     };
-    int commit_prepare_begin(CommitPrep& cp) {
-        REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
+    int commit_draws() {
         // randomness in the reference's order: b, alpha, epsilon, beta, gamma, delta (PoSCBasicTW.java:400-500)
         TRY(draw_ring_array(b));
         TRY(draw_ring_element(alpha));
         TRY(draw_integers(ebitlen + vbitlen + rbitlen, epsilon));
         TRY(draw_ring_array(beta));
         TRY(draw_ring_element(gamma));
-        TRY(draw_ring_element(delta));
+        return draw_ring_element(delta);
+    }
+    int commit_prepare_begin(CommitPrep& cp, bool draw = true) {
+        REQUIRE(!piinv.empty() && !prepared, "commit_prepare needs a prover instance, once per proof");
+        if (draw) TRY(commit_draws());
         cp.jobs.start([this, &cp] { return gexp(g, alpha, cp.ga); });
         cp.jobs.start([&] { return gexp(g, gamma, Cp_); });
         cp.jobs.start([&] { return gexp(g, delta, Dp_); });
@@ -1502,14 +1595,28 @@ struct vmn_posc : ProofBase {
         REQUIRE(out && !piinv.empty() && e.p, "commit needs a prover instance and the batching vector");
         CommitPrep cp;                                                            // (see vmn_pos::commit)
         const bool prepare_here = !prepared;
-        if (prepare_here) TRY(commit_prepare_begin(cp));
-        TRY(permuted_batch_vector(e, piinv, ipe));
-        RA x, y;
-        Bytes x_in, y_in;
-        TRY(scans(b, ipe, x, y, d, x_in, y_in));
         GA B, Bp;
-        TRY(bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp));
-        if (prepare_here) TRY(commit_prepare_finish(cp));
+        auto bridge = [&]() -> int {
+            TRY(permuted_batch_vector(e, piinv, ipe));
+            RA x, y;
+            Bytes x_in, y_in;
+            TRY(scans(b, ipe, x, y, d, x_in, y_in));
+            return bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp);
+        };
+        TRY(h0_table_job.join());
+        if (prepare_here && overlap_lanes() && !sharded) {
+            TRY(commit_draws());
+            LaneJob bridge_job;
+            TRY(bridge_job.start(G.grp, true, bridge));
+            int rc = commit_prepare_begin(cp, false);
+            if (rc == VMN_OK) rc = commit_prepare_finish(cp);
+            TRY(bridge_job.join());
+            TRY(rc);
+        } else {
+            if (prepare_here) TRY(commit_prepare_begin(cp));
+            TRY(bridge());
+            if (prepare_here) TRY(commit_prepare_finish(cp));
+        }
         std::unique_ptr<vmn_msg> m(new vmn_msg(G.ec));
         m->push(B);
         m->push_element(Ap_);
@@ -1598,21 +1705,13 @@ struct vmn_posc : ProofBase {
         prep.A.assign(G.eb, 0);
         prep.hk.assign(G.eb, 0);
         Num eprod;
+        int kE_bits = 0;
         HostJobs jobs;                                                            // (after everything its jobs touch)
+        LaneJob bridge_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // beside the GPU calls below
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });
-        TRY(vmn_garray_expprod(u, e, e_bits, prep.A.data()));                     // :660
-        TRY(vmn_garray_prod(u, uprod.data()));
-        TRY(vmn_garray_prod(h, hprod.data()));
-        TRY(last_local(cB, mylast));
-        TRY(vmn_rarray_prod(e, eprod_b.data()));
-        eprod = G.ring_from(eprod_b.data());
-        int kE_bits = 0;
         TRY(received_bits(ikE->ra, &kE_bits));
-        PendingProds hk_pending;                                                  // (see vmn_pos::verify_prepare)
-        std::vector<Bytes> hk_out;
-        TRY(hk_pending.begin({h}, ikE->ra, kE_bits));
         prep.deferred = defer_bridge && combined_form_pays();
         prep.kE_bits = kE_bits;
         prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
@@ -1621,7 +1720,18 @@ struct vmn_posc : ProofBase {
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
-        if (!sharded) TRY(queue_bridge(h0));
+        const bool bridge_aside = !sharded && overlap_lanes() && !prep.deferred;  // (see vmn_pos::verify_prepare)
+        if (bridge_aside) TRY(bridge_job.start(G.grp, true, [&]() -> int { return queue_bridge(h0); }));
+        TRY(vmn_garray_expprod(u, e, e_bits, prep.A.data()));                     // :660
+        TRY(vmn_garray_prod(u, uprod.data()));
+        TRY(vmn_garray_prod(h, hprod.data()));
+        TRY(last_local(cB, mylast));
+        TRY(vmn_rarray_prod(e, eprod_b.data()));
+        eprod = G.ring_from(eprod_b.data());
+        PendingProds hk_pending;                                                  // (see vmn_pos::verify_prepare)
+        std::vector<Bytes> hk_out;
+        TRY(hk_pending.begin({h}, ikE->ra, kE_bits));
+        if (!sharded && !bridge_aside) TRY(queue_bridge(h0));
         TRY(hk_pending.finish(G, hk_out));
         prep.hk = hk_out[0];
         std::vector<Bytes> lasts;
@@ -1642,6 +1752,7 @@ struct vmn_posc : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        TRY(bridge_job.join());
         prep.rep = rep;
         prep.serial = rep->serial;
         prep.epoch = epoch;
