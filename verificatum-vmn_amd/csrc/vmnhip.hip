@@ -484,7 +484,12 @@ static int helper_create(vmn_ctx* ctx) {
     h->parent = ctx;
     int least = 0, greatest = 0;                       // numerically lowest = highest priority
     VMN_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    VMN_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, greatest));
+    // VMN_HELPER_PRIORITY: "high" (default: a helper's short exports are scheduled between the protocol thread's tiles) or
+    // "normal" (the two lanes as equals: what the proof drivers' second lane wants -- measured)
+    const char* prio = getenv("VMN_HELPER_PRIORITY");
+    const bool normal = prio && (prio[0] == 'n' || prio[0] == '0');
+    if (normal) VMN_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    else VMN_HIP(hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, greatest));
     h->stream = h->own_stream;
     VMN_HIP(hipMalloc(&h->flags, 64 * sizeof(uint32_t)));
     VMN_HIP(hipMemsetAsync(h->flags, 0, 64 * sizeof(uint32_t), h->stream));
@@ -3196,16 +3201,16 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
 
 extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be, size_t n_hint, int uses_hint) {
     ARG_CHECK(grp && base_be && n_hint > 0, "bad argument");
-    VMN_ENTER(LANE(grp->ctx));
     const int uses = uses_hint < 1 ? 1 : (uses_hint > 16 ? 16 : uses_hint);
     const int ebits = grp->Q.nbits;
     vmn_group::FixedTable* ft = nullptr;
     std::vector<uint8_t> chain;
     if (!grp->P.ec) {
-        // Is there anything to build?  If so the squaring chain -- milliseconds of host work -- runs here, outside the table
-        // lock: a caller that prepares the table of a per-proof base on the helper lane (the proof drivers do, for h_0) must
-        // not stall the protocol thread's own fixed-base calls behind it.
+        // Is there anything to build?  If so the squaring chain -- milliseconds of host work -- runs here, holding neither the
+        // lane's lock nor the table lock: a caller that prepares the table of a per-proof base on the helper lane (the proof
+        // drivers do, for h_0) must not stall other calls of that lane, nor the protocol thread's fixed-base calls, behind it.
         {
+            VMN_ENTER(LANE(grp->ctx));
             std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
             VMN_TRY(fixed_table(grp, base_be, ebits, n_hint, &ft, uses, true));
             if (ft) return VMN_OK;
@@ -3213,6 +3218,7 @@ extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be
         const int w = fixed_window_for(grp, n_hint, ebits, uses);
         VMN_TRY(fixed_chain_host(grp, base_be, (size_t)((ebits + w - 1) / w) * w, chain));
     }
+    VMN_ENTER(LANE(grp->ctx));
     std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
     return fixed_table(grp, base_be, ebits, n_hint, &ft, uses, false, chain.empty() ? nullptr : &chain);
 }

@@ -1276,14 +1276,23 @@ struct vmn_pos : ProofBase {
         xs.insert(xs.end(), w.begin(), w.end());
         A.clear();
         F.clear();
+        (void)af_job.join();
         af_pending.reset(new PendingProds());
+        if (overlap_lanes()) {                                                    // small arrays: on the second lane (see verify_prepare)
+            PendingProds* pp = af_pending.get();
+            const vmn_rarray* ee = e;
+            const int bits = e_bits;
+            return af_job.start(G.grp, true, [pp, xs, ee, bits]() -> int { return pp->begin(xs, ee, bits); });
+        }
         return af_pending->begin(xs, e, e_bits);                                  // one sort of e for u and w (the device part)
     }
     // A and F are completed where they are first needed -- in verify_prepare, behind the reply side of check (B), whose powers
     // then run on the device while the host finishes these products (and the sharded form exchanges them)
     std::unique_ptr<PendingProds> af_pending;
+    LaneJob af_job;                        // (declared after af_pending: joined before it is destroyed)
     bool af_begun() const { return af_pending || !A.empty(); }
     int finish_af() {
+        TRY(af_job.join());
         if (!af_pending) return VMN_OK;
         std::unique_ptr<PendingProds> pend(std::move(af_pending));
         std::vector<Bytes> res;
@@ -1366,8 +1375,11 @@ struct vmn_pos : ProofBase {
         Bytes uprod(G.eb), hprod(G.eb), mylast, eprod_b(G.xb), t_h0, Blast, prev;
         Num eprod;
         int kE_bits = 0;
+        std::vector<const vmn_garray*> xs{h};
+        xs.insert(xs.end(), wp.begin(), wp.end());
+        PendingProds kE_pending;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        LaneJob bridge_job;
+        LaneJob kE_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // (A) :1016-1021
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });                       // (C) :1045-1048
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });                       // (D) :1051-1054
@@ -1375,8 +1387,8 @@ struct vmn_pos : ProofBase {
         // The reply side of check (B) :1030-1033 -- unless verify() follows at once and takes the combined form.  It needs the
         // element in front of this shard's B: h0 when there is one shard, and then it is queued here, behind the device part
         // of the products and in front of their host part (which it hides); with several shards it waits for the exchange.
-        // Small arrays: the powers of check (B) are ONE long launch that fills a third of the device -- they go to the second
-        // lane first, and everything else of this phase runs beside them.
+        // Small arrays: the powers of check (B) are ONE long launch that fills a third of the device -- the multi-exponentiations
+        // of this phase (and computeAF's before it) run on the second lane, so that this lane is free for those powers at once.
         TRY(received_bits(ikE->ra, &kE_bits));
         prep.deferred = defer_bridge && combined_form_pays();
         prep.kE_bits = kE_bits;
@@ -1386,20 +1398,18 @@ struct vmn_pos : ProofBase {
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
-        const bool bridge_aside = !sharded && overlap_lanes() && !prep.deferred;
-        if (bridge_aside) TRY(bridge_job.start(G.grp, true, [&]() -> int { return queue_bridge(h0); }));
+        const bool prods_aside = overlap_lanes();
+        if (prods_aside) TRY(kE_job.start(G.grp, true, [&]() -> int { return kE_pending.begin(xs, ikE->ra, kE_bits); }));
         // scalars that come back from the GPU (each blocks on the stream) ...
         TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
         TRY(vmn_garray_prod(h, hprod.data()));
         TRY(last_local(cB, mylast));
         TRY(vmn_rarray_prod(e, eprod_b.data()));                                  // :1014
         eprod = G.ring_from(eprod_b.data());
-        std::vector<const vmn_garray*> xs{h};
-        xs.insert(xs.end(), wp.begin(), wp.end());
-        PendingProds kE_pending;
-        TRY(kE_pending.begin(xs, ikE->ra, kE_bits));                              // :1021, :1063 — one sort of k_E (the device part)
-        if (!sharded && !bridge_aside) TRY(queue_bridge(h0));
+        if (!prods_aside) TRY(kE_pending.begin(xs, ikE->ra, kE_bits));            // :1021, :1063 — one sort of k_E (the device part)
+        if (!sharded) TRY(queue_bridge(h0));
         TRY(finish_af());
+        TRY(kE_job.join());
         TRY(kE_pending.finish(G, prep.kE_prods));
         // ... completed over the ranks in ONE exchange ...
         std::vector<Bytes> lasts;
@@ -1419,7 +1429,6 @@ struct vmn_pos : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
-        TRY(bridge_job.join());
         lastC = prep.C;
         lastD = prep.D;
         prep.rep = rep;
@@ -1706,8 +1715,10 @@ struct vmn_posc : ProofBase {
         prep.hk.assign(G.eb, 0);
         Num eprod;
         int kE_bits = 0;
+        PendingProds a_pending, hk_pending;                                       // (see vmn_pos::verify_prepare)
+        std::vector<Bytes> a_out, hk_out;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        LaneJob bridge_job;
+        LaneJob prods_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // beside the GPU calls below
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });
@@ -1720,18 +1731,27 @@ struct vmn_posc : ProofBase {
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
-        const bool bridge_aside = !sharded && overlap_lanes() && !prep.deferred;  // (see vmn_pos::verify_prepare)
-        if (bridge_aside) TRY(bridge_job.start(G.grp, true, [&]() -> int { return queue_bridge(h0); }));
-        TRY(vmn_garray_expprod(u, e, e_bits, prep.A.data()));                     // :660
+        const bool prods_aside = overlap_lanes();                                 // the multi-exponentiations on the second lane
+        if (prods_aside) {
+            TRY(prods_job.start(G.grp, true, [&]() -> int {
+                TRY(a_pending.begin({u}, e, e_bits));                             // :660
+                return hk_pending.begin({h}, ikE->ra, kE_bits);
+            }));
+        } else {
+            TRY(vmn_garray_expprod(u, e, e_bits, prep.A.data()));                 // :660
+        }
         TRY(vmn_garray_prod(u, uprod.data()));
         TRY(vmn_garray_prod(h, hprod.data()));
         TRY(last_local(cB, mylast));
         TRY(vmn_rarray_prod(e, eprod_b.data()));
         eprod = G.ring_from(eprod_b.data());
-        PendingProds hk_pending;                                                  // (see vmn_pos::verify_prepare)
-        std::vector<Bytes> hk_out;
-        TRY(hk_pending.begin({h}, ikE->ra, kE_bits));
-        if (!sharded && !bridge_aside) TRY(queue_bridge(h0));
+        if (!prods_aside) TRY(hk_pending.begin({h}, ikE->ra, kE_bits));
+        if (!sharded) TRY(queue_bridge(h0));
+        TRY(prods_job.join());
+        if (prods_aside) {
+            TRY(a_pending.finish(G, a_out));
+            prep.A = a_out[0];
+        }
         TRY(hk_pending.finish(G, hk_out));
         prep.hk = hk_out[0];
         std::vector<Bytes> lasts;
@@ -1752,7 +1772,6 @@ struct vmn_posc : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
-        TRY(bridge_job.join());
         prep.rep = rep;
         prep.serial = rep->serial;
         prep.epoch = epoch;
