@@ -3043,13 +3043,19 @@ static int fixed_chain_host(const vmn_group* g, const uint8_t* base_be, size_t c
         return VMN_ERR_FORMAT;
     }
     VMN_TRACE("fixed_table:chain_host");
+    // The rows leave in the HOST's Montgomery form (x R_h mod p, R_h = 2^(64 nl)): converting each back would be a second
+    // product per step of a strictly sequential chain.  One more row carries R_h^-1 mod p, and the device multiplies the
+    // rows by it once they are imported (fixed_table) -- chain products on thousands of lanes instead of on one core.
     const num64::Mod& hm = *m.hm64;
     num64::Num cur = hm.to_m(num64::from_be(base_be, g->nbytes, hm.nl));
-    sq_be.resize(chain * g->nbytes);
+    sq_be.resize((chain + 1) * g->nbytes);
     for (size_t j = 0; j < chain; ++j) {
-        num64::to_be(hm.from_m(cur), sq_be.data() + j * g->nbytes, g->nbytes);
-        hm.mmul(cur, cur, cur);
+        num64::to_be(cur, sq_be.data() + j * g->nbytes, g->nbytes);
+        hm.msqr(cur, cur);
     }
+    num64::Num one(hm.nl, 0);
+    one[0] = 1;
+    num64::to_be(hm.from_m(one), sq_be.data() + chain * g->nbytes, g->nbytes);           // R_h^-1 mod p
     return VMN_OK;
 }
 static int fixed_window_for(vmn_group* g, size_t n, int ebits, int reuse_hint) {
@@ -3161,15 +3167,17 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     VMN_TRACE("fixed_table:build");
     const size_t chain = (size_t)nwin * w;
     std::vector<uint8_t> own_chain;
-    if (!chain_be || chain_be->size() != chain * g->nbytes) {
+    if (!chain_be || chain_be->size() != (chain + 1) * g->nbytes) {
         VMN_TRY(fixed_chain_host(g, base_be, chain, own_chain));
         chain_be = &own_chain;
     }
     const std::vector<uint8_t>& sq_be = *chain_be;
     DevTmp sq(ctx);
-    VMN_TRY(sq.alloc(chain * Wd * sizeof(uint32_t)));
+    VMN_TRY(sq.alloc((chain + 1) * Wd * sizeof(uint32_t)));
     int ok = 1;
-    VMN_TRY(import_be(ctx, m, g->nbytes, sq_be.data(), chain, sq.as<uint32_t>(), &ok));
+    VMN_TRY(import_be(ctx, m, g->nbytes, sq_be.data(), chain + 1, sq.as<uint32_t>(), &ok));
+    // out of the host's Montgomery form: every row times R_h^-1 (the last row, broadcast)
+    VMN_TRY(mul_arrays(ctx, m, sq.as<uint32_t>(), sq.as<uint32_t>() + chain * Wd, 0, chain, sq.as<uint32_t>()));
     vmn_group::FixedTable ft;
     ft.wbits = w;
     ft.nwin = nwin;

@@ -612,12 +612,25 @@ struct ProofBase {
         }
         return fail(VMN_ERR_ARG, "%s: %zu elements, expected this rank's %zu or all %zu", what, n, N, Ntot);
     }
-    bool overlap_lanes() const { return N > 0 && N <= lane_overlap_max(); }
+    // Two kinds of overlap.  (1) HOST work beside device work -- the squaring chain of a new fixed-base table: always worth it
+    // for small arrays (prepare_base_table).  (2) two chains of KERNELS side by side: measured at N = 10^4 it LOSES
+    // (profiles/r04_lane_overlap.txt: a lone wave64 already keeps its SIMD's 16-lane ALU busy 4 cycles of every ~5.5, so a
+    // "latency-bound" chain is VALU-bound per SIMD, the wide geometries put a wave on every SIMD of the chip, and the wave that
+    // arrives second gets the leftover issue slots: a bucket level beside the powers of check (B) took 5.3 ms instead of
+    // 0.9 ms and the phase 16.2 ms instead of 11.7 ms).  It stays available for experiments: VMN_LANE_OVERLAP_COMPUTE=1.
+    bool prefetch_tables() const { return N > 0 && N <= lane_overlap_max(); }
+    bool overlap_lanes() const {
+        static const bool on = [] {
+            const char* e = getenv("VMN_LANE_OVERLAP_COMPUTE");
+            return e && *e == '1';
+        }();
+        return on && N > 0 && N <= lane_overlap_max();
+    }
     // the table of a per-proof base (h_0), built on the second lane as soon as the base is known: its squaring chain is
     // milliseconds of sequential host work that would otherwise sit in front of the first use (commit's bridging commitments)
     LaneJob h0_table_job;
     int prepare_base_table(const Bytes& base) {
-        if (G.ec || !overlap_lanes()) return VMN_OK;        // (curves build their chains on the device; large arrays hide the chain)
+        if (G.ec || !prefetch_tables()) return VMN_OK;      // (curves build their chains on the device; large arrays hide the chain)
         (void)h0_table_job.join();
         const Bytes b = base;                                // (a copy: the job may outlive the derived object's fields)
         vmn_group* grp = G.grp;
