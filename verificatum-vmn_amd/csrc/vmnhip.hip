@@ -3064,7 +3064,16 @@ static int fixed_window_for(vmn_group* g, size_t n, int ebits, int reuse_hint) {
     // A launch over fewer elements than the chip holds lanes costs as much as a full one (the per-lane chain of
     // products is what takes the time), so small arrays are priced at the lane capacity: the window grows and the
     // chain shortens (N = 3 x 10^4: w = 12 -> 14, 171 -> 147 sequential products per exponentiation).
-    const size_t lanes = m.ec ? (size_t)ctx->num_cus * 4 * 64 * 2 : (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
+    // Modular groups cut the chain of a small array into up to 16 pieces on as many times the lanes (vmn_group_exp_fixed), so
+    // an exponentiation of n elements is PRICED at the lanes it really occupies: max(n, lanes / pieces).  (Round 4: without
+    // this a per-proof base at N = 10^4 got a 2^15-entry window -- 4.5 M products to build, 1.8 ms of the device -- to save
+    // a fifth of two exponentiations of 0.55 ms.)
+    size_t lanes = m.ec ? (size_t)ctx->num_cus * 4 * 64 * 2 : (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
+    if (!m.ec) {
+        size_t parts = 1;
+        while (parts < 16 && 2 * parts * n <= fixed_split_fill()) parts *= 2;
+        lanes /= parts;
+    }
     return pick_fixed_window(std::max(n, lanes), ebits, elem_words(m) * sizeof(uint32_t), reuse_hint);
 }
 // probe = true: *out = the cached table when it serves, nullptr when one would have to be built (nothing is built)
@@ -3074,8 +3083,6 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
     const vmn_modulus& m = g->P;
     const size_t Wd = elem_words(m);
     std::string key(reinterpret_cast<const char*>(base_be), m.ec ? 2 * g->nbytes : g->nbytes);
-    const size_t lanes = m.ec ? (size_t)ctx->num_cus * 4 * 64 * 2 : (size_t)ctx->num_cus * blocks_per_cu(m) * (BLOCK / m.LPE);
-    n = std::max(n, lanes);
     int w = fixed_window_for(g, n, ebits, reuse_hint);
     int carry_uses = 1;
     *out = nullptr;
@@ -3087,7 +3094,7 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         // (only after many calls: allocating and mapping a 17 GB table takes ~0.6 s, so growing on its own pays off
         // for long-lived services only; a session that knows its long-lived bases says so at setup,
         // vmn_group_precompute_fixed)
-        const int w_many = ft.uses >= 64 ? pick_fixed_window(n, ebits, Wd * sizeof(uint32_t), 16) : w;
+        const int w_many = ft.uses >= 64 ? fixed_window_for(g, n, ebits, 16) : w;
         const bool grow = w_many >= ft.wbits + 2;
         if (!grow && ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {
             ft.last_use = ++g->fixed_clock;

@@ -619,18 +619,27 @@ struct ProofBase {
     // arrives second gets the leftover issue slots: a bucket level beside the powers of check (B) took 5.3 ms instead of
     // 0.9 ms and the phase 16.2 ms instead of 11.7 ms).  It stays available for experiments: VMN_LANE_OVERLAP_COMPUTE=1.
     bool prefetch_tables() const { return N > 0 && N <= lane_overlap_max(); }
+    // Curves are the exception: one point per lane, so an array of N <= 32 768 points is N / 64 waves on a chip of 1024 SIMDs
+    // and two chains of such kernels find SIMDs of their own (the two scalar multiplications of check (B) at N = 10^4:
+    // 1.58 + 1.55 ms one after the other, profiles/r04_timeline_p256_n10000.txt).  VMN_LANE_OVERLAP_EC_MAX moves that bound.
     bool overlap_lanes() const {
         static const bool on = [] {
             const char* e = getenv("VMN_LANE_OVERLAP_COMPUTE");
             return e && *e == '1';
         }();
-        return on && N > 0 && N <= lane_overlap_max();
+        static const size_t ec_max = [] {
+            const char* e = getenv("VMN_LANE_OVERLAP_EC_MAX");
+            return e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32768;
+        }();
+        if (N == 0) return false;
+        if (G.ec) return N <= ec_max;
+        return on && N <= lane_overlap_max();
     }
     // the table of a per-proof base (h_0), built on the second lane as soon as the base is known: its squaring chain is
     // milliseconds of sequential host work that would otherwise sit in front of the first use (commit's bridging commitments)
     LaneJob h0_table_job;
     int prepare_base_table(const Bytes& base) {
-        if (G.ec || !prefetch_tables()) return VMN_OK;      // (curves build their chains on the device; large arrays hide the chain)
+        if (!prefetch_tables()) return VMN_OK;              // (large arrays hide the chain; curves: a one-lane doubling chain on the device, 2.3 ms)
         (void)h0_table_job.join();
         const Bytes b = base;                                // (a copy: the job may outlive the derived object's fields)
         vmn_group* grp = G.grp;
@@ -1213,9 +1222,9 @@ struct vmn_pos : ProofBase {
             RA x, y;
             Bytes x_in, y_in;
             TRY(scans(b, ipe, x, y, d, x_in, y_in));                              // :583-604
+            TRY(h0_table_job.join());                                             // (the table of h_0, begun in precompute)
             return bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp);   // :606-648 (queued)
         };
-        TRY(h0_table_job.join());                                                 // (the table of h_0, begun in precompute)
         if (prepare_here && overlap_lanes() && !sharded) {
             // small arrays: the scans and the bridging commitments (a chain of short launches and four fixed-base powers) on the
             // second lane, F' (a multi-exponentiation over w') on this one -- neither fills the device
@@ -1392,7 +1401,7 @@ struct vmn_pos : ProofBase {
         xs.insert(xs.end(), wp.begin(), wp.end());
         PendingProds kE_pending;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        LaneJob kE_job;
+        LaneJob kE_job, left_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // (A) :1016-1021
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });                       // (C) :1045-1048
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });                       // (D) :1051-1054
@@ -1406,13 +1415,20 @@ struct vmn_pos : ProofBase {
         prep.deferred = defer_bridge && combined_form_pays();
         prep.kE_bits = kE_bits;
         prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
+        bool pair_launch = prep.paired;                                           // (modular groups: both powers in one launch)
         auto queue_bridge = [&](const Bytes& front) -> int {
-            if (prep.paired) return bridging_pair(g, front, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right);
+            if (pair_launch) return bridging_pair(g, front, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right);
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
         const bool prods_aside = overlap_lanes();
         if (prods_aside) TRY(kE_job.start(G.grp, true, [&]() -> int { return kE_pending.begin(xs, ikE->ra, kE_bits); }));
+        // curves, challenge known: B^v B' on the second lane as well, beside the reply side on this one
+        const bool left_aside = defer_bridge && G.ec && prods_aside && !prep.paired && !prep.deferred;
+        if (left_aside) {
+            TRY(left_job.start(G.grp, true, [&]() -> int { return bridging_left(cB, cBp, prep.left); }));
+            prep.paired = true;                                                   // (verify() takes prep.left)
+        }
         // scalars that come back from the GPU (each blocks on the stream) ...
         TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
         TRY(vmn_garray_prod(h, hprod.data()));
@@ -1442,6 +1458,7 @@ struct vmn_pos : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        TRY(left_job.join());
         lastC = prep.C;
         lastD = prep.D;
         prep.rep = rep;
@@ -1623,9 +1640,9 @@ struct vmn_posc : ProofBase {
             RA x, y;
             Bytes x_in, y_in;
             TRY(scans(b, ipe, x, y, d, x_in, y_in));
+            TRY(h0_table_job.join());
             return bridging_commitments(g, h0, x, y, x_in, y_in, beta, epsilon, B, Bp);
         };
-        TRY(h0_table_job.join());
         if (prepare_here && overlap_lanes() && !sharded) {
             TRY(commit_draws());
             LaneJob bridge_job;
@@ -1731,7 +1748,7 @@ struct vmn_posc : ProofBase {
         PendingProds a_pending, hk_pending;                                       // (see vmn_pos::verify_prepare)
         std::vector<Bytes> a_out, hk_out;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        LaneJob prods_job;
+        LaneJob prods_job, left_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // beside the GPU calls below
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });
@@ -1739,12 +1756,18 @@ struct vmn_posc : ProofBase {
         prep.deferred = defer_bridge && combined_form_pays();
         prep.kE_bits = kE_bits;
         prep.paired = defer_bridge && !prep.deferred && pair_form_pays();         // small arrays, challenge known: B^v rides along
+        bool pair_launch = prep.paired;
         auto queue_bridge = [&](const Bytes& front) -> int {
-            if (prep.paired) return bridging_pair(g, front, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right);
+            if (pair_launch) return bridging_pair(g, front, cB, cBp, ikB->ra, ikE->ra, kE_bits, prep.left, prep.right);
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
         const bool prods_aside = overlap_lanes();                                 // the multi-exponentiations on the second lane
+        const bool left_aside = defer_bridge && G.ec && prods_aside && !prep.paired && !prep.deferred;
+        if (left_aside) {                                                         // (see vmn_pos::verify_prepare)
+            TRY(left_job.start(G.grp, true, [&]() -> int { return bridging_left(cB, cBp, prep.left); }));
+            prep.paired = true;
+        }
         if (prods_aside) {
             TRY(prods_job.start(G.grp, true, [&]() -> int {
                 TRY(a_pending.begin({u}, e, e_bits));                             // :660
@@ -1785,6 +1808,7 @@ struct vmn_posc : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        TRY(left_job.join());
         prep.rep = rep;
         prep.serial = rep->serial;
         prep.epoch = epoch;
