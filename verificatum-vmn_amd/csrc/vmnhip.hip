@@ -959,6 +959,14 @@ static int curve_create(vmn_ctx* ctx, const CurveParams& cp, vmn_curve** out) {
     c->host.F = c->f64;
     c->host.cb = ((size_t)cp.bits + 7) / 8;
     c->host.fl = c->f64->nl;
+    {
+        const num64::Mod& F = *c->f64;
+        num64::Num two28(F.nl, 0), rd(F.nl, 0);
+        two28[0] = (uint64_t)1 << 28;
+        rd[0] = 1;
+        for (int j = 0; j < c->S; ++j) rd = F.mul(rd, two28);
+        c->rd_inv = F.inv(rd);
+    }
     const Big& pw = c->p_words;
     c->p1p = limbs_of(pw, S)[1] + 1;
     {   // the kernels carry the primes of these two sizes as compile-time constants (ec_kernels.h FieldPrime): same prime?
@@ -1143,6 +1151,7 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (n == 0) return VMN_OK;
     // a curve point in a byte tree is node(leaf(x), leaf(y)): 15 framing bytes around the two coordinates
     const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
+    if (m.ec && n <= 4 && !leaf_hdr && !pinned_async && !getenv("VMN_EC_EXPORT_DEVICE")) return ec_export_few_host(ctx, m, nbytes, d_in, n, be);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     if (checked_on_host) VMN_TRY(h2d(ctx, raw.p, be, n * stride));           // (small: through the pinned buffer, queued)
@@ -1171,6 +1180,54 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     VMN_TRY(read_flag(ctx, &fl));
     if (all_in_range) *all_in_range = (fl & 1u) ? 0 : 1;
     if (format_ok) *format_ok = (fl & 4u) ? 0 : 1;
+    return VMN_OK;
+}
+
+// A handful of curve points (the single elements a proof reads back: a product, the last B, h_0): the Jacobian rows come to the
+// host as they are and the host makes them affine (one binary-Euclid inversion per point, ~10 us) -- the device's export does a
+// Fermat inversion per point, a chain of ~380 dependent field products on one lane: 155 us of latency whatever the count
+// (profiles/r04_timeline_p256_n10000.txt), and a proof over a curve reads single points a dozen times.
+static int ec_export_few_host(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be) {
+    const int S = m.ec->S;
+    const size_t FW = (size_t)stride_for_limbs(S), ROW = 3 * FW;
+    std::vector<uint32_t> rows(n * ROW);
+    VMN_TRY(d2h(ctx, rows.data(), d_in, n * ROW * sizeof(uint32_t)));
+    const num64::Mod& F = *m.ec->f64;
+    // values are x R_d mod p with R_d = 2^(28 S), limbs normalised but the value lazy (a small multiple of p above x R_d)
+    const num64::Num& rdinv = m.ec->rd_inv;
+    auto field = [&](const uint32_t* limbs) {
+        uint8_t buf[96] = {0};                                  // big-endian: up to 21 limbs of 28 bits and a 32-bit top limb
+        const size_t nb = sizeof(buf);
+        unsigned __int128 acc = 0;                              // the bits not yet written, the lowest at the next byte position
+        int acc_bits = 0;
+        size_t pos = nb;
+        for (int j = 0; j < S; ++j) {                           // limb j sits at bit 28 j (a limb wider than 28 bits just carries on)
+            acc += (unsigned __int128)limbs[j] << acc_bits;
+            acc_bits += 28;
+            while (acc_bits >= 8) {
+                buf[--pos] = (uint8_t)acc;
+                acc >>= 8;
+                acc_bits -= 8;
+            }
+        }
+        while (acc != 0) {
+            buf[--pos] = (uint8_t)acc;
+            acc >>= 8;
+        }
+        return F.mul(F.reduce(buf, nb), rdinv);
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t* row = rows.data() + i * ROW;
+        uint8_t* dst = be + i * 2 * nbytes;
+        if (row[ROW - 1]) {                                     // the point at infinity: both coordinates all 0xff
+            memset(dst, 0xff, 2 * nbytes);
+            continue;
+        }
+        const num64::Num X = field(row), Y = field(row + FW), Z = field(row + 2 * FW);
+        const num64::Num zi = F.inv(Z), zi2 = F.mul(zi, zi);
+        num64::to_be(F.mul(X, zi2), dst, nbytes);
+        num64::to_be(F.mul(Y, F.mul(zi2, zi)), dst + nbytes, nbytes);
+    }
     return VMN_OK;
 }
 
@@ -3091,9 +3148,8 @@ static int fixed_table(vmn_group* g, const uint8_t* base_be, int ebits, size_t n
         vmn_group::FixedTable& ft = it->second;
         ft.uses += 1;
         // a base that keeps coming back earns a larger window (amortised over the uses so far, at most 16)
-        // (only after many calls: allocating and mapping a 17 GB table takes ~0.6 s, so growing on its own pays off
-        // for long-lived services only; a session that knows its long-lived bases says so at setup,
-        // vmn_group_precompute_fixed)
+        // (only after many calls: a larger table is tens of milliseconds of products and gigabytes of HBM; a session that knows
+        // its long-lived bases says so at setup, vmn_group_precompute_fixed)
         const int w_many = ft.uses >= 64 ? fixed_window_for(g, n, ebits, 16) : w;
         const bool grow = w_many >= ft.wbits + 2;
         if (!grow && ft.wbits >= w && ft.nwin * ft.wbits >= ebits) {

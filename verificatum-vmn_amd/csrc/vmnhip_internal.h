@@ -119,6 +119,7 @@ struct vmn_curve {
     uint32_t n0inv = 0;
     vmn::num64::Mod* f64 = nullptr;     // the field on 64-bit limbs and the curve over it on the host: the sequential tail (Horner over
     vmn::num64::HostCurve host;         //   the windows) of a multi-exponentiation, 20 x faster there than on one GPU lane
+    vmn::num64::Num rd_inv;             // 2^(-28 S) mod p: out of the device's Montgomery form, on the host (ec_export_few_host)
     uint32_t p1p = 0;              // limb 1 of the prime + 1 (ec_kernels.h mont_row)
     int ts_s = 0, ts_ewords = 0;   // Tonelli-Shanks (p = 1 mod 4): p - 1 = 2^ts_s Q; words of (Q - 1) / 2
     const uint32_t* d_ts_e = nullptr;

@@ -1121,7 +1121,7 @@ struct vmn_pos : ProofBase {
         jobs.start([&] { return gexp(g, alpha, ga); });
         TRY(prepare_base_table(h0));                             // the table of h_0 (used by commit): built beside this phase
         // :481  A' = g^alpha prod h_i^eps_i -- its device part is queued first, the permutation commitment behind it: the
-        // fixed-base powers of u then run while the host finishes the product (small arrays: on the second lane, beside it)
+        // fixed-base powers of u then run while the host finishes the product
         PendingProds hp_pending;
         std::vector<Bytes> hp_out;
         auto make_u = [&]() -> int {
@@ -1130,16 +1130,8 @@ struct vmn_pos : ProofBase {
             TRY(r_draw.rows(G.grp, pi.data() + lo, N, r_perm));
             return permutation_commitment_rows(G.grp, g.data(), h_, r_perm, pi.data() + lo, N, u_own.out());
         };
-        if (overlap_lanes()) {
-            LaneJob u_job;
-            TRY(u_job.start(G.grp, true, make_u));
-            const int rc_begin = hp_pending.begin({h}, epsilon, eps_bits);
-            TRY(u_job.join());
-            TRY(rc_begin);
-        } else {
-            TRY(hp_pending.begin({h}, epsilon, eps_bits));
-            TRY(make_u());
-        }
+        TRY(hp_pending.begin({h}, epsilon, eps_bits));           // (the second lane is busy with the table of h_0: one stream, in order)
+        TRY(make_u());
         u = u_own;
         TRY(hp_pending.finish(G, hp_out));
         hp = hp_out[0];
@@ -1401,7 +1393,7 @@ struct vmn_pos : ProofBase {
         xs.insert(xs.end(), wp.begin(), wp.end());
         PendingProds kE_pending;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        LaneJob kE_job, left_job;
+        LaneJob kE_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // (A) :1016-1021
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });                       // (C) :1045-1048
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });                       // (D) :1051-1054
@@ -1421,13 +1413,16 @@ struct vmn_pos : ProofBase {
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
+        // ONE job on the second lane (a lane is one in-order stream): curves with the challenge known start with B^v B', the
+        // long chain, beside the reply side of check (B) on this lane; then the multi-exponentiations with k_E
         const bool prods_aside = overlap_lanes();
-        if (prods_aside) TRY(kE_job.start(G.grp, true, [&]() -> int { return kE_pending.begin(xs, ikE->ra, kE_bits); }));
-        // curves, challenge known: B^v B' on the second lane as well, beside the reply side on this one
         const bool left_aside = defer_bridge && G.ec && prods_aside && !prep.paired && !prep.deferred;
-        if (left_aside) {
-            TRY(left_job.start(G.grp, true, [&]() -> int { return bridging_left(cB, cBp, prep.left); }));
-            prep.paired = true;                                                   // (verify() takes prep.left)
+        if (left_aside) prep.paired = true;                                       // (verify() takes prep.left)
+        if (prods_aside) {
+            TRY(kE_job.start(G.grp, true, [&, left_aside]() -> int {
+                if (left_aside) TRY(bridging_left(cB, cBp, prep.left));
+                return kE_pending.begin(xs, ikE->ra, kE_bits);
+            }));
         }
         // scalars that come back from the GPU (each blocks on the stream) ...
         TRY(vmn_garray_prod(u, uprod.data()));                                    // :1013
@@ -1458,7 +1453,6 @@ struct vmn_pos : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
-        TRY(left_job.join());
         lastC = prep.C;
         lastD = prep.D;
         prep.rep = rep;
@@ -1748,7 +1742,7 @@ struct vmn_posc : ProofBase {
         PendingProds a_pending, hk_pending;                                       // (see vmn_pos::verify_prepare)
         std::vector<Bytes> a_out, hk_out;
         HostJobs jobs;                                                            // (after everything its jobs touch)
-        LaneJob prods_job, left_job;
+        LaneJob prods_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // beside the GPU calls below
         jobs.start([&] { return gexp(g, k_C, prep.gkC); });
         jobs.start([&] { return gexp(g, k_D, prep.gkD); });
@@ -1764,12 +1758,10 @@ struct vmn_posc : ProofBase {
         };
         const bool prods_aside = overlap_lanes();                                 // the multi-exponentiations on the second lane
         const bool left_aside = defer_bridge && G.ec && prods_aside && !prep.paired && !prep.deferred;
-        if (left_aside) {                                                         // (see vmn_pos::verify_prepare)
-            TRY(left_job.start(G.grp, true, [&]() -> int { return bridging_left(cB, cBp, prep.left); }));
-            prep.paired = true;
-        }
+        if (left_aside) prep.paired = true;                                       // (see vmn_pos::verify_prepare)
         if (prods_aside) {
-            TRY(prods_job.start(G.grp, true, [&]() -> int {
+            TRY(prods_job.start(G.grp, true, [&, left_aside]() -> int {
+                if (left_aside) TRY(bridging_left(cB, cBp, prep.left));
                 TRY(a_pending.begin({u}, e, e_bits));                             // :660
                 return hk_pending.begin({h}, ikE->ra, kE_bits);
             }));
@@ -1808,7 +1800,6 @@ struct vmn_posc : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
-        TRY(left_job.join());
         prep.rep = rep;
         prep.serial = rep->serial;
         prep.epoch = epoch;
