@@ -1151,7 +1151,6 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (n == 0) return VMN_OK;
     // a curve point in a byte tree is node(leaf(x), leaf(y)): 15 framing bytes around the two coordinates
     const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
-    if (m.ec && n <= 4 && !leaf_hdr && !pinned_async && !getenv("VMN_EC_EXPORT_DEVICE")) return ec_export_few_host(ctx, m, nbytes, d_in, n, be);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     if (checked_on_host) VMN_TRY(h2d(ctx, raw.p, be, n * stride));           // (small: through the pinned buffer, queued)
@@ -1237,6 +1236,7 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (n == 0) return VMN_OK;
     // a curve point in a byte tree is node(leaf(x), leaf(y)): 15 framing bytes around the two coordinates
     const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
+    if (m.ec && n <= 4 && !leaf_hdr && !pinned_async && !getenv("VMN_EC_EXPORT_DEVICE")) return ec_export_few_host(ctx, m, nbytes, d_in, n, be);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
     note_work(ctx, m, m.ec ? 8.0 * (double)n : (double)n, m.ec ? (double)m.nbits * (double)n : 0.0);     // curves: one Fermat inversion per point
