@@ -175,10 +175,9 @@ struct LaneJob {
         if (!ctx || vmn_ctx_helper_mark(ctx) != VMN_OK) return f();
         try {
             fut = std::async(std::launch::async, [ctx, f]() -> int {
-                int rc = vmn_ctx_helper_begin(ctx);
-                if (rc != VMN_OK) return rc;
-                rc = f();
-                const int rc2 = vmn_ctx_helper_end(ctx);
+                const bool on_lane = vmn_ctx_helper_begin(ctx) == VMN_OK;      // (if not: the job still runs, on the caller's lane)
+                const int rc = f();
+                const int rc2 = on_lane ? vmn_ctx_helper_end(ctx) : (int)VMN_OK;
                 return rc != VMN_OK ? rc : rc2;
             });
         } catch (const std::system_error&) {        // no thread to be had: the job runs here and now, on this lane
@@ -1392,6 +1391,8 @@ struct vmn_pos : ProofBase {
         std::vector<const vmn_garray*> xs{h};
         xs.insert(xs.end(), wp.begin(), wp.end());
         PendingProds kE_pending;
+        std::promise<int> kE_begun;                                               // set by the lane job once the device part is queued
+        std::future<int> kE_begun_f = kE_begun.get_future();
         HostJobs jobs;                                                            // (after everything its jobs touch)
         LaneJob kE_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // (A) :1016-1021
@@ -1413,15 +1414,17 @@ struct vmn_pos : ProofBase {
             if (!prep.deferred) return bridging_right(g, front, cB, ikB->ra, ikE->ra, kE_bits, prep.right);
             return VMN_OK;
         };
-        // ONE job on the second lane (a lane is one in-order stream): curves with the challenge known start with B^v B', the
-        // long chain, beside the reply side of check (B) on this lane; then the multi-exponentiations with k_E
+        // ONE job on the second lane (a lane is one in-order stream): the multi-exponentiations with k_E, then -- curves with the
+        // challenge known -- B^v B', beside the reply side of check (B) on this lane
         const bool prods_aside = overlap_lanes();
         const bool left_aside = defer_bridge && G.ec && prods_aside && !prep.paired && !prep.deferred;
         if (left_aside) prep.paired = true;                                       // (verify() takes prep.left)
         if (prods_aside) {
             TRY(kE_job.start(G.grp, true, [&, left_aside]() -> int {
-                if (left_aside) TRY(bridging_left(cB, cBp, prep.left));
-                return kE_pending.begin(xs, ikE->ra, kE_bits);
+                const int rc = kE_pending.begin(xs, ikE->ra, kE_bits);    // first: its host-side tail (the Horner chains) then runs beside the powers
+                kE_begun.set_value(rc);
+                if (rc != VMN_OK) return rc;
+                return left_aside ? bridging_left(cB, cBp, prep.left) : (int)VMN_OK;
             }));
         }
         // scalars that come back from the GPU (each blocks on the stream) ...
@@ -1433,7 +1436,7 @@ struct vmn_pos : ProofBase {
         if (!prods_aside) TRY(kE_pending.begin(xs, ikE->ra, kE_bits));            // :1021, :1063 — one sort of k_E (the device part)
         if (!sharded) TRY(queue_bridge(h0));
         TRY(finish_af());
-        TRY(kE_job.join());
+        if (prods_aside) TRY(kE_begun_f.get());                                   // (queued, not finished: finish() waits for its event)
         TRY(kE_pending.finish(G, prep.kE_prods));
         // ... completed over the ranks in ONE exchange ...
         std::vector<Bytes> lasts;
@@ -1453,6 +1456,7 @@ struct vmn_pos : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        TRY(kE_job.join());
         lastC = prep.C;
         lastD = prep.D;
         prep.rep = rep;
@@ -1741,6 +1745,8 @@ struct vmn_posc : ProofBase {
         int kE_bits = 0;
         PendingProds a_pending, hk_pending;                                       // (see vmn_pos::verify_prepare)
         std::vector<Bytes> a_out, hk_out;
+        std::promise<int> prods_begun;
+        std::future<int> prods_begun_f = prods_begun.get_future();
         HostJobs jobs;                                                            // (after everything its jobs touch)
         LaneJob prods_job;
         jobs.start([&] { return gexp(g, k_A, prep.gkA); });                       // beside the GPU calls below
@@ -1761,9 +1767,11 @@ struct vmn_posc : ProofBase {
         if (left_aside) prep.paired = true;                                       // (see vmn_pos::verify_prepare)
         if (prods_aside) {
             TRY(prods_job.start(G.grp, true, [&, left_aside]() -> int {
-                if (left_aside) TRY(bridging_left(cB, cBp, prep.left));
-                TRY(a_pending.begin({u}, e, e_bits));                             // :660
-                return hk_pending.begin({h}, ikE->ra, kE_bits);
+                int rc = a_pending.begin({u}, e, e_bits);                         // :660
+                if (rc == VMN_OK) rc = hk_pending.begin({h}, ikE->ra, kE_bits);
+                prods_begun.set_value(rc);
+                if (rc != VMN_OK) return rc;
+                return left_aside ? bridging_left(cB, cBp, prep.left) : (int)VMN_OK;
             }));
         } else {
             TRY(vmn_garray_expprod(u, e, e_bits, prep.A.data()));                 // :660
@@ -1775,8 +1783,8 @@ struct vmn_posc : ProofBase {
         eprod = G.ring_from(eprod_b.data());
         if (!prods_aside) TRY(hk_pending.begin({h}, ikE->ra, kE_bits));
         if (!sharded) TRY(queue_bridge(h0));
-        TRY(prods_job.join());
         if (prods_aside) {
+            TRY(prods_begun_f.get());
             TRY(a_pending.finish(G, a_out));
             prep.A = a_out[0];
         }
@@ -1800,6 +1808,7 @@ struct vmn_posc : ProofBase {
         prep.prev = prev;
         if (sharded) TRY(queue_bridge(prev));
         TRY(jobs.join());
+        TRY(prods_job.join());
         prep.rep = rep;
         prep.serial = rep->serial;
         prep.epoch = epoch;
