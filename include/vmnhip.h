@@ -214,7 +214,8 @@ int vmn_garray_mul(const vmn_garray* x, const vmn_garray* y, vmn_garray** out);
  * ref: P/elgamal/DistrElGamalSessionBasic.java:487-502 (K3'), :406-452 (coefficients may be negative). */
 int vmn_garray_inv(const vmn_garray* x, vmn_garray** out);
 /* out[i] = x[i]^e * y[i]^f[i] as ONE simultaneous power: the squarings are shared between the two exponents
- * (max(bits(e), fbits) of them instead of the sum).  Modular groups only (VMN_ERR_UNSUPPORTED over curves).  The
+ * (max(bits(e), fbits) of them instead of the sum).  Curves: one chain of doublings for the two scalar multiplications
+ * (e acts through its residue modulo the group order).  The
  * verifiers' check (B) of PoSBasicTW.java:1023-1042 in the form B_i^v (B_{i-1}^{-1})^{k_E,i} B'_i = g^{k_B,i}. */
 int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t ebytes, const vmn_garray* y, const vmn_rarray* f, int fbits,
                     vmn_garray** out);

@@ -69,6 +69,66 @@ def test_scalar_multiplication_variable_fixed_and_shared(ecg):
     assert X.expInts(e612, 612).toInts() == c.exp_array(xs, e612)
 
 
+def test_two_scalar_multiplications_on_one_chain_of_doublings(ecg):
+    """vmn_garray_exp2 over a curve (k_ec_mulvar2, round 4): e * x[i] + f[i] * y[i] with a shared scalar e and per-point
+    scalars f -- the form a verifier's check (B) takes for large arrays (B_i^v (B_{i-1}^-1)^{k_E,i}).  Edge cases: zero
+    scalars on either side (the identity's table entry), e larger than the group order (acts through its residue), scalars
+    of unequal length, y = -x with f = e (everything cancels), points at infinity as bases."""
+    G, c = ecg
+    rnd = random.Random(44)
+    n = sz(c, 120)
+    xs, ys = pts(c, 45, n), pts(c, 46, n)
+    xs[3], ys[4] = None, None
+    ys[5] = c.neg(xs[5])
+    qbits = c.n.bit_length()
+    X, Y = G.toElementArray(xs), G.toElementArray(ys)
+    for e, fbits in ((rnd.randrange(1 << 256), qbits), (0, qbits), (1, 1), (c.n + 5, 40), (c.n - 1, qbits), (rnd.randrange(1 << 128), 64)):
+        fs = [rnd.randrange(1 << fbits) % c.n for _ in range(n)]
+        fs[0], fs[1] = 0, (1 << fbits) - 1 if fbits < qbits else c.n - 1
+        fs[5] = e % c.n if (e % c.n).bit_length() <= fbits else fs[5]
+        want = [c.add(c.mul(e % c.n, x), c.mul(f, y)) for x, y, f in zip(xs, ys, fs)]
+        assert X.exp2(e, Y, G.ringArray(fs), fbits).toInts() == want, (e.bit_length(), fbits)
+
+
+def test_check_b_in_its_combined_form_over_a_curve(vmn, gpu_ctx, entry, monkeypatch):
+    """Large arrays over a curve verify check (B) as (B_i^v (B_{i-1}^-1)^{k_E,i}) B'_i = g^{k_B,i} through k_ec_mulvar2
+    (VMN_COMBINED_MIN=1 forces that form at test size): transcript, verdicts and the verifier's intermediates as in the
+    separate form; a reply tampered in ONE k_B fails check (B) only."""
+    import mirror
+    from oracle import pyref_proofs as P
+    from proof_cases import check_pos, make_instance
+    from tape import Tape
+    monkeypatch.setenv("VMN_COMBINED_MIN", "1")
+    mods = mirror.load(entry, ("native", "mixnet", "hvzk", "elgamal"))
+    c = Curve("P-256")
+    K = P.ECAdapter(c)
+    G = vmn.ECqPGroup(gpu_ctx, "P-256")
+    n, width = 70, 1
+    h, pkey, w, t = make_instance(K, c.g, n, width, b"ec-combined")
+    H, W, WP, wp_o, s, S, pi = check_pos("native", mods, G, K, c.g, h, pkey, w, t, (128, 128, 64))
+    nat = mods["native"]
+    e, v = t.int_array(n, 128), t.int_array(1, 128)[0]
+    pr = nat.PoSBasicTW(G, 128, 128, 64, rand=Tape(b"ec-combined-prover", c.n))
+    pr.precompute(c.g, H, pi)
+    pr.setInstance(pkey, W, WP, S)
+    pr.setBatchVector(e)
+    com, rep = pr.commit(), pr.reply(v)
+    ver = nat.PoSBasicTW(G, 128, 128, 64)
+    ver.precompute(c.g, H)
+    ver.setPermutationCommitment(pr.u)
+    ver.setInstance(pkey, W, WP)
+    ver.setBatchVector(e)
+    ver.computeAF()
+    ver.setCommitment(com)
+    ver.setChallenge(v)
+    assert ver.verify(rep) and ver.verdicts == (True,) * 5
+    bad = dict(rep)
+    kb = rep["k_B"].toInts()
+    kb[n // 2] = (kb[n // 2] + 1) % c.n
+    bad["k_B"] = G.ringArray(kb)
+    assert not ver.verify(bad) and ver.verdicts == (True, False, True, True, True)
+
+
 def test_equality_is_of_group_elements_not_of_representations(ecg):
     G, c = ecg
     rnd = random.Random(6)

@@ -11,6 +11,8 @@
     KW __global__ void vmn::k_ec_equal<S_>(const vmn::u32*, const vmn::u32*, size_t, vmn::ECDev, vmn::u32*);                             \
     KW __global__ void vmn::k_ec_mulvar<S_>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, int, size_t, vmn::ECDev,      \
                                             vmn::u32*);                                                                                 \
+    KW __global__ void vmn::k_ec_mulvar2<S_>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, int, const vmn::u32*, const vmn::u32*, int,  \
+                                             size_t, int, int, size_t, vmn::ECDev, vmn::u32*);                                          \
     KW __global__ void vmn::k_ec_chain<S_>(vmn::u32*, const vmn::u32*, int, vmn::ECDev);                                                 \
     KW __global__ void vmn::k_ec_fixed_level<S_>(vmn::u32*, int, int, int, vmn::ECDev);                                                  \
     KW __global__ void vmn::k_ec_fixed_exp<S_>(vmn::u32*, const vmn::u32*, int, int, const vmn::u32*, int, size_t, vmn::ECDev);          \

@@ -765,6 +765,63 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_mulvar(u32* __restr
     }
 }
 
+// out[i] = e * x[i] + f[i] * y[i]  (one shared scalar e, per-lane scalars f): the two scalar multiplications of a verifier's
+// check (B) as ONE chain of doublings (round 4) -- B_i^v (B_{i-1}^-1)^{k_E,i} in the reference's multiplicative notation, the
+// caller hands in y = -B_shift (a negation is free on a curve).  Fixed windows of wbits bits for both scalars, two per-lane
+// tables in scratch: max(ebits, fbits) doublings + ceil(ebits / w) + ceil(fbits / w) additions + 2 (2^w - 2) for the tables,
+// against twice the doublings of two k_ec_mulvar launches.
+template <int S>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_mulvar2(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e,
+                                                      int ewords, int ebits, const u32* __restrict__ y, const u32* __restrict__ f,
+                                                      int fwords, size_t fstride, int fbits, int wbits, size_t n, ECDev E,
+                                                      u32* __restrict__ tab) {
+    constexpr int ROW = ECfg<S>::ROW;
+    const size_t ntiles = (n + BLOCK - 1) / BLOCK;
+    const int tsize = 1 << wbits;
+    u32* tx = tab + ((size_t)blockIdx.x * BLOCK + threadIdx.x) * (size_t)(2 * tsize) * ROW;
+    u32* ty = tx + (size_t)tsize * ROW;
+    const int bits = ebits > fbits ? ebits : fbits;
+    const int nwin = (bits + wbits - 1) / wbits;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        size_t el = t * BLOCK + threadIdx.x;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        const u32* fp = f + ec * fstride;
+        Pt<S> A;
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {          // the two tables: k * x and k * y, k < 2^w (entry 0: infinity)
+            u32* mytab = which ? ty : tx;
+            Pt<S> P;
+            pt_load<S>(P, (which ? y : x) + ec * ROW);
+            pt_set_inf<S>(A, E);
+            pt_store<S>(mytab, A);
+            pt_store<S>(mytab + ROW, P);
+            A = P;
+#pragma unroll 1
+            for (int k = 2; k < tsize; ++k) {
+                pt_add<S>(A, A, P, E);
+                pt_store<S>(mytab + (size_t)k * ROW, A);
+            }
+        }
+        pt_set_inf<S>(A, E);
+#pragma unroll 1
+        for (int wi = nwin - 1; wi >= 0; --wi) {
+#pragma unroll 1
+            for (int s = 0; s < wbits; ++s) pt_dbl<S>(A, A, E);      // (infinity stays infinity: the first window costs nothing real)
+            const u32 de = wi * wbits < ebits ? exp_digit(e, ewords, wi * wbits, wbits) : 0u;
+            const u32 df = wi * wbits < fbits ? exp_digit(fp, fwords, wi * wbits, wbits) : 0u;
+            Pt<S> T;
+            if (de) {                                                // (wave-uniform: e is shared)
+                pt_load<S>(T, tx + (size_t)de * ROW);
+                pt_add<S>(A, A, T, E);
+            }
+            pt_load<S>(T, ty + (size_t)df * ROW);                    // entry 0 is the identity: no branch per lane
+            pt_add<S>(A, A, T, E);
+        }
+        if (live) pt_store<S>(out + el * ROW, A);
+    }
+}
+
 // sq[j] = 2^j * base, j < count: the doubling chain of a fixed-base table, one lane (count ~ 256-400 doublings)
 // (launch bounds: without them the compiler budgets registers for 1024 threads per block and the point doubling spills --
 // the chain then took 27 us per doubling instead of 5)

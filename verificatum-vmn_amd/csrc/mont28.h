@@ -51,7 +51,7 @@ template <int S> __device__ __forceinline__ void mont_row_asm_first(u64 (&P)[S],
 template <int S> __device__ __forceinline__ void mont_row_asm_next(u64 (&P)[S], const u32 (&a)[S], u32 b, const u32 (&n)[S], u32 n0inv);
 // Squaring rows (see the generator): rows are grouped in blocks of SQR_BLK; a row multiplies only the
 // columns from its block's first column on, later blocks with the doubled limb.
-constexpr int SQR_BLK = 8;
+constexpr int SQR_BLK = 4;
 template <int S> __device__ __forceinline__ void mont_sqr_row_asm_first(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
 template <int S, int J0> __device__ __forceinline__ void mont_sqr_row_asm(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
 // LPE = 2 or 4 lanes per element (see the generator): L limbs per lane; lowmask = all ones on lane 0 of the

@@ -1728,14 +1728,16 @@ extern "C" int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t 
     vmn_group* g = x->grp;
     vmn_ctx* ctx = LANE(g->ctx);
     VMN_ENTER(ctx);
-    if (g->P.ec) {
-        set_error("vmn_garray_exp2: modular groups only");
-        return VMN_ERR_UNSUPPORTED;
-    }
     if (fbits <= 0 || fbits > g->Q.nbits) fbits = g->Q.nbits;
     const size_t n = x->n;
     int ewords = (int)((ebytes + 3) / 4);
     Big e = hostbig::from_be(e_be, ebytes, ewords);
+    if (g->P.ec) {                                       // scalars act modulo the group order
+        const vmn_modulus& q = g->Q;
+        std::vector<uint8_t> be((size_t)q.NW * 4);
+        num64::to_be(q.hm64->reduce(e_be, ebytes), be.data(), be.size());
+        e = hostbig::from_be(be.data(), be.size(), q.NW);
+    }
     const int ebits = std::max(1, hostbig::bit_length(e));
     ewords = (ebits + 31) / 32;
     vmn_garray* r = nullptr;
@@ -1749,7 +1751,26 @@ extern "C" int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t 
     if (rc == VMN_OK) rc = h2d(ctx, ew.p, e.data(), ewords * sizeof(uint32_t));
     if (rc == VMN_OK) rc = fw.alloc(n * (size_t)g->Q.NW * sizeof(uint32_t));
     if (rc == VMN_OK) rc = to_words(ctx, g->Q, f->d, n, fw.as<uint32_t>());
-    if (rc == VMN_OK) {
+    if (rc == VMN_OK && g->P.ec) {
+        // curves (round 4): one chain of doublings for both scalar multiplications, k_ec_mulvar2
+        const vmn_modulus& m = g->P;
+        const int wbits = 4;
+        const unsigned grid = std::min<unsigned>(grid_for(n), (unsigned)(ctx->num_cus * 2));
+        const size_t tab_bytes = (size_t)grid * BLOCK * ((size_t)2 << wbits) * elem_words(m) * sizeof(uint32_t);
+        rc = ensure_scratch(ctx, tab_bytes);
+        if (rc == VMN_OK) {
+            const int nw1 = (ebits + wbits - 1) / wbits, nw2 = (fbits + wbits - 1) / wbits;
+            note_work(ctx, m, (double)n * (EC_DBL * std::max(ebits, fbits) + EC_ADD * (nw1 + nw2 + 2 * ((1 << wbits) - 2))));
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_)                                                                                                              \
+    if (m.ec->S == S_)                                                                                                          \
+        rc = launch_light(ctx, "modpow", k_ec_mulvar2<S_>, grid, r->d, (const uint32_t*)x->d, (const uint32_t*)ew.as<uint32_t>(), \
+                          ewords, ebits, (const uint32_t*)y->d, (const uint32_t*)fw.as<uint32_t>(), g->Q.NW, (size_t)g->Q.NW,     \
+                          fbits, wbits, n, ecdev(m.ec), reinterpret_cast<uint32_t*>(ctx->scratch));
+            VMN_FOR_CURVES(X)
+#undef X
+        }
+    } else if (rc == VMN_OK) {
         const vmn_modulus& m = geom(ctx, g->P, n);
         const int wbits = std::min(pick_window(std::max(ebits, fbits)), 5);       // two tables per lane
         const unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));

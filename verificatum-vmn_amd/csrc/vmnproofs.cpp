@@ -907,10 +907,12 @@ struct ProofBase {
     // (arrays that do not fill the device twice over are latency-bound: the inversion's scans and its host round trip cost
     // more than the squarings they save, and the paired launch below does better -- profiles/r03_pair_sweep.txt;
     // VMN_COMBINED_MIN moves the threshold -- the tests run the combined form at their sizes with it)
+    // Curves (round 4): the same with a negation for the inverse (free) and k_ec_mulvar2's one chain of doublings for the two
+    // scalar multiplications -- from the size on where the second lane no longer hides one of them behind the other.
     bool combined_form_pays() const {
         const char* env = getenv("VMN_COMBINED_MIN");
-        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (size_t)131073;
-        return !G.ec && N >= min_n;
+        const size_t min_n = env ? (size_t)strtoull(env, nullptr, 10) : (G.ec ? (size_t)32769 : (size_t)131073);
+        return N >= min_n;
     }
     int bridging_combined(const Bytes& g, const Bytes& prev, const vmn_garray* B, const vmn_garray* Bp, const vmn_rarray* k_B,
                           const vmn_rarray* k_E, int kE_bits, GA& left, GA& right, int* done) {
