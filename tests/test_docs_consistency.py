@@ -16,7 +16,7 @@ def _load(path, name):
 
 def test_design_tables_are_those_of_the_committed_bench_line():
     dt = _load(os.path.join(ROOT, "tools", "design_tables.py"), "design_tables")
-    text = dt.render(os.path.join(ROOT, "profiles", "r03_bench_v10.json"))
+    text = dt.render(dt.DEFAULT)
     s = open(os.path.join(ROOT, "DESIGN.md")).read()
     block = s[s.index(dt.BEGIN) + len(dt.BEGIN):s.index(dt.END)].strip()
     assert block == text.strip(), "DESIGN.md §6 is stale: run python3 tools/design_tables.py"

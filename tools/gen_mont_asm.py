@@ -24,7 +24,7 @@ import sys
 
 
 P0REG = 2   # column 0 is pinned to v[2:3]: inline asm cannot name the low half of a 64-bit operand
-SQR_BLK = 4  # rows per block of the squaring schedule
+SQR_BLK = 1  # rows per block of the squaring schedule
 FILL_FROM_BLOCK = int(__import__("os").environ.get("VMN_ROW_FILL", "0"))
 LEAD = int(__import__("os").environ.get("VMN_ROW_LEAD", "3"))   # products issued ahead of the reduction (see _row)
 

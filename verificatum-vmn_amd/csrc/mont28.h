@@ -50,8 +50,10 @@ struct ModulusDev {
 template <int S> __device__ __forceinline__ void mont_row_asm_first(u64 (&P)[S], const u32 (&a)[S], u32 b, const u32 (&n)[S], u32 n0inv);
 template <int S> __device__ __forceinline__ void mont_row_asm_next(u64 (&P)[S], const u32 (&a)[S], u32 b, const u32 (&n)[S], u32 n0inv);
 // Squaring rows (see the generator): rows are grouped in blocks of SQR_BLK; a row multiplies only the
-// columns from its block's first column on, later blocks with the doubled limb.
-constexpr int SQR_BLK = 4;
+// columns from its block's first column on, later blocks with the doubled limb.  Round 4: blocks of ONE row (the fully
+// triangular schedule) -- rounds 1-3 used blocks of 8, whose 64 in-block products per 8 rows where the triangle needs 36
+// were 3 % of a squaring: 706.3 -> 696.1 ms on the headline, measured back to back (profiles/r04_sqr_block_sweep.txt).
+constexpr int SQR_BLK = 1;
 template <int S> __device__ __forceinline__ void mont_sqr_row_asm_first(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
 template <int S, int J0> __device__ __forceinline__ void mont_sqr_row_asm(u64 (&P)[S], const u32 (&a)[S], u32 b, u32 b2, const u32 (&n)[S], u32 n0inv);
 // LPE = 2 or 4 lanes per element (see the generator): L limbs per lane; lowmask = all ones on lane 0 of the
@@ -83,7 +85,7 @@ __device__ __forceinline__ void mont_mul_columns(u64 (&T)[S], const u32 (&a)[S],
 }
 
 // T = a * a / R mod N with the symmetric cross products formed once: the rows of block J0 skip the
-// columns before J0 (22 % fewer multiply-adds than the general product at S = 74).  a_lds holds a copy
+// columns before J0 (25 % fewer multiply-adds than the general product at S = 74).  a_lds holds a copy
 // of a (the row's own limb needs a dynamic index).
 template <int S, int J0>
 __device__ __forceinline__ void mont_sqr_blocks(u64 (&T)[S], const u32 (&a)[S], const u32* a_lds, int bstride,
@@ -175,7 +177,7 @@ __device__ __forceinline__ void mont_mul_columns_lanes(u64 (&T)[L], const u32 (&
 
 // Multi-lane squaring: T = a^2 / R mod N with every cross product formed once.  The rows whose multiplier limb belongs
 // to share u (rows uL .. uL + L - 1) run the block pattern of their LOCAL index on every lane (gen_mont_asm.py,
-// gen_pair_sqr): per lane LPE * (L^2 / 2 + 4 L) products instead of LPE * L^2.  a_lds holds a copy of a.
+// gen_pair_sqr): per lane LPE * (L^2 / 2 + L SQR_BLK / 2) products instead of LPE * L^2.  a_lds holds a copy of a.
 // LIM = the share's number of rows (L, or what is left of ROWS for the last share of a wide geometry: the limbs above
 // are zero, so are all the products the skipped rows would have formed).
 template <int L, int LPE, int ROWS, int LIM, int J0>
