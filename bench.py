@@ -281,14 +281,20 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 2, wid
         for a in (T, Mx, M, YT):
             a.free()
     runs = []
-    for step in range(steps):
-        H = Hs[step]
+    fam_instr = None
+    for step in range(steps + 1):
+        # The LAST pass is the instrumented one: the library's per-launch accounting (two HIP events per launch, read back
+        # by timing_report) is what the roofline breakdown comes from -- and costs ~10-20 us per launch, which at 350 launches
+        # and 10^4 ciphertexts is a fifth of the proof.  It runs on the generators of the first pass, after the timed passes,
+        # and its wall clock is reported as `instrumented_pass_ms`, never as the leg's figure.
+        instrumented = step == steps
+        H = Hs[0] if instrumented else Hs[step]
         # pi, alpha, the seed of the batching vector, gamma / delta / phi (width of them), v; the N-sized draws (s, r,
         # epsilon, b, beta) are expanded on the device from 32-byte seeds (vmn_random_source.array_seed)
         tape = ReplayWithDeviceArrays(rnd, [("permutation", n), ("ring_element",), ("int_array", 1, 256),
                                             ("ring_element",), ("ring_element",)] + [("ring_element",)] * width + [("int_array", 1, NV)])
         ctx.timing_reset()
-        ctx.timing_enable(True)
+        ctx.timing_enable(instrumented)
         gc.collect()        # release the previous pass's arrays into the pool before the clock starts
         sync()
         t0 = time.perf_counter()
@@ -322,13 +328,14 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 2, wid
         sync()
         t3 = time.perf_counter()
         ctx.timing_enable(False)
-        fam = ctx.timing_report()
-        runs.append({"kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
-                     "kernel_launches": sum(v[0] for v in fam.values()),
-                     "reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
-                     "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok), "roofline": leg_roofline(fam, (t3 - t0) * 1e3),
-                     # size of the Fiat-Shamir proof: u, commitment, reply as byte trees (p(N) of the reference's analysis)
-                     "proof_bytes": prover.u.byteTreeSize() + com.native.byteTreeSize() + rep.native.byteTreeSize()})
+        cur = {"reencrypt_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "verify_ms": (t3 - t2) * 1e3,
+               "total_ms": (t3 - t0) * 1e3, "accepted": bool(ok),
+               # size of the Fiat-Shamir proof: u, commitment, reply as byte trees (p(N) of the reference's analysis)
+               "proof_bytes": prover.u.byteTreeSize() + com.native.byteTreeSize() + rep.native.byteTreeSize()}
+        if instrumented:
+            fam_instr = (ctx.timing_report(), cur)
+        else:
+            runs.append(cur)
         for a in WP + S:
             a.free()
         com = rep = None                                   # the native messages own B, B', k_B, k_E
@@ -337,9 +344,15 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 2, wid
     out = dict(min(runs, key=lambda r: abs(r["total_ms"] - mean_of(runs, "total_ms"))))     # the pass nearest the mean carries the detail
     for key in ("reencrypt_ms", "prove_ms", "verify_ms", "total_ms"):
         out[key] = mean_of(runs, key)
+    fam, instr = fam_instr
+    out["kernel_ms_by_family"] = {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}
+    out["kernel_launches"] = sum(v[0] for v in fam.values())
+    out["roofline"] = leg_roofline(fam, out["total_ms"])          # the work of a pass against the MEAN wall clock of the timed passes
+    out["instrumented_pass_ms"] = instr["total_ms"]
+    out["accepted"] = all(r["accepted"] for r in runs) and instr["accepted"]
     out["passes_total_ms"] = [round(r["total_ms"], 2) for r in runs]
-    out["statistic"] = f"mean of {steps} passes, each on fresh generators h (the h_0 table is built inside the pass)"
-    out["accepted"] = all(r["accepted"] for r in runs)
+    out["statistic"] = (f"mean of {steps} passes, each on fresh generators h (the h_0 table is built inside the pass), per-launch event "
+                        "accounting OFF; the roofline breakdown comes from one more, instrumented pass (instrumented_pass_ms)")
     out["ciphertexts_per_s"] = n / (out["total_ms"] / 1e3)
     out["n"] = n
     out["width"] = width
@@ -514,7 +527,7 @@ def mix_prove_e2e(entry, vmn, ctx, grp, n: int, seed: int, sync):
     return out
 
 
-def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072):
+def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072, instrumented: bool = False):
     """BASELINE.json configs[2]: ElGamal ciphertexts over the 3072-bit ModPGroup (RFC 3526 group 15), width 1:
     offline  = permutation commitment (A4) + proof of a shuffle of commitments (A2, prove + verify)
     online   = re-encryption (A0) + commitment-consistent proof of a shuffle (A3, prove + verify, plain form).
@@ -544,7 +557,7 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072):
                                          ("int_array", 1, 256), ("ring_element",), ("ring_element",),   # e seed, alpha, beta (s, eps: device)
                                          ("int_array", 1, NV)])
     ctx.timing_reset()
-    ctx.timing_enable(True)
+    ctx.timing_enable(instrumented)          # (per-launch event accounting only in the extra, instrumented pass: see mix_prove)
     gc.collect()            # release the previous pass's arrays into the pool before the clock starts
     sync()
     t0 = time.perf_counter()
@@ -604,10 +617,10 @@ def mix_ccpos(entry, vmn, ctx, n: int, seed: int, sync, bits: int = 3072):
             # SURVEY.md §8d canonical BUDGET: 1090 M(96) per ciphertext online (M(96) = 18528 MAC; K2 at 384 products)
             "canonical_budget_TMACs_online_survey_8d": 1090 * 18528 * n / online / 1e12,      # NOT a roofline fraction: see `roofline`
             "roofline": leg_roofline(fam, (t4 - t0) * 1e3),          # offline + online: the counters cover the whole pass
-            "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+            "_fam": fam, "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
-def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width: int = 3):
+def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width: int = 3, instrumented: bool = False):
     """BASELINE.json configs[4] on one GPU: ElGamal ciphertexts over ECqPGroup P-256 (the reference's default group),
     width 3 (a ciphertext = 6 points): offline = permutation commitment; online = re-encryption (A0) +
     commitment-consistent proof of a shuffle (A3, prove + verify).  Point kernels: csrc/ec_kernels.h."""
@@ -637,7 +650,7 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
            [("int_array", 1, NV)]
     tape = ReplayWithDeviceArrays(bulk, plan)
     ctx.timing_reset()
-    ctx.timing_enable(True)
+    ctx.timing_enable(instrumented)          # (see mix_prove)
     gc.collect()            # release the previous pass's arrays into the pool before the clock starts
     sync()
     t0 = time.perf_counter()
@@ -679,15 +692,22 @@ def mix_ec(entry, vmn, ctx, n: int, seed: int, sync, curve: str = "P-256", width
             "ciphertexts_per_s_online": n / online,
             "setup": setup, **pre,
             "roofline": leg_roofline(fam, (t4 - t0) * 1e3),
-            "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
+            "_fam": fam, "kernel_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}}
 
 
-def mean_pass(runs, n: int, keys, rate_key: str, rate_name: str) -> dict:
+def mean_pass(runs, n: int, keys, rate_key: str, rate_name: str, instrumented: dict = None, fam=None) -> dict:
     """Fold the passes of a leg whose every pass is a cold start (own group, own tables): the MEAN of the timed keys, all
-    passes listed, the pass nearest the mean carrying the per-family detail, and the one-shot figure (mean set-up + mean)."""
+    passes listed, and the one-shot figure (mean set-up + mean).  The per-family breakdown and the roofline's work counts come
+    from `instrumented`, one more pass run with the library's per-launch event accounting on (its own wall clock is reported
+    as instrumented_pass_ms, not used): the work of a pass against the mean wall clock of the timed passes."""
     out = dict(min(runs, key=lambda r: abs(r[rate_key] - mean_of(runs, rate_key))))
     for k in keys:
         out[k] = mean_of(runs, k)
+    if instrumented is not None:
+        out["kernel_ms_by_family"] = instrumented["kernel_ms_by_family"]
+        out["roofline"] = leg_roofline(instrumented["_fam"], out["total_ms"])
+        out["instrumented_pass_ms"] = instrumented[rate_key]
+    out.pop("_fam", None)
     out[f"passes_{rate_key}"] = [round(r[rate_key], 2) for r in runs]
     out["passes_setup_ms"] = [round(r["setup"]["setup_ms"], 2) for r in runs]
     out["statistic"] = f"mean of {len(runs)} passes, each from a cold group (tables rebuilt)"
@@ -1587,15 +1607,16 @@ def main() -> None:
     def leg_ccpos():
         ctx.timing_reset()
         runs = [mix_ccpos(entry, vmn, ctx, args.ccpos_n, 4242 + k, barrier) for k in range(2)]
+        instr = mix_ccpos(entry, vmn, ctx, args.ccpos_n, 4242, barrier, instrumented=True)
         result["mix_ccpos_3072"] = mean_pass(runs, args.ccpos_n, ("offline_ms", "reencrypt_ms", "ccpos_prove_ms", "ccpos_verify_ms", "online_ms", "total_ms"),
-                                             "online_ms", "ciphertexts_per_s_online")
+                                             "online_ms", "ciphertexts_per_s_online", instr)
 
     def leg_ec():
         ctx.timing_reset()
         runs = [mix_ec(entry, vmn, ctx, args.ec_n, 555 + k, barrier) for k in range(2)]
+        instr = mix_ec(entry, vmn, ctx, args.ec_n, 555, barrier, instrumented=True)
         result["mix_ec_p256"] = mean_pass(runs, args.ec_n, ("offline_ms", "reencrypt_ms", "ccpos_prove_ms", "ccpos_verify_ms", "online_ms", "total_ms"),
-                                          "online_ms", "ciphertexts_per_s_online")
-        result["mix_ec_p256"]["passes_kernel_ms"] = [r["kernel_ms_by_family"] for r in runs]
+                                          "online_ms", "ciphertexts_per_s_online", instr)
 
     def leg_small():
         # BASELINE.json configs[0]'s size (the reference's demo: 10^4 ciphertexts, 2048 bits, width 1): below ~4 x 10^4
