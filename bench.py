@@ -70,7 +70,7 @@ def leg_roofline(fam: dict, wall_ms: float) -> dict:
             "frac_canonical_kernel_time": frac(canon, kernel_ms),
             "units": "frac: v_mad_u64_u32 executed (28-bit limbs); frac_canonical: the same products at SURVEY.md §8d's "
                      "M(s) = 2 s^2 + s on 32-bit limbs (the headline's unit)",
-            "by_family": by, "profiles": "profiles/r04_pmc_*.json (rocprofv3 --pmc passes of the dominant kernels)"}
+            "by_family": by, "profiles": "profiles/r04_pmc_kernels.json (rocprofv3 --pmc passes of the dominant kernels)"}
 
 
 def source_fingerprint(names=("mont28.h", "modp_kernels.h", "gen/mont_rows.inc")) -> str:
@@ -1314,6 +1314,8 @@ def main() -> None:
     ap.add_argument("--decrypt-elements", dest="dec_n", type=int, default=1_000_000,
                     help="ciphertexts of the verifiable-decryption leg (k = 3, threshold 2; 0 = skip; single GPU only)")
     ap.add_argument("--no-e2e", dest="no_e2e", action="store_true", help="skip the end-to-end pass of the mix + prove leg (profiling runs)")
+    ap.add_argument("--no-shapes", dest="no_shapes", action="store_true",
+                    help="skip modexp_by_shape (counter runs: the headline kernel must be the only k_modpow launch of the run)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = --elements / --mix-elements PER GPU (BASELINE configs[1] on every GPU), strong = in TOTAL "
                          "(north_star's 1M-ciphertext shuffle split over the GPUs); the mix legs always report both")
@@ -1463,7 +1465,7 @@ def main() -> None:
     valu_busy = None
     pmc_instr = None
     n_launch = n
-    pmc_file = "profiles/r03_pmc_kernels.json"
+    pmc_file = "profiles/r04_pmc_kernels.json"
     pmc_note = None
     try:
         with open(os.path.join(ROOT, pmc_file)) as f:
@@ -1667,7 +1669,7 @@ def main() -> None:
         """A leg that reports a one-shot figure starts from a group without cached tables."""
         return vmn.ModPGroup(ctx, p, q, g, nbytes=nbytes)
 
-    if args.n >= 10000 and not distributed:
+    if args.n >= 10000 and not distributed and not args.no_shapes:
         X.free()
         E.free()
         guarded("modexp_by_shape", leg_shapes)

@@ -27,6 +27,6 @@ def test_pmc_summary_belongs_to_the_kernels_in_the_tree():
     null and says why) -- but said out loud."""
     import warnings
     bench = _load(os.path.join(ROOT, "bench.py"), "bench_for_fingerprint")
-    pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")))
+    pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_kernels.json")))
     if pm["family_fingerprints"]["modp"] != bench.source_fingerprint():
-        warnings.warn("profiles/r03_pmc_kernels.json was measured on another build of the headline kernel: rerun tools/profile_pmc.sh")
+        warnings.warn("profiles/r04_pmc_kernels.json was measured on another build of the headline kernel: rerun tools/profile_pmc.sh")

@@ -15,11 +15,11 @@
 #        then: python3 tools/summarize_pmc.py gpurun_out/pmc_<tag> <N> profiles/<tag>_pmc_kernels.json
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_${1:-r03}
+OUT=gpurun_out/pmc_${1:-r04}
 N=${2:-262144}
 mkdir -p $OUT
 python3 __graft_entry__.py > $OUT/build.log 2>&1 || { echo "build failed"; tail -5 $OUT/build.log; exit 1; }
-CMD_A="python3 bench.py --steps 1 --warmup 1 --elements $N --mix-elements 0 --ccpos-elements 0 --ec-elements 0 --decrypt-elements 0 --skip-cpu"
+CMD_A="python3 bench.py --steps 1 --warmup 1 --elements $N --mix-elements 0 --ccpos-elements 0 --ec-elements 0 --decrypt-elements 0 --skip-cpu --no-shapes"
 CMD_B="python3 bench.py --steps 1 --warmup 0 --elements 2048 --mix-elements $N --ccpos-elements $N --ec-elements $N --decrypt-elements $N --skip-cpu --no-e2e"
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
 run() {   # run <dir> <command...>

@@ -282,6 +282,54 @@ static const size_t POOL_LIMIT = [] {
 }();
 
 static size_t block_class_of(vmn_ctx* ctx, const void* p, size_t fallback, bool forget);
+// ---- the table arena of a context (vmnhip_internal.h): dropped table blocks are kept for the next table ----------------
+static size_t table_arena_limit() {
+    static const size_t v = [] {
+        const char* env = getenv("VMN_TABLE_ARENA_BYTES");
+        return env && *env ? (size_t)strtoull(env, nullptr, 10) : (size_t)48 << 30;
+    }();
+    return v;
+}
+// the caller has made sure that no queued work still reads the block
+static void table_arena_put(vmn_ctx* lane, void* p, size_t bytes) {
+    if (!p) return;
+    vmn_ctx* root = lane->parent ? lane->parent : lane;
+    std::lock_guard<std::mutex> guard(root->table_arena_mu);
+    if (bytes > table_arena_limit()) {
+        (void)hipFree(p);
+        return;
+    }
+    root->table_arena.emplace_back(p, bytes);
+    root->table_arena_bytes += bytes;
+    while (root->table_arena_bytes > table_arena_limit() && !root->table_arena.empty()) {      // oldest first
+        (void)hipFree(root->table_arena.front().first);
+        root->table_arena_bytes -= root->table_arena.front().second;
+        root->table_arena.erase(root->table_arena.begin());
+    }
+}
+// the smallest kept block that holds `bytes` without wasting more than half of itself; nullptr when there is none
+static void* table_arena_take(vmn_ctx* lane, size_t bytes) {
+    vmn_ctx* root = lane->parent ? lane->parent : lane;
+    std::lock_guard<std::mutex> guard(root->table_arena_mu);
+    size_t best = root->table_arena.size();
+    for (size_t i = 0; i < root->table_arena.size(); ++i) {
+        const size_t have = root->table_arena[i].second;
+        if (have >= bytes && have <= 2 * bytes && (best == root->table_arena.size() || have < root->table_arena[best].second)) best = i;
+    }
+    if (best == root->table_arena.size()) return nullptr;
+    void* p = root->table_arena[best].first;
+    root->table_arena_bytes -= root->table_arena[best].second;
+    root->table_arena.erase(root->table_arena.begin() + (long)best);
+    return p;
+}
+static void table_arena_release(vmn_ctx* lane) {
+    vmn_ctx* root = lane->parent ? lane->parent : lane;
+    std::lock_guard<std::mutex> guard(root->table_arena_mu);
+    for (auto& b : root->table_arena) (void)hipFree(b.first);
+    root->table_arena.clear();
+    root->table_arena_bytes = 0;
+}
+
 static void pool_release_all(vmn_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool) {
@@ -447,6 +495,7 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
         (void)hipEventDestroy(r.stop);
     }
     pool_release_all(ctx);
+    if (!ctx->parent) table_arena_release(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -783,7 +832,7 @@ extern "C" void vmn_group_destroy(vmn_group* grp) {
     (void)hipStreamSynchronize(grp->ctx->stream);
     if (grp->ctx->helper) (void)hipStreamSynchronize(grp->ctx->helper->stream);
     for (auto& kv : grp->fixed) {
-        if (kv.second.d_tab) (void)hipFree(kv.second.d_tab);
+        table_arena_put(grp->ctx, kv.second.d_tab, kv.second.bytes);      // (both streams have drained: nothing reads them any more)
         if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
     }
     if (grp->curve) {
@@ -3077,11 +3126,15 @@ static void fixed_drop(vmn_group* g, std::map<std::string, vmn_group::FixedTable
     (void)hipStreamSynchronize(g->ctx->stream);                    // kernels reading the table may still be queued, on either lane
     if (g->ctx->helper) (void)hipStreamSynchronize(g->ctx->helper->stream);
     if (it->second.ready) (void)hipEventDestroy(it->second.ready);
-    if (it->second.d_tab) (void)hipFree(it->second.d_tab);
+    table_arena_put(g->ctx, it->second.d_tab, it->second.bytes);
     g->fixed_bytes -= it->second.bytes;
     g->fixed.erase(it);
 }
 static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
+    if (void* kept = table_arena_take(g->ctx, bytes)) {              // a block of a dropped table: no trip to the driver
+        *out = static_cast<uint32_t*>(kept);
+        return VMN_OK;
+    }
     for (;;) {
         bool over = g->fixed_bytes + bytes > fixed_cache_limit();
         hipError_t e = over && !g->fixed.empty() ? hipErrorOutOfMemory : hipMalloc(reinterpret_cast<void**>(out), bytes);
@@ -3090,6 +3143,7 @@ static int fixed_alloc(vmn_group* g, size_t bytes, uint32_t** out) {
         if (g->fixed.empty()) {
             if (over && hipMalloc(reinterpret_cast<void**>(out), bytes) == hipSuccess) return VMN_OK;   // one table larger than the bound
             (void)hipGetLastError();
+            table_arena_release(g->ctx);                                      // kept table blocks and
             for (vmn_ctx* c : {g->ctx, g->ctx->helper}) {                     // the cached array blocks go before the call fails
                 if (!c) continue;
                 std::lock_guard<std::recursive_mutex> guard__(c->mu);

@@ -67,6 +67,14 @@ struct vmn_ctx {
     bool marked = false;                  // helper lane: a mark has been recorded
     std::mutex order_mu;                  // helper lane: guards order_event / marked (both threads touch them)
     std::recursive_mutex mu;              // serialises the entry points of this lane (pool, scratch, flags and the stream are shared)
+    // Main lane: blocks of fixed-base tables that were dropped (a group closed, a table evicted or regrown), kept for the next
+    // table instead of going back to the driver.  A hipMalloc of gigabytes that FOLLOWS a hipFree of gigabytes was measured
+    // at 0.6-3 s on this machine (profiles/r04_alloc_latency.txt: 3.1 s for 34 GB; the bench's end-to-end leg met 1.1 s
+    // when it opened its group right after the previous leg had closed its own) while a first hipMalloc of 17 GB takes
+    // 0.3 ms -- so the blocks stay here, bounded by VMN_TABLE_ARENA_BYTES (default 48 GB).
+    std::vector<std::pair<void*, size_t>> table_arena;
+    size_t table_arena_bytes = 0;
+    std::mutex table_arena_mu;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
