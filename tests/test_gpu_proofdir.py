@@ -126,3 +126,115 @@ def test_vmnv_vectors_tool_prints_the_reference_format(entry, tmp_path):
     assert "PoS.k_E" not in text                      # N-sized vectors only with --arrays
     assert "accepted" in text
     assert json.load(open(os.path.join(nizkp, "params.json")))["vbitlenro"] == 256
+
+
+def test_precomputed_shuffle_directory_posc_keep_list_ccpos(entry, vmn, gpu_ctx, tmp_path):
+    """BASELINE configs[2] / [4]'s path through the reference's files: `vmn -precomp` for N_0 ciphertexts (PermutationCommitment01.bt,
+    PoSCCommitment01.bt, PoSCReply01.bt), then N < N_0 ciphertexts arrive (KeepList01.bt, Ciphertexts01.bt, CCPoSCommitment01.bt,
+    CCPoSReply01.bt); the verifier walks MixNetElGamalVerifyFiatShamirSession.java:1395-1500.  Width 2.  The seeds and challenges
+    the C++ path derives equal the Python restatement's from the same files, and the oracle's verifiers accept the files."""
+    import mirror
+    mods = mirror.load(entry, ("proofdir", "randomsource", "fiatshamir", "native"))
+    pd, rs, fs, nat = (mods[k] for k in ("proofdir", "randomsource", "fiatshamir", "native"))
+    grpd, _ = load_golden(512)
+    p, q, g = grpd["p"], grpd["q"], grpd["g"]
+    n_max, n, width = 30, 21, 2
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    params = _params(p, q, g, 512)
+    params["width"] = width
+    tape = rs.InsecureShaRandomSource(b"proofdir-cc", q)
+    y = pow(g, tape.ring_element(), p)
+    pkey = [g] * width + [y] * width
+    enc = [tape.ring_array(n) for _ in range(width)]
+    msg = [tape.ring_array(n) for _ in range(width)]
+    w = [pyref.exp_fixed(g, enc[c], p) for c in range(width)] + \
+        [pyref.mul(pyref.exp_fixed(g, msg[c], p), pyref.exp_fixed(y, enc[c], p), p) for c in range(width)]
+    W = [G.toElementArray(c) for c in w]
+    nizkp = str(tmp_path / "nizkp")
+    pd.write_inputs(nizkp, G, params, pkey, W)
+    prover_rand = rs.InsecureShaRandomSource(b"proofdir-cc-prover", q)
+    pi, R, U, H = pd.write_precomputation(nizkp, 1, G, params, n_max, prover_rand)
+    WP = pd.write_committed_shuffle(nizkp, 1, G, params, pkey, W, prover_rand, pi, R, U, H)
+    tv = {}
+    assert pd.verify_precomputed_shuffle(nizkp, 1, G, params, pkey, n_max, tv)
+
+    # ---- the same files through the Python restatement
+    rho = pd.global_prefix(params)
+    h = pyref_prg.modp_generators(pyref_prg.random_oracle(rho + fs.leaf(b"generators"), 256), n_max, p, q, 100)
+    assert H.toInts() == h
+    u_bt = open(pd.pc_file(nizkp, 1), "rb").read()
+    u, _ = _leaves(u_bt, G.elem_bytes)
+    s1 = pyref_prg.random_oracle(rho + b"\x00\x00\x00\x00\x03" + fs.leaf(G.enc_el(g)) + G.toElementArray(h).toByteTree() + u_bt, 256)
+    assert tv["PoSC.s"] == s1.hex()
+    com_bt = open(pd.poscc_file(nizkp, 1), "rb").read()
+    v1 = int.from_bytes(pyref_prg.random_oracle(rho + b"\x00\x00\x00\x00\x02" + fs.leaf(s1) + com_bt, 256), "big")
+    assert tv["PoSC.v"] == format(v1, "x")
+    val = lambda x: x.toInts() if hasattr(x, "toInts") else x
+    com = nat.Message.fromByteTree(G, com_bt, nat.PoSCBasicTW._com_kinds, [n_max, 1, n_max, 1, 1])
+    rep = nat.Message.fromByteTree(G, open(pd.poscr_file(nizkp, 1), "rb").read(), nat.PoSCBasicTW._rep_kinds, [1, n_max, 1, 1, n_max])
+    com_o = {k: val(com.item(i)) for i, k in enumerate(("B", "Ap", "Bp", "Cp", "Dp"))}
+    for k in ("Ap", "Cp", "Dp"):
+        com_o[k] = com_o[k][0]
+    rep_o = {k: val(rep.item(i)) for i, k in enumerate(("k_A", "k_B", "k_C", "k_D", "k_E"))}
+    for k in ("k_A", "k_C", "k_D"):
+        rep_o[k] = rep_o[k][0]
+    ov = P.PoSC(p, q, 256, 256, 100)
+    ov.setInstance(g, h, u)
+    ov.setBatchVector(pyref_prg.random_integers(s1, n_max, 256))
+    ov.setCommitment(com_o)
+    assert ov.verify(rep_o, v1)
+    assert (tv["PoSC.A"], tv["PoSC.C"], tv["PoSC.D"]) == tuple(format(x, "x") for x in (ov.A, ov.C, ov.D))
+    # the keep list and the CCPoS seed
+    kl = open(pd.kl_file(nizkp, 1), "rb").read()
+    keep = [b == 1 for b in kl[5:]]
+    assert len(keep) == n_max and sum(keep) == n
+    u_s = [x for x, k in zip(u, keep) if k]
+    l0, l1 = open(pd.l_file(nizkp, 0), "rb").read(), open(pd.l_file(nizkp, 1), "rb").read()
+    inst = b"\x00\x00\x00\x00\x06" + fs.leaf(G.enc_el(g)) + G.toElementArray(h[:n]).toByteTree() + G.toElementArray(u_s).toByteTree() + \
+        fs.element_tree(G, pkey) + l0 + l1
+    s2 = pyref_prg.random_oracle(rho + inst, 256)
+    assert tv["CCPoS.s"] == s2.hex()
+    cc_bt = open(pd.ccposc_file(nizkp, 1), "rb").read()
+    v2 = int.from_bytes(pyref_prg.random_oracle(rho + b"\x00\x00\x00\x00\x02" + fs.leaf(s2) + cc_bt, 256), "big")
+    assert tv["CCPoS.v"] == format(v2, "x")
+    cc = nat.Message.fromByteTree(G, cc_bt, nat.CCPoSBasicW._com_kinds, [1, 2 * width])
+    cr = nat.Message.fromByteTree(G, open(pd.ccposr_file(nizkp, 1), "rb").read(), nat.CCPoSBasicW._rep_kinds, [1, width, n])
+    K = P.ModPAdapter(p, q)
+    oc = P.GCCPoS(K, 256, 256, 100)
+    oc.setInstance(g, h[:n], u_s, pkey, w, [c.toInts() for c in WP])
+    oc.setBatchVector(pyref_prg.random_integers(s2, n, 256))
+    oc.setCommitment({"Ap": val(cc.item(0))[0], "Bp": val(cc.item(1))})
+    oc.computeAB()
+    assert oc.verify({"k_A": val(cr.item(0))[0], "k_B": val(cr.item(1)), "k_E": val(cr.item(2))}, v2)
+    assert tv["CCPoS.A"] == format(oc.A, "x") and tv["CCPoS.B"] == "(" + ", ".join(format(x, "x") for x in oc.B) + ")"
+
+    # ---- tampering: a keep list with the wrong number of flags, a flipped reply byte
+    good = open(pd.kl_file(nizkp, 1), "rb").read()
+    bad = bytearray(good)
+    i = 5 + keep.index(False)
+    bad[i] = 1
+    open(pd.kl_file(nizkp, 1), "wb").write(bytes(bad))
+    assert not pd.verify_precomputed_shuffle(nizkp, 1, G, params, pkey, n_max)
+    open(pd.kl_file(nizkp, 1), "wb").write(good)
+    path = pd.ccposr_file(nizkp, 1)
+    good = open(path, "rb").read()
+    bad = bytearray(good)
+    bad[-1] ^= 1
+    open(path, "wb").write(bytes(bad))
+    assert not pd.verify_precomputed_shuffle(nizkp, 1, G, params, pkey, n_max)
+    open(path, "wb").write(good)
+    assert pd.verify_precomputed_shuffle(nizkp, 1, G, params, pkey, n_max)
+
+
+def test_vmnv_vectors_tool_on_a_precomputed_shuffle(entry, tmp_path):
+    nizkp = str(tmp_path / "demo_cc")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vmnv_vectors.py"), "--demo", nizkp, "-n", "25", "--bits", "2048",
+                          "--precomputed", "32"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    for name in ("der.rho", "PoSC.s", "PoSC.v", "CCPoS.s", "CCPoS.v"):
+        assert f"\nTEST VECTOR\n{name} - " in text, name
+    assert "accepted" in text
+    for name in ("PermutationCommitment01.bt", "PoSCCommitment01.bt", "PoSCReply01.bt", "KeepList01.bt", "CCPoSCommitment01.bt",
+                 "CCPoSReply01.bt", "Ciphertexts01.bt"):
+        assert os.path.getsize(os.path.join(nizkp, "proofs", name)) > 0

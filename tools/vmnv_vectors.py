@@ -27,8 +27,17 @@ DESCRIPTIONS = {                      # MixNetElGamalVerifyFiatShamirTool.java:8
     "PoS.Ap": "PoS. Commitment components.", "PoS.Bp": "PoS. Commitment components.", "PoS.Cp": "PoS. Commitment components.",
     "PoS.Dp": "PoS. Commitment components.", "PoS.Fp": "PoS. Commitment components.", "PoS.k_A": "PoS. Reply components.",
     "PoS.k_B": "PoS. Reply components.", "PoS.k_C": "PoS. Reply components.", "PoS.k_D": "PoS. Reply components.",
-    "PoS.k_E": "PoS. Reply components.", "PoS.k_F": "PoS. Reply components."}
-ORDER = ["der.rho", "bas.h", "PoS.s", "PoS.A", "PoS.F", "PoS.B", "PoS.Ap", "PoS.Bp", "PoS.Cp", "PoS.Dp", "PoS.Fp", "PoS.v", "PoS.C",
+    "PoS.k_E": "PoS. Reply components.", "PoS.k_F": "PoS. Reply components.",
+    "PoSC.s": "PoSC. Seed to derive batching vector in hexadecimal notation.",
+    "PoSC.v": "PoSC. Integer challenge in hexadecimal notation.",
+    "CCPoS.s": "CCPoS. Seed to derive batching vector in hexadecimal notation.",
+    "CCPoS.v": "CCPoS. Integer challenge in hexadecimal notation.",
+    # not registered by the reference (private fields of its classes): printed for diffing two builds of THIS code
+    "PoSC.A": "[not in the reference] PoSC. Batched permutation commitment.", "PoSC.C": "[not in the reference] PoSC. Derived intermediate values.",
+    "PoSC.D": "[not in the reference] PoSC. Derived intermediate values.", "CCPoS.A": "[not in the reference] CCPoS. Batched permutation commitment.",
+    "CCPoS.B": "[not in the reference] CCPoS. Batched input ciphertexts."}
+ORDER = ["der.rho", "bas.h", "PoSC.s", "PoSC.v", "PoSC.A", "PoSC.C", "PoSC.D", "CCPoS.s", "CCPoS.A", "CCPoS.B", "CCPoS.v",
+         "PoS.s", "PoS.A", "PoS.F", "PoS.B", "PoS.Ap", "PoS.Bp", "PoS.Cp", "PoS.Dp", "PoS.Fp", "PoS.v", "PoS.C",
          "PoS.D", "PoS.k_A", "PoS.k_B", "PoS.k_C", "PoS.k_D", "PoS.k_E", "PoS.k_F"]
 
 
@@ -52,6 +61,9 @@ def main():
     ap.add_argument("--arrays", action="store_true", help="also the N-sized vectors (bas.h, PoS.B, PoS.Bp, PoS.k_B, PoS.k_E)")
     ap.add_argument("--demo", action="store_true", help="write the directory first: synthetic list, C++ prover")
     ap.add_argument("-n", type=int, default=100)
+    ap.add_argument("--precomputed", type=int, default=0, metavar="N_0",
+                    help="the directory holds a PRECOMPUTED shuffle for N_0 ciphertexts (PoSC + keep list + CCPoS files) instead of a PoS; "
+                         "with --demo: write one (N_0 >= n)")
     ap.add_argument("--bits", type=int, default=2048)
     args = ap.parse_args()
     import json
@@ -72,8 +84,14 @@ def main():
         T = grp.ringArray(rnd.ring_array(args.n))
         M = grp.exp(g, grp.ringArray(rnd.ring_array(args.n)))
         W = [grp.exp(g, T), M.mul(grp.exp(y, T))]
+        params["N_0"] = args.precomputed
         proofdir.write_inputs(args.nizkp, grp, params, pkey, W)
-        proofdir.write_shuffle(args.nizkp, args.l, grp, params, pkey, W, randomsource.SecureRandomSource(q))
+        prover = randomsource.SecureRandomSource(q)
+        if args.precomputed:
+            pi, R, U, H = proofdir.write_precomputation(args.nizkp, args.l, grp, params, args.precomputed, prover)
+            proofdir.write_committed_shuffle(args.nizkp, args.l, grp, params, pkey, W, prover, pi, R, U, H)
+        else:
+            proofdir.write_shuffle(args.nizkp, args.l, grp, params, pkey, W, prover)
         print(f"wrote {args.nizkp}: {args.n} ciphertexts, party {args.l}", file=sys.stderr)
     with open(os.path.join(args.nizkp, proofdir.PARAMS)) as f:
         params = json.load(f)
@@ -84,12 +102,19 @@ def main():
     flat = [leaf for part in tree for leaf in (part if isinstance(part, list) else [part])]
     pkey = [grp.dec_el(b) for b in flat]
     vectors = {}
-    verdict = proofdir.verify_shuffle(args.nizkp, args.l, grp, params, pkey, vectors, with_arrays=args.arrays)
+    n0 = args.precomputed or int(params.get("N_0", 0))
+    if n0:
+        verdict = proofdir.verify_precomputed_shuffle(args.nizkp, args.l, grp, params, pkey, n0, vectors)
+        if args.t == "der,PoS":
+            args.t = "der,PoSC,CCPoS"
+    else:
+        verdict = proofdir.verify_shuffle(args.nizkp, args.l, grp, params, pkey, vectors, with_arrays=args.arrays)
     wanted = set(args.t.split(","))
     for name in ORDER:
         if name in vectors and selected(name, wanted):
             print(f"\nTEST VECTOR\n{name} - {DESCRIPTIONS[name]}\n{vectors[name]}")
-    print(f"\nverdict of party {args.l}: {'accepted' if verdict else 'REJECTED'}   verdicts(A,B,C,D,F) = {vectors.get('verdicts(A,B,C,D,F)')}")
+    print(f"\nverdict of party {args.l}: {'accepted' if verdict else 'REJECTED'}" +
+          (f"   verdicts(A,B,C,D,F) = {vectors['verdicts(A,B,C,D,F)']}" if "verdicts(A,B,C,D,F)" in vectors else ""))
     sys.exit(0 if verdict else 1)
 
 

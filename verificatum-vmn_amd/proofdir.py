@@ -292,3 +292,244 @@ def verify_shuffle(nizkp: str, l: int, grp, params: dict, pkey: Sequence, vector
     for a in W + WP + [H, U]:
         a.free()
     return bool(verdict)
+
+
+# =============================================================================================================================
+# The precomputed shuffle: permutation commitment + PoSC offline, shrink + re-encryption + CCPoS online (BASELINE configs[2], [4])
+#     <nizkp>/proofs/PermutationCommitment%02d.bt   u for N_0 ciphertexts     mixnet/PermutationCommitment.java:228-230, 364
+#     <nizkp>/proofs/PoSCCommitment%02d.bt, PoSCReply%02d.bt                  hvzk/PoSCTW.java:221-235
+#     <nizkp>/proofs/KeepList%02d.bt                the positions kept for N  mixnet/PermutationCommitment.java:240-242, 413, 455
+#     <nizkp>/proofs/CCPoSCommitment%02d.bt, CCPoSReply%02d.bt                hvzk/CCPoSW.java:274-288
+#     <nizkp>/proofs/Ciphertexts%02d.bt             the output list
+# Prover: PermutationCommitment.generate :251-366 + PoSCTW.prove :73-134; shrink :390-471; ShufflerElGamalSession committed
+# shuffle :789-792 + CCPoSW.prove :75-158.  Verifier: readPermutationCommitment :618-636, verifyPoSC :652-703, shrinkPermComm
+# :714-746, verifyCCPoS :757-830 of MixNetElGamalVerifyFiatShamirSession.java.
+# =============================================================================================================================
+def poscc_file(nizkp, l):
+    return _p(nizkp, "proofs", "PoSCCommitment%02d.bt" % l)
+
+
+def poscr_file(nizkp, l):
+    return _p(nizkp, "proofs", "PoSCReply%02d.bt" % l)
+
+
+def kl_file(nizkp, l):
+    return _p(nizkp, "proofs", "KeepList%02d.bt" % l)
+
+
+def ccposc_file(nizkp, l):
+    return _p(nizkp, "proofs", "CCPoSCommitment%02d.bt" % l)
+
+
+def ccposr_file(nizkp, l):
+    return _p(nizkp, "proofs", "CCPoSReply%02d.bt" % l)
+
+
+def _booleans_tree(flags) -> bytes:
+    """A boolean array as a byte tree: one leaf, one byte per flag (ByteTree.booleanArrayToByteTree is VCR code, not in the
+    reference tree: [NOT-IN-REF], restated from the verifier specification)."""
+    return fs.leaf(bytes(1 if f else 0 for f in flags))
+
+
+def _read_booleans(path: str, n: int):
+    with open(path, "rb") as f:
+        buf = f.read()
+    if len(buf) != 5 + n or buf[0] != 1 or int.from_bytes(buf[1:5], "big") != n or any(b > 1 for b in buf[5:]):
+        return None
+    return [b == 1 for b in buf[5:]]
+
+
+def _seed_and_challenge(chal, hn, head: bytes, parts, commit_fn, NV):
+    """The two random-oracle calls around a commitment: seed = RO(rho || node(parts...)); v = RO(rho || node(leaf(seed),
+    commitment)) as a positive integer.  `parts`: byte strings / file paths hashed in order after `head`."""
+    bits = 8 * hashlib.new(hn).digest_size
+    d = chal.start(bits)
+    d.update(head)
+    for part in parts:
+        if isinstance(part, str):
+            with open(part, "rb") as f:
+                d.update(f.read())
+        else:
+            d.update(part)
+    seed = chal.finish(d, bits)
+    com_bt = commit_fn(seed)
+    v = int.from_bytes(chal.challenge(fs._hdr(0, 2) + fs.leaf(seed) + com_bt, NV), "big")
+    return seed, com_bt, v
+
+
+def write_precomputation(nizkp: str, l: int, grp, params: dict, n_max: int, rand, H: Optional[PGroupElementArray] = None):
+    """`vmn -precomp` of party l for N_0 = n_max ciphertexts: the permutation commitment u and its proof of a shuffle of
+    commitments.  Returns the prover's secrets for the online phase: (pi, R, U, H)."""
+    os.makedirs(_p(nizkp, "proofs"), exist_ok=True)
+    NV, NE, NR = int(params["vbitlenro"]), int(params["ebitlenro"]), int(params["rbitlen"])
+    hn = _hashname(params)
+    rho = global_prefix(params)
+    chal = fs.Challenger(rho, hn)
+    if H is None:
+        H = derive_generators(grp, params, rho, n_max)
+    g = grp.g
+    pi = rand.permutation(n_max)
+    R = native.random_ring_array_native(grp, rand, n_max, NR)
+    U = native.permutation_commitment_native(grp, g, H, R, pi)
+    u_bt = U.toByteTree()
+    with open(pc_file(nizkp, l), "wb") as f:                                     # PermutationCommitment.java:364
+        f.write(u_bt)
+    P = native.PoSCBasicTW(grp, NV, NE, NR, rand=rand)                           # PoSCTW.prove :73-134
+    P.setInstance(g, H, U, R, pi)
+    box = {}
+
+    def commit(seed):
+        P.setBatchVectorSeed(seed)
+        box["com"] = P.commit()
+        bt = box["com"].native.toByteTree()
+        with open(poscc_file(nizkp, l), "wb") as f:
+            f.write(bt)
+        return bt
+    _, _, v = _seed_and_challenge(chal, hn, fs._hdr(0, 3) + fs.leaf(grp.enc_el(g)), [H.toByteTree(), u_bt], commit, NV)
+    rep = P.reply(v)
+    with open(poscr_file(nizkp, l), "wb") as f:
+        f.write(rep.native.toByteTree())
+    box.clear()
+    rep = None
+    P.free()
+    return pi, R, U, H
+
+
+def write_committed_shuffle(nizkp: str, l: int, grp, params: dict, pkey: Sequence, W: Sequence[PGroupElementArray], rand,
+                            pi, R, U, H) -> List[PGroupElementArray]:
+    """The online phase for the N <= N_0 ciphertexts that arrived (W = the list in l_file(nizkp, l - 1)): shrink
+    (PermutationCommitment.java:390-471, keep list to its file), re-encrypt and permute (ShufflerElGamalSession.java:789-792),
+    CCPoSW.prove (:75-158).  Returns w'."""
+    NV, NE, NR = int(params["vbitlenro"]), int(params["ebitlenro"]), int(params["rbitlen"])
+    n, width = W[0].size(), len(W) // 2
+    hn = _hashname(params)
+    chal = fs.Challenger(global_prefix(params), hn)
+    g = grp.g
+    keep, pi_s = native.permutation_shrink_native(pi, n)
+    with open(kl_file(nizkp, l), "wb") as f:
+        f.write(_booleans_tree(keep))
+    U_s, R_s, H_s = U.extract(keep), R.copyOfRange(0, n), H.copyOfRange(0, n)
+    S = [native.random_ring_array_native(grp, rand, n, NR) for _ in range(width)]
+    WP = native.reencrypt_native(grp, pkey, W, S, pi_s)
+    write_ciphertexts(l_file(nizkp, l), WP)
+    P = native.CCPoSBasicW(grp, NV, NE, NR, rand=rand)
+    P.setInstance(g, H_s, U_s, pkey, W, WP, R_s, pi_s, S)
+    box = {}
+
+    def commit(seed):
+        P.setBatchVectorSeed(seed)
+        box["com"] = P.commit()
+        bt = box["com"].native.toByteTree()
+        with open(ccposc_file(nizkp, l), "wb") as f:
+            f.write(bt)
+        return bt
+    _, _, v = _seed_and_challenge(chal, hn, fs._hdr(0, 6) + fs.leaf(grp.enc_el(g)),
+                                  [H_s.toByteTree(), U_s.toByteTree(), fs.element_tree(grp, pkey), l_file(nizkp, l - 1), l_file(nizkp, l)],
+                                  commit, NV)
+    rep = P.reply(v)
+    with open(ccposr_file(nizkp, l), "wb") as f:
+        f.write(rep.native.toByteTree())
+    box.clear()
+    rep = None
+    P.free()
+    for a in S + [U_s, R_s, H_s]:
+        a.free()
+    return WP
+
+
+def verify_precomputed_shuffle(nizkp: str, l: int, grp, params: dict, pkey: Sequence, n_max: int,
+                               vectors: Optional[Dict[str, str]] = None) -> bool:
+    """The standalone verifier's path for a precomputed shuffle of party l (MixNetElGamalVerifyFiatShamirSession.java
+    :1395-1500): readPermutationCommitment(N_0), verifyPoSC, read the output, shrinkPermComm through the keep list, verifyCCPoS.
+    `vectors` receives der.rho, PoSC.s, PoSC.v, CCPoS.s, CCPoS.v (the names the reference registers, Tool.java:155-175) and the
+    verifiers' intermediates (PoSC.A/C/D, CCPoS.A, CCPoS.B: not printed by the reference; for diffing two builds of this code)."""
+    tv = vectors if vectors is not None else {}
+    NV, NE, NR = int(params["vbitlenro"]), int(params["ebitlenro"]), int(params["rbitlen"])
+    width = len(pkey) // 2
+    hn = _hashname(params)
+    rho = global_prefix(params)
+    tv["der.rho"] = rho.hex()
+    chal = fs.Challenger(rho, hn)
+    bits = 8 * hashlib.new(hn).digest_size
+    g = grp.g
+    H = derive_generators(grp, params, rho, n_max)
+    with open(pc_file(nizkp, l), "rb") as f:                                     # readPermutationCommitment :618-636
+        u_bt = f.read()
+    try:
+        U = grp.toElementArrayFromByteTree(u_bt, n_max)
+        if not U.isMember():
+            raise ValueError("u outside the group")
+    except (ValueError, native.VmnError):
+        return False
+    # ---- verifyPoSC :652-703
+    V = native.PoSCBasicTW(grp, NV, NE, NR)
+    V.setInstance(g, H, U)
+    seed = chal.challenge(fs._hdr(0, 3) + fs.leaf(grp.enc_el(g)) + H.toByteTree() + u_bt, bits)
+    tv["PoSC.s"] = seed.hex()
+    V.setBatchVectorSeed(seed)
+    with open(poscc_file(nizkp, l), "rb") as f:
+        com_bt = f.read()
+    com = native.Message.fromByteTree(grp, com_bt, native.PoSCBasicTW._com_kinds, [n_max, 1, n_max, 1, 1])
+    if com is None:
+        return False
+    V.setCommitment(com)
+    v = int.from_bytes(chal.challenge(fs._hdr(0, 2) + fs.leaf(seed) + com_bt, NV), "big")
+    tv["PoSC.v"] = format(v, "x")
+    V.setChallenge(v)
+    with open(poscr_file(nizkp, l), "rb") as f:
+        rep = native.Message.fromByteTree(grp, f.read(), native.PoSCBasicTW._rep_kinds, [1, n_max, 1, 1, n_max])
+    if rep is None:
+        return False
+    ok_posc = V.verify(rep)
+    tv["PoSC.A"], tv["PoSC.C"], tv["PoSC.D"] = _hex(V.getA()), _hex(V.getC()), _hex(V.getD())
+    com = rep = None
+    V.free()
+    if not ok_posc:            # (the reference then takes the generators for u and goes on; a harness stops with the verdict)
+        return False
+    # ---- the lists, the keep list, verifyCCPoS :757-830
+    W = read_ciphertexts(grp, l_file(nizkp, l - 1), width)
+    if W is None:
+        return False
+    n = W[0].size()
+    WP = read_ciphertexts(grp, l_file(nizkp, l), width, n)
+    if WP is None:
+        return False
+    keep = _read_booleans(kl_file(nizkp, l), n_max)
+    if keep is None or sum(keep) != n:                                           # shrinkPermComm :714-746 fails the party
+        return False
+    U_s, H_s = U.extract(keep), H.copyOfRange(0, n)
+    C = native.CCPoSBasicW(grp, NV, NE, NR)
+    C.setInstance(g, H_s, U_s, pkey, W, WP)
+    d = chal.start(bits)
+    d.update(fs._hdr(0, 6) + fs.leaf(grp.enc_el(g)))
+    d.update(H_s.toByteTree())
+    d.update(U_s.toByteTree())
+    d.update(fs.element_tree(grp, pkey))
+    for path in (l_file(nizkp, l - 1), l_file(nizkp, l)):
+        with open(path, "rb") as f:
+            d.update(f.read())
+    seed2 = chal.finish(d, bits)
+    tv["CCPoS.s"] = seed2.hex()
+    C.setBatchVectorSeed(seed2)
+    C.computeAB()
+    A, B = C.getAB()
+    tv["CCPoS.A"], tv["CCPoS.B"] = _hex(A), "(" + ", ".join(_hex(x) for x in B) + ")"
+    with open(ccposc_file(nizkp, l), "rb") as f:
+        com_bt = f.read()
+    com = native.Message.fromByteTree(grp, com_bt, native.CCPoSBasicW._com_kinds, [1, 2 * width])
+    if com is None:
+        return False
+    C.setCommitment(com)
+    v2 = int.from_bytes(chal.challenge(fs._hdr(0, 2) + fs.leaf(seed2) + com_bt, NV), "big")
+    tv["CCPoS.v"] = format(v2, "x")
+    C.setChallenge(v2)
+    with open(ccposr_file(nizkp, l), "rb") as f:
+        rep = native.Message.fromByteTree(grp, f.read(), native.CCPoSBasicW._rep_kinds, [1, width, n])
+    if rep is None:
+        return False
+    verdict = C.verify(rep)
+    com = rep = None
+    C.free()
+    for a in W + WP + [H, U, U_s, H_s]:
+        a.free()
+    return bool(verdict)
