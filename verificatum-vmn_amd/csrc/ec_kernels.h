@@ -135,8 +135,9 @@ __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 
 }
 // r = a^2 / R (mod p): row i multiplies only the limbs j >= i, the later ones by 2 a[i] -- each cross product a[i] a[j] is
 // formed once, doubled, in row min(i, j) (an earlier row than in f_mul, the same column; a column is complete when it is
-// reduced, in row i + j >= max(i, j)).  S (S + 1) / 2 + S^2 multiply-adds instead of 2 S^2.  Column bound: S doubled
-// products < 2^59 (the top limb of a lazy value may reach 2^30) + S reductions < 2^56: far below 2^64 for S <= 15.
+// reduced, in row i + j >= max(i, j)).  S (S + 1) / 2 + S^2 multiply-adds instead of 2 S^2.  Column bound: the operand may be
+// a carry-less sum (f_addl: limbs < 2^29), so a column holds at most S products < 2^58 (a doubled cross product counts twice)
+// + S reduction products < 2^56: < 2^62.8 for S <= 21.
 template <int S>
 __device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
     u64 P[S];
@@ -164,6 +165,28 @@ __device__ __forceinline__ void f_add(u32 (&r)[S], const u32 (&a)[S], const u32 
         r[j] = j == S - 1 ? c : (c & LIMB_MASK);      // the top limb keeps the excess (value stays < 2^(28 S))
         c = j == S - 1 ? 0 : (c >> LIMB_BITS);
     }
+}
+// r = a + b limb by limb, NO carries: the limbs of the sum reach 2^29 (2^29.6 for a sum of three).  Only for sums that are
+// consumed at once by a product (a column of f_mul / f_sqr holds S products of limbs: 10 x 2^(29 + 29) or 15 x 2^58 < 2^62
+// leaves room for the reduction rows), or as the SUBTRAHEND / minuend of f_sub (a signed carry chain in 32 bits: limbs below
+// 2^30 cannot overflow it).  Never stored, never compared, never the operand of f_small: one instruction per limb instead of three.
+template <int S>
+__device__ __forceinline__ void f_addl(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S]) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) r[j] = a[j] + b[j];
+}
+// A necessary condition for a = 0 mod p that costs four instructions, for a value with NORMALISED limbs (the result of
+// f_sub) below 2^28 p: then a = k p with k < 2^28, and for a prime that is -1 modulo 2^84 (limbs 0..2 all ones: P-256) the
+// limbs 1 and 2 of k p = k 2^84 (...) - k are all ones (k > 0) or zero (k = 0).  A random difference passes with probability
+// 2^-55; only then does the caller pay the canonical test (f_is_zero: the reduction half of a product).  Other primes: true.
+template <int S>
+__device__ __forceinline__ bool f_maybe_zero(const u32 (&a)[S]) {
+    using FP = FieldPrime<S>;
+    if constexpr (FP::known) {
+        if constexpr (FP::limb[0] == LIMB_MASK && FP::limb[1] == LIMB_MASK && FP::limb[2] == LIMB_MASK)
+            return (a[1] & a[2]) == LIMB_MASK || (a[1] | a[2]) == 0;
+    }
+    return true;
 }
 // r = a - b + 64p  (b must be < 64p);  BIG: r = a - b + 256p (b < 256p).
 // Bounds inside the point formulas (multiples of p): products < 2, small differences < 66, the two
@@ -396,12 +419,12 @@ __device__ __forceinline__ void pt_dbl(Pt<S>& R, const Pt<S>& P, const ECDev& E)
     f_sqr<S>(gamma, P.Y, E);
     f_mul<S>(beta, P.X, gamma, E);
     f_sub<S>(t1, P.X, delta, E);
-    f_add<S>(t2, P.X, delta);
+    f_addl<S>(t2, P.X, delta);
     f_mul<S>(t3, t1, t2, E);
     f_small<S, 3>(alpha, t3);                          // alpha = 3 (X - delta)(X + delta)
-    f_add<S>(t1, P.Y, P.Z);
+    f_addl<S>(t1, P.Y, P.Z);
     f_sqr<S>(t2, t1, E);
-    f_add<S>(t3, gamma, delta);
+    f_addl<S>(t3, gamma, delta);
     u32 Z3[S];
     f_sub<S>(Z3, t2, t3, E);                           // (Y + Z)^2 - gamma - delta
     f_sqr<S>(t1, alpha, E);
@@ -436,28 +459,28 @@ __device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q,
     f_mul<S>(S2, t1, Z1Z1, E);
     f_sub<S>(H, U2, U1, E);
     f_sub<S>(rr, S2, S1, E);
-    bool hz = f_is_zero<S>(H, E);
+    bool hz = f_maybe_zero<S>(H) && f_is_zero<S>(H, E);
     bool special = P.inf || Q.inf || hz;
     Pt<S> G;                                           // general-case result
     {
         u32 I[S], J[S], r[S], V[S];
-        f_add<S>(t1, H, H);
+        f_addl<S>(t1, H, H);
         f_sqr<S>(I, t1, E);                            // (2H)^2
         f_mul<S>(J, H, I, E);
-        f_add<S>(r, rr, rr);
+        f_addl<S>(r, rr, rr);
         f_mul<S>(V, U1, I, E);
         f_sqr<S>(t1, r, E);
-        f_add<S>(t2, V, V);
-        f_add<S>(t2, t2, J);
+        f_addl<S>(t2, V, V);
+        f_addl<S>(t2, t2, J);
         f_sub<S>(G.X, t1, t2, E);                      // r^2 - J - 2V
         f_sub<S, true>(t1, V, G.X, E);
         f_mul<S>(t2, r, t1, E);
         f_mul<S>(t1, S1, J, E);
-        f_add<S>(t1, t1, t1);
+        f_addl<S>(t1, t1, t1);
         f_sub<S>(G.Y, t2, t1, E);                      // r (V - X3) - 2 S1 J
-        f_add<S>(t1, P.Z, Q.Z);
+        f_addl<S>(t1, P.Z, Q.Z);
         f_sqr<S>(t2, t1, E);
-        f_add<S>(t1, Z1Z1, Z2Z2);
+        f_addl<S>(t1, Z1Z1, Z2Z2);
         f_sub<S>(t2, t2, t1, E);
         f_mul<S>(G.Z, t2, H, E);                       // ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
         G.inf = 0;
@@ -489,28 +512,28 @@ __device__ __forceinline__ void pt_madd(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q
     f_mul<S>(S2, Q.Y, t1, E);
     f_sub<S, true>(H, U2, P.X, E);
     f_sub<S, true>(t1, S2, P.Y, E);                    // S2 - Y1
-    bool hz = f_is_zero<S>(H, E);
+    bool hz = f_maybe_zero<S>(H) && f_is_zero<S>(H, E);
     bool special = P.inf || Q.inf || hz;
     Pt<S> G;
     {
         f_sqr<S>(HH, H, E);
         f_small<S, 4>(I, HH);
         f_mul<S>(J, H, I, E);
-        f_add<S>(r, t1, t1);
+        f_addl<S>(r, t1, t1);
         f_mul<S>(V, P.X, I, E);
         f_sqr<S>(t2, r, E);
         u32 t3[S];
-        f_add<S>(t3, V, V);
-        f_add<S>(t3, t3, J);
+        f_addl<S>(t3, V, V);
+        f_addl<S>(t3, t3, J);
         f_sub<S>(G.X, t2, t3, E);                      // r^2 - J - 2V
         f_sub<S, true>(t2, V, G.X, E);
         f_mul<S>(t3, r, t2, E);
         f_mul<S>(t2, P.Y, J, E);
-        f_add<S>(t2, t2, t2);
+        f_addl<S>(t2, t2, t2);
         f_sub<S>(G.Y, t3, t2, E);                      // r (V - X3) - 2 Y1 J
-        f_add<S>(t2, P.Z, H);
+        f_addl<S>(t2, P.Z, H);
         f_sqr<S>(t3, t2, E);
-        f_add<S>(t2, Z1Z1, HH);
+        f_addl<S>(t2, Z1Z1, HH);
         f_sub<S>(G.Z, t3, t2, E);                      // (Z1 + H)^2 - Z1Z1 - HH
         G.inf = 0;
     }
@@ -539,23 +562,23 @@ __device__ __forceinline__ void pt_mmadd(Pt<S>& R, const Pt<S>& P, const Pt<S>& 
     u32 H[S], HH[S], I[S], J[S], r[S], V[S], t1[S], t2[S], t3[S];
     f_sub<S, true>(H, Q.X, P.X, E);
     f_sub<S, true>(t1, Q.Y, P.Y, E);                   // Y2 - Y1
-    bool hz = f_is_zero<S>(H, E);
+    bool hz = f_maybe_zero<S>(H) && f_is_zero<S>(H, E);
     bool special = P.inf || Q.inf || hz;
     Pt<S> G;
     {
         f_sqr<S>(HH, H, E);
         f_small<S, 4>(I, HH);
         f_mul<S>(J, H, I, E);
-        f_add<S>(r, t1, t1);
+        f_addl<S>(r, t1, t1);
         f_mul<S>(V, P.X, I, E);
         f_sqr<S>(t2, r, E);
-        f_add<S>(t3, V, V);
-        f_add<S>(t3, t3, J);
+        f_addl<S>(t3, V, V);
+        f_addl<S>(t3, t3, J);
         f_sub<S>(G.X, t2, t3, E);                      // r^2 - J - 2V
         f_sub<S, true>(t2, V, G.X, E);
         f_mul<S>(t3, r, t2, E);
         f_mul<S>(t2, P.Y, J, E);
-        f_add<S>(t2, t2, t2);
+        f_addl<S>(t2, t2, t2);
         f_sub<S>(G.Y, t3, t2, E);                      // r (V - X3) - 2 Y1 J
         f_add<S>(G.Z, H, H);                           // 2 H
         G.inf = 0;
@@ -1077,13 +1100,16 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* _
             pt_mmadd<S>(A, A, B, E);
             ++k0;
         }
-    }
-    for (u32 k = k0; k < end; ++k) {
-        if constexpr (FIRST) {                         // the first level adds rows of the (normalised) input array
+        // (Running one row ahead of the addition -- the index and the row of k + 1 in flight while row k is added -- was
+        // measured and changes nothing, profiles/r04_ec_instruction_diet.txt: the other wave of the SIMD already hides the
+        // gather; the kernel is bound by the instructions it issues.)
+        for (u32 k = k0; k < end; ++k) {
             pt_load_normalised<S>(B, row(k));
             if (sorted[k] >> 31) f_neg<S>(B.Y, B.Y, E);
             pt_madd<S>(A, A, B, E);
-        } else {
+        }
+    } else {
+        for (u32 k = k0; k < end; ++k) {
             pt_load<S>(B, row(k));
             pt_add<S>(A, A, B, E);
         }
