@@ -9,7 +9,8 @@
 // 14 for P-384, in Montgomery form mod p): a field product is a fully unrolled CIOS of 2*S^2
 // v_mad_u64_u32 with lazily reduced operands — no LDS, no carries inside the product (same column
 // argument as mont28.h).  Field values are kept "lazy": limbs normalised to 28 bits, value allowed to be
-// a small multiple of p (products come out < 2p, sums add their bounds, a difference adds 64p);
+// a small multiple of p (products come out < 2p -- < 17p inside the point formulas of P-256, mont_row -- sums add their
+// bounds, a difference adds 64p);
 // Montgomery products accept operands up to 2^12 p, so no reduction is needed inside a point operation.
 //
 // Device row of a point: Jacobian (X, Y, Z), 3*FW words (FW = S rounded up to 4), the last padding word
@@ -38,6 +39,7 @@ struct ECDev {
     const u32* ts_c;   // z^Q for a fixed non-residue z, Montgomery form, S limbs
     u32 n0inv;         // -p^{-1} mod 2^28
     u32 p1p;           // p[1] + 1 (limb 1 of the prime, plus the carry fold of mont_row)
+    u32 c16;           // 16, as a run-time value: `hi * 16 + c` must stay ONE v_mad_u64_u32 (mont_row, wide digits)
     int pwords;        // words of pm2
 };
 
@@ -89,10 +91,42 @@ struct FieldPrime<15> {
                                      0xfffffffu, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x00fffffu, 0u};
 };
 // one reduction row of a CIOS product: P <- (P + m p) / 2^28 with m = -P[0] / p mod 2^28; the top column is left to the caller
+// WIDE rows (the point formulas over P-256): the quotient digit is the whole low WORD of column 0, x = P[0] mod 2^32, not its
+// low 28 bits -- any digit = -P[0] / p mod 2^28 clears the limb, and x is one (x p = -x mod 2^28).  With p[0] = 2^28 - 1,
+// P[0] + x p[0] = (P[0] - x) + x 2^28 = hi 2^32 + x 2^28 (hi = P[0] >> 32): its carry into column 1 is 16 hi + x, so the row is
+//     P[0] <- x (p[1] + 1) + (16 hi + P[1]),    P[j-1] <- x p[j] + P[j]
+// -- two multiply-adds and NOTHING else where the 28-bit digit pays a mask, a 64-bit shift and a 64-bit add: 20 instructions
+// fewer per product of ten limbs (of ~216).  The price: a digit below 2^32 instead of 2^28 adds up to 16 p to the result, so a
+// product leaves below 17 p, not 2 p (the bounds of the point formulas are stated for that: pt_dbl, pt_add, pt_madd), and a
+// column holds S operand products (< 2^58: one operand may be a carry-less sum) + NZ digit products (< 2^60, NZ = non-zero
+// limbs of p above limb 0) -- wide_digit_ok checks that this stays below 2^64: P-256 (6 of 9) yes, P-384 (13 of 14) no.
+// Everything that canonicalises, compares, inverts or exports keeps the exact rows (results < 2 p).
 template <int S>
+constexpr bool wide_digit_ok() {
+    using FP = FieldPrime<S>;
+    if constexpr (!FP::known) {
+        return false;
+    } else {
+        if (FP::limb[0] != LIMB_MASK || FP::limb[1] == 0) return false;
+        unsigned nz = 0;
+        for (int j = 1; j < S; ++j) nz += FP::limb[j] != 0;
+        // in units of 2^58: S + 4 nz, + 1 for the carries (16 hi < 2^36) and the column shifted in; 2^64 = 64 units
+        return (unsigned)S + 4u * nz + 1u < 64u;
+    }
+}
+template <int S, bool WIDE = false>
 __device__ __forceinline__ void mont_row(u64 (&P)[S], const ECDev& E) {
     using FP = FieldPrime<S>;
-    if constexpr (FP::known) {
+    if constexpr (WIDE) {
+        static_assert(wide_digit_ok<S>(), "wide quotient digits need p = -1 mod 2^28 and room in the columns");
+        const u32 x = (u32)P[0], hi = (u32)(P[0] >> 32);
+        P[0] = (u64)x * E.p1p + ((u64)hi * E.c16 + P[1]);  // (a literal 16 becomes shift + mask + 64-bit add)
+#pragma unroll
+        for (int j = 2; j < S; ++j) {
+            if (FP::limb[j] == 0) P[j - 1] = P[j];
+            else P[j - 1] = (u64)x * E.p[j] + P[j];
+        }
+    } else if constexpr (FP::known) {
         // The VALUES of the non-zero limbs still come from E.p (scalar registers), not from the table: with literal
         // constants the compiler "strength-reduces" m * 2^24 and m * 15 into shifts / 32-bit multiplies plus 64-bit adds --
         // two or three issue slots where one v_mad_u64_u32 does it (seen in the ISA; every VALU instruction costs the
@@ -118,7 +152,7 @@ __device__ __forceinline__ void mont_row(u64 (&P)[S], const ECDev& E) {
     }
 }
 // r = a * b / R  (mod p), result < 2p for operands with a*b < R*p
-template <int S>
+template <int S, bool WIDE = false>
 __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const ECDev& E) {
     u64 P[S];
 #pragma unroll
@@ -128,7 +162,7 @@ __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 
             if (i == 0 || j == S - 1) P[j] = (u64)a[j] * b[i];
             else P[j] = (u64)a[j] * b[i] + P[j];
         }
-        mont_row<S>(P, E);
+        mont_row<S, WIDE>(P, E);
     }
     P[S - 1] = 0;
     f_norm<S>(r, P);
@@ -138,7 +172,7 @@ __device__ __forceinline__ void f_mul(u32 (&r)[S], const u32 (&a)[S], const u32 
 // reduced, in row i + j >= max(i, j)).  S (S + 1) / 2 + S^2 multiply-adds instead of 2 S^2.  Column bound: the operand may be
 // a carry-less sum (f_addl: limbs < 2^29), so a column holds at most S products < 2^58 (a doubled cross product counts twice)
 // + S reduction products < 2^56: < 2^62.8 for S <= 21.
-template <int S>
+template <int S, bool WIDE = false>
 __device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDev& E) {
     u64 P[S];
 #pragma unroll
@@ -150,7 +184,7 @@ __device__ __forceinline__ void f_sqr(u32 (&r)[S], const u32 (&a)[S], const ECDe
             if (i == 0 || j == S - 1) P[j] = (u64)a[j] * mult;         // a fresh column (the top one is vacated by every shift)
             else P[j] = (u64)a[j] * mult + P[j];
         }
-        mont_row<S>(P, E);
+        mont_row<S, WIDE>(P, E);
     }
     P[S - 1] = 0;
     f_norm<S>(r, P);
@@ -189,9 +223,12 @@ __device__ __forceinline__ bool f_maybe_zero(const u32 (&a)[S]) {
     return true;
 }
 // r = a - b + 64p  (b must be < 64p);  BIG: r = a - b + 256p (b < 256p).
-// Bounds inside the point formulas (multiples of p): products < 2, small differences < 66, the two
-// differences with a difference as subtrahend (and the negation) use BIG and stay < 264; every product
-// then has operands whose bounds multiply to far less than 2^24 (the Montgomery limit R/p).
+// Bounds inside the point formulas (multiples of p; c = 2 for exact products, 17 for the wide-digit products of P-256,
+// mont_row): products < c, sums of up to three of them (every subtrahend of the 64p form) < 3c = 51 < 64, a coordinate
+// as it leaves a formula < c + 64 = 81, the differences with a coordinate as subtrahend (and the negation) use BIG and stay
+// < c + 256 = 273, a doubled one < 546, Z of the all-affine addition (2H) < 546; the largest operand pair is
+// (Z1 + Z2)^2 < 1200^2 = 2^20.5 -- every product has operands whose bounds multiply to less than 2^24 (the Montgomery limit
+// R / p).  pt_dbl multiplies two products by 8 before subtracting them in the 64p form: those two stay exact (< 2).
 template <int S, bool BIG = false>
 __device__ __forceinline__ void f_sub(u32 (&r)[S], const u32 (&a)[S], const u32 (&b)[S], const ECDev& E) {
     const u32* __restrict__ mp = BIG ? E.mp2 : E.mp;
@@ -414,27 +451,28 @@ __device__ __forceinline__ void pt_store(u32* __restrict__ row, const Pt<S>& P) 
 // dbl-2001-b (a = -3): 3M + 5S, valid for every input (infinity stays infinity through the flag)
 template <int S>
 __device__ __forceinline__ void pt_dbl(Pt<S>& R, const Pt<S>& P, const ECDev& E) {
+    constexpr bool W = wide_digit_ok<S>();             // products below 17 p instead of 2 p (mont_row)
     u32 delta[S], gamma[S], beta[S], alpha[S], t1[S], t2[S], t3[S];
-    f_sqr<S>(delta, P.Z, E);
-    f_sqr<S>(gamma, P.Y, E);
-    f_mul<S>(beta, P.X, gamma, E);
+    f_sqr<S, W>(delta, P.Z, E);
+    f_sqr<S, W>(gamma, P.Y, E);
+    f_mul<S, false>(beta, P.X, gamma, E);
     f_sub<S>(t1, P.X, delta, E);
     f_addl<S>(t2, P.X, delta);
-    f_mul<S>(t3, t1, t2, E);
+    f_mul<S, W>(t3, t1, t2, E);
     f_small<S, 3>(alpha, t3);                          // alpha = 3 (X - delta)(X + delta)
     f_addl<S>(t1, P.Y, P.Z);
-    f_sqr<S>(t2, t1, E);
+    f_sqr<S, W>(t2, t1, E);
     f_addl<S>(t3, gamma, delta);
     u32 Z3[S];
     f_sub<S>(Z3, t2, t3, E);                           // (Y + Z)^2 - gamma - delta
-    f_sqr<S>(t1, alpha, E);
+    f_sqr<S, W>(t1, alpha, E);
     f_small<S, 8>(t2, beta);
     u32 X3[S];
     f_sub<S>(X3, t1, t2, E);                           // alpha^2 - 8 beta
     f_small<S, 4>(t1, beta);
     f_sub<S, true>(t2, t1, X3, E);
-    f_mul<S>(t3, alpha, t2, E);
-    f_sqr<S>(t1, gamma, E);
+    f_mul<S, W>(t3, alpha, t2, E);
+    f_sqr<S, false>(t1, gamma, E);
     f_small<S, 8>(t2, t1);
     f_sub<S>(R.Y, t3, t2, E);                          // alpha (4 beta - X3) - 8 gamma^2
 #pragma unroll
@@ -448,15 +486,16 @@ __device__ __forceinline__ void pt_dbl(Pt<S>& R, const Pt<S>& P, const ECDev& E)
 // add-2007-bl: 11M + 5S; exceptional inputs handled exactly
 template <int S>
 __device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q, const ECDev& E) {
+    constexpr bool W = wide_digit_ok<S>();             // products below 17 p instead of 2 p (mont_row)
     u32 Z1Z1[S], Z2Z2[S], U1[S], U2[S], S1[S], S2[S], H[S], rr[S], t1[S], t2[S];
-    f_sqr<S>(Z1Z1, P.Z, E);
-    f_sqr<S>(Z2Z2, Q.Z, E);
-    f_mul<S>(U1, P.X, Z2Z2, E);
-    f_mul<S>(U2, Q.X, Z1Z1, E);
-    f_mul<S>(t1, P.Y, Q.Z, E);
-    f_mul<S>(S1, t1, Z2Z2, E);
-    f_mul<S>(t1, Q.Y, P.Z, E);
-    f_mul<S>(S2, t1, Z1Z1, E);
+    f_sqr<S, W>(Z1Z1, P.Z, E);
+    f_sqr<S, W>(Z2Z2, Q.Z, E);
+    f_mul<S, W>(U1, P.X, Z2Z2, E);
+    f_mul<S, W>(U2, Q.X, Z1Z1, E);
+    f_mul<S, W>(t1, P.Y, Q.Z, E);
+    f_mul<S, W>(S1, t1, Z2Z2, E);
+    f_mul<S, W>(t1, Q.Y, P.Z, E);
+    f_mul<S, W>(S2, t1, Z1Z1, E);
     f_sub<S>(H, U2, U1, E);
     f_sub<S>(rr, S2, S1, E);
     bool hz = f_maybe_zero<S>(H) && f_is_zero<S>(H, E);
@@ -465,24 +504,24 @@ __device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q,
     {
         u32 I[S], J[S], r[S], V[S];
         f_addl<S>(t1, H, H);
-        f_sqr<S>(I, t1, E);                            // (2H)^2
-        f_mul<S>(J, H, I, E);
+        f_sqr<S, W>(I, t1, E);                            // (2H)^2
+        f_mul<S, W>(J, H, I, E);
         f_addl<S>(r, rr, rr);
-        f_mul<S>(V, U1, I, E);
-        f_sqr<S>(t1, r, E);
+        f_mul<S, W>(V, U1, I, E);
+        f_sqr<S, W>(t1, r, E);
         f_addl<S>(t2, V, V);
         f_addl<S>(t2, t2, J);
         f_sub<S>(G.X, t1, t2, E);                      // r^2 - J - 2V
         f_sub<S, true>(t1, V, G.X, E);
-        f_mul<S>(t2, r, t1, E);
-        f_mul<S>(t1, S1, J, E);
+        f_mul<S, W>(t2, r, t1, E);
+        f_mul<S, W>(t1, S1, J, E);
         f_addl<S>(t1, t1, t1);
         f_sub<S>(G.Y, t2, t1, E);                      // r (V - X3) - 2 S1 J
         f_addl<S>(t1, P.Z, Q.Z);
-        f_sqr<S>(t2, t1, E);
+        f_sqr<S, W>(t2, t1, E);
         f_addl<S>(t1, Z1Z1, Z2Z2);
         f_sub<S>(t2, t2, t1, E);
-        f_mul<S>(G.Z, t2, H, E);                       // ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
+        f_mul<S, W>(G.Z, t2, H, E);                       // ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
         G.inf = 0;
     }
     if (special) {                                     // rare: wave-divergent
@@ -501,38 +540,39 @@ __device__ __forceinline__ void pt_add(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q,
 
 // madd-2007-bl: P (Jacobian) + Q with Q NORMALISED (Z = 1, or the infinity flag): 7M + 4S instead of 11M + 5S.  The rows of
 // a normalised array keep the three-coordinate layout (Z = the Montgomery one), so every other kernel reads them as they
-// are.  Bounds (multiples of p): X1, Y1, Z1 < 66 as they leave an addition or a doubling, so the differences with them as
-// subtrahend use the 256p form (< 258); the largest product is r * (V - X3) < 516 * 258 p^2, far below R p = 2^24 p^2.
+// are.  Bounds (multiples of p): X1, Y1, Z1 < 81 as they leave an addition or a doubling, so the differences with them as
+// subtrahend use the 256p form (< 273); the largest product is r * (V - X3) < 546 * 273 p^2, far below R p = 2^24 p^2.
 template <int S>
 __device__ __forceinline__ void pt_madd(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q, const ECDev& E) {
+    constexpr bool W = wide_digit_ok<S>();             // products below 17 p instead of 2 p (mont_row)
     u32 Z1Z1[S], U2[S], S2[S], H[S], HH[S], I[S], J[S], r[S], V[S], t1[S], t2[S];
-    f_sqr<S>(Z1Z1, P.Z, E);
-    f_mul<S>(U2, Q.X, Z1Z1, E);
-    f_mul<S>(t1, P.Z, Z1Z1, E);
-    f_mul<S>(S2, Q.Y, t1, E);
+    f_sqr<S, W>(Z1Z1, P.Z, E);
+    f_mul<S, W>(U2, Q.X, Z1Z1, E);
+    f_mul<S, W>(t1, P.Z, Z1Z1, E);
+    f_mul<S, W>(S2, Q.Y, t1, E);
     f_sub<S, true>(H, U2, P.X, E);
     f_sub<S, true>(t1, S2, P.Y, E);                    // S2 - Y1
     bool hz = f_maybe_zero<S>(H) && f_is_zero<S>(H, E);
     bool special = P.inf || Q.inf || hz;
     Pt<S> G;
     {
-        f_sqr<S>(HH, H, E);
+        f_sqr<S, W>(HH, H, E);
         f_small<S, 4>(I, HH);
-        f_mul<S>(J, H, I, E);
+        f_mul<S, W>(J, H, I, E);
         f_addl<S>(r, t1, t1);
-        f_mul<S>(V, P.X, I, E);
-        f_sqr<S>(t2, r, E);
+        f_mul<S, W>(V, P.X, I, E);
+        f_sqr<S, W>(t2, r, E);
         u32 t3[S];
         f_addl<S>(t3, V, V);
         f_addl<S>(t3, t3, J);
         f_sub<S>(G.X, t2, t3, E);                      // r^2 - J - 2V
         f_sub<S, true>(t2, V, G.X, E);
-        f_mul<S>(t3, r, t2, E);
-        f_mul<S>(t2, P.Y, J, E);
+        f_mul<S, W>(t3, r, t2, E);
+        f_mul<S, W>(t2, P.Y, J, E);
         f_addl<S>(t2, t2, t2);
         f_sub<S>(G.Y, t3, t2, E);                      // r (V - X3) - 2 Y1 J
         f_addl<S>(t2, P.Z, H);
-        f_sqr<S>(t3, t2, E);
+        f_sqr<S, W>(t3, t2, E);
         f_addl<S>(t2, Z1Z1, HH);
         f_sub<S>(G.Z, t3, t2, E);                      // (Z1 + H)^2 - Z1Z1 - HH
         G.inf = 0;
@@ -556,9 +596,11 @@ __device__ __forceinline__ void pt_madd(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q
 // mmadd-2007-bl: P + Q with BOTH operands normalised (Z = 1, or the infinity flag): 4M + 2S.  The first addition of every
 // chunk of the first bucket-tree level adds two rows of the normalised input arrays (round 4: one addition in seven of that
 // level at 6 field products instead of 11).  P.Z is not read.  Bounds: X, Y of a normalised row < 2 (a negated Y < 66), so
-// H, Y2 - Y1 in the 256p form < 258; Z3 = 2H < 516, inside what the next mixed addition accepts (operands up to 2^12 p).
+// H, Y2 - Y1 in the 256p form < 273 (wide-digit products: rows < 17); Z3 = 2H < 546, inside what the next mixed addition
+// accepts (operands up to 2^12 p).
 template <int S>
 __device__ __forceinline__ void pt_mmadd(Pt<S>& R, const Pt<S>& P, const Pt<S>& Q, const ECDev& E) {
+    constexpr bool W = wide_digit_ok<S>();
     u32 H[S], HH[S], I[S], J[S], r[S], V[S], t1[S], t2[S], t3[S];
     f_sub<S, true>(H, Q.X, P.X, E);
     f_sub<S, true>(t1, Q.Y, P.Y, E);                   // Y2 - Y1
@@ -566,18 +608,18 @@ __device__ __forceinline__ void pt_mmadd(Pt<S>& R, const Pt<S>& P, const Pt<S>& 
     bool special = P.inf || Q.inf || hz;
     Pt<S> G;
     {
-        f_sqr<S>(HH, H, E);
+        f_sqr<S, W>(HH, H, E);
         f_small<S, 4>(I, HH);
-        f_mul<S>(J, H, I, E);
+        f_mul<S, W>(J, H, I, E);
         f_addl<S>(r, t1, t1);
-        f_mul<S>(V, P.X, I, E);
-        f_sqr<S>(t2, r, E);
+        f_mul<S, W>(V, P.X, I, E);
+        f_sqr<S, W>(t2, r, E);
         f_addl<S>(t3, V, V);
         f_addl<S>(t3, t3, J);
         f_sub<S>(G.X, t2, t3, E);                      // r^2 - J - 2V
         f_sub<S, true>(t2, V, G.X, E);
-        f_mul<S>(t3, r, t2, E);
-        f_mul<S>(t2, P.Y, J, E);
+        f_mul<S, W>(t3, r, t2, E);
+        f_mul<S, W>(t2, P.Y, J, E);
         f_addl<S>(t2, t2, t2);
         f_sub<S>(G.Y, t3, t2, E);                      // r (V - X3) - 2 Y1 J
         f_add<S>(G.Z, H, H);                           // 2 H

@@ -902,6 +902,7 @@ static ECDev ecdev(const vmn_curve* c) {
     E.pp14 = c->d_pp14;
     E.n0inv = c->n0inv;
     E.p1p = c->p1p;
+    E.c16 = 16;
     E.pwords = c->NW;
     E.ts_s = c->ts_s;
     E.ts_ewords = c->ts_ewords;
