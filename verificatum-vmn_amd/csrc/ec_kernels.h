@@ -655,6 +655,142 @@ __device__ __forceinline__ void pt_mmadd(Pt<S>& R, const Pt<S>& P, const Pt<S>& 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Running sums in XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2).  A lane that adds a run of NORMALISED rows into
+// one sum -- a chunk of the first bucket level, the table rows of a fixed-base power -- pays Z1^2 and Z1^3 again in every
+// mixed Jacobian addition (1S + 1M of its 7M + 4S).  With ZZ and ZZZ carried along the mixed addition is madd-2008-s,
+// 8M + 2S and half the sums and differences; the sum goes back to a Jacobian row at the end of the run,
+// (X ZZ, Y ZZZ, ZZ): 2M once (ZZ^2 = (ZZ)^2 and ZZ^3 = ZZZ^2, so the row means the same point).  Only registers change: rows
+// in memory stay Jacobian.  Bounds as in pt_madd: X, Y < 81 (subtrahends of the 256p form), ZZ, ZZZ products.
+// The exceptional cases go through the Jacobian code (pt_dbl) and come back: rare and wave-divergent.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+struct PtX {
+    u32 X[S], Y[S], ZZ[S], ZZZ[S];
+    u32 inf;
+};
+template <int S>
+__device__ __forceinline__ void ptx_from_normalised(PtX<S>& A, const Pt<S>& P, const ECDev& E) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        A.X[j] = P.X[j];
+        A.Y[j] = P.Y[j];
+        A.ZZ[j] = E.one[j];
+        A.ZZZ[j] = E.one[j];
+    }
+    A.inf = P.inf;
+}
+template <int S>
+__device__ __forceinline__ void ptx_from_jacobian(PtX<S>& A, const Pt<S>& P, const ECDev& E) {
+    f_sqr<S>(A.ZZ, P.Z, E);
+    f_mul<S>(A.ZZZ, A.ZZ, P.Z, E);
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        A.X[j] = P.X[j];
+        A.Y[j] = P.Y[j];
+    }
+    A.inf = P.inf;
+}
+template <int S>
+__device__ __forceinline__ void ptx_to_jacobian(Pt<S>& R, const PtX<S>& A, const ECDev& E) {
+    if (A.inf) {
+        pt_set_inf<S>(R, E);
+    } else {
+        f_mul<S>(R.X, A.X, A.ZZ, E);
+        f_mul<S>(R.Y, A.Y, A.ZZZ, E);
+#pragma unroll
+        for (int j = 0; j < S; ++j) R.Z[j] = A.ZZ[j];
+        R.inf = 0;
+    }
+}
+// the tail both additions share: from Pd = x2' - X1, Rd = y2' - Y1 (256p form), X1, Y1 to X3, Y3, PP, PPP
+template <int S>
+__device__ __forceinline__ void ptx_tail(u32 (&X3)[S], u32 (&Y3)[S], u32 (&PP)[S], u32 (&PPP)[S], const u32 (&Pd)[S], const u32 (&Rd)[S],
+                                         const u32 (&X1)[S], const u32 (&Y1)[S], const ECDev& E) {
+    constexpr bool W = wide_digit_ok<S>();
+    u32 Qv[S], t1[S], t2[S], t3[S];
+    f_sqr<S, W>(PP, Pd, E);
+    f_mul<S, W>(PPP, Pd, PP, E);
+    f_mul<S, W>(Qv, X1, PP, E);
+    f_sqr<S, W>(t1, Rd, E);
+    f_addl<S>(t2, Qv, Qv);
+    f_addl<S>(t2, t2, PPP);                            // 2Q + PPP < 51
+    f_sub<S>(X3, t1, t2, E);                           // R^2 - PPP - 2Q
+    f_sub<S, true>(t1, Qv, X3, E);
+    f_mul<S, W>(t2, Rd, t1, E);
+    f_mul<S, W>(t3, Y1, PPP, E);
+    f_sub<S>(Y3, t2, t3, E);                           // R (Q - X3) - Y1 PPP
+}
+// A += Q, Q normalised (madd-2008-s)
+template <int S>
+__device__ __forceinline__ void ptx_madd(PtX<S>& A, const Pt<S>& Q, const ECDev& E) {
+    constexpr bool W = wide_digit_ok<S>();
+    u32 U2[S], S2[S], Pd[S], Rd[S], PP[S], PPP[S], X3[S], Y3[S];
+    f_mul<S, W>(U2, Q.X, A.ZZ, E);
+    f_mul<S, W>(S2, Q.Y, A.ZZZ, E);
+    f_sub<S, true>(Pd, U2, A.X, E);
+    f_sub<S, true>(Rd, S2, A.Y, E);
+    const bool hz = f_maybe_zero<S>(Pd) && f_is_zero<S>(Pd, E);
+    const bool special = A.inf || Q.inf || hz;
+    if (!special) {
+        ptx_tail<S>(X3, Y3, PP, PPP, Pd, Rd, A.X, A.Y, E);
+        f_mul<S, W>(A.ZZ, A.ZZ, PP, E);
+        f_mul<S, W>(A.ZZZ, A.ZZZ, PPP, E);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            A.X[j] = X3[j];
+            A.Y[j] = Y3[j];
+        }
+    } else if (A.inf) {                                // rare from here on
+        ptx_from_normalised<S>(A, Q, E);
+    } else if (Q.inf) {
+    } else if (f_is_zero<S>(Rd, E)) {                  // the same point: double the normalised one
+        Pt<S> D, G;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            D.X[j] = Q.X[j];
+            D.Y[j] = Q.Y[j];
+            D.Z[j] = E.one[j];
+        }
+        D.inf = 0;
+        pt_dbl<S>(G, D, E);
+        ptx_from_jacobian<S>(A, G, E);
+    } else {
+        A.inf = 1;                                     // opposite points
+    }
+}
+// A = P + Q, both normalised (mmadd-2008-s: ZZ3 = PP, ZZZ3 = PPP)
+template <int S>
+__device__ __forceinline__ void ptx_mmadd(PtX<S>& A, const Pt<S>& P, const Pt<S>& Q, const ECDev& E) {
+    u32 Pd[S], Rd[S];
+    f_sub<S, true>(Pd, Q.X, P.X, E);
+    f_sub<S, true>(Rd, Q.Y, P.Y, E);
+    const bool hz = f_maybe_zero<S>(Pd) && f_is_zero<S>(Pd, E);
+    const bool special = P.inf || Q.inf || hz;
+    if (!special) {
+        ptx_tail<S>(A.X, A.Y, A.ZZ, A.ZZZ, Pd, Rd, P.X, P.Y, E);
+        A.inf = 0;
+    } else if (P.inf) {
+        ptx_from_normalised<S>(A, Q, E);
+    } else if (Q.inf) {
+        ptx_from_normalised<S>(A, P, E);
+    } else if (f_is_zero<S>(Rd, E)) {
+        Pt<S> D, G;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            D.X[j] = P.X[j];
+            D.Y[j] = P.Y[j];
+            D.Z[j] = E.one[j];
+        }
+        D.inf = 0;
+        pt_dbl<S>(G, D, E);
+        ptx_from_jacobian<S>(A, G, E);
+    } else {
+        ptx_from_normalised<S>(A, P, E);               // (any finite coordinates: the flag is what counts)
+        A.inf = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernels (one point per lane; no LDS)
 // ---------------------------------------------------------------------------------------------
 // big-endian x || y (nbytes each; all 0xff = infinity) -> rows.  flags |= 1: coordinate >= p or point not on the
@@ -988,11 +1124,16 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_fixed_exp(u32* __re
     Pt<S> A, B;
     u32 d = exp_digit(ep, ewords, 0, w);
     pt_load<S>(A, T + (size_t)d * ROW);
+    if (nwin > 1) {                                    // the table is normalised when it is built: the sum runs in XYZZ registers
+        PtX<S> R;
+        ptx_from_normalised<S>(R, A, E);
 #pragma unroll 1
-    for (int k = 1; k < nwin; ++k) {
-        d = exp_digit(ep, ewords, k * w, w);
-        pt_load_normalised<S>(B, T + (((size_t)k << w) + d) * ROW);
-        pt_madd<S>(A, A, B, E);                        // the table is normalised when it is built
+        for (int k = 1; k < nwin; ++k) {
+            d = exp_digit(ep, ewords, k * w, w);
+            pt_load_normalised<S>(B, T + (((size_t)k << w) + d) * ROW);
+            ptx_madd<S>(R, B, E);
+        }
+        ptx_to_jacobian<S>(A, R, E);
     }
     pt_store<S>(out + el * ROW, A);
 }
@@ -1136,19 +1277,22 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* _
     u32 k0 = start + 1;
     if constexpr (FIRST) {
         if (sorted[start] >> 31) f_neg<S>(A.Y, A.Y, E);
-        if (k0 < end) {                                // the first addition of the chunk: both rows normalised (4M + 2S)
+        if (k0 < end) {
+            // the chunk's sum runs in XYZZ registers (ptx_madd: 8M + 2S per row); its first addition takes two normalised
+            // rows (4M + 2S), the Jacobian row it is stored as costs 2M at the end
+            PtX<S> R;
             pt_load_normalised<S>(B, row(k0));
             if (sorted[k0] >> 31) f_neg<S>(B.Y, B.Y, E);
-            pt_mmadd<S>(A, A, B, E);
-            ++k0;
-        }
-        // (Running one row ahead of the addition -- the index and the row of k + 1 in flight while row k is added -- was
-        // measured and changes nothing, profiles/r04_ec_instruction_diet.txt: the other wave of the SIMD already hides the
-        // gather; the kernel is bound by the instructions it issues.)
-        for (u32 k = k0; k < end; ++k) {
-            pt_load_normalised<S>(B, row(k));
-            if (sorted[k] >> 31) f_neg<S>(B.Y, B.Y, E);
-            pt_madd<S>(A, A, B, E);
+            ptx_mmadd<S>(R, A, B, E);
+            // (Running one row ahead of the addition -- the index and the row of k + 1 in flight while row k is added -- was
+            // measured and changes nothing, profiles/r04_ec_instruction_diet.txt: the other wave of the SIMD already hides the
+            // gather; the kernel is bound by the instructions it issues.)
+            for (u32 k = k0 + 1; k < end; ++k) {
+                pt_load_normalised<S>(B, row(k));
+                if (sorted[k] >> 31) f_neg<S>(B.Y, B.Y, E);
+                ptx_madd<S>(R, B, E);
+            }
+            ptx_to_jacobian<S>(A, R, E);
         }
     } else {
         for (u32 k = k0; k < end; ++k) {

@@ -3695,7 +3695,9 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         const char* e = getenv("VMN_TREE_FANIN");
         return e && *e ? (uint32_t)std::max(4, atoi(e)) : 0u;
     }();
-    const uint32_t F = F_env ? F_env : 8;
+    // Curves: 16 -- the sum of a chunk runs in XYZZ registers and is turned into a Jacobian row once per chunk (2 products),
+    // and the upper levels add Jacobian rows at 11M + 5S: both favour longer chunks (profiles/r04_ec_fanin_sweep_xyzz.txt).
+    const uint32_t F = F_env ? F_env : (m.ec ? 16 : 8);
     DevTmp meta(ctx), sorted(ctx), buckets(ctx), wres(ctx), itemsA(ctx), itemsB(ctx);
     // u32 scratch: counts[nb] | cursor[nb] | off0[nb+1] | per tree level l < LV: cnt_l[nb], off_l[nb+1] | bsum | misc.
     // The shape of the product trees depends on the exponents only: the per-level counts and offsets are computed once,
