@@ -55,6 +55,12 @@ struct ECfg {
 #define VMN_EC_MINW 2
 #endif
     static constexpr int MINW = S <= 10 ? VMN_EC_MINW : 1;
+    // The two kernels that add runs of normalised rows into XYZZ registers (first bucket level, fixed-base powers) fit 168
+    // registers without a spill (135 / 125 used when asked; tools/resource_usage.sh) -- the others do not.
+#ifndef VMN_EC_MINW_RUN
+#define VMN_EC_MINW_RUN 3
+#endif
+    static constexpr int MINW_RUN = S <= 10 ? VMN_EC_MINW_RUN : 1;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1115,7 +1121,7 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_fixed_level(u32* __
 
 // K2: out[i] = sum_k T[k][digit_k(e[i])]
 template <int S>
-__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW_RUN) k_ec_fixed_exp(u32* __restrict__ out, const u32* __restrict__ T, int w, int nwin,
                                                         const u32* __restrict__ e, int ewords, size_t n, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW;
     size_t el = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1248,7 +1254,7 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32*
 // K3 product-tree level (see k_bucket_level, also for the arrays of one launch).  FIRST: the inputs are NORMALISED arrays
 // (k_ec_normalize), read through `sorted`.
 template <int S, bool FIRST>
-__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_level(u32* __restrict__ out, size_t out_stride, LevelInputs ins,
+__global__ void __launch_bounds__(BLOCK, FIRST ? ECfg<S>::MINW_RUN : ECfg<S>::MINW) k_ec_bucket_level(u32* __restrict__ out, size_t out_stride, LevelInputs ins,
                                                            unsigned blocks_per_array,
                                                            const u32* __restrict__ sorted, const u32* __restrict__ off_in,
                                                            const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
