@@ -16,12 +16,12 @@
     KW __global__ void vmn::k_ec_chain<S_>(vmn::u32*, const vmn::u32*, int, vmn::ECDev);                                                 \
     KW __global__ void vmn::k_ec_fixed_level<S_>(vmn::u32*, int, int, int, vmn::ECDev);                                                  \
     KW __global__ void vmn::k_ec_fixed_exp<S_>(vmn::u32*, const vmn::u32*, int, int, const vmn::u32*, int, size_t, vmn::ECDev);          \
-    KW __global__ void vmn::k_finv_up<S_, true>(vmn::u32*, vmn::u32*, const vmn::u32*, size_t, size_t, vmn::ECDev);                      \
-    KW __global__ void vmn::k_finv_up<S_, false>(vmn::u32*, vmn::u32*, const vmn::u32*, size_t, size_t, vmn::ECDev);                     \
+    KW __global__ void vmn::k_finv_up<S_, true>(vmn::u32*, vmn::u32*, vmn::LevelInputs, unsigned, size_t, size_t, vmn::ECDev);           \
+    KW __global__ void vmn::k_finv_up<S_, false>(vmn::u32*, vmn::u32*, vmn::LevelInputs, unsigned, size_t, size_t, vmn::ECDev);          \
     KW __global__ void vmn::k_finv_top<S_>(vmn::u32*, const vmn::u32*, size_t, vmn::ECDev);                                              \
     KW __global__ void vmn::k_finv_down<S_>(vmn::u32*, const vmn::u32*, const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::ECDev);   \
-    KW __global__ void vmn::k_ec_normalize_down<S_>(vmn::u32*, const vmn::u32*, const vmn::u32*, const vmn::u32*, size_t, size_t,        \
-                                                    vmn::ECDev);                                                                        \
+    KW __global__ void vmn::k_ec_normalize_down<S_>(vmn::u32*, vmn::LevelInputs, unsigned, const vmn::u32*, const vmn::u32*, size_t,     \
+                                                    size_t, vmn::ECDev);                                                                \
     KW __global__ void vmn::k_ec_bucket_level<S_, true>(vmn::u32*, size_t, vmn::LevelInputs, unsigned, const vmn::u32*, const vmn::u32*, \
                                                         const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32, vmn::ECDev);        \
     KW __global__ void vmn::k_ec_bucket_level<S_, false>(vmn::u32*, size_t, vmn::LevelInputs, unsigned, const vmn::u32*, const vmn::u32*, \

@@ -1153,8 +1153,19 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW_RUN) k_ec_fixed_exp(u32* 
 // Field arrays (pref, tot, inv) are FW words per value.
 template <int S>
 __device__ __forceinline__ void f_store(u32* __restrict__ p, const u32 (&a)[S]) {
+    // whole 16-byte words, the padding behind the limbs written as zero (a value owns FW words): three stores instead of ten,
+    // and no byte of a cache line left for the memory system to merge
+    constexpr int FW = ECfg<S>::FW;
+    uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
-    for (int j = 0; j < S; ++j) p[j] = a[j];
+    for (int k = 0; k < FW / 4; ++k) {
+        uint4 v;
+        v.x = 4 * k + 0 < S ? a[4 * k + 0] : 0;
+        v.y = 4 * k + 1 < S ? a[4 * k + 1] : 0;
+        v.z = 4 * k + 2 < S ? a[4 * k + 2] : 0;
+        v.w = 4 * k + 3 < S ? a[4 * k + 3] : 0;
+        q[k] = v;
+    }
 }
 template <int S>
 __device__ __forceinline__ void z_of_row(u32 (&z)[S], const u32* __restrict__ row, const ECDev& E) {
@@ -1167,13 +1178,20 @@ __device__ __forceinline__ void z_of_row(u32 (&z)[S], const u32* __restrict__ ro
     }
 }
 // up: pref[i] = the product of the values of i's chunk before i, tot[c] = the product of chunk c.  ROWS: v[i] is the Z of point row i.
+// The k arrays of one call go through the two ROW-level kernels in ONE launch (block b works for array b / blocks_per_array,
+// as in k_ec_bucket_level): a lane's chunk is a chain of K dependent load + product steps, so a launch lasts one chain whatever
+// its size -- seven launches of a third of the device each were seven chains in a row (round 4: 4.1 -> 1.6 ms per pass of configs[4]).
 template <int S, bool ROWS>
-__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_up(u32* __restrict__ pref, u32* __restrict__ tot, const u32* __restrict__ v,
-                                                                  size_t n, size_t K, ECDev E) {
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_up(u32* __restrict__ pref, u32* __restrict__ tot, LevelInputs vs,
+                                                                  unsigned blocks_per_array, size_t n, size_t K, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW, FW = ECfg<S>::FW;
     // chunk c = the values c, c + nl, c + 2 nl ... (nl lanes): neighbouring lanes touch neighbouring rows
     const size_t nl = (n + K - 1) / K;
-    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned arr = blockIdx.x / blocks_per_array;          // (wave-uniform)
+    const u32* __restrict__ v = vs.p[arr];
+    pref += (size_t)arr * n * FW;
+    tot += (size_t)arr * nl * FW;
+    size_t c = (size_t)(blockIdx.x % blocks_per_array) * BLOCK + threadIdx.x;
     if (c >= nl) return;
     u32 acc[S], z[S];
 #pragma unroll
@@ -1219,12 +1237,17 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_down(u32* __restr
 }
 // the lowest level, fused with the use of the inverses: out[i] = (X zi^2, Y zi^3, 1)
 template <int S>
-__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32* __restrict__ out, const u32* __restrict__ in,
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32* __restrict__ out, LevelInputs ins, unsigned blocks_per_array,
                                                                             const u32* __restrict__ invtot, const u32* __restrict__ pref,
                                                                             size_t n, size_t K, ECDev E) {
     constexpr int ROW = ECfg<S>::ROW, FW = ECfg<S>::FW;
     const size_t nl = (n + K - 1) / K;
-    size_t c = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned arr = blockIdx.x / blocks_per_array;          // (wave-uniform; see k_finv_up)
+    const u32* __restrict__ in = ins.p[arr];
+    out += (size_t)arr * n * ROW;
+    invtot += (size_t)arr * nl * FW;
+    pref += (size_t)arr * n * FW;
+    size_t c = (size_t)(blockIdx.x % blocks_per_array) * BLOCK + threadIdx.x;
     if (c >= nl) return;
     u32 run[S];
     f_load<S>(run, invtot + c * FW);

@@ -3466,22 +3466,35 @@ static int ec_normalize(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* cons
     if (m.ec->S == S_) {                                                                                                             \
         note_work(ctx, m, products);                                                                                                 \
         rc = VMN_OK;                                                                                                                 \
-        for (size_t a = 0; a < k && rc == VMN_OK; ++a)                                                                               \
-            rc = launch_light(ctx, "normalize", k_finv_up<S_, true>, grid_for(n1), B + off_pref[0] + a * n * FWd,                    \
-                              B + off_val[1] + a * n1 * FWd, ins[a], n, K, ecdev(m.ec));                                             \
-        for (size_t l = 1; l + 1 < L && rc == VMN_OK; ++l)                                                                           \
-            rc = launch_light(ctx, "normalize", k_finv_up<S_, false>, grid_for(sizes[l + 1]), B + off_pref[l], B + off_val[l + 1],   \
-                              (const uint32_t*)(B + off_val[l]), sizes[l], K, ecdev(m.ec));                                          \
+        const unsigned bpa = (unsigned)((n1 + BLOCK - 1) / BLOCK);                       /* blocks per array of the two row-level launches */ \
+        for (size_t a0 = 0; a0 < k && rc == VMN_OK; a0 += LEVEL_ARRAYS) {                                                            \
+            const size_t ga = std::min<size_t>(LEVEL_ARRAYS, k - a0);                                                                \
+            LevelInputs li{};                                                                                                        \
+            for (size_t a = 0; a < ga; ++a) li.p[a] = ins[a0 + a];                                                                   \
+            rc = launch_light(ctx, "normalize", k_finv_up<S_, true>, (unsigned)(bpa * ga), B + off_pref[0] + a0 * n * FWd,     \
+                              B + off_val[1] + a0 * n1 * FWd, li, bpa, n, K, ecdev(m.ec));                                           \
+        }                                                                                                                            \
+        for (size_t l = 1; l + 1 < L && rc == VMN_OK; ++l) {                                                                         \
+            LevelInputs li{};                                                                                                        \
+            li.p[0] = B + off_val[l];                                                                                                \
+            const unsigned bl = (unsigned)((sizes[l + 1] + BLOCK - 1) / BLOCK);                                                      \
+            rc = launch_light(ctx, "normalize", k_finv_up<S_, false>, bl, B + off_pref[l], B + off_val[l + 1], li, bl,         \
+                              sizes[l], K, ecdev(m.ec));                                                                             \
+        }                                                                                                                            \
         if (rc == VMN_OK)                                                                                                            \
             rc = launch_light(ctx, "normalize", k_finv_top<S_>, grid_for(sizes[L - 1]), B + off_inv[L - 1],                          \
                               (const uint32_t*)(B + off_val[L - 1]), sizes[L - 1], ecdev(m.ec));                                     \
         for (size_t l = L - 2; l >= 1 && rc == VMN_OK; --l)                                                                          \
             rc = launch_light(ctx, "normalize", k_finv_down<S_>, grid_for(sizes[l + 1]), B + off_inv[l], (const uint32_t*)(B + off_inv[l + 1]), \
                               (const uint32_t*)(B + off_pref[l]), (const uint32_t*)(B + off_val[l]), sizes[l], K, ecdev(m.ec));      \
-        for (size_t a = 0; a < k && rc == VMN_OK; ++a)                                                                               \
-            rc = launch_light(ctx, "normalize", k_ec_normalize_down<S_>, grid_for(n1), out + a * n * Wd, ins[a],                     \
-                              (const uint32_t*)(B + off_inv[1] + a * n1 * FWd), (const uint32_t*)(B + off_pref[0] + a * n * FWd), n, \
-                              K, ecdev(m.ec));                                                                                       \
+        for (size_t a0 = 0; a0 < k && rc == VMN_OK; a0 += LEVEL_ARRAYS) {                                                            \
+            const size_t ga = std::min<size_t>(LEVEL_ARRAYS, k - a0);                                                                \
+            LevelInputs li{};                                                                                                        \
+            for (size_t a = 0; a < ga; ++a) li.p[a] = ins[a0 + a];                                                                   \
+            rc = launch_light(ctx, "normalize", k_ec_normalize_down<S_>, (unsigned)(bpa * ga), out + a0 * n * Wd, li, bpa,     \
+                              (const uint32_t*)(B + off_inv[1] + a0 * n1 * FWd), (const uint32_t*)(B + off_pref[0] + a0 * n * FWd),  \
+                              n, K, ecdev(m.ec));                                                                                    \
+        }                                                                                                                            \
     }
     VMN_FOR_CURVES(X)
 #undef X
