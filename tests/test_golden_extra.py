@@ -110,8 +110,11 @@ def test_proof_transcripts_are_reproducible_and_accepted_by_the_oracle_verifier(
 
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("first_level_rows", ["normalised", "as they are"])
 @pytest.mark.parametrize("fname", ["ec_p224.json", "ec_p256.json", "ec_p384.json", "ec_p521.json"])
-def test_hip_curve_kernels_reproduce_the_golden_vectors(fname, vmn, gpu_ctx):
+def test_hip_curve_kernels_reproduce_the_golden_vectors(fname, first_level_rows, vmn, gpu_ctx, monkeypatch):
+    # both first levels of a multi-exponentiation over a curve (tests/test_gpu_ec.py: first_level_rows)
+    monkeypatch.setenv("VMN_EC_NORMALISE_MIN", "0" if first_level_rows == "normalised" else "1000000000")
     rec = load(fname)
     G = vmn.ECqPGroup(gpu_ctx, rec["curve"])
     for case in rec["cases"]:

@@ -14,6 +14,15 @@ def ecg(request, vmn, gpu_ctx):
     return vmn.ECqPGroup(gpu_ctx, request.param), Curve(request.param)
 
 
+@pytest.fixture(params=["normalised", "as they are"])
+def first_level_rows(request, monkeypatch):
+    """A multi-exponentiation over a curve normalises its input rows (Z := 1) and adds them with the mixed formulas -- or, for
+    small calls, adds the rows as they are with full additions (vmnhip.hip: VMN_EC_NORMALISE_MIN points, default 131072).
+    The cases below are small: without this fixture only the second path would ever meet them."""
+    monkeypatch.setenv("VMN_EC_NORMALISE_MIN", "0" if request.param == "normalised" else "1000000000")
+    return request.param
+
+
 def sz(c, n):
     """The affine Python reference costs bits^3: the 521-bit curve runs the same cases on a third of the points."""
     return n if c.p.bit_length() <= 384 else max(8, n // 3)
@@ -147,7 +156,7 @@ def test_equality_is_of_group_elements_not_of_representations(ecg):
     assert X.exp(A).mul(X.exp(B)).equals(X.exp(A.add(B)))
 
 
-def test_multi_exponentiation_and_movement(ecg):
+def test_multi_exponentiation_and_movement(ecg, first_level_rows):
     G, c = ecg
     rnd = random.Random(8)
     for n in (1, 2, 33, sz(c, 300)):
@@ -184,7 +193,7 @@ def test_multi_exponentiation_and_movement(ecg):
     assert G.exp(base[0], G.ringArray(es)).toInts() == [c.mul(e, base[0]) for e in es]
 
 
-def test_signed_window_recoding_of_the_multi_exponentiation(ecg):
+def test_signed_window_recoding_of_the_multi_exponentiation(ecg, first_level_rows):
     """Curves sort the exponents by SIGNED window digits (light_kernels.h signed_digit): exponents whose digits sit on the
     recoding's edges for every window width the library may pick -- every digit exactly 2^(c-1) (a carry arrives or not), one
     above and one below, all ones (a carry through every window), the top bits of the order -- against the oracle."""
@@ -230,7 +239,7 @@ def test_scalar_field_arrays(ecg):
 
 
 @pytest.mark.parametrize("impl,curve_name", [("native", "P-256"), ("native", "P-384"), ("native", "P-224"), ("native", "P-521")])
-def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, curve_name, vmn, gpu_ctx, entry):
+def test_proof_of_shuffle_and_ccpos_over_p256_match_the_oracle(impl, curve_name, vmn, gpu_ctx, entry, first_level_rows):
     """PoS and CCPoS with ECqPGroup P-256 (the reference's default group): the GPU provers' messages equal the
     group-generic Python restatement on the same tape; verifiers accept; a tampered reply is rejected."""
     import importlib.util, os, sys

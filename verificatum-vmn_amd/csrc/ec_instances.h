@@ -26,6 +26,8 @@
                                                         const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32, vmn::ECDev);        \
     KW __global__ void vmn::k_ec_bucket_level<S_, false>(vmn::u32*, size_t, vmn::LevelInputs, unsigned, const vmn::u32*, const vmn::u32*, \
                                                          const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32, vmn::ECDev);       \
+    KW __global__ void vmn::k_ec_bucket_first_jacobian<S_>(vmn::u32*, size_t, vmn::LevelInputs, unsigned, const vmn::u32*, const vmn::u32*, \
+                                                           const vmn::u32*, const vmn::u32*, size_t, size_t, vmn::u32, vmn::ECDev);     \
     KW __global__ void vmn::k_ec_reduce<S_>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t, vmn::ECDev);                             \
     KW __global__ void vmn::k_ec_scan_totals<S_>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t, int, vmn::ECDev);                   \
     KW __global__ void vmn::k_ec_scan_apply<S_>(vmn::u32*, const vmn::u32*, const vmn::u32*, size_t, size_t, size_t, int, vmn::ECDev);   \

@@ -1332,6 +1332,52 @@ __global__ void __launch_bounds__(BLOCK, FIRST ? ECfg<S>::MINW_RUN : ECfg<S>::MI
     pt_store<S>(out + t * ROW, A);
 }
 
+// The first level over rows that are NOT normalised (small calls, vmnhip.hip ec_normalise_pays): the gather through `sorted` and
+// the signs of k_ec_bucket_level<S, true>, full additions.  Normalising costs a fixed chain of launches with one Fermat power
+// at its top (~0.3 ms per call whatever the size); below ~10^5 points the dearer additions are cheaper than that.
+template <int S>
+__global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_bucket_first_jacobian(u32* __restrict__ out, size_t out_stride, LevelInputs ins,
+                                                           unsigned blocks_per_array,
+                                                           const u32* __restrict__ sorted, const u32* __restrict__ off_in,
+                                                           const u32* __restrict__ cnt_in, const u32* __restrict__ off_out,
+                                                           size_t nbuckets, size_t total_out, u32 F, ECDev E) {
+    constexpr int ROW = ECfg<S>::ROW;
+    const unsigned arr = blockIdx.x / blocks_per_array;          // (wave-uniform)
+    const u32* __restrict__ in = ins.p[arr];
+    out += (size_t)arr * out_stride;
+    size_t t = (size_t)(blockIdx.x % blocks_per_array) * BLOCK + threadIdx.x;
+    if (t >= total_out) return;
+    size_t lo = 0, hi = nbuckets;
+    while (hi - lo > 1) {
+        size_t mid = (lo + hi) >> 1;
+        if (off_out[mid] <= t) lo = mid; else hi = mid;
+    }
+    size_t b = lo;
+    u32 j = (u32)(t - off_out[b]);
+    u32 start = off_in[b] + j * F;
+    u32 end = off_in[b] + cnt_in[b];
+    if (end > start + F) end = start + F;
+    auto load_signed = [&](Pt<S>& P, u32 k) {
+        const u32 s = sorted[k];
+        pt_load<S>(P, in + (size_t)(s & 0x7fffffffu) * ROW);
+        if (s >> 31) {                                 // a negative digit: -Y in the 256p form (Y of a row < 81 p)
+            u32 z[S], y[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) z[i] = 0;
+            f_sub<S, true>(y, z, P.Y, E);
+#pragma unroll
+            for (int i = 0; i < S; ++i) P.Y[i] = y[i];
+        }
+    };
+    Pt<S> A, B;
+    load_signed(A, start);
+    for (u32 k = start + 1; k < end; ++k) {
+        load_signed(B, k);
+        pt_add<S>(A, A, B, E);
+    }
+    pt_store<S>(out + t * ROW, A);
+}
+
 // K5: strided sum (see k_reduce_strided)
 template <int S>
 __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_reduce(u32* __restrict__ out, const u32* __restrict__ x, size_t len, size_t Lout,

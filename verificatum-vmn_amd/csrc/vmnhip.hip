@@ -180,18 +180,21 @@ static int launch(vmn_ctx* ctx, const char* family, void (*kernel)(KArgs...), un
 // multiply-adds (multiplication + reduction half); a squaring S^2 (reduction) + S (S + LPE SQR_BLK) / 2 (block-symmetric
 // multiplication half, summed over the LPE lanes of the element).  Curve points: field products
 // (S = 10 / 15), 16 per addition (11M + 5S), 8 per doubling (3M + 5S).  Only recorded while timing is on.
-static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double squarings = 0) {
+static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double squarings = 0, double canon_products = -1) {
     if (!ctx->timing) return 0;
     const double S = m.ec ? (double)m.ec->S : (double)m.S;              // columns
     const double Rw = m.ec ? S : (double)m.rows;                         // rows (< S in a wide geometry)
     // the same products priced in SURVEY.md §8d's unit: 32 x 32-bit multiply-accumulates of a product / squaring on
     // s = ceil(bits / 32) limbs, M(s) = 2 s^2 + s, Q(s) = s (s + 1) / 2 + s^2 + s -- the unit of the headline's roofline
     const double s32 = (double)((m.nbits + 31) / 32);
-    ctx->next_canon = products * (2 * s32 * s32 + s32) + squarings * (m.ec ? 2 * s32 * s32 + s32 : s32 * (s32 + 1) / 2 + s32 * s32 + s32);
+    // (canon_products: a launch whose formulas execute fewer products than the ones the canonical count was fixed on -- the
+    // running sums of the curve kernels, EC_MADD_RUN -- keeps its canonical price)
+    ctx->next_canon = (canon_products >= 0 ? canon_products : products) * (2 * s32 * s32 + s32) +
+                      squarings * (m.ec ? 2 * s32 * s32 + s32 : s32 * (s32 + 1) / 2 + s32 * s32 + s32);
     if (m.ec) {
         // a field product: S^2 for the multiplication half + S x (non-zero limbs of p, less limb 0 whose carry is folded into
         // column 1) for the reduction rows of the compile-time primes (ec_kernels.h mont_row: 6 of 10 for P-256, 12 of 15 for P-384)
-        const double nz = m.ec->S == 10 ? 6 : m.ec->S == 15 ? 12 : S;
+        const double nz = m.ec->S == 10 ? 7 : m.ec->S == 15 ? 12 : S;       // (P-256: 6 limbs + the carry product of the wide-digit rows)
         ctx->next_mads = (products + squarings) * (S * S + S * nz);
         return 0;
     }
@@ -202,6 +205,8 @@ static int note_work(vmn_ctx* ctx, const vmn_modulus& m, double products, double
 // in field products (S^2 + S nz multiply-adds, see note_work): a product 1, a squaring ~0.775 (symmetric), a zero test 0.5 (reduction only)
 // add = 11M + 5S + zero test, mixed add = 7M + 4S + zero test, doubling = 3M + 5S, normalising one point ~7 + inversion / K
 static const double EC_ADD = 15.4, EC_MADD = 10.6, EC_DBL = 6.9, EC_NORM = 7.0, EC_INV = 380;
+// round 4: a row added into a running sum in XYZZ registers executes 8M + 2S + 2M / run; its canonical price stays EC_MADD
+static const double EC_MADD_RUN = 9.7;
 
 static unsigned light_grid(vmn_ctx* ctx, size_t work_items) {
     size_t blocks = (work_items + BLOCK - 1) / BLOCK;
@@ -3394,7 +3399,7 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
         rc = VMN_ERR_ARG;
 #define X(S_, NW_)                                                                                                   \
     if (m.ec->S == S_)                                                                                               \
-        rc = note_work(ctx, m, EC_MADD * (double)n * (ft->nwin - 1)) ? 0 : launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
+        rc = note_work(ctx, m, EC_MADD_RUN * (double)n * (ft->nwin - 1), 0, EC_MADD * (double)n * (ft->nwin - 1)) ? 0 : launch_light(ctx, "fixed", k_ec_fixed_exp<S_>, grid_for(n), r->d, (const uint32_t*)ft->d_tab, ft->wbits, \
                           ft->nwin, (const uint32_t*)ew.as<uint32_t>(), grp->Q.NW, n, ecdev(m.ec));
         VMN_FOR_CURVES(X)
 #undef X
@@ -3798,7 +3803,12 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         }
     }
     DevTmp normalised(ctx);                              // curves: the k arrays with Z = 1, so that the first level's additions are mixed
-    if (m.ec) {
+    // ... unless the call is small: normalising is a fixed chain of ~10 short launches with a Fermat power at its top (~0.3 ms
+    // whatever the size), the full additions it saves cost k n nwin x ~1100 instructions.  VMN_EC_NORMALISE_MIN moves the bound.
+    const char* nm_env = getenv("VMN_EC_NORMALISE_MIN");        // (read per call: the tests run both first levels at their sizes)
+    const size_t normalise_min = nm_env && *nm_env ? (size_t)strtoull(nm_env, nullptr, 10) : (size_t)131072;
+    const bool ec_rows_normalised = m.ec && k * n >= normalise_min;
+    if (ec_rows_normalised) {
         VMN_TRACE("expprod:normalise");
         VMN_TRY(normalised.alloc(k * n * Wd * sizeof(uint32_t)));
         VMN_TRY(ec_normalize(ctx, m, xs, k, n, normalised.as<uint32_t>()));
@@ -3816,7 +3826,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         const uint32_t* cnt_in = counts;
         const uint32_t* off_in = off0;
         LevelInputs ins{};
-        for (size_t a = 0; a < gl; ++a) ins.p[a] = m.ec ? normalised.as<uint32_t>() + (arr0 + a) * n * Wd : xs[arr0 + a];
+        for (size_t a = 0; a < gl; ++a) ins.p[a] = ec_rows_normalised ? normalised.as<uint32_t>() + (arr0 + a) * n * Wd : xs[arr0 + a];
         uint32_t* items_out = itemsA.as<uint32_t>();
         uint32_t* items_other = itemsB.as<uint32_t>();
         size_t out_cap = cap0, other_cap = cap1;
@@ -3832,7 +3842,12 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
                 const unsigned bpa = grid_for(total_out);
 #define X(S_, NW_)                                                                                                     \
     if (m.ec->S == S_) {                                                                                               \
-        rc = note_work(ctx, m, (first ? EC_MADD : EC_ADD) * level_products) ? 0 : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, bpa * (unsigned)gl, items_out, out_stride, ins, bpa, \
+        rc = note_work(ctx, m, (first && ec_rows_normalised ? EC_MADD_RUN : EC_ADD) * level_products, 0,                        \
+                       (first && ec_rows_normalised ? EC_MADD : EC_ADD) * level_products) ? 0                                  \
+             : first && !ec_rows_normalised ? launch_light(ctx, "expprod", k_ec_bucket_first_jacobian<S_>, bpa * (unsigned)gl, items_out, out_stride, ins, bpa, \
+                                  (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_of((int)level),    \
+                                  nbuckets, total_out, F, ecdev(m.ec))                                                 \
+             : first ? launch_light(ctx, "expprod", k_ec_bucket_level<S_, true>, bpa * (unsigned)gl, items_out, out_stride, ins, bpa, \
                                   (const uint32_t*)sorted.as<uint32_t>(), off_in, cnt_in, (const uint32_t*)off_of((int)level),    \
                                   nbuckets, total_out, F, ecdev(m.ec))                                                 \
                    : launch_light(ctx, "expprod", k_ec_bucket_level<S_, false>, bpa * (unsigned)gl, items_out, out_stride, ins, bpa,        \
