@@ -46,6 +46,20 @@ def test_import_export_and_curve_check(ecg, vmn):
         G.toElementArray([bad])
 
 
+def test_export_of_a_large_array_normalises_its_rows_first(ecg, monkeypatch):
+    """The export kernel inverts Z with one Fermat power per point; from VMN_EC_EXPORT_NORMALISE_MIN points on (default 262144)
+    the rows go through the batched inversion of the multi-exponentiations first and are exported as they are.  Same bytes."""
+    G, c = ecg
+    base = pts(c, 31, sz(c, 60))
+    X = G.toElementArray(base + [None, c.g])
+    J = X.exp(7).mul(X)                                    # Jacobian rows with Z != 1: 8 P; the identity stays the identity
+    want = [c.mul(8, p) for p in base] + [None, c.mul(8, c.g)]
+    assert J.toInts() == want
+    monkeypatch.setenv("VMN_EC_EXPORT_NORMALISE_MIN", "1")
+    assert J.toInts() == want
+    assert X.toInts() == base + [None, c.g]                # rows that already have Z = 1
+
+
 def test_pointwise_group_operation_with_exceptional_cases(ecg):
     G, c = ecg
     a = pts(c, 2, 40)

@@ -1286,6 +1286,7 @@ static int ec_export_few_host(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes,
 }
 
 // (pinned_async: `be` is pinned host memory and the copy is only queued -- the caller orders itself behind it)
+static int ec_normalize(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* const* ins, size_t k, size_t n, uint32_t* out);
 static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const uint32_t* d_in, size_t n, uint8_t* be,
                      int leaf_hdr = 0, bool pinned_async = false) {
     if (n == 0) return VMN_OK;
@@ -1294,13 +1295,30 @@ static int export_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     if (m.ec && n <= 4 && !leaf_hdr && !pinned_async && !getenv("VMN_EC_EXPORT_DEVICE")) return ec_export_few_host(ctx, m, nbytes, d_in, n, be);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
-    note_work(ctx, m, m.ec ? 8.0 * (double)n : (double)n, m.ec ? (double)m.nbits * (double)n : 0.0);     // curves: one Fermat inversion per point
+    // Curves: the export kernel inverts Z per point -- a Fermat power of ~380 products, 25 times the rest of a point's export.
+    // One chain of them lasts 0.16 ms whatever the array (up to a device full of lanes); from there on the rows are normalised
+    // first by the batched inversion of the multi-exponentiations (~8 products per point) and exported as they are.
+    DevTmp affine_rows(ctx);
+    int ec_rows_affine = 0;
+    if (m.ec) {
+        const char* env = getenv("VMN_EC_EXPORT_NORMALISE_MIN");          // (read per call: the tests run both exports at their sizes)
+        const size_t min_n = env && *env ? (size_t)strtoull(env, nullptr, 10) : (size_t)262144;
+        if (n >= min_n) {
+            VMN_TRY(affine_rows.alloc(n * (size_t)m.W * sizeof(uint32_t)));
+            const uint32_t* one_array[1] = {d_in};
+            VMN_TRY(ec_normalize(ctx, m, one_array, 1, n, affine_rows.as<uint32_t>()));
+            d_in = affine_rows.as<uint32_t>();
+            ec_rows_affine = 2;
+        }
+    }
+    if (ec_rows_affine) note_work(ctx, m, 2.0 * (double)n);
+    else note_work(ctx, m, m.ec ? 8.0 * (double)n : (double)n, m.ec ? (double)m.nbits * (double)n : 0.0);     // curves: one Fermat inversion per point
     int rc = VMN_ERR_ARG;
     if (m.ec) {
 #define X(S_, NW_)                                                                                               \
     if (m.ec->S == S_)                                                                                           \
         rc = launch_light(ctx, "export", k_ec_export<S_, NW_>, grid_for(n), raw.as<uint8_t>(), nbytes, stride,   \
-                          leaf_hdr, d_in, n, ecdev(m.ec));
+                          leaf_hdr | ec_rows_affine, d_in, n, ecdev(m.ec));
         VMN_FOR_CURVES(X)
 #undef X
     } else {
