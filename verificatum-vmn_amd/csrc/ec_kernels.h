@@ -1204,14 +1204,23 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_finv_up(u32* __restric
     tot += (size_t)arr * nl * FW;
     size_t c = (size_t)(blockIdx.x % blocks_per_array) * BLOCK + threadIdx.x;
     if (c >= nl) return;
-    u32 acc[S], z[S];
+    // (the loads do not depend on the chain of products: the value of step k + 1 is requested before the product of step k --
+    // a launch holds only n / K lanes, two waves per SIMD at 10^6 points, and nothing else would hide the latency)
+    u32 acc[S], z[S], zn[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) acc[j] = E.one[j];
+    auto fetch = [&](u32 (&dst)[S], size_t i) {
+        if constexpr (ROWS) z_of_row<S>(dst, v + i * ROW, E);
+        else f_load<S>(dst, v + i * FW);
+    };
+    fetch(z, c);
     for (size_t i = c; i < n; i += nl) {
+        const size_t nx = i + nl < n ? i + nl : i;     // (the last step fetches its own value again)
+        fetch(zn, nx);
         f_store<S>(pref + i * FW, acc);
-        if constexpr (ROWS) z_of_row<S>(z, v + i * ROW, E);
-        else f_load<S>(z, v + i * FW);
         f_mul<S>(acc, acc, z, E);
+#pragma unroll
+        for (int j = 0; j < S; ++j) z[j] = zn[j];
     }
     f_store<S>(tot + c * FW, acc);
 }
@@ -1263,13 +1272,21 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32*
     u32 run[S];
     f_load<S>(run, invtot + c * FW);
     const size_t cnt = (n - c + nl - 1) / nl;          // points of this chunk
+    // one point ahead of the products (see k_finv_up): the prefix and the row of the next step are requested first
+    u32 pr[S], prn[S];
+    Pt<S> P, Pn;
+    if (cnt > 0) {
+        const size_t i0 = c + (cnt - 1) * nl;
+        f_load<S>(pr, pref + i0 * FW);
+        pt_load<S>(P, in + i0 * ROW);
+    }
     for (size_t k = cnt; k-- > 0;) {
         const size_t i = c + k * nl;
-        u32 zi[S], zi2[S], zi3[S], pr[S];
-        f_load<S>(pr, pref + i * FW);
+        const size_t nx = k > 0 ? i - nl : i;          // (the last step fetches its own point again)
+        f_load<S>(prn, pref + nx * FW);
+        pt_load<S>(Pn, in + nx * ROW);
+        u32 zi[S], zi2[S], zi3[S];
         f_mul<S>(zi, run, pr, E);                      // 1 / Z_i
-        Pt<S> P;
-        pt_load<S>(P, in + i * ROW);
         if (P.inf) {
             pt_set_inf<S>(P, E);                       // (took part with Z = 1: the running inverse is unchanged)
         } else {
@@ -1282,6 +1299,9 @@ __global__ void __launch_bounds__(BLOCK, ECfg<S>::MINW) k_ec_normalize_down(u32*
             for (int j = 0; j < S; ++j) P.Z[j] = E.one[j];
         }
         pt_store<S>(out + i * ROW, P);
+        P = Pn;
+#pragma unroll
+        for (int j = 0; j < S; ++j) pr[j] = prn[j];
     }
 }
 

@@ -3464,7 +3464,13 @@ extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const
 // per call, not once per array).  Field scratch: pref of level 0 (k n), per upper level its values, their inverses, pref.
 static int ec_normalize(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* const* ins, size_t k, size_t n, uint32_t* out) {
     if (n == 0 || k == 0) return VMN_OK;
-    const size_t FWd = (size_t)stride_for_limbs(m.ec->S), Wd = (size_t)m.W, K = 8, TOP = 2048;
+    // K values per lane and level: a launch holds n / K lanes, each a chain of K load + product steps (VMN_EC_NORMALISE_CHUNK,
+    // profiles/r04_ec_normalise_chunk_sweep.txt)
+    static const size_t K_env = [] {
+        const char* e = getenv("VMN_EC_NORMALISE_CHUNK");
+        return e && *e ? (size_t)std::max(2, atoi(e)) : (size_t)0;
+    }();
+    const size_t FWd = (size_t)stride_for_limbs(m.ec->S), Wd = (size_t)m.W, K = K_env ? K_env : 8, TOP = 2048;
     const size_t n1 = (n + K - 1) / K;                       // chunks (= level-1 values) per array
     std::vector<size_t> sizes{k * n, k * n1};                // values per level (level 0: the Z's of the rows, k arrays of n)
     while (sizes.back() > TOP) sizes.push_back((sizes.back() + K - 1) / K);
