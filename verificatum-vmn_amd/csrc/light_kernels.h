@@ -20,6 +20,18 @@ __device__ __forceinline__ void split_chunk(size_t t, int per, size_t& row, int&
     }
 }
 
+// ---- clearing and uploading SMALL things as kernels ------------------------------------------------
+// hipMemsetAsync / hipMemcpyAsync go through the runtime's blit path; between kernels of the same stream each of them cost
+// 55-70 us of idle device in the small-size timelines (profiles/r04_timeline_p256_n10000_after.txt) where a kernel launch
+// costs 7.  A flag word, a histogram of a few thousand counters, a seed or a scalar in a pinned slot are moved by these two
+// instead (pinned host memory is mapped into the device's address space: the upload kernel reads it in place).
+__global__ void __launch_bounds__(BLOCK) k_zero_words(u32* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) p[i] = 0;
+}
+__global__ void __launch_bounds__(BLOCK) k_copy_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+}
+
 // ---- generic exclusive scan of a u32 array (three tiny kernels; n up to a few million) ----------
 constexpr int SCAN_ITEMS = 16;                         // items per thread
 

@@ -420,6 +420,23 @@ static void pool_free(vmn_ctx* ctx, void* p, size_t bytes) {
 // size uploads something in front of every other kernel, and each of those waits used to drain the device.
 static int h2d(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return VMN_OK;
+    if (bytes <= vmn_ctx::UP_SLOT) {                          // the ring of small pinned slots (vmnhip_internal.h)
+        if (!ctx->up_ring) {
+            VMN_HIP(hipHostMalloc(&ctx->up_ring, vmn_ctx::UP_SLOT * vmn_ctx::UP_SLOTS, hipHostMallocDefault));
+            for (unsigned i = 0; i < vmn_ctx::UP_SLOTS; ++i) VMN_HIP(hipEventCreateWithFlags(&ctx->up_done[i], hipEventDisableTiming));
+        }
+        const unsigned slot = ctx->up_next++ % vmn_ctx::UP_SLOTS;
+        if (ctx->up_pending[slot]) VMN_HIP(hipEventSynchronize(ctx->up_done[slot]));      // (32 uploads ago: long done)
+        void* at = (char*)ctx->up_ring + (size_t)slot * vmn_ctx::UP_SLOT;
+        memcpy(at, src, bytes);
+        // (a kernel that reads the pinned slot in place, not hipMemcpyAsync: light_kernels.h k_copy_bytes)
+        hipLaunchKernelGGL(k_copy_bytes, dim3((unsigned)((bytes + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, (uint8_t*)dst,
+                           (const uint8_t*)at, bytes);
+        VMN_HIP(hipGetLastError());
+        VMN_HIP(hipEventRecord(ctx->up_done[slot], ctx->stream));
+        ctx->up_pending[slot] = true;
+        return VMN_OK;
+    }
     if (bytes <= STAGE_BYTES) {
         VMN_TRY(stage_ready(ctx));
         if (ctx->stage_read_pending) VMN_HIP(hipEventSynchronize(ctx->stage_read));     // the previous upload has left the buffer
@@ -431,6 +448,21 @@ static int h2d(vmn_ctx* ctx, void* dst, const void* src, size_t bytes) {
     }
     VMN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     VMN_HIP(hipStreamSynchronize(ctx->stream));          // src is pageable / may go out of scope
+    return VMN_OK;
+}
+
+// zero `bytes` (a multiple of 4) of device memory on the lane's stream: a kernel up to 4 MB (see k_zero_words), the runtime's
+// memset beyond
+static int dev_zero(vmn_ctx* ctx, void* p, size_t bytes) {
+    if (!bytes) return VMN_OK;
+    if (bytes <= ((size_t)4 << 20) && bytes % 4 == 0) {
+        const size_t n = bytes / 4;
+        const unsigned grid = (unsigned)std::min<size_t>((n + BLOCK - 1) / BLOCK, 1024);
+        hipLaunchKernelGGL(k_zero_words, dim3(grid), dim3(BLOCK), 0, ctx->stream, (uint32_t*)p, n);
+        VMN_HIP(hipGetLastError());
+        return VMN_OK;
+    }
+    VMN_HIP(hipMemsetAsync(p, 0, bytes, ctx->stream));
     return VMN_OK;
 }
 
@@ -505,6 +537,11 @@ extern "C" void vmn_ctx_destroy(vmn_ctx* ctx) {
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->stage_read) (void)hipEventDestroy(ctx->stage_read);
+    if (ctx->up_ring) {
+        (void)hipHostFree(ctx->up_ring);
+        for (hipEvent_t e : ctx->up_done)
+            if (e) (void)hipEventDestroy(e);
+    }
     for (void* sp : ctx->stage_pending)
         if (sp) (void)hipHostFree(sp);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1208,9 +1245,9 @@ static int import_be(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const ui
     const size_t stride = m.ec ? 2 * nbytes + (leaf_hdr ? 15 : 0) : nbytes + (leaf_hdr ? 5 : 0);
     DevTmp raw(ctx);
     VMN_TRY(raw.alloc(n * stride + 8));
-    if (checked_on_host) VMN_TRY(h2d(ctx, raw.p, be, n * stride));           // (small: through the pinned buffer, queued)
+    if (checked_on_host || n * stride <= vmn_ctx::UP_SLOT) VMN_TRY(h2d(ctx, raw.p, be, n * stride));    // (small: a pinned slot, queued)
     else VMN_HIP(hipMemcpyAsync(raw.p, be, n * stride, hipMemcpyHostToDevice, ctx->stream));
-    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    VMN_TRY(dev_zero(ctx, ctx->flags, sizeof(uint32_t)));
     note_work(ctx, m, (m.ec ? 7.0 : 1.0) * (double)n);
     int rc = VMN_ERR_ARG;
     if (m.ec) {
@@ -1748,11 +1785,15 @@ extern "C" int vmn_garray_exp_ints(const vmn_garray* x, const uint8_t* exps_be, 
     DevTmp ew(ctx);
     int rc = ew.alloc(hw.size() * sizeof(uint32_t));
     if (rc == VMN_OK && !hw.empty()) {
-        hipError_t he = hipMemcpyAsync(ew.p, hw.data(), hw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);   // hw is pageable host memory
-        if (he != hipSuccess) {
-            set_error("exponent upload failed: %s", hipGetErrorString(he));
-            rc = VMN_ERR_DEVICE;
+        if (hw.size() * sizeof(uint32_t) <= vmn_ctx::UP_SLOT) {
+            rc = h2d(ctx, ew.p, hw.data(), hw.size() * sizeof(uint32_t));      // (a pinned slot: queued, no synchronisation)
+        } else {
+            hipError_t he = hipMemcpyAsync(ew.p, hw.data(), hw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);   // hw is pageable host memory
+            if (he != hipSuccess) {
+                set_error("exponent upload failed: %s", hipGetErrorString(he));
+                rc = VMN_ERR_DEVICE;
+            }
         }
     }
     if (rc == VMN_OK) rc = modpow_words(ctx, g->P, x->d, ew.as<uint32_t>(), ewords, (size_t)ewords, ebits, x->n, r->d);
@@ -1976,7 +2017,7 @@ extern "C" int vmn_garray_exp_pair(const vmn_garray* x, const uint8_t* e_be, siz
 static int compare_arrays(vmn_ctx* ctx, const vmn_modulus& m, const uint32_t* x, const uint32_t* y, size_t n, int* equal) {
     *equal = 1;
     if (n == 0) return VMN_OK;
-    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    VMN_TRY(dev_zero(ctx, ctx->flags, sizeof(uint32_t)));
     if (m.ec) {                        // Jacobian rows: equality of group elements, not of bytes
         int rc = VMN_ERR_ARG;
 #define X(S_, NW_) \
@@ -2467,7 +2508,7 @@ extern "C" int vmn_rarray_max_bits(const vmn_rarray* x, int* bits) {
     DevTmp ew(ctx);
     VMN_TRY(ew.alloc(x->n * (size_t)g->Q.NW * sizeof(uint32_t)));
     VMN_TRY(to_words(ctx, g->Q, x->d, x->n, ew.as<uint32_t>()));
-    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    VMN_TRY(dev_zero(ctx, ctx->flags, sizeof(uint32_t)));
     VMN_TRY(launch_light(ctx, "ring", k_words_maxbits, grid_for(x->n), (const uint32_t*)ew.as<uint32_t>(), x->n, g->Q.NW, ctx->flags));
     uint32_t v = 0;
     VMN_TRY(read_flag(ctx, &v));
@@ -2789,7 +2830,7 @@ static int import_dev(vmn_ctx* ctx, const vmn_modulus& m, size_t nbytes, const u
                       int* all_in_range) {
     if (all_in_range) *all_in_range = 1;
     if (n == 0) return VMN_OK;
-    VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+    VMN_TRY(dev_zero(ctx, ctx->flags, sizeof(uint32_t)));
     int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                               \
     if (m.S == S_)                                                                                                     \
@@ -2835,7 +2876,7 @@ static int prg_residues(vmn_ctx* ctx, const vmn_modulus& m, const PrgSeed& w, si
     hostbig::to_be(c, cbe.data(), mb);
     VMN_TRY(cdev.alloc(Wd * sizeof(uint32_t)));
     int ok = 1;
-    VMN_TRY(import_be(ctx, m, mb, cbe.data(), 1, cdev.as<uint32_t>(), &ok));
+    VMN_TRY(import_be(ctx, m, mb, cbe.data(), 1, cdev.as<uint32_t>(), &ok, 0, nullptr, true));      // (< m by construction: only queued)
     VMN_TRY(prg_rows(ctx, w, n, vb, vbits, 0, top_len, top_len, rows, sel));
     VMN_TRY(import_dev(ctx, m, top_len, rows.as<uint8_t>(), 2, n, acc.as<uint32_t>(), nullptr));
     uint32_t* cur = acc.as<uint32_t>();
@@ -3774,7 +3815,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
     // counting sort of (window, digit)
     {
     VMN_TRACE("expprod:sort");
-    VMN_HIP(hipMemsetAsync(counts, 0, nbuckets * sizeof(uint32_t), ctx->stream));
+    VMN_TRY(dev_zero(ctx, counts, nbuckets * sizeof(uint32_t)));
     const unsigned gx = std::max<unsigned>(1, std::min<unsigned>((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)(ctx->num_cus * 8 / std::max(nwin, 1) + 1)));
     if (sgn) {
         VMN_TRY(launch_light(ctx, "expprod_sort", k_bucket_hist<true>, gx * (unsigned)nwin, counts, e_words, ewords, n, c, nwin, gx, ebits));
@@ -3800,7 +3841,7 @@ static int expprod_words(vmn_group* g, const uint32_t* const* xs, size_t k, cons
         // come back in one copy.
         const uint32_t* cnt_in = counts;
         uint32_t hm[2 * LV] = {0};
-        VMN_HIP(hipMemsetAsync(misc, 0, 2 * LV * sizeof(uint32_t), ctx->stream));
+        VMN_TRY(dev_zero(ctx, misc, 2 * LV * sizeof(uint32_t)));
         auto queue_level = [&](int level) -> int {
             VMN_TRY(launch_light(ctx, "expprod_sort", k_task_counts, grid_for(nbuckets), cnt_of(level), cnt_in, nbuckets, F, misc + 2 * level + 1));
             VMN_TRY(scan_u32(off_of(level), (uint32_t*)nullptr, cnt_of(level), misc + 2 * level));
@@ -4106,7 +4147,7 @@ extern "C" int vmn_garray_is_member(const vmn_garray* x, int* all_members) {
         Big pm1 = m.n_words;
         pm1[0] -= 1;
         if (hostbig::cmp(twoq, pm1) == 0) {
-            VMN_HIP(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), ctx->stream));
+            VMN_TRY(dev_zero(ctx, ctx->flags, sizeof(uint32_t)));
             int rc = VMN_ERR_ARG;
 #define X(S_, NW_, LPE_)                                                                                                   \
     if constexpr (LPE_ == 1) {                                                                                             \

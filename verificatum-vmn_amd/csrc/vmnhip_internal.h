@@ -89,6 +89,16 @@ struct vmn_ctx {
                                           //   16 us instead of 27 us per read-back (tools/micro/copy_latency.hip); allocated on first use
     hipEvent_t stage_read = nullptr;      // recorded behind the latest host-to-device copy out of `stage` (the host waits for it before writing there again)
     bool stage_read_pending = false;
+    // Small uploads (seeds, scalars, single elements: up to UP_SLOT bytes) go through a ring of pinned slots, one event each:
+    // the host waits only when all UP_SLOTS uploads are still in flight.  Through the one `stage` buffer every small upload
+    // waited for the previous one -- which sits behind everything queued on the stream: a stream synchronisation per scalar,
+    // 55-70 us of idle device each (profiles/r04_timeline_p256_n10000_after.txt: 28 of them in one commit phase).
+    static constexpr size_t UP_SLOT = 16384;
+    static constexpr unsigned UP_SLOTS = 32;
+    void* up_ring = nullptr;
+    hipEvent_t up_done[UP_SLOTS] = {};
+    bool up_pending[UP_SLOTS] = {};
+    unsigned up_next = 0;
     static constexpr int PENDING_SLOTS = 2;          // multi-exponentiations in flight on this lane (vmn_pending): a verifier's A, F and its k_E products
     void* stage_pending[PENDING_SLOTS] = {nullptr, nullptr};     // their pinned landing buffers
     size_t stage_pending_bytes[PENDING_SLOTS] = {0, 0};
