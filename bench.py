@@ -1181,9 +1181,10 @@ def modexp_by_shape(entry, vmn, ctx, p, q, g, n: int, sync, cores: int, with_cpu
     out = {"n": n, "group": "RFC 3526 group 14 (2048 bits)", "fixed_base_table": setup,
            "unit": "ops/s (K3: exponentiated-and-multiplied terms/s)"}
     for name, (fn, canon_budget, _fam) in shapes.items():
-        r = fn()
-        if hasattr(r, "free"):
-            r.free()
+        for _ in range(2):                                      # warm-up (the first shape also settles the pool after the set-up)
+            r = fn()
+            if hasattr(r, "free"):
+                r.free()
         ctx.timing_reset()
         ctx.timing_enable(True)
         sync()
