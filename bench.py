@@ -372,6 +372,7 @@ def mix_prove(entry, vmn, ctx, grp, n: int, seed: int, sync, steps: int = 2, wid
         out["fiat_shamir_bytes"] = fs_bytes
     for a in Hs + W:
         a.free()
+    grp.releaseFixed(y)                                  # the key of this synthetic instance will not come back
     return out
 
 

@@ -187,6 +187,10 @@ int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray
  * the same way when it is handed a generator it will exponentiate many times.  Bases that are never announced get
  * the one-call window on first use. */
 int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be, size_t n_hint, int uses_hint);
+/* The table of a base that will not be used again (a prover's per-proof base h_0 when the proof object is freed -- the
+ * reference frees a proof's arrays in PoSBasicTW.free(), P/hvzk/PoSBasicTW.java:1088-1101; VCR keeps no table beyond a call):
+ * it leaves the group's cache and its memory serves the next table of that size.  Unknown base: no effect. */
+int vmn_group_release_fixed(vmn_group* grp, const uint8_t* base_be);
 /* K3  X.expProd(E) = prod_i X[i]^E[i] -> one element (big-endian, elem_bytes).
  * ref: P/hvzk/PoSBasicTW.java:408, 409, 481, 690, 1021, 1063; P/hvzk/CCPoSBasicW.java:380, 391, 497-503. */
 int vmn_garray_expprod(const vmn_garray* x, const vmn_rarray* e, int ebits, uint8_t* out_be);

@@ -322,6 +322,66 @@ def test_fixed_base_table_cache_is_bounded(vmn, gpu_ctx, monkeypatch):
             assert G.exp(b, E).toInts() == pyref.exp_fixed(b, es, p), rnd
 
 
+def test_released_table_leaves_the_cache_and_the_base_still_works(vmn, gpu_ctx):
+    """vmn_group_release_fixed: the table of a base that will not come back (a prover's h_0, released when the proof object is
+    freed) leaves the group's cache; a later use of the same base rebuilds it; an unknown base is no error."""
+    grp, _ = load_golden(1024)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    es = pyref.stream_ints(b"release/e", 200, q)
+    E = G.ringArray(es)
+    b1, b2 = (pow(g, k, p) for k in pyref.stream_ints(b"release/b", 2, q))
+    empty = G.tableBytes()
+    assert G.exp(b1, E).toInts() == pyref.exp_fixed(b1, es, p)
+    one = G.tableBytes()
+    assert one > empty
+    assert G.exp(b2, E).toInts() == pyref.exp_fixed(b2, es, p)
+    assert G.tableBytes() > one
+    G.releaseFixed(b2)
+    assert G.tableBytes() == one
+    G.releaseFixed(b2)                                       # unknown by now
+    G.releaseFixed(pow(g, 12345, p))                         # never seen
+    assert G.tableBytes() == one
+    assert G.exp(b2, E).toInts() == pyref.exp_fixed(b2, es, p)
+    G.releaseFixed(b1)
+    G.releaseFixed(b2)
+    assert G.tableBytes() == empty
+
+
+def test_a_freed_prover_returns_the_table_of_its_base(vmn, gpu_ctx, entry):
+    """The per-proof base h_0 of a PoS prover gets a fixed-base table (N exponents in commit); freeing the proof object
+    releases it, so a session of proofs on fresh generators holds one such table at a time, not one per proof."""
+    import mirror
+    from tape import Tape
+    nat = mirror.load(entry, ("native",))["native"]
+    grp, _ = load_golden(1024)
+    p, q, g = grp["p"], grp["q"], grp["g"]
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    n, NV, NE, NR = 64, 128, 128, 64
+    seen = []
+    y = pow(g, Tape(b"release-key", q).ring_element(), p)      # one key for the session: its table stays, like g's
+    for k in range(3):
+        t = Tape(b"release-prover-%d" % k, q)
+        h = [pow(g, x, p) for x in t.ring_array(n)]
+        w = [[pow(g, x, p) for x in t.ring_array(n)] for _ in range(2)]
+        pi = t.permutation(n)
+        s = [t.ring_array(n)]
+        H, W, S = G.toElementArray(h), [G.toElementArray(c) for c in w], [G.ringArray(c) for c in s]
+        pkey = [g, y]
+        WP = nat.reencrypt_native(G, pkey, W, S, pi)
+        pr = nat.PoSBasicTW(G, NV, NE, NR, rand=Tape(b"prover-%d" % k, q))
+        pr.precompute(g, H, pi)
+        pr.setInstance(pkey, W, WP, S)
+        pr.setBatchVector(t.int_array(n, NE))
+        pr.commit()
+        during = G.tableBytes()
+        pr.free()
+        after = G.tableBytes()
+        assert after < during, (k, during, after)
+        seen.append(after)
+    assert seen[0] == seen[1] == seen[2]                     # nothing of a freed prover is left behind
+
+
 def test_array_pool_levels_off_and_nothing_stays_live(vmn, groups):
     """Temporaries whose size depends on the data (the level buffers of a multi-exponentiation) land in size classes,
     so repeated calls on different data reuse the cached blocks instead of adding new ones; when every array of a

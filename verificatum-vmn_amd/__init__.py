@@ -389,6 +389,11 @@ class ModPGroup:
         ``uses_hint`` calls on arrays of about ``n_hint`` exponents (``vmn_group_precompute_fixed``)."""
         _check(lib().vmn_group_precompute_fixed(self._h, self.enc_el(base), C.c_size_t(n_hint), C.c_int(uses_hint)))
 
+    def releaseFixed(self, base) -> None:
+        """The table of a base that will not be used again leaves the cache; its memory serves the next table of that size
+        (``vmn_group_release_fixed``; the proof drivers do this for a prover's h_0 when the proof object is freed)."""
+        _check(lib().vmn_group_release_fixed(self._h, self.enc_el(base)))
+
     def tableBytes(self) -> int:
         """Bytes of HBM the cached fixed-base tables of this group hold (``vmn_group_table_bytes``)."""
         return int(lib().vmn_group_table_bytes(self._h))

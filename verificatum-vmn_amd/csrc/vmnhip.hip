@@ -3434,6 +3434,20 @@ extern "C" int vmn_group_precompute_fixed(vmn_group* grp, const uint8_t* base_be
     return fixed_table(grp, base_be, ebits, n_hint, &ft, uses, false, chain.empty() ? nullptr : &chain);
 }
 
+// The table of a base that will not come back (the per-proof base h_0 of a prover that is being freed): out of the group's cache,
+// into the context's table arena -- where the next proof's table of the same size takes it from, so that a session of proofs
+// allocates its per-proof table ONCE.  (A table that merely ages out of the cache goes the same way, fixed_drop.)  Unknown
+// base: nothing happens.
+extern "C" int vmn_group_release_fixed(vmn_group* grp, const uint8_t* base_be) {
+    ARG_CHECK(grp && base_be, "null argument");
+    VMN_ENTER(LANE(grp->ctx));
+    std::lock_guard<std::recursive_mutex> tab_guard(grp->tab_mu);
+    std::string key(reinterpret_cast<const char*>(base_be), grp->P.ec ? 2 * grp->nbytes : grp->nbytes);
+    auto it = grp->fixed.find(key);
+    if (it != grp->fixed.end()) fixed_drop(grp, it);
+    return VMN_OK;
+}
+
 extern "C" int vmn_group_exp_fixed(vmn_group* grp, const uint8_t* base_be, const vmn_rarray* e, vmn_garray** out) {
     ARG_CHECK(grp && base_be && e && out, "null argument");
     ARG_CHECK(e->grp == grp, "exponent array belongs to another group");

@@ -637,7 +637,15 @@ struct ProofBase {
     // the table of a per-proof base (h_0), built on the second lane as soon as the base is known: its squaring chain is
     // milliseconds of sequential host work that would otherwise sit in front of the first use (commit's bridging commitments)
     LaneJob h0_table_job;
+    Bytes per_proof_base;                                    // h_0 of a prover: its table goes back to the arena with this object
+    void release_base_table() {
+        if (per_proof_base.empty()) return;
+        (void)h0_table_job.join();
+        (void)vmn_group_release_fixed(G.grp, per_proof_base.data());
+        per_proof_base.clear();
+    }
     int prepare_base_table(const Bytes& base) {
+        per_proof_base = base;
         if (!prefetch_tables()) return VMN_OK;              // (large arrays hide the chain; curves: a one-lane doubling chain on the device, 2.3 ms)
         (void)h0_table_job.join();
         const Bytes b = base;                                // (a copy: the job may outlive the derived object's fields)
@@ -2904,7 +2912,10 @@ CREATE(vmn_ccpos, vmn_ccpos_create)
 #define NONNULL(p) \
     if (!(p)) return fail(VMN_ERR_ARG, "%s: null proof object", __func__)
 
-void vmn_pos_free(vmn_pos* p) { delete p; }
+void vmn_pos_free(vmn_pos* p) {
+    if (p) p->release_base_table();
+    delete p;
+}
 vmn_group* vmn_pos_group(const vmn_pos* p) { return p ? p->G.grp : nullptr; }
 vmn_group* vmn_posc_group(const vmn_posc* p) { return p ? p->G.grp : nullptr; }
 vmn_group* vmn_ccpos_group(const vmn_ccpos* p) { return p ? p->G.grp : nullptr; }
@@ -3009,7 +3020,10 @@ int vmn_pos_get_D(vmn_pos* p, uint8_t* out_be) {
 }
 size_t vmn_pos_width(const vmn_pos* p) { return p ? p->width : 0; }
 
-void vmn_posc_free(vmn_posc* p) { delete p; }
+void vmn_posc_free(vmn_posc* p) {
+    if (p) p->release_base_table();
+    delete p;
+}
 int vmn_posc_set_instance(vmn_posc* p, const uint8_t* g_be, const vmn_garray* h, const vmn_garray* u, const vmn_rarray* r,
                           const uint32_t* pi) {
     NONNULL(p);
