@@ -1503,7 +1503,7 @@ def main() -> None:
                         f"{source_fingerprint()}): its counters are not used; rerun tools/profile_pmc.sh")
             print("bench.py: " + pmc_note, file=sys.stderr)
         else:
-            pmc = pmc_all["kernels"]["k_modpow<vmn::Cfg<74, 1>"]
+            pmc = pmc_all["kernels"].get("k_modpow_phased<vmn::Cfg<74, 1>") or pmc_all["kernels"]["k_modpow<vmn::Cfg<74, 1>"]
             traffic = pmc["hbm_bytes_per_unit"] * n
             valu_busy = pmc["valu_busy_frac"]
             pmc_instr = pmc["valu_instr_per_unit"]
@@ -1532,7 +1532,7 @@ def main() -> None:
                    "gpus_visible": n_devices, "rehearsal_ranks_share_gpus": bool(distributed and n_devices < world),
                    "scaling": args.scaling if distributed else "weak",
                    "note": "element-wise op: contiguous shards, no data-path collective; the mix legs below exchange scalars only"},
-        "roofline": {"bound": "valu-int", "kernel": "k_modpow<74>", "achieved": achieved, "peak": PEAK_TMACS,
+        "roofline": {"bound": "valu-int", "kernel": "k_modpow_phased<74>", "achieved": achieved, "peak": PEAK_TMACS,
                      "unit": "TMAC/s (32x32->64-bit multiply-accumulate)", "frac": achieved / PEAK_TMACS,
                      "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                      "traffic": traffic, "traffic_source": pmc_note or f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build, bytes per element x n)",

@@ -322,6 +322,29 @@ def test_fixed_base_table_cache_is_bounded(vmn, gpu_ctx, monkeypatch):
             assert G.exp(b, E).toInts() == pyref.exp_fixed(b, es, p), rnd
 
 
+@pytest.mark.parametrize("bits,n", [(2048, 1500), (3072, 700), (1024, 2100), (4096, 300)])
+def test_modpow_in_phases_is_the_same_power(bits, n, vmn, gpu_ctx, monkeypatch):
+    """Arrays of more than one round of tiles run k_modpow_phased: a tile's power is cut into runs of windows that different
+    workgroups take from a queue, the running value and the window table handed over through memory.  With the "device" shrunk
+    to two workgroup slots (VMN_MODPOW_MAX_BLOCKS) small arrays take that kernel too: ragged sizes, full-length and short
+    exponents, against Python's pow."""
+    grp, _ = load_golden(bits) if bits in (1024, 2048) else (None, None)
+    if grp is None:
+        p, q, g = pyref.modp_group(bits)
+    else:
+        p, q, g = grp["p"], grp["q"], grp["g"]
+    monkeypatch.setenv("VMN_MODPOW_MAX_BLOCKS", "2")
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    xs = [pow(g, k, p) for k in pyref.stream_ints(b"phased/x%d" % bits, n, q)]
+    X = G.toElementArray(xs)
+    for ebits in (q.bit_length(), 256, 37):
+        es = [e % (1 << ebits) for e in pyref.stream_ints(b"phased/e%d" % ebits, n, 1 << ebits)]
+        es[0], es[-1] = 0, (1 << ebits) - 1 if ebits < q.bit_length() else q - 1
+        es = [e % q for e in es]
+        got = X.exp(G.ringArray(es), 0 if ebits == q.bit_length() else ebits).toInts()
+        assert got == [pow(x, e, p) for x, e in zip(xs, es)], (bits, ebits)
+
+
 def test_released_table_leaves_the_cache_and_the_base_still_works(vmn, gpu_ctx):
     """vmn_group_release_fixed: the table of a base that will not come back (a prover's h_0, released when the proof object is
     freed) leaves the group's cache; a later use of the same base rebuilds it; an unknown base is no error."""

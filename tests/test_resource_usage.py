@@ -34,6 +34,12 @@ def test_headline_kernel_stays_on_the_right_side_of_the_register_cliff(tmp_path)
     for name, r in modpow.items():
         assert r["occupancy"] == 2, (name, r)                     # two waves per SIMD: what the roofline figure assumes
         assert r["scratch"] <= 256, (name, r)                     # prologue only (188 B in round 3); a spill in the row loop is KBs
+    # the headline's kernel since round 4: the same power in phases from a queue of units.  276 B of scratch, none of it in the
+    # squaring rows (the block of 8251 multiply-adds has no scratch access; the window loop has three per window)
+    phased = {k: v for k, v in rep.items() if "k_modpow_phasedINS_3CfgILi74ELi1E" in k}
+    assert phased, sorted(rep)[:5]
+    for name, r in phased.items():
+        assert r["occupancy"] == 2 and r["scratch"] <= 320, (name, r)
     # the row-loop kernels of the proof legs: no scratch at all, two waves
     for key in ("k_fixed_expINS_3CfgILi74ELi1E", "k_bucket_levelINS_3CfgILi74ELi1E", "k_mulINS_3CfgILi74ELi1E"):
         hits = {k: v for k, v in rep.items() if key in k}

@@ -20,6 +20,9 @@
                                                       vmn::u32);                                                                         \
     KW __global__ void vmn::k_modpow<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, int, size_t,     \
                                                          const vmn::u32*, vmn::u32, const vmn::u32*, vmn::u32*);                         \
+    KW __global__ void vmn::k_modpow_phased<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, int,      \
+                                                                size_t, const vmn::u32*, vmn::u32, const vmn::u32*, vmn::u32*, int,      \
+                                                                vmn::u32*, vmn::u32*);                                                   \
     KW __global__ void vmn::k_modpow2<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, const vmn::u32*,  \
                                                           const vmn::u32*, int, size_t, int, int, size_t, const vmn::u32*, vmn::u32,      \
                                                           const vmn::u32*, vmn::u32*);                                                  \

@@ -676,6 +676,109 @@ k_modpow(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_modpow for arrays of MORE than one round of tiles, in phases.  Every tile of k_modpow takes the same time T, so an
+// array of r = ntiles / slots rounds finishes after ceil(r) T: 10^6 elements are 7.63 rounds of the 512 workgroup slots and
+// cost 8 -- 4.6 % of the launch is the idle tail of its last round (measured: 0.632 of the roof at exactly 2 rounds,
+// 0.603 at 7.63).  Here a tile's power is cut into `phases` runs of windows and the workgroups take (phase, tile) units
+// from a queue in phase-major order: P x 7.63 rounds of units of T / P each, the tail is at most one UNIT.  Between its
+// phases a tile's running value lives in out[], its window table in a table of its OWN (per element, not per lane slot:
+// another workgroup continues it).  Unit u = (phase, tile) needs (phase - 1, tile), which is unit u - ntiles: handed out
+// earlier, to a workgroup that is therefore running and waits for nothing later than itself -- the spin below always ends,
+// whatever part of the grid is resident.  Same products in the same order as k_modpow: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_modpow_phased(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e, int ewords, size_t estride,
+                int ebits, int wbits, size_t n, const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ one_m,
+                u32* __restrict__ tab, int phases, u32* __restrict__ queue, u32* __restrict__ done) {
+    constexpr int W = C::W;
+    extern __shared__ u32 lds[];
+    __shared__ u32 s_unit;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const u32 ntiles = (u32)((n + C::EPB - 1) / C::EPB);
+    const u32 nunits = ntiles * (u32)phases;
+    const int tsize = 1 << wbits;
+    const int nwin = (ebits + wbits - 1) / wbits;
+    const int M = nwin - 1;                              // windows of the main loop (the top one is the first table read)
+    // ONE thread-0 region per turn -- the hand-over of the finished unit and the fetch of the next, between two barriers.  (With
+    // the fetch at the top of the loop and the hand-over at its bottom, two thread-0 regions sit around the back edge: the
+    // compiler lets the other lanes of wave 0 run ahead into the next turn's barrier while lane 0 is still signalling, the
+    // barrier counts go out of step and the kernel hangs -- tools/micro/queue_handoff.hip reproduces both forms.)
+    if (threadIdx.x == 0) s_unit = atomicAdd(queue, 1u);
+    __syncthreads();
+    for (;;) {
+        const u32 u = (u32)__builtin_amdgcn_readfirstlane((int)s_unit);
+        if (u >= nunits) break;
+        const int ph = (int)(u / ntiles);
+        const u32 t = u - (u32)ph * ntiles;
+        if (ph > 0) {                                    // the tile's previous phase, run by another workgroup
+            if (threadIdx.x == 0) {
+                long spins = 0;                          // (a unit lasts milliseconds: 2^28 polls are minutes -- a bug, and then a trap, not a hang)
+                while (__hip_atomic_load(done + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (u32)ph) {
+                    if (++spins > (1L << 28)) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        size_t el = (size_t)t * C::EPB + ln.eslot;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        const u32* ep = e + ec * estride;
+        u32* mytab = tab + ((size_t)t * C::EPB + ln.eslot) * (size_t)tsize * W;
+        u32 a[C::L];
+        if (ph == 0) {
+            // table: tab[0] = 1, tab[1] = x, tab[k] = tab[k-1] * x
+            load_elem<C>(a, x + ec * W, ln);
+            {
+                u32 o[C::L];
+                load_modulus<C>(o, one_m, ln);
+                store_elem<C>(mytab, o, ln);
+            }
+            store_elem<C>(mytab + W, a, ln);
+            regs_to_lds<C>(ln, a);
+#pragma unroll 1
+            for (int k = 2; k < tsize; ++k) {
+                u32 r[C::L];
+                mont_mul<C>(r, a, ln, nn, n0inv);          // x * tab[k-1]
+                store_elem<C>(mytab + (size_t)k * W, r, ln);
+                regs_to_lds<C>(ln, r);
+            }
+            u32 d = exp_digit(ep, ewords, (nwin - 1) * wbits, wbits);
+            load_elem<C>(a, mytab + (size_t)d * W, ln);
+        } else {
+            load_elem<C>(a, out + ec * W, ln);
+        }
+        // the windows of this phase: M - 1 - M ph / P  down to  M - M (ph + 1) / P
+        const int hi = M - 1 - (int)((long)M * ph / phases), lo = M - (int)((long)M * (ph + 1) / phases);
+#pragma unroll 1
+        for (int wi = hi; wi >= lo; --wi) {
+#pragma unroll 1
+            for (int s = 0; s < wbits; ++s) {
+                regs_to_lds<C>(ln, a);
+                mont_sqr<C>(a, a, ln, nn, n0inv);
+            }
+            u32 d = exp_digit(ep, ewords, wi * wbits, wbits);
+            load_elem_to_lds<C>(ln, mytab + (size_t)d * W);
+            mont_mul<C>(a, a, ln, nn, n0inv);
+        }
+        if (ph == phases - 1) canonicalize<C>(a, nn, ln);
+        if (live) store_elem<C>(out + el * W, a, ln);
+        const bool hand_on = ph < phases - 1;            // another workgroup continues this tile
+        if (hand_on) __threadfence();
+        __syncthreads();                                 // every store of the unit is out; everybody has read s_unit
+        if (threadIdx.x == 0) {
+            if (hand_on) (void)__hip_atomic_exchange(done + t, (u32)(ph + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_unit = atomicAdd(queue, 1u);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Simultaneous power of two bases (Straus): out[i] = x[i]^e1 * y[i]^e2 with the squarings shared -- max(ebits1, ebits2)
 // squarings instead of their sum.  Either exponent may be shared (stride 0) or per element.  Per-lane tables of both bases
 // in scratch (2 * 2^w rows).  Used by the verifiers' check (B) in the form B_i^v (B_{i-1}^{-1})^{k_E,i}.

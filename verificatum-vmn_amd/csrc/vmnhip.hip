@@ -1507,6 +1507,36 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x, 
         note_work(ctx, m, (double)n * (nwin - 1 + (1 << wbits) - 2), (double)n * (nwin - 1) * wbits);
     }
     int rc = VMN_ERR_ARG;
+    // More than one round of tiles: the power in phases from a queue of (phase, tile) units (k_modpow_phased), so that the
+    // launch ends with a tail of one unit instead of one whole tile -- 10^6 elements are 7.63 rounds and cost 8 otherwise.
+    // VMN_MODPOW_PHASES: 1 = one phase (k_modpow); default 16.
+    static const int phases_env = [] {
+        const char* e = getenv("VMN_MODPOW_PHASES");
+        return e && *e ? std::max(1, atoi(e)) : 16;
+    }();
+    if (const char* mb = getenv("VMN_MODPOW_MAX_BLOCKS")) {       // test hook: a "device" of few workgroup slots, so that small arrays take the phased kernel
+        const int v = atoi(mb);
+        if (v >= 1) max_blocks = std::min<unsigned>(max_blocks, (unsigned)v);
+    }
+    const size_t epb = (size_t)(BLOCK / m.LPE);
+    const size_t ntiles = (n + epb - 1) / epb;
+    const int main_windows = (ebits + wbits - 1) / wbits - 1;
+    const int phases = ntiles > (size_t)max_blocks && ntiles < ((size_t)1 << 26) ? std::min(phases_env, std::max(1, main_windows)) : 1;
+    if (phases > 1) {
+        const size_t ptab_bytes = ntiles * epb * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);      // a table per ELEMENT
+        DevTmp ptab(ctx), sync_words(ctx);
+        VMN_TRY(ptab.alloc(ptab_bytes));
+        VMN_TRY(sync_words.alloc((ntiles + 1) * sizeof(uint32_t)));
+        VMN_TRY(dev_zero(ctx, sync_words.p, (ntiles + 1) * sizeof(uint32_t)));
+        uint32_t* queue = sync_words.as<uint32_t>();
+#define X(S_, NW_, LPE_)                                                                                                 \
+    if (m.S == S_)                                                                                                 \
+        rc = launch(ctx, "modpow", k_modpow_phased<Cfg<S_, LPE_>>, max_blocks, lds_bytes(m), out, x, e_words, ewords, estride, ebits, \
+                    wbits, n, m.d_n, m.n0inv, m.d_one, ptab.as<uint32_t>(), phases, queue, queue + 1);
+        VMN_FOR_SIZES(X)
+#undef X
+        return rc;
+    }
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
         rc = launch(ctx, "modpow", k_modpow<Cfg<S_, LPE_>>, grid, lds_bytes(m), out, x, e_words, ewords, estride, ebits, wbits, \
