@@ -322,7 +322,7 @@ def test_fixed_base_table_cache_is_bounded(vmn, gpu_ctx, monkeypatch):
             assert G.exp(b, E).toInts() == pyref.exp_fixed(b, es, p), rnd
 
 
-@pytest.mark.parametrize("bits,n", [(2048, 1500), (3072, 700), (1024, 2100), (4096, 300)])
+@pytest.mark.parametrize("bits,n", [(2048, 600), (3072, 300), (1024, 700), (4096, 150)])      # (three tiles and a ragged fourth)
 def test_modpow_in_phases_is_the_same_power(bits, n, vmn, gpu_ctx, monkeypatch):
     """Arrays of more than one round of tiles run k_modpow_phased: a tile's power is cut into runs of windows that different
     workgroups take from a queue, the running value and the window table handed over through memory.  With the "device" shrunk
@@ -337,7 +337,7 @@ def test_modpow_in_phases_is_the_same_power(bits, n, vmn, gpu_ctx, monkeypatch):
     G = vmn.ModPGroup(gpu_ctx, p, q, g)
     xs = [pow(g, k, p) for k in pyref.stream_ints(b"phased/x%d" % bits, n, q)]
     X = G.toElementArray(xs)
-    for ebits in (q.bit_length(), 256, 37):
+    for ebits in (q.bit_length(), 37):                     # (the expected values are Python pows: a third of a minute in all)
         es = [e % (1 << ebits) for e in pyref.stream_ints(b"phased/e%d" % ebits, n, 1 << ebits)]
         es[0], es[-1] = 0, (1 << ebits) - 1 if ebits < q.bit_length() else q - 1
         es = [e % q for e in es]
