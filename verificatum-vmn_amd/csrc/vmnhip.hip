@@ -1522,10 +1522,13 @@ static int modpow_words(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x, 
     const size_t ntiles = (n + epb - 1) / epb;
     const int main_windows = (ebits + wbits - 1) / wbits - 1;
     const int phases = ntiles > (size_t)max_blocks && ntiles < ((size_t)1 << 26) ? std::min(phases_env, std::max(1, main_windows)) : 1;
-    if (phases > 1) {
-        const size_t ptab_bytes = ntiles * epb * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);      // a table per ELEMENT
-        DevTmp ptab(ctx), sync_words(ctx);
-        VMN_TRY(ptab.alloc(ptab_bytes));
+    // a window table per ELEMENT (9.5 GB for 10^6 x 2048 bits, w = 5): where that does not fit -- more than 64 GB, or the
+    // allocation fails -- the power runs tile by tile with a table per lane slot, as it always did
+    const size_t ptab_bytes = ntiles * epb * ((size_t)1 << wbits) * elem_words(m) * sizeof(uint32_t);
+    DevTmp ptab(ctx), sync_words(ctx);
+    bool phased = phases > 1 && ptab_bytes <= ((size_t)64 << 30);
+    if (phased && ptab.alloc(ptab_bytes) != VMN_OK) phased = false;
+    if (phased) {
         VMN_TRY(sync_words.alloc((ntiles + 1) * sizeof(uint32_t)));
         VMN_TRY(dev_zero(ctx, sync_words.p, (ntiles + 1) * sizeof(uint32_t)));
         uint32_t* queue = sync_words.as<uint32_t>();
