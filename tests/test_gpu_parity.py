@@ -546,6 +546,26 @@ def test_simultaneous_power_and_array_inverse(bits, groups, oracle_for):
         assert got == want, (e.bit_length(), fbits)
 
 
+@pytest.mark.parametrize("bits,n", [(2048, 600), (3072, 300)])
+def test_simultaneous_power_in_phases_is_the_same_power(bits, n, vmn, gpu_ctx, oracle_for, monkeypatch):
+    """k_modpow2_phased (arrays of more than one round of tiles; here a "device" of two workgroup slots): the simultaneous
+    power handed from workgroup to workgroup between runs of windows, against the GMP oracle -- the shapes of a verifier's
+    check (B): a shared 256-bit exponent with per-element 612-bit ones, and unequal window counts the other way round."""
+    grp, _ = load_golden(bits) if bits == 2048 else (None, None)
+    p, q, g = (grp["p"], grp["q"], grp["g"]) if grp else pyref.modp_group(bits)
+    orc = oracle_for(p, q)
+    monkeypatch.setenv("VMN_MODPOW_MAX_BLOCKS", "2")
+    G = vmn.ModPGroup(gpu_ctx, p, q, g)
+    xs, fs = _inputs(b"exp2-phased-%d" % bits, n, p, q)
+    ys = [pow(x, 5, p) for x in xs[::-1]]
+    X, Y = G.toElementArray(xs), G.toElementArray(ys)
+    for e, fbits in ((pyref.stream_ints(b"exp2p/e", 1, 1 << 256)[0] | (1 << 255), 612), ((1 << 700) + 12345, 41), (0, 300)):
+        f = [v % (1 << fbits) for v in fs]
+        f[0], f[-1] = 0, (1 << fbits) - 1
+        got = X.exp2(e, Y, G.ringArray(f), fbits).toInts()
+        assert got == orc.mul(orc.exp_scalar(xs, e), orc.exp_array(ys, f)), (bits, e.bit_length(), fbits)
+
+
 def test_inner_products_in_one_round_trip(vmn, groups):
     """vmn_rarray_inner_products against Python: products and plain sums mixed, arrays of different lengths (1 element, one
     beyond a reduction pass, empty)."""

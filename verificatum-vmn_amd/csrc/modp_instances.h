@@ -26,6 +26,10 @@
     KW __global__ void vmn::k_modpow2<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int, const vmn::u32*,  \
                                                           const vmn::u32*, int, size_t, int, int, size_t, const vmn::u32*, vmn::u32,      \
                                                           const vmn::u32*, vmn::u32*);                                                  \
+    KW __global__ void vmn::k_modpow2_phased<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::u32*, int, size_t, int,          \
+                                                                 const vmn::u32*, const vmn::u32*, int, size_t, int, int, size_t,        \
+                                                                 const vmn::u32*, vmn::u32, const vmn::u32*, vmn::u32*, int, vmn::u32*,  \
+                                                                 vmn::u32*);                                                            \
     KW __global__ void vmn::k_modpow_shared<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::SlideStep*, int, int, size_t,      \
                                                                 const vmn::u32*, vmn::u32, vmn::u32*);                                  \
     KW __global__ void vmn::k_modpow_jobs<vmn::Cfg<S_, LPE_>>(vmn::ModpowJob, vmn::ModpowJob, unsigned, int, const vmn::u32*, vmn::u32,    \

@@ -853,6 +853,112 @@ k_modpow2(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restric
     }
 }
 
+// k_modpow2 for arrays of more than one round of tiles: the same simultaneous power in phases from a queue of (phase, tile)
+// units (see k_modpow_phased -- the queue, the hand-over and the ONE thread-0 region per turn are the same); both tables
+// of a tile live in a table of its own (2 * 2^w rows per element).
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_modpow2_phased(u32* __restrict__ out, const u32* __restrict__ x, const u32* __restrict__ e1, int ewords1, size_t estride1, int ebits1,
+                 const u32* __restrict__ y, const u32* __restrict__ e2, int ewords2, size_t estride2, int ebits2, int wbits, size_t n,
+                 const u32* __restrict__ nmod, u32 n0inv, const u32* __restrict__ one_m, u32* __restrict__ tab, int phases,
+                 u32* __restrict__ queue, u32* __restrict__ done) {
+    constexpr int W = C::W;
+    extern __shared__ u32 lds[];
+    __shared__ u32 s_unit;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const u32 ntiles = (u32)((n + C::EPB - 1) / C::EPB);
+    const u32 nunits = ntiles * (u32)phases;
+    const int tsize = 1 << wbits;
+    const int nwin1 = (ebits1 + wbits - 1) / wbits, nwin2 = (ebits2 + wbits - 1) / wbits;
+    const int nwin = nwin1 > nwin2 ? nwin1 : nwin2;
+    if (threadIdx.x == 0) s_unit = atomicAdd(queue, 1u);
+    __syncthreads();
+    for (;;) {
+        const u32 u = (u32)__builtin_amdgcn_readfirstlane((int)s_unit);
+        if (u >= nunits) break;
+        const int ph = (int)(u / ntiles);
+        const u32 t = u - (u32)ph * ntiles;
+        if (ph > 0) {
+            if (threadIdx.x == 0) {
+                long spins = 0;
+                while (__hip_atomic_load(done + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (u32)ph) {
+                    if (++spins > (1L << 28)) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        size_t el = (size_t)t * C::EPB + ln.eslot;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        const u32* ep1 = e1 + ec * estride1;
+        const u32* ep2 = e2 + ec * estride2;
+        u32* tab1 = tab + ((size_t)t * C::EPB + ln.eslot) * (size_t)(2 * tsize) * W;
+        u32* tab2 = tab1 + (size_t)tsize * W;
+        u32 a[C::L];
+        if (ph == 0) {
+            // tables: tab[0] = 1, tab[1] = base, tab[k] = tab[k-1] * base
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) {
+                u32* tb = which ? tab2 : tab1;
+                {
+                    u32 o[C::L];
+                    load_modulus<C>(o, one_m, ln);
+                    store_elem<C>(tb, o, ln);
+                }
+                load_elem<C>(a, (which ? y : x) + ec * W, ln);
+                store_elem<C>(tb + W, a, ln);
+                regs_to_lds<C>(ln, a);
+#pragma unroll 1
+                for (int k = 2; k < tsize; ++k) {
+                    u32 r[C::L];
+                    mont_mul<C>(r, a, ln, nn, n0inv);          // base * tab[k-1]
+                    store_elem<C>(tb + (size_t)k * W, r, ln);
+                    regs_to_lds<C>(ln, r);
+                }
+            }
+            load_modulus<C>(a, one_m, ln);
+        } else {
+            load_elem<C>(a, out + ec * W, ln);
+        }
+        // the windows of this phase: nwin - 1 - nwin ph / P  down to  nwin - nwin (ph + 1) / P
+        const int hi = nwin - 1 - (int)((long)nwin * ph / phases), lo = nwin - (int)((long)nwin * (ph + 1) / phases);
+#pragma unroll 1
+        for (int wi = hi; wi >= lo; --wi) {
+            if (wi != nwin - 1) {
+#pragma unroll 1
+                for (int s = 0; s < wbits; ++s) {
+                    regs_to_lds<C>(ln, a);
+                    mont_sqr<C>(a, a, ln, nn, n0inv);
+                }
+            }
+            if (wi < nwin1) {
+                u32 d = exp_digit(ep1, ewords1, wi * wbits, wbits);
+                load_elem_to_lds<C>(ln, tab1 + (size_t)d * W);
+                mont_mul<C>(a, a, ln, nn, n0inv);
+            }
+            if (wi < nwin2) {
+                u32 d = exp_digit(ep2, ewords2, wi * wbits, wbits);
+                load_elem_to_lds<C>(ln, tab2 + (size_t)d * W);
+                mont_mul<C>(a, a, ln, nn, n0inv);
+            }
+        }
+        if (ph == phases - 1) canonicalize<C>(a, nn, ln);
+        if (live) store_elem<C>(out + el * W, a, ln);
+        const bool hand_on = ph < phases - 1;
+        if (hand_on) __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (hand_on) (void)__hip_atomic_exchange(done + t, (u32)(ph + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_unit = atomicAdd(queue, 1u);
+        }
+        __syncthreads();
+    }
+}
+
 // =============================================================================================
 // second part: fixed-base tables (K2), multi-exponentiation (K3), reductions (K5), comparison
 // (K6), data movement (K7) and the ring kernels over Z_q (K8).

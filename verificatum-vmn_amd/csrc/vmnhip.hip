@@ -1920,11 +1920,42 @@ extern "C" int vmn_garray_exp2(const vmn_garray* x, const uint8_t* e_be, size_t 
     } else if (rc == VMN_OK) {
         const vmn_modulus& m = geom(ctx, g->P, n);
         const int wbits = std::min(pick_window(std::max(ebits, fbits)), 5);       // two tables per lane
-        const unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+        unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+        if (const char* mb = getenv("VMN_MODPOW_MAX_BLOCKS")) {       // (test hook, see modpow_words)
+            const int v = atoi(mb);
+            if (v >= 1) max_blocks = std::min<unsigned>(max_blocks, (unsigned)v);
+        }
         const unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
         const size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * ((size_t)2 << wbits) * elem_words(m) * sizeof(uint32_t);
         rc = ensure_scratch(ctx, tab_bytes);
-        if (rc == VMN_OK) {
+        // more than one round of tiles: in phases from a queue of units (k_modpow2_phased; modpow_words has the reasons)
+        const size_t epb = (size_t)(BLOCK / m.LPE), ntiles = (n + epb - 1) / epb;
+        const int nwin_all = (std::max(ebits, fbits) + wbits - 1) / wbits;
+        static const int phases_env2 = [] {
+            const char* e = getenv("VMN_MODPOW_PHASES");
+            return e && *e ? std::max(1, atoi(e)) : 16;
+        }();
+        const int phases = ntiles > (size_t)max_blocks && ntiles < ((size_t)1 << 26) ? std::min(phases_env2, std::max(1, nwin_all)) : 1;
+        const size_t ptab_bytes = ntiles * epb * ((size_t)2 << wbits) * elem_words(m) * sizeof(uint32_t);
+        DevTmp ptab(ctx), sync_words(ctx);
+        bool phased = rc == VMN_OK && phases > 1 && ptab_bytes <= ((size_t)64 << 30);
+        if (phased && ptab.alloc(ptab_bytes) != VMN_OK) phased = false;
+        if (phased) rc = sync_words.alloc((ntiles + 1) * sizeof(uint32_t));
+        if (phased && rc == VMN_OK) rc = dev_zero(ctx, sync_words.p, (ntiles + 1) * sizeof(uint32_t));
+        if (phased && rc == VMN_OK) {
+            const int nw1 = (ebits + wbits - 1) / wbits, nw2 = (fbits + wbits - 1) / wbits;
+            note_work(ctx, m, (double)n * (nw1 + nw2 + 2 * ((1 << wbits) - 2)), (double)n * (std::max(nw1, nw2) - 1) * wbits);
+            uint32_t* queue = sync_words.as<uint32_t>();
+            rc = VMN_ERR_ARG;
+#define X(S_, NW_, LPE_)                                                                                                       \
+    if (m.S == S_)                                                                                                             \
+        rc = launch(ctx, "modpow", k_modpow2_phased<Cfg<S_, LPE_>>, max_blocks, lds_bytes(m), r->d, (const uint32_t*)x->d,        \
+                    (const uint32_t*)ew.as<uint32_t>(), ewords, (size_t)0, ebits, (const uint32_t*)y->d,                         \
+                    (const uint32_t*)fw.as<uint32_t>(), g->Q.NW, (size_t)g->Q.NW, fbits, wbits, n, m.d_n, m.n0inv, m.d_one,    \
+                    ptab.as<uint32_t>(), phases, queue, queue + 1);
+            VMN_FOR_SIZES(X)
+#undef X
+        } else if (rc == VMN_OK) {
             const int nw1 = (ebits + wbits - 1) / wbits, nw2 = (fbits + wbits - 1) / wbits;
             note_work(ctx, m, (double)n * (nw1 + nw2 + 2 * ((1 << wbits) - 2)), (double)n * (std::max(nw1, nw2) - 1) * wbits);
             rc = VMN_ERR_ARG;
