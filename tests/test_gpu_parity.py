@@ -671,3 +671,8 @@ def test_one_exponent_for_the_whole_array_sliding_window(bits, vmn, gpu_ctx, ora
     monkeypatch.delenv("VMN_SLIDING_WINDOW")
     small = G.toElementArray(xs[:7], checked=False)            # a handful of elements: the widest geometry
     assert small.exp(full).toInts() == orc.exp_scalar(xs[:7], full)
+    # arrays of more than one round of tiles walk the schedule in phases (k_modpow_shared_phased); on a "device" of ONE
+    # workgroup slot this array is one: a full-length secret, a schedule of a few steps, a single window
+    monkeypatch.setenv("VMN_MODPOW_MAX_BLOCKS", "1")
+    for e in (full, q - 1, (1 << 129) - 1, 1 << 200, 1 << 33):
+        assert X.exp(e).toInts() == orc.exp_scalar(xs, e), hex(e)[:20]

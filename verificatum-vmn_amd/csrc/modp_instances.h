@@ -32,6 +32,9 @@
                                                                  vmn::u32*);                                                            \
     KW __global__ void vmn::k_modpow_shared<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::SlideStep*, int, int, size_t,      \
                                                                 const vmn::u32*, vmn::u32, vmn::u32*);                                  \
+    KW __global__ void vmn::k_modpow_shared_phased<vmn::Cfg<S_, LPE_>>(vmn::u32*, const vmn::u32*, const vmn::SlideStep*, int, int,      \
+                                                                       size_t, const vmn::u32*, vmn::u32, vmn::u32*, int, vmn::u32*,     \
+                                                                       vmn::u32*);                                                      \
     KW __global__ void vmn::k_modpow_jobs<vmn::Cfg<S_, LPE_>>(vmn::ModpowJob, vmn::ModpowJob, unsigned, int, const vmn::u32*, vmn::u32,    \
                                                               const vmn::u32*, vmn::u32*);                                             \
     KW __global__ void vmn::k_reduce_strided<vmn::Cfg<S_, LPE_>, true>(vmn::u32*, const vmn::u32*, size_t, size_t, size_t,               \

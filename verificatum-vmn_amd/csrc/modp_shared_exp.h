@@ -71,6 +71,95 @@ k_modpow_shared(u32* __restrict__ out, const u32* __restrict__ x, const SlideSte
     }
 }
 
+// k_modpow_shared for arrays of more than one round of tiles: the schedule's steps in phases from a queue of (phase, tile) units
+// (see k_modpow_phased, modp_kernels.h: the queue, the hand-over between workgroups and the ONE thread-0 region per turn are the
+// same); a tile's table of odd powers lives in a table of its own.  The decryption factors of a party -- one full-length secret
+// exponent over every ciphertext -- are this kernel's large case.
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::MINW)
+k_modpow_shared_phased(u32* __restrict__ out, const u32* __restrict__ x, const SlideStep* __restrict__ steps, int nsteps, int tsize,
+                       size_t n, const u32* __restrict__ nmod, u32 n0inv, u32* __restrict__ tab, int phases, u32* __restrict__ queue,
+                       u32* __restrict__ done) {
+    constexpr int W = C::W;
+    extern __shared__ u32 lds[];
+    __shared__ u32 s_unit;
+    Lane<C> ln(lds);
+    u32 nn[C::L];
+    load_modulus<C>(nn, nmod, ln);
+    const u32 ntiles = (u32)((n + C::EPB - 1) / C::EPB);
+    const u32 nunits = ntiles * (u32)phases;
+    const int M = nsteps - 1;                            // steps of the main loop (step 0 is the first table read)
+    if (threadIdx.x == 0) s_unit = atomicAdd(queue, 1u);
+    __syncthreads();
+    for (;;) {
+        const u32 u = (u32)__builtin_amdgcn_readfirstlane((int)s_unit);
+        if (u >= nunits) break;
+        const int ph = (int)(u / ntiles);
+        const u32 t = u - (u32)ph * ntiles;
+        if (ph > 0) {
+            if (threadIdx.x == 0) {
+                long spins = 0;
+                while (__hip_atomic_load(done + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (u32)ph) {
+                    if (++spins > (1L << 28)) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        size_t el = (size_t)t * C::EPB + ln.eslot;
+        bool live = el < n;
+        size_t ec = live ? el : n - 1;
+        u32* mytab = tab + ((size_t)t * C::EPB + ln.eslot) * (size_t)tsize * W;
+        u32 a[C::L];
+        if (ph == 0) {
+            u32 x2[C::L];
+            // table of odd powers: tab[0] = x, tab[k] = tab[k-1] * x^2
+            load_elem<C>(a, x + ec * W, ln);
+            store_elem<C>(mytab, a, ln);
+            regs_to_lds<C>(ln, a);
+            mont_sqr<C>(x2, a, ln, nn, n0inv);
+#pragma unroll 1
+            for (int k = 1; k < tsize; ++k) {
+                regs_to_lds<C>(ln, a);
+                u32 r[C::L];
+                mont_mul<C>(r, x2, ln, nn, n0inv);         // x^2 * tab[k-1]
+                store_elem<C>(mytab + (size_t)k * W, r, ln);
+#pragma unroll
+                for (int j = 0; j < C::L; ++j) a[j] = r[j];
+            }
+            load_elem<C>(a, mytab + (size_t)steps[0].idx * W, ln);
+        } else {
+            load_elem<C>(a, out + ec * W, ln);
+        }
+        // the steps of this phase: 1 + M ph / P  up to  M (ph + 1) / P
+        const int s_lo = 1 + (int)((long)M * ph / phases), s_hi = (int)((long)M * (ph + 1) / phases);
+#pragma unroll 1
+        for (int s = s_lo; s <= s_hi; ++s) {
+            const int sq = steps[s].sq, idx = steps[s].idx;
+#pragma unroll 1
+            for (int q = 0; q < sq; ++q) {
+                regs_to_lds<C>(ln, a);
+                mont_sqr<C>(a, a, ln, nn, n0inv);
+            }
+            if (idx >= 0) {
+                load_elem_to_lds<C>(ln, mytab + (size_t)idx * W);
+                mont_mul<C>(a, a, ln, nn, n0inv);
+            }
+        }
+        if (ph == phases - 1) canonicalize<C>(a, nn, ln);
+        if (live) store_elem<C>(out + el * W, a, ln);
+        const bool hand_on = ph < phases - 1;
+        if (hand_on) __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (hand_on) (void)__hip_atomic_exchange(done + t, (u32)(ph + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_unit = atomicAdd(queue, 1u);
+        }
+        __syncthreads();
+    }
+}
+
 // Two independent exponentiations in ONE launch (small arrays): job 0 = out0[i] = x0[i]^e0 (one exponent for all), job 1 =
 // out1[i] = x1[i]^e1[i] (per-element exponents).  A verifier's check (B) in its separate form needs B^v and B_shift^(k_E): at the
 // reference's demo size (10^4 ciphertexts) each of the two kernels alone leaves 40 % of the SIMDs without a wave, and they

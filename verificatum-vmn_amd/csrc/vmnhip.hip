@@ -1593,7 +1593,11 @@ static int modpow_shared(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x,
     }
     const int tsize = 1 << (w - 1);
     const vmn_modulus& m = geom(ctx, m0, n);
-    const unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+    unsigned max_blocks = (unsigned)(ctx->num_cus * blocks_per_cu(m));
+    if (const char* mb = getenv("VMN_MODPOW_MAX_BLOCKS")) {       // (test hook, see modpow_words)
+        const int v = atoi(mb);
+        if (v >= 1) max_blocks = std::min<unsigned>(max_blocks, (unsigned)v);
+    }
     const unsigned grid = std::min<unsigned>(egrid(m, n), max_blocks);
     const size_t tab_bytes = (size_t)grid * (BLOCK / m.LPE) * (size_t)tsize * elem_words(m) * sizeof(uint32_t);
     VMN_TRY(ensure_scratch(ctx, tab_bytes));
@@ -1602,6 +1606,32 @@ static int modpow_shared(vmn_ctx* ctx, const vmn_modulus& m0, const uint32_t* x,
     VMN_TRY(h2d(ctx, dsteps.p, steps.data(), steps.size() * sizeof(SlideStep)));
     note_work(ctx, m, (double)n * (double)(mults + tsize - 1), (double)n * (double)(squarings + 1));
     int rc = VMN_ERR_ARG;
+    // more than one round of tiles: in phases from a queue of units (k_modpow_shared_phased; modpow_words has the reasons)
+    {
+        const size_t epb = (size_t)(BLOCK / m.LPE), ntiles = (n + epb - 1) / epb;
+        static const int phases_env3 = [] {
+            const char* e = getenv("VMN_MODPOW_PHASES");
+            return e && *e ? std::max(1, atoi(e)) : 16;
+        }();
+        const int phases = ntiles > (size_t)max_blocks && ntiles < ((size_t)1 << 26) ? std::min(phases_env3, std::max(1, (int)steps.size() - 1)) : 1;
+        const size_t ptab_bytes = ntiles * epb * (size_t)tsize * elem_words(m) * sizeof(uint32_t);
+        DevTmp ptab(ctx), sync_words(ctx);
+        bool phased = phases > 1 && ptab_bytes <= ((size_t)64 << 30);
+        if (phased && ptab.alloc(ptab_bytes) != VMN_OK) phased = false;
+        if (phased) {
+            VMN_TRY(sync_words.alloc((ntiles + 1) * sizeof(uint32_t)));
+            VMN_TRY(dev_zero(ctx, sync_words.p, (ntiles + 1) * sizeof(uint32_t)));
+            uint32_t* queue = sync_words.as<uint32_t>();
+#define X(S_, NW_, LPE_)                                                                                                 \
+    if (m.S == S_)                                                                                                 \
+        rc = launch(ctx, "modpow", k_modpow_shared_phased<Cfg<S_, LPE_>>, max_blocks, lds_bytes(m), out, x,                  \
+                    (const SlideStep*)dsteps.as<SlideStep>(), (int)steps.size(), tsize, n, m.d_n, m.n0inv, ptab.as<uint32_t>(), \
+                    phases, queue, queue + 1);
+            VMN_FOR_SIZES(X)
+#undef X
+            return rc;
+        }
+    }
 #define X(S_, NW_, LPE_)                                                                                                 \
     if (m.S == S_)                                                                                                 \
         rc = launch(ctx, "modpow", k_modpow_shared<Cfg<S_, LPE_>>, grid, lds_bytes(m), out, x, (const SlideStep*)dsteps.as<SlideStep>(), \
